@@ -1,0 +1,376 @@
+"""Forward / backward procedures of the BM-NAS fusion cell on the HIP kernels.
+
+No autograd here: every ``*_fwd`` returns its outputs plus a ``saved`` object, every
+``*_bwd`` consumes it.  ``bmnas.functions`` wraps them into torch.autograd.Function so the
+nn.Module mirror (models/search/darts/*.py) behaves like the reference's modules.
+
+Math and reference citations: SURVEY.md Appendix A; kernel contracts: include/bmnas_hip.h.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib
+
+ATTN_DROP = 0.1     # ScaledDotAttn's hard-coded nn.Dropout(0.1) (node_operations.py:89)
+
+
+# ------------------------------------------------------------------------ dropout state
+class _DropState:
+    """Counter-based dropout bookkeeping: seed = torch.initial_seed(), offset advances with
+    every dropout site so masks never repeat; the backward reuses the saved descriptor."""
+
+    def __init__(self):
+        self.offset = 0
+
+    def make(self, p, numel, training):
+        if not training or p <= 0.0:
+            return lib.NO_DROP
+        d = lib.make_dropout(p, torch.initial_seed(), self.offset)
+        self.offset += (numel + 3) // 4
+        return d
+
+
+DROP = _DropState()
+
+
+def _empty(like, *shape):
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+def _zeros(like, *shape):
+    return torch.zeros(shape, device=like.device, dtype=torch.float32)
+
+
+class Arena:
+    """One zero-filled fp32 buffer carved into the gradient tensors that the kernels
+    accumulate into with atomics (a single memset instead of one per tensor)."""
+
+    def __init__(self):
+        self.req = []
+        self.total = 0
+        self.buf = None
+
+    def ask(self, *shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        self.req.append((self.total, n, tuple(shape)))
+        self.total += (n + 3) // 4 * 4
+        return len(self.req) - 1
+
+    def alloc(self, device):
+        self.buf = torch.zeros(self.total, device=device, dtype=torch.float32)
+        return self
+
+    def view(self, idx):
+        off, n, shape = self.req[idx]
+        return self.buf[off:off + n].view(shape)
+
+
+class Pack:
+    """Plain attribute bag for parameter / gradient packs."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class GradSlot:
+    """A lazily allocated gradient buffer that remembers whether it has been written
+    (first writer overwrites, later writers accumulate)."""
+    __slots__ = ('t', 'like', 'written')
+
+    def __init__(self, like):
+        self.like = like
+        self.t = None
+        self.written = False
+
+    def buf(self):
+        if self.t is None:
+            self.t = torch.empty_like(self.like)
+        return self.t
+
+    def acc_bit(self):
+        """Returns 1 if the kernel must accumulate, then marks the slot written."""
+        a = 1 if self.written else 0
+        self.written = True
+        return a
+
+    def get(self):
+        if self.t is None or not self.written:
+            return None
+        return self.t
+
+
+def _write_group(slots):
+    """(buffers, accumulate_mask) for a kernel writing slots[j] (None = skip).  The same slot
+    may appear several times only for kernels that document in-order read-modify-write
+    (mixsum_bwd); it is then overwritten by its first occurrence and accumulated after."""
+    bufs, mask = [], 0
+    for j, s in enumerate(slots):
+        if s is None:
+            bufs.append(None)
+            continue
+        bufs.append(s.buf())
+        if s.acc_bit():
+            mask |= (1 << j)
+    return bufs, mask
+
+
+# ---------------------------------------------------------------------------- K1 mixsum
+def mixsum_fwd(xs, w_row0, w_stride=2):
+    """out = sum_j w_j xs[j]; w_row0 = view whose data_ptr is edge 0's weight."""
+    out = torch.empty_like(xs[0])
+    lib.mixsum_fwd(xs, w_row0, w_stride, out)
+    return out
+
+
+def mixsum_bwd(xs, slots, w_row0, g, dw_row0, w_stride=2):
+    bufs, mask = _write_group(slots)
+    lib.mixsum_bwd(xs, bufs, w_row0, w_stride, g, dw_row0, mask)
+
+
+# -------------------------------------------------------------------- conv + BatchNorm
+class ConvBnSaved:
+    __slots__ = ('srcs', 'C_src', 'W', 'ldw', 'U', 'chan', 'M', 'training', 'dup')
+
+
+def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, dup=0):
+    """U = conv1x1(cat(srcs)) (+ batch statistics) and the fused BN affine `chan`.
+    W is (M, ldw) row-major with the first len(srcs)*C_src columns used."""
+    x0 = srcs[0]
+    b, L = x0.shape[0], x0.shape[2]
+    M = bn_w.numel()
+    U = _empty(x0, b, M, L)
+    part, n_part = None, 0
+    if training:
+        if b * L < 2:
+            raise ValueError('Expected more than 1 value per channel when training, got input size '
+                             f'{[b, M, L]}')            # same refusal as nn.BatchNorm1d
+        n_part = lib.conv1x1_num_partials(b, L)
+        part = _empty(x0, n_part * M * 2)
+    lib.conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M)
+    chan = _empty(x0, 4 * M)
+    lib.bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan)
+    sv = ConvBnSaved()
+    sv.srcs, sv.C_src, sv.W, sv.ldw, sv.U, sv.chan, sv.M = list(srcs), C_src, W, ldw, U, chan, M
+    sv.training, sv.dup = training, dup
+    return U, chan, sv
+
+
+def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias):
+    """dV (gradient w.r.t. the BN output, with bn_grad already reduced) -> in place dU;
+    then data gradient into src_slots and weight/bias gradient (+=) into dW / dbias."""
+    b, L = sv.U.shape[0], sv.U.shape[2]
+    lib.bn_bwd_apply(dV, sv.U, sv.chan, bn_grad, b, sv.M, L, sv.training)
+    # destinations that alias each other inside ONE data-gradient launch would race:
+    # give later duplicates a scratch buffer and add it afterwards (rare: node_multiplier
+    # reaching back to the duplicated x/y inputs).
+    seen, extra, slots = {}, [], []
+    for q, s in enumerate(src_slots):
+        if s is not None and id(s) in seen:
+            tmp = GradSlot(s.like)
+            extra.append((s, tmp))
+            slots.append(tmp)
+        else:
+            if s is not None:
+                seen[id(s)] = q
+            slots.append(s)
+    bufs, mask = _write_group(slots)
+    if any(x is not None for x in bufs):
+        lib.conv1x1_bwd_data(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M)
+    for s, tmp in extra:
+        s.buf().add_(tmp.buf())
+    if dW is not None:
+        lib.conv1x1_bwd_weight(dV, sv.srcs, sv.C_src, dW, dW.shape[1], dbias, sv.dup, b, L, sv.M)
+
+
+# -------------------------------------------------------------- search-mode NodeMixedOp
+class MixedSaved:
+    pass
+
+
+def node_mixed_fwd(x, y, gamma_row, P, training):
+    """NodeMixedOp.forward (node_operations.py:118-120).  P: parameter pack of one NodeMixedOp
+    (see models.search.darts.node_operations.NodeMixedOp.pack()).  x may be y (search)."""
+    b, C, L = x.shape
+    same = x is y or x.data_ptr() == y.data_ptr()
+    sv = MixedSaved()
+    sv.x, sv.y, sv.same, sv.gamma, sv.P, sv.training = x, y, same, gamma_row, P, training
+    # attention branch
+    sv.d_attn = DROP.make(P.attn_p, x.numel(), training)
+    p1 = torch.empty_like(x)
+    sv.stats1 = _empty(x, b * 2)
+    lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.stats1, b, C, L, sv.d_attn)
+    sv.p1 = p1
+    # stacked [LinearGLU | ConcatFC] conv + BN
+    if same:
+        Weff = _empty(x, 3 * C, C)
+        lib.fold_weight(P.stack_W, Weff, 3 * C, C)
+        U, chan, sv.conv = conv_bn_fwd([x], C, Weff, C, P.stack_bias, P.stack_bn_w, P.stack_bn_b,
+                                       P.stack_rm, P.stack_rv, P.stack_nbt, training, dup=C)
+    else:
+        U, chan, sv.conv = conv_bn_fwd([x, y], C, P.stack_W, 2 * C, P.stack_bias, P.stack_bn_w,
+                                       P.stack_bn_b, P.stack_rm, P.stack_rv, P.stack_nbt, training)
+    sv.d_glu = DROP.make(P.glu_p, x.numel(), training)
+    sv.d_fc = DROP.make(P.fc_p, x.numel(), training)
+    out = torch.empty_like(x)
+    lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc)
+    return out, sv
+
+
+def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G):
+    """g: grad of the mixed output.  dgamma_row (4 floats, +=), x_slot / y_slot: GradSlots
+    (y_slot None when x is y).  G: gradient pack (stack_dW, stack_dbias, stack_bn_grad,
+    dln_w, dln_b), all += ."""
+    x, y = sv.x, sv.y
+    b, C, L = x.shape
+    M = 3 * C
+    dV = _empty(x, b, M, L)
+    bn_grad = G.stack_bn_grad            # [dW_bn (3C) | dB_bn (3C)], zero-initialised by caller
+    if sv.same:
+        dxb, acc = x_slot.buf(), x_slot.acc_bit()
+        lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
+                         dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc)
+        conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias)
+        lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.stats1, dxb, None, 1, G.dln_w, G.dln_b,
+                        b, C, L, sv.d_attn)
+    else:
+        dxb, dyb = x_slot.buf(), y_slot.buf()
+        acc = x_slot.acc_bit() | (y_slot.acc_bit() << 1)
+        lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, dyb, acc,
+                         dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc)
+        conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot, y_slot], G.stack_dW, G.stack_dbias)
+        lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.stats1, dxb, dyb, 3, G.dln_w, G.dln_b,
+                        b, C, L, sv.d_attn)
+
+
+# ------------------------------------------------------------------- search-mode NodeCell
+class NodeCellSaved:
+    pass
+
+
+def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm):
+    """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
+    device tensors.  NP: parameter pack of the NodeCell."""
+    b, C, L = x.shape
+    sv = NodeCellSaved()
+    sv.x, sv.ns, sv.nm, sv.NP, sv.training = x, ns, nm, NP, training
+    sv.beta_w, sv.gamma_w = beta_w, gamma_w
+    states = [x, y]
+    sv.zs, sv.mixed, sv.offsets = [], [], []
+    offset = 0
+    for t in range(ns):
+        z = mixsum_fwd(states, beta_w[offset:, 1])
+        s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training)
+        sv.zs.append(z)
+        sv.mixed.append(msv)
+        sv.offsets.append(offset)
+        offset += len(states)
+        states.append(s)
+    sv.states = states
+    tail = states[-nm:]
+    if nm != 1:
+        Wo = NP.out_conv_w.view(C, nm * C)
+        V, chan, sv.oconv = conv_bn_fwd(tail, C, Wo, nm * C, NP.out_conv_b, NP.bn_w, NP.bn_b,
+                                        NP.bn_rm, NP.bn_rv, NP.bn_nbt, training)
+        sv.d_out = DROP.make(NP.out_p, x.numel(), training)
+        o = torch.empty_like(x)
+        lib.bn_relu_fwd(V, chan, o, b, C, L, sv.d_out)
+    else:
+        o = tail[0]
+    sv.o = o
+    out = torch.empty_like(x)
+    sv.stats = _empty(x, b * 2)
+    lib.cat_ln_fwd([o], x, NP.ln_w, NP.ln_b, out, sv.stats, b, C, L, False)
+    return out, sv
+
+
+def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG):
+    """g: grad of the node output.  x_slot / y_slot: GradSlots of the two inputs (the same
+    object in search mode).  dbeta_w / dgamma_w: zero-initialised (k_in,2)/(ns,4) buffers
+    receiving the gradients w.r.t. the SOFTMAXED weights.  NG: gradient pack."""
+    x = sv.x
+    b, C, L = x.shape
+    ns, nm, NP = sv.ns, sv.nm, sv.NP
+    slots = [x_slot, y_slot] + [GradSlot(x) for _ in range(ns)]
+    tail = list(range(2 + ns - nm, 2 + ns))
+    if nm != 1:
+        d_o = GradSlot(x)
+        bufs, mask = _write_group([d_o])
+        racc = x_slot.acc_bit()
+        lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
+                       mask | (racc << 31), NG.dln_w, NG.dln_b, b, C, L, False)
+        dV = _empty(x, b, C, L)
+        lib.bn_relu_bwd(d_o.buf(), sv.oconv.U, sv.oconv.chan, dV, NG.bn_grad, b, C, L, sv.d_out)
+        conv_bn_bwd(sv.oconv, dV, NG.bn_grad, [slots[j] for j in tail],
+                    NG.out_conv_dW.view(C, nm * C), NG.out_conv_db)
+    else:
+        bufs, mask = _write_group([slots[tail[0]]])
+        racc = x_slot.acc_bit()
+        lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
+                       mask | (racc << 31), NG.dln_w, NG.dln_b, b, C, L, False)
+    for t in reversed(range(ns)):
+        gs = slots[2 + t].get()
+        if gs is None:
+            continue                                    # this inner state feeds nothing
+        z_slot = GradSlot(x)
+        node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t])
+        off = sv.offsets[t]
+        n_in = 2 + t
+        mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.beta_w[off:, 1], z_slot.buf(),
+                   dbeta_w[off:, 1])
+
+
+# ------------------------------------------------------------------- search-mode FusionCell
+class CellSaved:
+    pass
+
+
+def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm):
+    """FusionCell.forward (model_search.py:50-68) with the step nodes in search mode
+    (FusionNode(x, x), model_search.py:59).  alpha_w (k, 2) softmaxed device tensor."""
+    N = len(xs)
+    b, C, L = xs[0].shape
+    sv = CellSaved()
+    sv.N, sv.S, sv.M, sv.CP, sv.alpha_w = N, S, M, CP, alpha_w
+    states = list(xs)
+    sv.sifs, sv.nodes, sv.offsets = [], [], []
+    offset = 0
+    for i in range(S):
+        sif = mixsum_fwd(states, alpha_w[offset:, 1])
+        out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm)
+        sv.sifs.append(sif)
+        sv.nodes.append(nsv)
+        sv.offsets.append(offset)
+        offset += len(states)
+        states.append(out)
+    sv.states = states
+    out = _empty(xs[0], b, M * C * L)
+    sv.stats = _empty(xs[0], b * 2)
+    lib.cat_ln_fwd(states[-M:], None, CP.ln_w, CP.ln_b, out, sv.stats, b, C, L, True)
+    return out, sv
+
+
+def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
+    """Returns the list of input gradients (None where not needed).  d*_w: zero-initialised
+    buffers for the gradients w.r.t. the softmaxed arch weights.  CG: gradient pack."""
+    N, S, M, CP = sv.N, sv.S, sv.M, sv.CP
+    x0 = sv.states[0]
+    b, C, L = x0.shape
+    slots = [GradSlot(x0) if (j >= N or need_input_grads[j]) else None for j in range(N + S)]
+    tail = slots[-M:]
+    bufs, mask = _write_group(tail)
+    lib.cat_ln_bwd(g, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, bufs, None, mask, CG.dln_w,
+                   CG.dln_b, b, C, L, True)
+    for i in reversed(range(S)):
+        gn = slots[N + i].get()
+        if gn is None:
+            continue
+        sif_slot = GradSlot(x0)
+        node_cell_bwd(sv.nodes[i], gn, sif_slot, sif_slot, dbeta_ws[i], dgamma_ws[i], CG.nodes[i])
+        off = sv.offsets[i]
+        n_in = N + i
+        mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
+                   dalpha_w[off:, 1])
+    return [s.get() if s is not None else None for s in slots[:N]]

@@ -1,0 +1,267 @@
+"""torch.autograd.Function wrappers over bmnas.cell / bmnas.lib.
+
+Every Function requires CUDA(HIP) fp32 tensors and the built shared library; there is no
+CPU or eager-PyTorch fallback on the product path (bmnas.lib raises if the .so is absent).
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import cell as K
+from . import lib
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f'bmnas: {what} needs tensors on a HIP device (got {t.device}); the fusion-cell '
+                           'hot path runs only on the gfx950 kernels — there is no CPU fallback')
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise TypeError(f'bmnas kernels are fp32 only (got {t.dtype})')
+    return t
+
+
+# ------------------------------------------------------------------- arch softmax
+class ArchSoftmaxFn(Function):
+    """softmax(logits, dim=-1) for the (rows, 2|4) architecture parameters
+    (model_search.py:95, node_search.py:102-103)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        _require_gpu(logits, 'arch softmax')
+        a = _c(_f32(logits))
+        w = torch.empty_like(a)
+        lib.arch_softmax_fwd(a, w, a.shape[0], a.shape[1])
+        ctx.save_for_backward(w)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        (w,) = ctx.saved_tensors
+        da = torch.empty_like(w)
+        lib.arch_softmax_bwd(w, _c(dw), da, w.shape[0], w.shape[1])
+        return da
+
+
+def arch_softmax(logits, device):
+    if logits.device != device:
+        logits = logits.to(device)        # reference keeps alphas on the CPU; tracked copy
+    return ArchSoftmaxFn.apply(logits)
+
+
+# --------------------------------------------------------------------------- K1
+class MixSumFn(Function):
+    """out = sum_j w[j] * xs[j]  (w: (n_in,) device tensor)."""
+
+    @staticmethod
+    def forward(ctx, w, *xs):
+        _require_gpu(xs[0], 'mixed-edge sum')
+        xs = [_c(_f32(x)) for x in xs]
+        w = _c(_f32(w))
+        out = torch.empty_like(xs[0])
+        lib.mixsum_fwd(xs, w, 1, out)
+        ctx.xs, ctx.w = xs, w
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, w = ctx.xs, ctx.w
+        g = _c(g)
+        need_w = ctx.needs_input_grad[0]
+        dw = torch.zeros_like(w) if need_w else None
+        dxs = [torch.empty_like(x) if ctx.needs_input_grad[1 + j] else None for j, x in enumerate(xs)]
+        lib.mixsum_bwd(xs, dxs, w, 1, g, dw, 0)
+        return (dw, *dxs)
+
+
+# ------------------------------------------------------------------------ K6 / K7
+class CatLnFn(Function):
+    """LayerNorm([n_src*C, L]) of cat(srcs, 1) (+ resid), optional ReLU; output (b, n_src*C, L)."""
+
+    @staticmethod
+    def forward(ctx, relu, ln_w, ln_b, resid, *srcs):
+        _require_gpu(srcs[0], 'concat + LayerNorm')
+        srcs = [_c(_f32(s)) for s in srcs]
+        resid = None if resid is None else _c(resid)
+        b, C, L = srcs[0].shape
+        n = len(srcs)
+        out = torch.empty((b, n * C, L), device=srcs[0].device, dtype=torch.float32)
+        stats = torch.empty(b * 2, device=srcs[0].device, dtype=torch.float32)
+        lw, lb = _c(ln_w), _c(ln_b)
+        lib.cat_ln_fwd(srcs, resid, lw, lb, out, stats, b, C, L, relu)
+        ctx.relu, ctx.srcs, ctx.resid, ctx.lw, ctx.lb, ctx.stats = relu, srcs, resid, lw, lb, stats
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        srcs, resid = ctx.srcs, ctx.resid
+        b, C, L = srcs[0].shape
+        g = _c(g)
+        dsrcs = [torch.empty_like(s) if ctx.needs_input_grad[4 + q] else None for q, s in enumerate(srcs)]
+        dres = torch.empty_like(resid) if (resid is not None and ctx.needs_input_grad[3]) else None
+        dw = torch.zeros_like(ctx.lw)
+        db = torch.zeros_like(ctx.lb)
+        lib.cat_ln_bwd(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dsrcs, dres, 0, dw, db, b, C, L, ctx.relu)
+        return (None, dw, db, dres, *dsrcs)
+
+
+# ----------------------------------------------------------------------------- K3
+class SdpaLnFn(Function):
+    """ScaledDotAttn.forward (node_operations.py:92-108)."""
+
+    @staticmethod
+    def forward(ctx, x, y, ln_w, ln_b, p, training):
+        _require_gpu(x, 'scaled-dot attention')
+        x, y = _c(_f32(x)), _c(_f32(y))
+        b, C, L = x.shape
+        out = torch.empty_like(x)
+        stats = torch.empty(b * 2, device=x.device, dtype=torch.float32)
+        drop = K.DROP.make(p, x.numel(), training)
+        lw, lb = _c(ln_w), _c(ln_b)
+        lib.sdpa_ln_fwd(x, y, lw, lb, out, stats, b, C, L, drop)
+        ctx.x, ctx.y, ctx.lw, ctx.stats, ctx.drop = x, y, lw, stats, drop
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.x, ctx.y
+        b, C, L = x.shape
+        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        dw, db = torch.zeros_like(ctx.lw), torch.zeros_like(ctx.lw)
+        lib.sdpa_ln_bwd(_c(g), None, x, y, ctx.lw, ctx.stats, dx, dy, 0, dw, db, b, C, L, ctx.drop)
+        return dx, dy, dw, db, None, None
+
+
+# ------------------------------------------------- conv1x1 + BN + {GLU | ReLU} + dropout
+class ConvBnActFn(Function):
+    """cat(srcs) -> Conv1d(k=1) -> BatchNorm1d -> glu(dim=1) | relu -> Dropout(p).
+    LinearGLU (node_operations.py:30-39), ConcatFC (:49-56), NodeCell out_conv
+    (node_search.py:59-64).  bn buffers are updated in place in training mode."""
+
+    @staticmethod
+    def forward(ctx, act, p, training, rm, rv, nbt, conv_w, conv_b, bn_w, bn_b, *srcs):
+        _require_gpu(srcs[0], 'conv1x1 + BatchNorm')
+        srcs = [_c(_f32(s)) for s in srcs]
+        b, C_src, L = srcs[0].shape
+        M = conv_w.shape[0]
+        K_in = len(srcs) * C_src
+        W = _c(conv_w).view(M, K_in)
+        U, chan, sv = K.conv_bn_fwd(srcs, C_src, W, K_in, _c(conv_b), _c(bn_w), _c(bn_b), rm, rv, nbt,
+                                    training)
+        if act == 'glu':
+            Cout = M // 2
+            out = torch.empty((b, Cout, L), device=U.device, dtype=torch.float32)
+            drop = K.DROP.make(p, out.numel(), training)
+            lib.bn_glu_fwd(U, chan, out, b, Cout, L, drop)
+        else:
+            out = torch.empty((b, M, L), device=U.device, dtype=torch.float32)
+            drop = K.DROP.make(p, out.numel(), training)
+            lib.bn_relu_fwd(U, chan, out, b, M, L, drop)
+        ctx.act, ctx.sv, ctx.drop, ctx.wshape = act, sv, drop, tuple(conv_w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sv, act = ctx.sv, ctx.act
+        U = sv.U
+        b, M, L = U.shape
+        g = _c(g)
+        dV = torch.empty_like(U)
+        bn_grad = torch.zeros(2 * M, device=U.device, dtype=torch.float32)
+        if act == 'glu':
+            lib.bn_glu_bwd(g, U, sv.chan, dV, bn_grad, b, M // 2, L, ctx.drop)
+        else:
+            lib.bn_relu_bwd(g, U, sv.chan, dV, bn_grad, b, M, L, ctx.drop)
+        slots = [K.GradSlot(s) if ctx.needs_input_grad[10 + q] else None for q, s in enumerate(sv.srcs)]
+        dW = torch.zeros((M, sv.ldw), device=U.device, dtype=torch.float32)
+        dbias = torch.zeros(M, device=U.device, dtype=torch.float32)
+        K.conv_bn_bwd(sv, dV, bn_grad, slots, dW, dbias)
+        dsrcs = [s.get() if s is not None else None for s in slots]
+        return (None, None, None, None, None, None, dW.view(ctx.wshape), dbias, bn_grad[:M], bn_grad[M:],
+                *dsrcs)
+
+
+# ---------------------------------------------------------------- search NodeMixedOp
+class NodeMixedFn(Function):
+    """NodeMixedOp.forward(x, y, weights) (node_operations.py:118-120) as one fused
+    sequence (attention+LN, stacked conv GEMM + BN statistics, gamma-mix)."""
+
+    @staticmethod
+    def forward(ctx, op, training, x, y, gamma_row, *params):
+        _require_gpu(x, 'NodeMixedOp')
+        same = x is y
+        x = _c(_f32(x))
+        y = x if same else _c(_f32(y))
+        P = op.pack()
+        out, sv = K.node_mixed_fwd(x, y, _c(gamma_row), P, training)
+        ctx.op, ctx.sv = op, sv
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sv, op = ctx.sv, ctx.op
+        x = sv.x
+        G = op.grad_pack(x.device)
+        dgamma = torch.zeros(4, device=x.device, dtype=torch.float32)
+        xs = K.GradSlot(x)
+        ys = None if sv.same else K.GradSlot(sv.y)
+        K.node_mixed_bwd(sv, _c(g), dgamma, xs, ys, G)
+        dx = xs.get()
+        if sv.same:
+            # x and y are the same tensor object: autograd adds both returned halves
+            dx_half, dy = dx, torch.zeros_like(dx)
+        else:
+            dx_half, dy = dx, ys.get()
+        return (None, None, dx_half, dy, dgamma, *op.grads_in_param_order(G))
+
+
+# -------------------------------------------------------------------- fused FusionCell
+class FusedCellFn(Function):
+    """FusionCell.forward in search mode (model_search.py:50-68 with FusionNode(x, x)):
+    the whole cell — mixed edges, step nodes, LayerNorm tail — as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, cell, training, alpha_w, *tensors):
+        N, S = cell.num_input_nodes, cell._steps
+        xs = [_c(_f32(t)) for t in tensors[:N]]
+        _require_gpu(xs[0], 'FusionCell')
+        arch = tensors[N:N + 2 * S]
+        dev = xs[0].device
+        beta_ws, gamma_ws = [], []
+        for i in range(S):
+            bt, gm = _c(arch[2 * i]), _c(arch[2 * i + 1])
+            bw, gw = torch.empty_like(bt), torch.empty_like(gm)
+            lib.arch_softmax_fwd(bt, bw, bt.shape[0], bt.shape[1])
+            lib.arch_softmax_fwd(gm, gw, gm.shape[0], gm.shape[1])
+            beta_ws.append(bw)
+            gamma_ws.append(gw)
+        CP = cell.pack()
+        out, sv = K.fusion_cell_fwd(xs, _c(alpha_w), beta_ws, gamma_ws, CP, training, S,
+                                    cell._multiplier, cell.args.node_steps, cell.args.node_multiplier)
+        ctx.cell, ctx.sv, ctx.beta_ws, ctx.gamma_ws, ctx.N, ctx.S = cell, sv, beta_ws, gamma_ws, N, S
+        ctx.dev = dev
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cell, sv, N, S = ctx.cell, ctx.sv, ctx.N, ctx.S
+        dev = ctx.dev
+        need_in = [ctx.needs_input_grad[3 + j] for j in range(N)]
+        # one zero-filled arena for every gradient that is accumulated with atomics
+        CG, dalpha_w, dbeta_ws, dgamma_ws = cell.grad_pack(dev, sv.alpha_w, ctx.beta_ws, ctx.gamma_ws)
+        dxs = K.fusion_cell_bwd(sv, _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws, CG)
+        darch = []
+        for i in range(S):
+            bw, gw = ctx.beta_ws[i], ctx.gamma_ws[i]
+            db, dg = torch.empty_like(bw), torch.empty_like(gw)
+            lib.arch_softmax_bwd(bw, dbeta_ws[i], db, bw.shape[0], bw.shape[1])
+            lib.arch_softmax_bwd(gw, dgamma_ws[i], dg, gw.shape[0], gw.shape[1])
+            darch += [db, dg]
+        return (None, None, dalpha_w, *dxs, *darch, *cell.grads_in_param_order(CG))

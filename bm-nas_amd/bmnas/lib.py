@@ -1,0 +1,238 @@
+"""ctypes binding of libbmnas_hip.so (C ABI: include/bmnas_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is
+absent, importing/using this module raises.  Every wrapper takes torch CUDA(HIP) fp32
+contiguous tensors, passes raw device pointers + the current torch stream, and turns a
+non-zero return code into an exception.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libbmnas_hip.so')
+MAX_PTRS = 16
+
+
+class BmnasError(RuntimeError):
+    pass
+
+
+class Dropout(C.Structure):
+    """bmnas_dropout_t"""
+    _fields_ = [('thr', C.c_uint32), ('scale', C.c_float), ('seed', C.c_uint64),
+                ('offset', C.c_uint64)]
+
+
+NO_DROP = Dropout(0, 1.0, 0, 0)
+
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_I = C.c_int
+_I64 = C.c_int64
+_U32 = C.c_uint32
+
+SIGNATURES = {
+    'bmnas_version': ([], _I),
+    'bmnas_mixsum_fwd': ([_PP, _I, _P, _I, _P, _I64, _P], _I),
+    'bmnas_mixsum_bwd': ([_PP, _PP, _I, _P, _I, _P, _P, _U32, _I64, _P], _I),
+    'bmnas_cat_ln_fwd': ([_PP, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_cat_ln_bwd': ([_P, _PP, _I, _P, _P, _P, _P, _PP, _P, _U32, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_sdpa_ln_fwd': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_sdpa_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_conv1x1_num_partials': ([_I, _I], _I),
+    'bmnas_conv1x1_fwd': ([_PP, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P], _I),
+    'bmnas_conv1x1_bwd_data': ([_P, _P, _I, _PP, _I, _I, _U32, _I, _I, _I, _P], _I),
+    'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
+    'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
+    'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
+    'bmnas_node_mix_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _I, _I, _I,
+                            Dropout, Dropout, _P], _I),
+    'bmnas_bn_glu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_bn_glu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_bn_relu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_bn_relu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_bn_bwd_apply': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
+    'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises BmnasError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BmnasError(f'{LIB_PATH} is missing: build it with `python -m bmnas.build` '
+                         '(hipcc --offload-arch=gfx950); there is no fallback path')
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        kind = {-1: 'bad argument', -2: 'unsupported shape', -3: 'limit exceeded'}.get(rc, f'hipError {rc}')
+        raise BmnasError(f'{name} failed: {kind} (rc={rc})')
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
+        (t.device, t.dtype, t.is_contiguous())
+    return t.data_ptr()
+
+
+def _ptrs(ts):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = _ptr(t)
+    return arr
+
+
+def version():
+    return load().bmnas_version()
+
+
+def make_dropout(p, seed, offset):
+    """thr = p * 2^32; p == 0 (or eval) -> NO_DROP."""
+    if p <= 0.0:
+        return NO_DROP
+    if p >= 1.0:
+        raise ValueError('dropout p must be < 1')
+    thr = int(p * 4294967296.0)
+    if thr <= 0:
+        return NO_DROP
+    return Dropout(min(thr, 0xFFFFFFFF), 1.0 / (1.0 - p), seed & 0xFFFFFFFFFFFFFFFF,
+                   offset & 0xFFFFFFFFFFFFFFFF)
+
+
+# ------------------------------------------------------------------------- wrappers
+def mixsum_fwd(xs, w, w_stride, out):
+    """w: tensor whose data_ptr() is the weight of edge 0; edge j at +j*w_stride floats."""
+    _check(load().bmnas_mixsum_fwd(_ptrs(xs), len(xs), w.data_ptr(), w_stride, _ptr(out),
+                                   out.numel(), _stream()), 'mixsum_fwd')
+
+
+def mixsum_bwd(xs, dxs, w, w_stride, g, dw, acc_mask):
+    _check(load().bmnas_mixsum_bwd(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, _ptr(g),
+                                   None if dw is None else dw.data_ptr(), acc_mask, g.numel(),
+                                   _stream()), 'mixsum_bwd')
+
+
+def cat_ln_fwd(srcs, resid, ln_w, ln_b, out, stats, b, Cc, L, relu):
+    _check(load().bmnas_cat_ln_fwd(_ptrs(srcs), len(srcs), _ptr(resid), _ptr(ln_w), _ptr(ln_b),
+                                   _ptr(out), _ptr(stats), b, Cc, L, int(relu), _stream()), 'cat_ln_fwd')
+
+
+def cat_ln_bwd(g, srcs, resid, ln_w, ln_b, stats, dsrcs, dresid, acc_mask, dln_w, dln_b, b, Cc, L, relu):
+    _check(load().bmnas_cat_ln_bwd(_ptr(g), _ptrs(srcs), len(srcs), _ptr(resid), _ptr(ln_w), _ptr(ln_b),
+                                   _ptr(stats), _ptrs(dsrcs), _ptr(dresid), acc_mask, _ptr(dln_w),
+                                   _ptr(dln_b), b, Cc, L, int(relu), _stream()), 'cat_ln_bwd')
+
+
+def sdpa_ln_fwd(x, y, ln_w, ln_b, out, stats, b, Cc, L, drop):
+    _check(load().bmnas_sdpa_ln_fwd(_ptr(x), _ptr(y), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(stats),
+                                    b, Cc, L, drop, _stream()), 'sdpa_ln_fwd')
+
+
+def sdpa_ln_bwd(g, gscale, x, y, ln_w, stats, dx, dy, acc_mask, dln_w, dln_b, b, Cc, L, drop):
+    _check(load().bmnas_sdpa_ln_bwd(_ptr(g), None if gscale is None else gscale.data_ptr(), _ptr(x),
+                                    _ptr(y), _ptr(ln_w), _ptr(stats), _ptr(dx), _ptr(dy), acc_mask,
+                                    _ptr(dln_w), _ptr(dln_b), b, Cc, L, drop, _stream()), 'sdpa_ln_bwd')
+
+
+def conv1x1_num_partials(b, L):
+    n = load().bmnas_conv1x1_num_partials(b, L)
+    if n < 0:
+        _check(n, 'conv1x1_num_partials')
+    return n
+
+
+def conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M):
+    _check(load().bmnas_conv1x1_fwd(_ptrs(srcs), len(srcs), C_src, W.data_ptr(), ldw, _ptr(bias),
+                                    _ptr(U), _ptr(part), b, L, M, _stream()), 'conv1x1_fwd')
+
+
+def conv1x1_bwd_data(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M):
+    _check(load().bmnas_conv1x1_bwd_data(_ptr(dU), W.data_ptr(), ldw, _ptrs(dsrcs), len(dsrcs), C_src,
+                                         acc_mask, b, L, M, _stream()), 'conv1x1_bwd_data')
+
+
+def conv1x1_bwd_weight(dU, srcs, C_src, dW, ldw, dbias, dup_cols, b, L, M):
+    _check(load().bmnas_conv1x1_bwd_weight(_ptr(dU), _ptrs(srcs), len(srcs), C_src, dW.data_ptr(), ldw,
+                                           None if dbias is None else dbias.data_ptr(), dup_cols, b, L,
+                                           M, _stream()), 'conv1x1_bwd_weight')
+
+
+def fold_weight(W, Weff, M, Cc):
+    _check(load().bmnas_fold_weight(W.data_ptr(), _ptr(Weff), M, Cc, _stream()), 'fold_weight')
+
+
+def bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan):
+    """nbt: int64 tensor of 1..k consecutive counters (or None)."""
+    _check(load().bmnas_bn_finalize(_ptr(part), n_part, b, L, M, bn_w.data_ptr(), bn_b.data_ptr(),
+                                    None if rm is None else rm.data_ptr(),
+                                    None if rv is None else rv.data_ptr(),
+                                    None if nbt is None else nbt.data_ptr(),
+                                    0 if nbt is None else nbt.numel(), int(training),
+                                    chan.data_ptr(), _stream()), 'bn_finalize')
+
+
+def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc):
+    _check(load().bmnas_node_mix_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), gamma.data_ptr(),
+                                     _ptr(out), b, Cc, L, dglu, dfc, _stream()), 'node_mix_fwd')
+
+
+def node_mix_bwd(g, x, y, p1, U, chan, gamma, dgamma, dx, dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc):
+    _check(load().bmnas_node_mix_bwd(_ptr(g), _ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan),
+                                     gamma.data_ptr(), None if dgamma is None else dgamma.data_ptr(),
+                                     _ptr(dx), _ptr(dy), acc_mask, _ptr(dV), _ptr(bn_grad), b, Cc, L,
+                                     dglu, dfc, _stream()), 'node_mix_bwd')
+
+
+def bn_glu_fwd(U, chan, out, b, Cc, L, drop):
+    _check(load().bmnas_bn_glu_fwd(_ptr(U), _ptr(chan), _ptr(out), b, Cc, L, drop, _stream()), 'bn_glu_fwd')
+
+
+def bn_glu_bwd(g, U, chan, dV, bn_grad, b, Cc, L, drop):
+    _check(load().bmnas_bn_glu_bwd(_ptr(g), _ptr(U), _ptr(chan), _ptr(dV), _ptr(bn_grad), b, Cc, L, drop,
+                                   _stream()), 'bn_glu_bwd')
+
+
+def bn_relu_fwd(U, chan, out, b, M, L, drop):
+    _check(load().bmnas_bn_relu_fwd(_ptr(U), _ptr(chan), _ptr(out), b, M, L, drop, _stream()), 'bn_relu_fwd')
+
+
+def bn_relu_bwd(g, U, chan, dV, bn_grad, b, M, L, drop):
+    _check(load().bmnas_bn_relu_bwd(_ptr(g), _ptr(U), _ptr(chan), _ptr(dV), _ptr(bn_grad), b, M, L, drop,
+                                    _stream()), 'bn_relu_bwd')
+
+
+def bn_bwd_apply(dV, U, chan, bn_grad, b, M, L, training):
+    _check(load().bmnas_bn_bwd_apply(_ptr(dV), _ptr(U), _ptr(chan), _ptr(bn_grad), b, M, L,
+                                     int(training), _stream()), 'bn_bwd_apply')
+
+
+def arch_softmax_fwd(logits, w, rows, cols):
+    _check(load().bmnas_arch_softmax_fwd(logits.data_ptr(), w.data_ptr(), rows, cols, _stream()),
+           'arch_softmax_fwd')
+
+
+def arch_softmax_bwd(w, dw, dlogits, rows, cols):
+    _check(load().bmnas_arch_softmax_bwd(w.data_ptr(), dw.data_ptr(), dlogits.data_ptr(), rows, cols,
+                                         _stream()), 'arch_softmax_bwd')

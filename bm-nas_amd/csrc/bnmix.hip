@@ -1,0 +1,523 @@
+// BatchNorm bookkeeping + the elementwise halves of K2/K4/K5: BN-apply + GLU / ReLU +
+// dropout + gamma-weighted NodeMixedOp combine, and their backward (phase A: activation
+// backward + per-channel batch reductions; phase B: BatchNorm input gradient).
+// All HBM-streaming float4 kernels.  In the backward a thread owns one (channel, l4) slot
+// and walks a chunk of samples, so the per-channel sums stay in registers and cost one
+// atomic per channel per workgroup.
+#include "common.hpp"
+#include "../../include/bmnas_hip.h"
+
+namespace {
+
+constexpr float kEps = 1e-5f;
+constexpr float kMomentum = 0.1f;
+
+__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ part, int n_part,
+                                                     int b, int L, int M,
+                                                     const float* __restrict__ bn_w,
+                                                     const float* __restrict__ bn_b,
+                                                     float* running_mean, float* running_var,
+                                                     int64_t* nbt, int n_nbt, int training,
+                                                     float* __restrict__ chan) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float mean, rstd;
+  if (training) {
+    const int N = b * L;
+    float tot = 0.f;
+    for (int p = 0; p < n_part; ++p) tot += part[((int64_t)p * M + m) * 2];
+    mean = tot / (float)N;
+    float m2 = 0.f;
+    for (int p = 0; p < n_part; ++p) {
+      int cnt = N - 32 * p;
+      cnt = cnt > 32 ? 32 : cnt;
+      const float sp = part[((int64_t)p * M + m) * 2];
+      const float d = sp / (float)cnt - mean;
+      m2 += part[((int64_t)p * M + m) * 2 + 1] + (float)cnt * d * d;
+    }
+    const float var = m2 / (float)N;
+    rstd = 1.f / sqrtf(var + kEps);
+    if (running_mean != nullptr) {
+      running_mean[m] = (1.f - kMomentum) * running_mean[m] + kMomentum * mean;
+      const float unbiased = m2 / (float)(N - 1);
+      running_var[m] = (1.f - kMomentum) * running_var[m] + kMomentum * unbiased;
+    }
+    if (m < n_nbt && nbt != nullptr) nbt[m] += 1;
+  } else {
+    mean = running_mean[m];
+    rstd = 1.f / sqrtf(running_var[m] + kEps);
+  }
+  const float scale = bn_w[m] * rstd;
+  chan[m] = mean;
+  chan[M + m] = rstd;
+  chan[2 * M + m] = scale;
+  chan[3 * M + m] = bn_b[m] - mean * scale;
+}
+
+__device__ __forceinline__ float4 affine4(float4 u, float sc, float sh) {
+  return make_float4(fmaf(u.x, sc, sh), fmaf(u.y, sc, sh), fmaf(u.z, sc, sh), fmaf(u.w, sc, sh));
+}
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// s = g0*(x+y) + g1*p1 + g2*drop(va*sigmoid(vg)) + g3*drop(relu(vf))
+__global__ __launch_bounds__(256) void node_mix_fwd_k(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ p1,
+    const float* __restrict__ U, const float* __restrict__ chan, const float* __restrict__ gamma,
+    float* __restrict__ out, int b, int C, int L, DropCfg dglu, DropCfg dfc) {
+  const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
+  const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
+  const int64_t total = (int64_t)b * cl4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int s = (int)(i / cl4);
+    const int r = (int)(i - (int64_t)s * cl4);
+    const int c = r / l4n;
+    const int64_t e = i * 4;
+    const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;      // (s, c, l) inside U's first C block
+    const float4 va = affine4(ld4(U + ub), chan[2 * M + c], chan[3 * M + c]);
+    const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), chan[2 * M + C + c], chan[3 * M + C + c]);
+    const float4 vf = affine4(ld4(U + ub + (int64_t)2 * C * L), chan[2 * M + 2 * C + c], chan[3 * M + 2 * C + c]);
+    const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
+    const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e);
+    float4 o;
+    o.x = g0 * (xv.x + yv.x) + g1 * pv.x + g2 * (va.x * sigmoidf(vg.x) * m2.x) + g3 * (fmaxf(vf.x, 0.f) * m3.x);
+    o.y = g0 * (xv.y + yv.y) + g1 * pv.y + g2 * (va.y * sigmoidf(vg.y) * m2.y) + g3 * (fmaxf(vf.y, 0.f) * m3.y);
+    o.z = g0 * (xv.z + yv.z) + g1 * pv.z + g2 * (va.z * sigmoidf(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
+    o.w = g0 * (xv.w + yv.w) + g1 * pv.w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
+    st4(out + e, o);
+  }
+}
+
+// reduce v over the l4n adjacent lanes that share a channel row (l4n in {1, 2, 4})
+__device__ __forceinline__ float row_sum(float v, int l4n) {
+  if (l4n >= 2) v += __shfl_xor(v, 1, 64);
+  if (l4n >= 4) v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void node_mix_bwd_k(
+    const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ y,
+    const float* __restrict__ p1, const float* __restrict__ U, const float* __restrict__ chan,
+    const float* __restrict__ gamma, float* dgamma, float* dx, float* dy, uint32_t acc_mask,
+    float* __restrict__ dV, float* bn_grad, int b, int C, int L, int chunk, DropCfg dglu,
+    DropCfg dfc) {
+  __shared__ float red[4];
+  const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
+  const int r = blockIdx.x * 256 + threadIdx.x;      // float4 slot inside one sample's (C, L) tile
+  const bool active = r < cl4;
+  const int c = active ? r / l4n : 0;
+  const float g0 = gamma[0], g2 = gamma[2], g3 = gamma[3];
+  float sc[3], sh[3], mu[3], rs[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    mu[k] = chan[k * C + c];
+    rs[k] = chan[M + k * C + c];
+    sc[k] = chan[2 * M + k * C + c];
+    sh[k] = chan[3 * M + k * C + c];
+  }
+  float dgam[4] = {0.f, 0.f, 0.f, 0.f};
+  float sw[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+  const int s_beg = blockIdx.y * chunk;
+  int s_end = s_beg + chunk;
+  if (s_end > b) s_end = b;
+  if (active) {
+    for (int s = s_beg; s < s_end; ++s) {
+      const int64_t e = ((int64_t)s * cl4 + r) * 4;
+      const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
+      const float4 ua = ld4(U + ub), ug = ld4(U + ub + (int64_t)C * L), uf = ld4(U + ub + (int64_t)2 * C * L);
+      const float4 gv = ld4(g + e), xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e);
+      const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
+      const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+      const float uaq[4] = {ua.x, ua.y, ua.z, ua.w}, ugq[4] = {ug.x, ug.y, ug.z, ug.w},
+                  ufq[4] = {uf.x, uf.y, uf.z, uf.w};
+      const float xq[4] = {xv.x + yv.x, xv.y + yv.y, xv.z + yv.z, xv.w + yv.w};
+      const float pq[4] = {pv.x, pv.y, pv.z, pv.w};
+      const float m2q[4] = {m2.x, m2.y, m2.z, m2.w}, m3q[4] = {m3.x, m3.y, m3.z, m3.w};
+      float da[4], dg[4], df[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float va = fmaf(uaq[t], sc[0], sh[0]), vg = fmaf(ugq[t], sc[1], sh[1]),
+                    vf = fmaf(ufq[t], sc[2], sh[2]);
+        const float sg = sigmoidf(vg);
+        dgam[0] += gq[t] * xq[t];
+        dgam[1] += gq[t] * pq[t];
+        dgam[2] += gq[t] * (va * sg * m2q[t]);
+        dgam[3] += gq[t] * (fmaxf(vf, 0.f) * m3q[t]);
+        const float gm2 = g2 * gq[t] * m2q[t];
+        da[t] = gm2 * sg;
+        dg[t] = gm2 * va * sg * (1.f - sg);
+        df[t] = (vf > 0.f) ? g3 * gq[t] * m3q[t] : 0.f;
+        sw[0] += da[t] * (uaq[t] - mu[0]) * rs[0];
+        sw[1] += dg[t] * (ugq[t] - mu[1]) * rs[1];
+        sw[2] += df[t] * (ufq[t] - mu[2]) * rs[2];
+        sb[0] += da[t]; sb[1] += dg[t]; sb[2] += df[t];
+      }
+      st4(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
+      st4(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
+      st4(dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
+      const float4 d0 = f4_scale(gv, g0);
+      if (dx != nullptr) {
+        float4 v = (dy == nullptr) ? f4_scale(d0, 2.f) : d0;
+        if (acc_mask & 1u) v = f4_add(v, ld4(dx + e));
+        st4(dx + e, v);
+      }
+      if (dy != nullptr) {
+        float4 v = d0;
+        if (acc_mask & 2u) v = f4_add(v, ld4(dy + e));
+        st4(dy + e, v);
+      }
+    }
+  }
+  // per-channel batch sums -> BatchNorm affine gradients
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float w = row_sum(sw[k], l4n), bb = row_sum(sb[k], l4n);
+    if (active && (r % l4n) == 0) {
+      atomicAdd(bn_grad + k * C + c, w);
+      atomicAdd(bn_grad + M + k * C + c, bb);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float t = block_sum256(dgam[q], red);
+    if (threadIdx.x == 0 && dgamma != nullptr) atomicAdd(dgamma + q, t);
+  }
+}
+
+
+// standalone LinearGLU tail: out = drop(va * sigmoid(vg)), U is (b, 2C, L) = [a | gate]
+__global__ __launch_bounds__(256) void bn_glu_fwd_k(const float* __restrict__ U,
+                                                    const float* __restrict__ chan,
+                                                    float* __restrict__ out, int b, int C, int L,
+                                                    DropCfg d) {
+  const int cl4 = C * L / 4, l4n = L / 4, M = 2 * C;
+  const int64_t total = (int64_t)b * cl4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int s = (int)(i / cl4);
+    const int r = (int)(i - (int64_t)s * cl4);
+    const int c = r / l4n;
+    const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
+    const float4 va = affine4(ld4(U + ub), chan[2 * M + c], chan[3 * M + c]);
+    const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), chan[2 * M + C + c], chan[3 * M + C + c]);
+    const float4 m = drop_mult4(d, (uint64_t)(i * 4));
+    st4(out + i * 4, make_float4(va.x * sigmoidf(vg.x) * m.x, va.y * sigmoidf(vg.y) * m.y,
+                                  va.z * sigmoidf(vg.z) * m.z, va.w * sigmoidf(vg.w) * m.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
+                                                    const float* __restrict__ U,
+                                                    const float* __restrict__ chan,
+                                                    float* __restrict__ dV, float* bn_grad, int b,
+                                                    int C, int L, int chunk, DropCfg d) {
+  const int cl4 = C * L / 4, l4n = L / 4, M = 2 * C;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const bool active = r < cl4;
+  const int c = active ? r / l4n : 0;
+  float sc[2], sh[2], mu[2], rs[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    mu[k] = chan[k * C + c];
+    rs[k] = chan[M + k * C + c];
+    sc[k] = chan[2 * M + k * C + c];
+    sh[k] = chan[3 * M + k * C + c];
+  }
+  float sw[2] = {0.f, 0.f}, sb[2] = {0.f, 0.f};
+  const int s_beg = blockIdx.y * chunk;
+  int s_end = s_beg + chunk;
+  if (s_end > b) s_end = b;
+  if (active) {
+    for (int s = s_beg; s < s_end; ++s) {
+      const int64_t e = ((int64_t)s * cl4 + r) * 4;
+      const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
+      const float4 ua = ld4(U + ub), ug = ld4(U + ub + (int64_t)C * L), gv = ld4(g + e);
+      const float4 m = drop_mult4(d, (uint64_t)e);
+      const float uaq[4] = {ua.x, ua.y, ua.z, ua.w}, ugq[4] = {ug.x, ug.y, ug.z, ug.w},
+                  gq[4] = {gv.x, gv.y, gv.z, gv.w}, mq[4] = {m.x, m.y, m.z, m.w};
+      float da[4], dg[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float va = fmaf(uaq[t], sc[0], sh[0]), vg = fmaf(ugq[t], sc[1], sh[1]);
+        const float sg = sigmoidf(vg);
+        const float gm = gq[t] * mq[t];
+        da[t] = gm * sg;
+        dg[t] = gm * va * sg * (1.f - sg);
+        sw[0] += da[t] * (uaq[t] - mu[0]) * rs[0];
+        sw[1] += dg[t] * (ugq[t] - mu[1]) * rs[1];
+        sb[0] += da[t]; sb[1] += dg[t];
+      }
+      st4(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
+      st4(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float w = row_sum(sw[k], l4n), bb = row_sum(sb[k], l4n);
+    if (active && (r % l4n) == 0) {
+      atomicAdd(bn_grad + k * C + c, w);
+      atomicAdd(bn_grad + M + k * C + c, bb);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_fwd_k(const float* __restrict__ U,
+                                                     const float* __restrict__ chan,
+                                                     float* __restrict__ out, int b, int M, int L,
+                                                     DropCfg d) {
+  const int ml4 = M * L / 4, l4n = L / 4;
+  const int64_t total = (int64_t)b * ml4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i % ml4);
+    const int c = r / l4n;
+    const float4 v = affine4(ld4(U + i * 4), chan[2 * M + c], chan[3 * M + c]);
+    const float4 m = drop_mult4(d, (uint64_t)(i * 4));
+    st4(out + i * 4, make_float4(fmaxf(v.x, 0.f) * m.x, fmaxf(v.y, 0.f) * m.y,
+                                  fmaxf(v.z, 0.f) * m.z, fmaxf(v.w, 0.f) * m.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g,
+                                                     const float* __restrict__ U,
+                                                     const float* __restrict__ chan,
+                                                     float* __restrict__ dV, float* bn_grad, int b,
+                                                     int M, int L, int chunk, DropCfg d) {
+  const int ml4 = M * L / 4, l4n = L / 4;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const bool active = r < ml4;
+  const int c = active ? r / l4n : 0;
+  const float mu = chan[c], rs = chan[M + c], sc = chan[2 * M + c], sh = chan[3 * M + c];
+  float sw = 0.f, sb = 0.f;
+  const int s_beg = blockIdx.y * chunk;
+  int s_end = s_beg + chunk;
+  if (s_end > b) s_end = b;
+  if (active) {
+    for (int s = s_beg; s < s_end; ++s) {
+      const int64_t e = ((int64_t)s * ml4 + r) * 4;
+      const float4 u = ld4(U + e), gv = ld4(g + e);
+      const float4 m = drop_mult4(d, (uint64_t)e);
+      const float uq[4] = {u.x, u.y, u.z, u.w}, gq[4] = {gv.x, gv.y, gv.z, gv.w},
+                  mq[4] = {m.x, m.y, m.z, m.w};
+      float dv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float v = fmaf(uq[t], sc, sh);
+        dv[t] = (v > 0.f) ? gq[t] * mq[t] : 0.f;
+        sw += dv[t] * (uq[t] - mu) * rs;
+        sb += dv[t];
+      }
+      st4(dV + e, make_float4(dv[0], dv[1], dv[2], dv[3]));
+    }
+  }
+  const float w = row_sum(sw, l4n), bb = row_sum(sb, l4n);
+  if (active && (r % l4n) == 0) {
+    atomicAdd(bn_grad + c, w);
+    atomicAdd(bn_grad + M + c, bb);
+  }
+}
+
+// dU = scale * (dV - db/N - u_hat * dw/N)   (training);  dU = scale * dV  (eval)
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(float* __restrict__ dV,
+                                                      const float* __restrict__ U,
+                                                      const float* __restrict__ chan,
+                                                      const float* __restrict__ bn_grad, int b,
+                                                      int M, int L, int training) {
+  const int ml4 = M * L / 4, l4n = L / 4;
+  const int64_t total = (int64_t)b * ml4;
+  const float invN = 1.f / (float)(b * L);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i % ml4);
+    const int c = r / l4n;
+    const float sc = chan[2 * M + c];
+    float4 d = ld4(dV + i * 4);
+    if (training) {
+      const float mu = chan[c], rs = chan[M + c];
+      const float kw = bn_grad[c] * invN, kb = bn_grad[M + c] * invN;
+      const float4 u = ld4(U + i * 4);
+      d.x = sc * (d.x - kb - (u.x - mu) * rs * kw);
+      d.y = sc * (d.y - kb - (u.y - mu) * rs * kw);
+      d.z = sc * (d.z - kb - (u.z - mu) * rs * kw);
+      d.w = sc * (d.w - kb - (u.w - mu) * rs * kw);
+    } else {
+      d = f4_scale(d, sc);
+    }
+    st4(dV + i * 4, d);
+  }
+}
+
+__global__ void arch_softmax_fwd_k(const float* __restrict__ a, float* __restrict__ w, int rows,
+                                   int cols) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float mx = a[r * cols];
+  for (int p = 1; p < cols; ++p) mx = fmaxf(mx, a[r * cols + p]);
+  float den = 0.f;
+  for (int p = 0; p < cols; ++p) den += expf(a[r * cols + p] - mx);
+  for (int p = 0; p < cols; ++p) w[r * cols + p] = expf(a[r * cols + p] - mx) / den;
+}
+
+__global__ void arch_softmax_bwd_k(const float* __restrict__ w, const float* __restrict__ dw,
+                                   float* __restrict__ da, int rows, int cols) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float dot = 0.f;
+  for (int p = 0; p < cols; ++p) dot += w[r * cols + p] * dw[r * cols + p];
+  for (int p = 0; p < cols; ++p) da[r * cols + p] = w[r * cols + p] * (dw[r * cols + p] - dot);
+}
+
+inline int stream_grid(int64_t total) {
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+inline DropCfg to_cfg(const bmnas_dropout_t& d) {
+  DropCfg c;
+  c.thr = d.thr; c.scale = d.scale; c.seed = d.seed; c.offset = d.offset;
+  return c;
+}
+
+// samples walked per workgroup in the backward reductions: keep >= ~512 workgroups
+inline int pick_chunk(int b, int slots4) {
+  const int xblocks = (slots4 + 255) / 256;
+  int chunk = (b * xblocks + 511) / 512;
+  if (chunk < 1) chunk = 1;
+  if (chunk > 16) chunk = 16;
+  return chunk;
+}
+
+}  // namespace
+
+extern "C" int bmnas_version(void) { return 100; }
+
+extern "C" int bmnas_bn_finalize(const float* part, int n_part, int b, int L, int M,
+                                 const float* bn_w, const float* bn_b, float* running_mean,
+                                 float* running_var, int64_t* num_batches_tracked, int n_nbt,
+                                 int training, float* chan, void* stream) {
+  if (!bn_w || !bn_b || !chan || M < 1 || b < 1 || L < 1) return BMNAS_E_ARG;
+  if (training && (!part || n_part < 1 || b * L < 2)) return BMNAS_E_ARG;
+  if (!training && (!running_mean || !running_var)) return BMNAS_E_ARG;
+  hipLaunchKernelGGL(bn_finalize_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, part,
+                     n_part, b, L, M, bn_w, bn_b, running_mean, running_var, num_batches_tracked,
+                     n_nbt, training, chan);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const float* U,
+                                  const float* chan, const float* gamma, float* out, int b, int C,
+                                  int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
+                                  void* stream) {
+  if (!x || !y || !p1 || !U || !chan || !gamma || !out || b < 0 || C < 1) return BMNAS_E_ARG;
+  if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  const int64_t total = (int64_t)b * C * L / 4;
+  hipLaunchKernelGGL(node_mix_fwd_k, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x,
+                     y, p1, U, chan, gamma, out, b, C, L, to_cfg(drop_glu), to_cfg(drop_fc));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_node_mix_bwd(const float* g, const float* x, const float* y, const float* p1,
+                                  const float* U, const float* chan, const float* gamma,
+                                  float* dgamma, float* dx, float* dy, uint32_t accumulate_mask,
+                                  float* dV, float* bn_grad, int b, int C, int L,
+                                  bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream) {
+  if (!g || !x || !y || !p1 || !U || !chan || !gamma || !dV || !bn_grad || b < 0 || C < 1)
+    return BMNAS_E_ARG;
+  if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  const int cl4 = C * L / 4;
+  const int chunk = pick_chunk(b, cl4);
+  dim3 grid((cl4 + 255) / 256, (b + chunk - 1) / chunk);
+  hipLaunchKernelGGL(node_mix_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, x, y, p1, U, chan,
+                     gamma, dgamma, dx, dy, accumulate_mask, dV, bn_grad, b, C, L, chunk,
+                     to_cfg(drop_glu), to_cfg(drop_fc));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+
+extern "C" int bmnas_bn_glu_fwd(const float* U, const float* chan, float* out, int b, int C, int L,
+                                bmnas_dropout_t drop, void* stream) {
+  if (!U || !chan || !out || b < 0 || C < 1) return BMNAS_E_ARG;
+  if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  const int64_t total = (int64_t)b * C * L / 4;
+  hipLaunchKernelGGL(bn_glu_fwd_k, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, U,
+                     chan, out, b, C, L, to_cfg(drop));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_bn_glu_bwd(const float* g, const float* U, const float* chan, float* dV,
+                                float* bn_grad, int b, int C, int L, bmnas_dropout_t drop,
+                                void* stream) {
+  if (!g || !U || !chan || !dV || !bn_grad || b < 0 || C < 1) return BMNAS_E_ARG;
+  if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  const int cl4 = C * L / 4;
+  const int chunk = pick_chunk(b, cl4);
+  dim3 grid((cl4 + 255) / 256, (b + chunk - 1) / chunk);
+  hipLaunchKernelGGL(bn_glu_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, U, chan, dV, bn_grad,
+                     b, C, L, chunk, to_cfg(drop));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_bn_relu_fwd(const float* U, const float* chan, float* out, int b, int M, int L,
+                                 bmnas_dropout_t drop, void* stream) {
+  if (!U || !chan || !out || b < 0 || M < 1) return BMNAS_E_ARG;
+  if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  const int64_t total = (int64_t)b * M * L / 4;
+  hipLaunchKernelGGL(bn_relu_fwd_k, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, U,
+                     chan, out, b, M, L, to_cfg(drop));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_bn_relu_bwd(const float* g, const float* U, const float* chan, float* dV,
+                                 float* bn_grad, int b, int M, int L, bmnas_dropout_t drop,
+                                 void* stream) {
+  if (!g || !U || !chan || !dV || !bn_grad || b < 0 || M < 1) return BMNAS_E_ARG;
+  if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  const int ml4 = M * L / 4;
+  const int chunk = pick_chunk(b, ml4);
+  dim3 grid((ml4 + 255) / 256, (b + chunk - 1) / chunk);
+  hipLaunchKernelGGL(bn_relu_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, U, chan, dV, bn_grad,
+                     b, M, L, chunk, to_cfg(drop));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_bn_bwd_apply(float* dV, const float* U, const float* chan,
+                                  const float* bn_grad, int b, int M, int L, int training,
+                                  void* stream) {
+  if (!dV || !U || !chan || !bn_grad || b < 0 || M < 1) return BMNAS_E_ARG;
+  if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  const int64_t total = (int64_t)b * M * L / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_k, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, dV,
+                     U, chan, bn_grad, b, M, L, training);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_arch_softmax_fwd(const float* logits, float* w, int rows, int cols,
+                                      void* stream) {
+  if (!logits || !w || rows < 1 || cols < 1) return BMNAS_E_ARG;
+  hipLaunchKernelGGL(arch_softmax_fwd_k, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                     logits, w, rows, cols);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_arch_softmax_bwd(const float* w, const float* dw, float* dlogits, int rows,
+                                      int cols, void* stream) {
+  if (!w || !dw || !dlogits || rows < 1 || cols < 1) return BMNAS_E_ARG;
+  hipLaunchKernelGGL(arch_softmax_bwd_k, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, w,
+                     dw, dlogits, rows, cols);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,90 @@
+// Shared device helpers for the BM-NAS fusion-cell kernels (gfx950 / CDNA4 only).
+// wave = 64 lanes everywhere; fp32 MFMA 16x16x4 is the only matrix instruction used.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BMNAS_MAX_PTRS 16
+#define BMNAS_WAVE 64
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct PtrsIn { const float* p[BMNAS_MAX_PTRS]; };
+struct PtrsOut { float* p[BMNAS_MAX_PTRS]; };
+
+// Counter-based dropout: keep element e iff philox(seed, offset + e/4)[e%4] >= thr.
+// thr == 0 -> identity (eval mode or p == 0).  scale = 1/(1-p).
+struct DropCfg {
+  uint32_t thr;
+  float scale;
+  uint64_t seed;
+  uint64_t offset;
+};
+
+#define BMNAS_CHECK_LAUNCH()                         \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x2545F491u, c3 = 0x9E3779B1u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+// mask*scale multipliers for the float4 starting at flat element index e (e % 4 == 0)
+__device__ __forceinline__ float4 drop_mult4(const DropCfg& d, uint64_t e) {
+  if (d.thr == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);
+  uint4 r = philox4x32_10(d.offset + (e >> 2), d.seed);
+  return make_float4(r.x >= d.thr ? d.scale : 0.f, r.y >= d.thr ? d.scale : 0.f,
+                     r.z >= d.thr ? d.scale : 0.f, r.w >= d.thr ? d.scale : 0.f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over the 256 threads of a block; every thread gets the result.
+// red must hold >= 4 floats; two __syncthreads.
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) {
+  return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+__device__ __forceinline__ float f4_dot(float4 a, float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ float f4_hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+static inline int ilog2_exact(int v) {   // host: log2 of a power of two, else -1
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return ((1 << l) == v) ? l : -1;
+}

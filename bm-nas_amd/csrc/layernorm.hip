@@ -1,0 +1,232 @@
+// K6 / K7 — channel-concat (+ residual) + LayerNorm([D/L, L]) (+ ReLU), one workgroup per
+// sample: the whole (D = n_src*C*L)-element sample lives in registers (VPT float4 per
+// thread), two block reductions (mean, then centred second moment), one coalesced write.
+// Algorithmic bytes fwd: (n_src [+1 resid] + n_src) * T (+ 2*D*4 params), T = b*C*L*4.
+#include "common.hpp"
+#include "../../include/bmnas_hip.h"
+
+namespace {
+
+constexpr float kEps = 1e-5f;
+
+struct LnSrc {
+  const float* p[4];
+};
+struct LnDst {
+  float* p[4];
+};
+
+// float4 index i (within the concatenated sample) -> pointer into source q
+__device__ __forceinline__ const float* src_ptr(const LnSrc& s, int i4, int cl4, int sample) {
+  const int q = i4 / cl4;
+  const int off = i4 - q * cl4;
+  return s.p[q] + ((int64_t)sample * cl4 + off) * 4;
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void cat_ln_fwd_k(LnSrc srcs, const float* __restrict__ resid,
+                                                    const float* __restrict__ ln_w,
+                                                    const float* __restrict__ ln_b,
+                                                    float* __restrict__ out,
+                                                    float* __restrict__ stats, int cl4, int d4,
+                                                    int relu) {
+  __shared__ float red[4];
+  const int s = blockIdx.x;
+  float4 v[VPT];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < d4) {
+      v[k] = ld4(src_ptr(srcs, i, cl4, s));
+      if (resid != nullptr) v[k] = f4_add(v[k], ld4(resid + ((int64_t)s * d4 + i) * 4));
+      sum += f4_hsum(v[k]);
+    } else {
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float inv_d = 1.f / (float)(d4 * 4);
+  const float mean = block_sum256(sum, red) * inv_d;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < d4) {
+      const float4 c = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
+      sq += f4_dot(c, c);
+    }
+  }
+  const float var = block_sum256(sq, red) * inv_d;
+  const float rstd = 1.f / sqrtf(var + kEps);
+  if (threadIdx.x == 0) {
+    stats[2 * s] = mean;
+    stats[2 * s + 1] = rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < d4) {
+      const float4 w = ld4(ln_w + (int64_t)i * 4), bb = ld4(ln_b + (int64_t)i * 4);
+      float4 o;
+      o.x = (v[k].x - mean) * rstd * w.x + bb.x;
+      o.y = (v[k].y - mean) * rstd * w.y + bb.y;
+      o.z = (v[k].z - mean) * rstd * w.z + bb.z;
+      o.w = (v[k].w - mean) * rstd * w.w + bb.w;
+      if (relu) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      }
+      st4(out + ((int64_t)s * d4 + i) * 4, o);
+    }
+  }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void cat_ln_bwd_k(const float* __restrict__ g, LnSrc srcs,
+                                                    const float* __restrict__ resid,
+                                                    const float* __restrict__ ln_w,
+                                                    const float* __restrict__ ln_b,
+                                                    const float* __restrict__ stats, LnDst dsrcs,
+                                                    float* dresid, uint32_t acc_mask, float* dln_w,
+                                                    float* dln_b, int cl4, int d4, int relu) {
+  __shared__ float red[4];
+  const int s = blockIdx.x;
+  const float mean = stats[2 * s], rstd = stats[2 * s + 1];
+  float4 xh[VPT], dxh[VPT];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < d4) {
+      float4 x = ld4(src_ptr(srcs, i, cl4, s));
+      if (resid != nullptr) x = f4_add(x, ld4(resid + ((int64_t)s * d4 + i) * 4));
+      const float4 w = ld4(ln_w + (int64_t)i * 4);
+      float4 gy = ld4(g + ((int64_t)s * d4 + i) * 4);
+      float4 h;
+      h.x = (x.x - mean) * rstd; h.y = (x.y - mean) * rstd;
+      h.z = (x.z - mean) * rstd; h.w = (x.w - mean) * rstd;
+      if (relu) {
+        const float4 bb = ld4(ln_b + (int64_t)i * 4);
+        if (h.x * w.x + bb.x <= 0.f) gy.x = 0.f;
+        if (h.y * w.y + bb.y <= 0.f) gy.y = 0.f;
+        if (h.z * w.z + bb.z <= 0.f) gy.z = 0.f;
+        if (h.w * w.w + bb.w <= 0.f) gy.w = 0.f;
+      }
+      if (dln_w != nullptr) {
+        float* pw = dln_w + (int64_t)i * 4;
+        float* pb = dln_b + (int64_t)i * 4;
+        atomicAdd(pw + 0, gy.x * h.x); atomicAdd(pw + 1, gy.y * h.y);
+        atomicAdd(pw + 2, gy.z * h.z); atomicAdd(pw + 3, gy.w * h.w);
+        atomicAdd(pb + 0, gy.x); atomicAdd(pb + 1, gy.y);
+        atomicAdd(pb + 2, gy.z); atomicAdd(pb + 3, gy.w);
+      }
+      const float4 d = f4_mul(gy, w);
+      xh[k] = h;
+      dxh[k] = d;
+      s1 += f4_hsum(d);
+      s2 += f4_dot(d, h);
+    } else {
+      xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dxh[k] = xh[k];
+    }
+  }
+  const float inv_d = 1.f / (float)(d4 * 4);
+  const float m1 = block_sum256(s1, red) * inv_d;
+  const float m2 = block_sum256(s2, red) * inv_d;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < d4) {
+      float4 dx;
+      dx.x = rstd * (dxh[k].x - m1 - xh[k].x * m2);
+      dx.y = rstd * (dxh[k].y - m1 - xh[k].y * m2);
+      dx.z = rstd * (dxh[k].z - m1 - xh[k].z * m2);
+      dx.w = rstd * (dxh[k].w - m1 - xh[k].w * m2);
+      const int q = i / cl4;
+      const int off = i - q * cl4;
+      float* d = dsrcs.p[q];
+      if (d != nullptr) {
+        float* a = d + ((int64_t)s * cl4 + off) * 4;
+        st4(a, (acc_mask & (1u << q)) ? f4_add(dx, ld4(a)) : dx);
+      }
+      if (dresid != nullptr) {
+        float* a = dresid + ((int64_t)s * d4 + i) * 4;
+        st4(a, (acc_mask & (1u << 31)) ? f4_add(dx, ld4(a)) : dx);
+      }
+    }
+  }
+}
+
+inline int pick_vpt(int d4) {
+  const int need = (d4 + 255) / 256;
+  if (need <= 1) return 1;
+  if (need <= 2) return 2;
+  if (need <= 4) return 4;
+  if (need <= 8) return 8;
+  if (need <= 16) return 16;
+  return -1;
+}
+
+}  // namespace
+
+#define LN_DISPATCH(V, CALL)      \
+  switch (V) {                    \
+    case 1: CALL(1); break;       \
+    case 2: CALL(2); break;       \
+    case 4: CALL(4); break;       \
+    case 8: CALL(8); break;       \
+    case 16: CALL(16); break;     \
+    default: return BMNAS_E_LIMIT; \
+  }
+
+extern "C" int bmnas_cat_ln_fwd(const float* const* srcs, int n_src, const float* resid,
+                                const float* ln_w, const float* ln_b, float* out, float* stats,
+                                int b, int C, int L, int relu, void* stream) {
+  if (!srcs || !ln_w || !ln_b || !out || !stats || n_src < 1 || b < 0 || C < 1 || L < 1)
+    return BMNAS_E_ARG;
+  if (n_src > 4) return BMNAS_E_LIMIT;
+  if (resid && n_src != 1) return BMNAS_E_ARG;
+  if ((C * L) % 4 != 0) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  LnSrc s{};
+  for (int q = 0; q < n_src; ++q) {
+    if (!srcs[q]) return BMNAS_E_ARG;
+    s.p[q] = srcs[q];
+  }
+  const int cl4 = C * L / 4, d4 = cl4 * n_src;
+  const int vpt = pick_vpt(d4);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(V) hipLaunchKernelGGL(cat_ln_fwd_k<V>, dim3(b), dim3(256), 0, st, s, resid, ln_w, ln_b, out, stats, cl4, d4, relu)
+  LN_DISPATCH(vpt, CALL)
+#undef CALL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_src,
+                                const float* resid, const float* ln_w, const float* ln_b,
+                                const float* stats, float* const* dsrcs, float* dresid,
+                                uint32_t accumulate_mask, float* dln_w, float* dln_b, int b, int C,
+                                int L, int relu, void* stream) {
+  if (!g || !srcs || !ln_w || !ln_b || !stats || !dsrcs || n_src < 1 || b < 0 || C < 1 || L < 1)
+    return BMNAS_E_ARG;
+  if ((dln_w == nullptr) != (dln_b == nullptr)) return BMNAS_E_ARG;
+  if (n_src > 4) return BMNAS_E_LIMIT;
+  if (resid && n_src != 1) return BMNAS_E_ARG;
+  if ((C * L) % 4 != 0) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  LnSrc s{};
+  LnDst d{};
+  for (int q = 0; q < n_src; ++q) {
+    if (!srcs[q]) return BMNAS_E_ARG;
+    s.p[q] = srcs[q];
+    d.p[q] = dsrcs[q];
+  }
+  const int cl4 = C * L / 4, d4 = cl4 * n_src;
+  const int vpt = pick_vpt(d4);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(V) hipLaunchKernelGGL(cat_ln_bwd_k<V>, dim3(b), dim3(256), 0, st, g, s, resid, ln_w, ln_b, stats, d, dresid, accumulate_mask, dln_w, dln_b, cl4, d4, relu)
+  LN_DISPATCH(vpt, CALL)
+#undef CALL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}

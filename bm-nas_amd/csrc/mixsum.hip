@@ -1,0 +1,153 @@
+// K1 — architecture-weighted mixed-edge sum (FusionMixedOp summed over incoming edges).
+// Pure HBM-streaming kernels: one float4 per lane per input, all n_in loads issued before
+// the FMAs; the backward fuses the n_in dx writes with n_in dot products
+// (wave shuffle -> LDS -> one atomic per workgroup per scalar).
+// Algorithmic bytes: fwd (n_in + 1) * T, bwd (2 * n_in + 1) * T, T = n_elem * 4.
+#include "common.hpp"
+#include "../../include/bmnas_hip.h"
+
+namespace {
+
+template <int NIN>
+__global__ __launch_bounds__(256) void mixsum_fwd_k(PtrsIn xs, const float* __restrict__ w,
+                                                    int w_stride, float* __restrict__ out,
+                                                    int64_t n4) {
+  float wj[NIN];
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) wj[j] = w[j * w_stride];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 v[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+    float4 acc = f4_scale(v[0], wj[0]);
+#pragma unroll
+    for (int j = 1; j < NIN; ++j) {
+      acc.x = fmaf(wj[j], v[j].x, acc.x);
+      acc.y = fmaf(wj[j], v[j].y, acc.y);
+      acc.z = fmaf(wj[j], v[j].z, acc.z);
+      acc.w = fmaf(wj[j], v[j].w, acc.w);
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+
+template <int NIN>
+__global__ __launch_bounds__(256) void mixsum_bwd_k(PtrsIn xs, PtrsOut dxs,
+                                                    const float* __restrict__ w, int w_stride,
+                                                    const float* __restrict__ g, float* dw,
+                                                    uint32_t acc_mask, int64_t n4) {
+  __shared__ float red[4 * NIN];
+  float wj[NIN], part[NIN];
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) {
+    wj[j] = w[j * w_stride];
+    part[j] = 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    if (dw != nullptr) {
+      float4 v[NIN];
+#pragma unroll
+      for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+#pragma unroll
+      for (int j = 0; j < NIN; ++j) part[j] += f4_dot(g4, v[j]);
+    }
+    // dx_j: destinations may alias each other (the same state feeding two edges), so the
+    // read-modify-writes stay in program order through non-restrict pointers.
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+      float* d = dxs.p[j];
+      if (d == nullptr) continue;
+      float4 r = f4_scale(g4, wj[j]);
+      if (acc_mask & (1u << j)) r = f4_add(r, reinterpret_cast<float4*>(d)[i]);
+      reinterpret_cast<float4*>(d)[i] = r;
+    }
+  }
+  if (dw == nullptr) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) {
+    float s = wave_sum(part[j]);
+    if (lane == 0) red[wave * NIN + j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NIN) {
+    const int j = threadIdx.x;
+    atomicAdd(dw + j * w_stride, red[j] + red[NIN + j] + red[2 * NIN + j] + red[3 * NIN + j]);
+  }
+}
+
+inline int grid_for(int64_t n4) {
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+#define MIXSUM_DISPATCH(N, CALL) \
+  switch (N) {                   \
+    case 1: CALL(1); break;      \
+    case 2: CALL(2); break;      \
+    case 3: CALL(3); break;      \
+    case 4: CALL(4); break;      \
+    case 5: CALL(5); break;      \
+    case 6: CALL(6); break;      \
+    case 7: CALL(7); break;      \
+    case 8: CALL(8); break;      \
+    case 9: CALL(9); break;      \
+    case 10: CALL(10); break;    \
+    case 11: CALL(11); break;    \
+    case 12: CALL(12); break;    \
+    case 13: CALL(13); break;    \
+    case 14: CALL(14); break;    \
+    case 15: CALL(15); break;    \
+    case 16: CALL(16); break;    \
+    default: return BMNAS_E_LIMIT; \
+  }
+
+extern "C" int bmnas_mixsum_fwd(const float* const* xs, int n_in, const float* w, int w_stride,
+                                float* out, int64_t n_elem, void* stream) {
+  if (!xs || !w || !out || n_in < 1 || n_elem < 0 || w_stride < 1) return BMNAS_E_ARG;
+  if (n_in > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
+  if (n_elem % 4 != 0) return BMNAS_E_SHAPE;
+  if (n_elem == 0) return 0;
+  PtrsIn p{};
+  for (int j = 0; j < n_in; ++j) {
+    if (!xs[j]) return BMNAS_E_ARG;
+    p.p[j] = xs[j];
+  }
+  const int64_t n4 = n_elem / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(N) hipLaunchKernelGGL(mixsum_fwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, w, w_stride, out, n4)
+  MIXSUM_DISPATCH(n_in, CALL)
+#undef CALL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n_in,
+                                const float* w, int w_stride, const float* g, float* dw,
+                                uint32_t accumulate_mask, int64_t n_elem, void* stream) {
+  if (!xs || !dxs || !w || !g || n_in < 1 || n_elem < 0 || w_stride < 1) return BMNAS_E_ARG;
+  if (n_in > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
+  if (n_elem % 4 != 0) return BMNAS_E_SHAPE;
+  if (n_elem == 0) return 0;
+  PtrsIn p{};
+  PtrsOut d{};
+  for (int j = 0; j < n_in; ++j) {
+    if (!xs[j]) return BMNAS_E_ARG;
+    p.p[j] = xs[j];
+    d.p[j] = dxs[j];
+  }
+  const int64_t n4 = n_elem / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(N) hipLaunchKernelGGL(mixsum_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, g, dw, accumulate_mask, n4)
+  MIXSUM_DISPATCH(n_in, CALL)
+#undef CALL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,70 @@
+"""Discrete (found) step node built from a StepGenotype.
+
+Mirror of the reference's models/search/darts/node.py (Found_NodeCell :8-76,
+Found_FusionNode :78-91).  The reference's ablation nodes (:94-184) look up primitive
+names that are not in STEP_STEP_OPS and cannot be constructed; they are not mirrored.
+"""
+import torch.nn as nn
+
+from bmnas.functions import CatLnFn, ConvBnActFn
+
+from .node_operations import STEP_STEP_OPS
+from .operations import OPS
+
+
+class Found_NodeCell(nn.Module):
+    def __init__(self, node_steps, node_multiplier, args, step_genotype):
+        super().__init__()
+        self.args = args
+        self.node_steps = node_steps
+        self.node_multiplier = node_multiplier
+        self.C, self.L = args.C, args.L
+        self.num_input_nodes = 2
+
+        self.edge_ops = nn.ModuleList()
+        self.node_ops = nn.ModuleList()
+        op_names, indices = zip(*step_genotype.inner_edges)
+        self.compile(op_names, indices, step_genotype.inner_steps)
+
+        if node_multiplier != 1:
+            self.out_conv = nn.Conv1d(self.C * node_multiplier, self.C, 1, 1)
+            self.bn = nn.BatchNorm1d(self.C)
+            self.out_dropout = nn.Dropout(args.drpt)
+        self.ln = nn.LayerNorm([self.C, self.L])
+        self.dropout = nn.Dropout(args.drpt)
+
+    def compile(self, edge_op_names, edge_indices, inner_steps):
+        for name in edge_op_names:
+            self.edge_ops.append(OPS[name](self.C, self.L, self.args))
+        self.edge_indices = edge_indices
+        for name in inner_steps:
+            self.node_ops.append(STEP_STEP_OPS[name](self.C, self.L, self.args))
+
+    def forward(self, x, y):
+        states = [x, y]
+        for i in range(self.node_steps):
+            in_x = self.edge_ops[2 * i](states[self.edge_indices[2 * i]])
+            in_y = self.edge_ops[2 * i + 1](states[self.edge_indices[2 * i + 1]])
+            states.append(self.node_ops[i](in_x, in_y))
+        tail = states[-self.node_multiplier:]
+        if self.node_multiplier != 1:
+            bn = self.bn
+            out = ConvBnActFn.apply('relu', self.out_dropout.p, self.training, bn.running_mean,
+                                    bn.running_var, bn.num_batches_tracked, self.out_conv.weight,
+                                    self.out_conv.bias, bn.weight, bn.bias, *tail)
+        else:
+            out = tail[0]
+        return CatLnFn.apply(False, self.ln.weight, self.ln.bias, x, out)
+
+
+class Found_FusionNode(nn.Module):
+    def __init__(self, node_steps, node_multiplier, args, step_genotype):
+        super().__init__()
+        self.node_steps = node_steps
+        self.node_multiplier = node_multiplier
+        self.node_cell = Found_NodeCell(node_steps, node_multiplier, args, step_genotype)
+        self.num_input_nodes = 2
+        self.num_keep_edges = 2
+
+    def forward(self, x, y):
+        return self.node_cell(x, y)

@@ -1,0 +1,185 @@
+/* bmnas_hip.h — C ABI of libbmnas_hip.so: the MI355X (gfx950) kernels of the BM-NAS
+ * fusion-search hot path.
+ *
+ * The reference (Somedaywilldo/BM-NAS) is pure Python/PyTorch: it has no FFI for this
+ * path; its "interface" is the nn.Module surface of models/search/darts/{operations,node_operations,model_search,node_search}.py.  This
+ * library sits UNDER that surface: the host-side mirror (bm-nas_amd/models/...) keeps the
+ * reference's class names/signatures and calls these entry points through ctypes from
+ * torch.autograd.Function bodies.  Each entry point below cites the reference code it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - every tensor pointer is a DEVICE pointer to contiguous fp32, caller-owned (allocated
+ *     by PyTorch's caching allocator); feature tensors are (b, C, L) with L innermost;
+ *   - `xs`/`dxs`-style arguments are HOST arrays of device pointers (<= BMNAS_MAX_PTRS);
+ *   - `stream` is a hipStream_t; work is enqueued asynchronously, nothing synchronises,
+ *     nothing allocates, no mutable global state (re-entrant per stream, capturable
+ *     into a hipGraph);
+ *   - return value: 0 = ok, > 0 = hipError_t from the launch, < 0 = argument error
+ *     (BMNAS_E_*); no exception crosses the boundary;
+ *   - shape limits: L in {4, 8, 16}; C % 16 == 0; at most 16 pointers per list.
+ *   - "accumulate" flags: 0 -> destination is overwritten, 1 -> destination += result.
+ *   - reductions over the batch (arch-weight dot products, LayerNorm / BatchNorm affine
+ *     gradients, split-N weight gradients) use fp32 atomics into buffers the CALLER has
+ *     zeroed (or that hold a running sum to add to).
+ */
+#ifndef BMNAS_HIP_H
+#define BMNAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMNAS_MAX_PTRS 16
+#define BMNAS_E_ARG (-1)      /* null pointer / non-positive size                        */
+#define BMNAS_E_SHAPE (-2)    /* shape outside the supported set (see limits above)      */
+#define BMNAS_E_LIMIT (-3)    /* too many pointers / LDS budget exceeded                 */
+
+/* Dropout descriptor: Philox4x32-10 counter RNG, element e of a tensor is kept iff
+ * philox(seed, offset + e/4)[e%4] >= thr (thr = p * 2^32), and scaled by `scale` = 1/(1-p).
+ * thr == 0 means identity (eval mode, or p == 0).  The backward call passes the SAME
+ * descriptor and regenerates the mask — no mask tensor is stored.  Replaces nn.Dropout
+ * at node_operations.py:27,38 / :46,55 / :89,105 and node_search.py:42,64. */
+typedef struct {
+  uint32_t thr;
+  float scale;
+  uint64_t seed;
+  uint64_t offset;
+} bmnas_dropout_t;
+
+int bmnas_version(void);
+
+/* ---- K1: architecture-weighted mixed-edge sum ---------------------------------------
+ * out[e] = sum_j w[j*w_stride] * xs[j][e]   over n_elem elements.
+ * Replaces sum(FusionMixedOp_j(h_j, weights[offset+j])) at model_search.py:58 and
+ * node_search.py:54 (FusionMixedOp.forward operations.py:104-105 with Zero :18-20 and
+ * Identity :92-93).  w points at the 'skip' column of the softmaxed edge rows
+ * (w_stride = 2).  The 'none' primitive contributes w0*(x*0) = 0 for finite x and is not
+ * evaluated (differs from the reference only for non-finite inputs). */
+int bmnas_mixsum_fwd(const float* const* xs, int n_in, const float* w, int w_stride,
+                     float* out, int64_t n_elem, void* stream);
+/* dxs[j] (=|+=) w_j * g  (dxs[j] may be NULL to skip; bit j of accumulate_mask selects +=);
+ * dw[j*w_stride] += <g, xs[j]> (atomic; dw may be NULL to skip the dot products). */
+int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n_in, const float* w,
+                     int w_stride, const float* g, float* dw, uint32_t accumulate_mask,
+                     int64_t n_elem, void* stream);
+
+/* ---- K6 / K7: channel-concat (+ residual) + LayerNorm (+ ReLU) -------------------------
+ * x = cat(srcs[0..n_src), dim=1) (+ resid if non-NULL; n_src must be 1 then);
+ * out = LayerNorm_[n_src*C, L](x; ln_w, ln_b) (eps 1e-5, biased variance), optional ReLU.
+ * stats[s*2+{0,1}] = mean, rstd of sample s (saved for backward).
+ * K7 = FusionCell.forward tail model_search.py:63-67 (n_src = multiplier, relu = 1);
+ * K6 = NodeCell.forward tail node_search.py:67-68 (n_src = 1, resid = x, relu = 0). */
+int bmnas_cat_ln_fwd(const float* const* srcs, int n_src, const float* resid, const float* ln_w,
+                     const float* ln_b, float* out, float* stats, int b, int C, int L, int relu,
+                     void* stream);
+/* g: gradient of `out`.  dsrcs[q] (NULL to skip) / dresid (NULL to skip) receive the input
+ * gradient (acc bits: bit q for dsrcs[q], bit 31 for dresid); dln_w / dln_b += (atomic). */
+int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_src, const float* resid,
+                     const float* ln_w, const float* ln_b, const float* stats,
+                     float* const* dsrcs, float* dresid, uint32_t accumulate_mask,
+                     float* dln_w, float* dln_b, int b, int C, int L, int relu, void* stream);
+
+/* ---- K3: scaled-dot attention + dropout + LayerNorm -----------------------------------
+ * ScaledDotAttn.forward node_operations.py:92-108: q = x^T, k = y, v = y^T,
+ * scores = q@k / sqrt(C), softmax(-1), out = (attn@v)^T, Dropout, LayerNorm([C, L]).
+ * One wavefront per 16 rows (= 16/L samples); QK^T and AV on v_mfma_f32_16x16x4_f32,
+ * row softmax by in-lane + cross-lane (xor 16/32) reductions.  stats as in cat_ln. */
+int bmnas_sdpa_ln_fwd(const float* x, const float* y, const float* ln_w, const float* ln_b,
+                      float* out, float* stats, int b, int C, int L, bmnas_dropout_t drop,
+                      void* stream);
+/* g: gradient of out, multiplied in-kernel by *gscale if gscale != NULL (the gamma weight
+ * of the mixed op).  dx / dy (=|+=, bit0 / bit1 of accumulate_mask); if dy == NULL the
+ * y-gradient is added into dx (search mode, x is y).  dln_w/dln_b += (atomic). */
+int bmnas_sdpa_ln_bwd(const float* g, const float* gscale, const float* x, const float* y,
+                      const float* ln_w, const float* stats, float* dx, float* dy,
+                      uint32_t accumulate_mask, float* dln_w, float* dln_b, int b, int C, int L,
+                      bmnas_dropout_t drop, void* stream);
+
+/* ---- K4 / K5 / out_conv: channel-concat + 1x1 Conv1d as an fp32-MFMA GEMM ----------------
+ * U[s, m, l] = bias[m] + sum_k W[m*ldw + k] * cat(srcs)[s, k, l],  k < n_src*C_src, m < M.
+ * Replaces torch.cat + nn.Conv1d(k=1) at node_operations.py:32-33, :51-52 and
+ * node_search.py:59-61 (several convs sharing the same input may be stacked along M).
+ * If part != NULL (train-mode BatchNorm follows): per-channel partial batch statistics
+ * part[(p*M + m)*2 + {0,1}] = (sum, M2 about the partial's own mean) over the p-th block
+ * of 32 (sample,l) columns; p < bmnas_conv1x1_num_partials(b, L). */
+int bmnas_conv1x1_num_partials(int b, int L);
+int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const float* W, int ldw,
+                      const float* bias, float* U, float* part, int b, int L, int M,
+                      void* stream);
+/* dsrcs[q][s, c, l] (=|+=) sum_m W[m*ldw + q*C_src + c] * dU[s, m, l]   (dsrcs[q] NULL: skip) */
+int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, float* const* dsrcs,
+                           int n_src, int C_src, uint32_t accumulate_mask, int b, int L, int M,
+                           void* stream);
+/* dW[m*ldw + k] += sum_{s,l} dU[s,m,l] * cat(srcs)[s,k,l];  dbias[m] += sum_{s,l} dU[s,m,l]
+ * (atomic adds: caller zeroes; dbias may be NULL).  If dup_cols > 0 the same value is also
+ * added at column k + dup_cols (folded x-is-y weights, see bmnas_fold_weight). */
+int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* srcs, int n_src, int C_src,
+                             float* dW, int ldw, float* dbias, int dup_cols, int b, int L, int M,
+                             void* stream);
+/* Weff[m*C + c] = W[m*2C + c] + W[m*2C + C + c]: the conv applied to cat[z, z] (search mode,
+ * NodeMixedOp(z, z) at node_search.py:55) equals Weff applied to z. */
+int bmnas_fold_weight(const float* W, float* Weff, int M, int C, void* stream);
+
+/* ---- BatchNorm1d bookkeeping ------------------------------------------------------------
+ * Combines the GEMM's partial statistics (Chan's parallel variance), or uses the running
+ * statistics in eval mode, into per-channel mean[m], rstd[m] and the fused affine
+ * scale[m] = bn_w*rstd, shift[m] = bn_b - mean*scale; in training mode also updates
+ * running_mean / running_var (momentum 0.1, unbiased variance) and the n_nbt consecutive
+ * int64 num_batches_tracked counters (several stacked BatchNorms), like nn.BatchNorm1d (node_operations.py:26,34 / :45,53, node_search.py:40,62).
+ * chan[4*M] = mean | rstd | scale | shift. */
+int bmnas_bn_finalize(const float* part, int n_part, int b, int L, int M, const float* bn_w,
+                      const float* bn_b, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, int n_nbt, int training, float* chan,
+                      void* stream);
+
+/* ---- K2: the gamma-weighted NodeMixedOp combine -------------------------------------------
+ * NodeMixedOp.forward node_operations.py:118-120 over [Sum, ScaleDotAttn, LinearGLU, ConcatFC]:
+ *   s = g0*(x+y) + g1*p1 + g2*drop(glu(BN(U[:, 0:2C]))) + g3*drop(relu(BN(U[:, 2C:3C])))
+ * gamma: 4 device floats (softmaxed row).  U: (b, 3C, L) stacked conv output [GLU | ConcatFC],
+ * chan: its bn_finalize output (M = 3C).  p1 = attention branch output. */
+int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const float* U,
+                       const float* chan, const float* gamma, float* out, int b, int C, int L,
+                       bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
+/* Backward, phase A (elementwise + reductions):  g = grad of s.
+ *   dgamma[q] += <g, p_q>;  dx / dy (=|+=) g0*g (dy NULL: both into dx);
+ *   dV[s, m, l] = gradient w.r.t. the BatchNorm OUTPUT (b, 3C, L);
+ *   bn_grad[m] += sum dV*u_hat (= dBN.weight), bn_grad[3C + m] += sum dV (= dBN.bias). */
+int bmnas_node_mix_bwd(const float* g, const float* x, const float* y, const float* p1,
+                       const float* U, const float* chan, const float* gamma, float* dgamma,
+                       float* dx, float* dy, uint32_t accumulate_mask, float* dV, float* bn_grad,
+                       int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
+                       void* stream);
+
+/* ---- standalone LinearGLU tail (Found nets): out = drop(glu(BN(U))), U (b, 2C, L) --------
+ * node_operations.py:34-38.  Backward phase A like bmnas_node_mix_bwd (M = 2C). */
+int bmnas_bn_glu_fwd(const float* U, const float* chan, float* out, int b, int C, int L,
+                     bmnas_dropout_t drop, void* stream);
+int bmnas_bn_glu_bwd(const float* g, const float* U, const float* chan, float* dV, float* bn_grad,
+                     int b, int C, int L, bmnas_dropout_t drop, void* stream);
+
+/* ---- BN + ReLU + dropout: ConcatFC tail (node_operations.py:53-55) and the NodeCell
+ * out_conv tail (node_search.py:60-64) ---------------------------------------------------- */
+int bmnas_bn_relu_fwd(const float* U, const float* chan, float* out, int b, int M, int L,
+                      bmnas_dropout_t drop, void* stream);
+int bmnas_bn_relu_bwd(const float* g, const float* U, const float* chan, float* dV, float* bn_grad,
+                      int b, int M, int L, bmnas_dropout_t drop, void* stream);
+
+/* Backward, phase B: BatchNorm input gradient, in place on dV (b, M, L):
+ *   training: dU = scale*(dV - bn_grad[M+m]/N - u_hat*bn_grad[m]/N), N = b*L;  eval: dU = scale*dV. */
+int bmnas_bn_bwd_apply(float* dV, const float* U, const float* chan, const float* bn_grad, int b,
+                       int M, int L, int training, void* stream);
+
+/* ---- architecture-parameter softmax (model_search.py:95, node_search.py:102-103) -----------
+ * Row softmax of `rows` rows of `cols` (2 or 4) logits; backward:
+ * dlogit[r,:] (=) w[r,:] * (dw[r,:] - sum_p w[r,p]*dw[r,p]). */
+int bmnas_arch_softmax_fwd(const float* logits, float* w, int rows, int cols, void* stream);
+int bmnas_arch_softmax_bwd(const float* w, const float* dw, float* dlogits, int rows, int cols,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMNAS_HIP_H */

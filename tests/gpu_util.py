@@ -1,0 +1,84 @@
+"""Helpers for the -m gpu parity tests: build the product modules on cuda:0 from the same
+deterministic synthetic tensors (oracle/synth.py) the golden generator used."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import fusion_oracle as fo
+from oracle import synth
+
+
+class Args:
+    def __init__(self, cfg, drpt=None):
+        self.C, self.L = cfg.C, cfg.L
+        self.drpt = cfg.drpt if drpt is None else drpt
+        self.num_input_nodes = cfg.N
+        self.num_keep_edges = 2
+        self.node_steps, self.node_multiplier = cfg.ns, cfg.nm
+        self.steps, self.multiplier = cfg.S, cfg.M
+        self.parallel = False
+        self.weight_decay = 1e-4
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def set_mode(module, mode):
+    """'eval' -> eval(); 'train_nodrop' -> train() with every dropout an identity (the golden
+    vectors' drpt=1e-12 / ScaledDotAttn.dropout.p=0 recipe); 'train' -> train()."""
+    if mode == 'eval':
+        module.eval()
+        return
+    module.train()
+    if mode == 'train_nodrop':
+        for m in module.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+
+
+def build_search_net(cfg, seed, mode, arch_scale=0.5):
+    from models.search.darts.model_search import FusionNetwork
+    net = FusionNetwork(cfg.S, cfg.M, cfg.N, 2, Args(cfg), criterion=None)
+    net.load_state_dict(synth.make_params(cfg, seed))
+    for dst, src in zip(net.arch_parameters(), synth.make_arch(cfg, seed, arch_scale)):
+        dst.data.copy_(src)
+    net.to(dev())
+    set_mode(net, mode)
+    return net
+
+
+def build_found_net(cfg, genotype, seed, mode):
+    from models.search.darts.genotypes import Genotype, StepGenotype
+    from models.search.darts.model import Found_FusionNetwork
+    g = Genotype(edges=[tuple(e) for e in genotype.edges],
+                 steps=[StepGenotype(inner_edges=[tuple(e) for e in s.inner_edges],
+                                     inner_steps=list(s.inner_steps), inner_concat=list(s.inner_concat))
+                        for s in genotype.steps],
+                 concat=list(genotype.concat))
+    net = Found_FusionNetwork(cfg.S, cfg.M, cfg.N, 2, Args(cfg), None, g)
+    net.load_state_dict(synth.make_params(cfg, seed, fo.found_param_shapes(cfg, genotype)))
+    net.to(dev())
+    set_mode(net, mode)
+    return net
+
+
+def scale_tol(want, rel=1e-4, floor=1e-6):
+    """absolute tolerance = rel * (largest magnitude of the expected tensor)"""
+    w = np.asarray(want, dtype=np.float64)
+    return max(floor, rel * float(np.abs(w).max()) if w.size else floor)
+
+
+def assert_close_scaled(name, got, want, rel=1e-4, floor=1e-6):
+    """|got - want| <= rel * (|want| + max|want|): fp32 parity at 1e-4 of the tensor's scale."""
+    got = np.asarray(got.detach().cpu().numpy() if torch.is_tensor(got) else got, dtype=np.float64)
+    want = np.asarray(want.detach().cpu().numpy() if torch.is_tensor(want) else want, dtype=np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    if want.size == 0:
+        return
+    tol = rel * np.abs(want) + scale_tol(want, rel, floor)
+    err = np.abs(got - want)
+    if not np.isfinite(got).all() or not (err <= tol).all():
+        i = int(np.argmax(err - tol))
+        raise AssertionError(f'{name}: max|err|={np.nanmax(err):.3e} (scale {np.abs(want).max():.3e}) at flat {i}: '
+                             f'got {got.reshape(-1)[i]!r} want {want.reshape(-1)[i]!r}')

@@ -1,0 +1,238 @@
+"""-m gpu: every HIP kernel of libbmnas_hip.so (through the C ABI) against the CPU oracle
+on the same seeded inputs.  Tolerance: 1e-4 of the expected tensor's scale (fp32)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fusion_oracle as fo
+from gpu_util import Args, assert_close_scaled, dev, set_mode
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(gen, *shape):
+    return torch.from_numpy(gen.standard_normal(shape).astype(np.float32))
+
+
+def _gen(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def test_library_loads_and_reports_version():
+    from bmnas import lib
+    assert lib.version() >= 100
+
+
+@pytest.mark.parametrize('n_in,shape', [(1, (3, 16, 8)), (2, (5, 16, 8)), (6, (7, 192, 16)),
+                                        (9, (4, 128, 8)), (16, (2, 16, 4))])
+def test_mixsum_fwd_bwd(n_in, shape):
+    from bmnas.functions import MixSumFn
+    g = _gen(n_in)
+    xs = [_rand(g, *shape) for _ in range(n_in)]
+    W = torch.softmax(_rand(g, n_in, 2), -1)
+    go = _rand(g, *shape)
+    # oracle
+    xo = [x.clone().requires_grad_(True) for x in xs]
+    Wo = W.clone().requires_grad_(True)
+    ref = fo.mixed_edge_sum(xo, Wo, 0)
+    ref.backward(go)
+    # HIP
+    xd = [x.to(dev()).requires_grad_(True) for x in xs]
+    Wd = W.to(dev()).requires_grad_(True)
+    out = MixSumFn.apply(Wd[:, 1], *xd)
+    out.backward(go.to(dev()))
+    assert_close_scaled('out', out, ref)
+    for j in range(n_in):
+        assert_close_scaled(f'dx{j}', xd[j].grad, xo[j].grad)
+    assert_close_scaled('dW[:,1]', Wd.grad[:, 1], Wo.grad[:, 1])
+    assert float(Wd.grad[:, 0].abs().max()) == 0.0        # 'none' weight: exactly zero gradient
+
+
+@pytest.mark.parametrize('n_src,b,C,L,relu,resid', [(1, 3, 16, 8, False, True), (2, 5, 192, 16, True, False),
+                                                     (3, 2, 16, 16, True, False), (1, 4, 128, 8, False, True),
+                                                     (2, 1, 512, 16, True, False)])
+def test_cat_ln_fwd_bwd(n_src, b, C, L, relu, resid):
+    from bmnas.functions import CatLnFn
+    g = _gen(100 + n_src + C)
+    srcs = [_rand(g, b, C, L) for _ in range(n_src)]
+    res = _rand(g, b, C, L) if resid else None
+    w = 1 + 0.1 * _rand(g, n_src * C, L)
+    bb = 0.1 * _rand(g, n_src * C, L)
+    go = _rand(g, b, n_src * C, L)
+
+    def run(tensors, device, fn):
+        ts = [t.detach().clone().to(device).requires_grad_(True) for t in tensors]
+        out = fn(ts)
+        out.backward(go.to(device))
+        return out, [t.grad for t in ts]
+
+    tensors = srcs + [w, bb] + ([res] if resid else [])
+
+    def oracle(ts):
+        x = torch.cat(ts[:n_src], 1)
+        if resid:
+            x = x + ts[-1]
+        y = F.layer_norm(x, (n_src * C, L), ts[n_src], ts[n_src + 1], fo.EPS)
+        return F.relu(y) if relu else y
+
+    def hip(ts):
+        return CatLnFn.apply(relu, ts[n_src], ts[n_src + 1], ts[-1] if resid else None, *ts[:n_src])
+
+    ro, rg = run(tensors, 'cpu', oracle)
+    ho, hg = run(tensors, dev(), hip)
+    assert_close_scaled('out', ho, ro)
+    for i, (a, b_) in enumerate(zip(hg, rg)):
+        assert_close_scaled(f'grad{i}', a, b_)
+
+
+@pytest.mark.parametrize('b,C,L,same', [(4, 16, 8, False), (5, 16, 8, True), (3, 32, 16, False),
+                                        (7, 48, 4, False), (2, 192, 16, True), (9, 128, 8, False),
+                                        (1, 16, 16, True)])
+def test_sdpa_ln_fwd_bwd(b, C, L, same):
+    from bmnas.functions import SdpaLnFn
+    g = _gen(200 + b + C + L)
+    x = _rand(g, b, C, L)
+    y = x if same else _rand(g, b, C, L)
+    w = 1 + 0.1 * _rand(g, C, L)
+    bb = 0.1 * _rand(g, C, L)
+    go = _rand(g, b, C, L)
+
+    def run(device, fn):
+        xd = x.detach().clone().to(device).requires_grad_(True)
+        yd = xd if same else y.detach().clone().to(device).requires_grad_(True)
+        wd = w.detach().clone().to(device).requires_grad_(True)
+        bd = bb.detach().clone().to(device).requires_grad_(True)
+        out = fn(xd, yd, wd, bd)
+        out.backward(go.to(device))
+        return out, [xd.grad, yd.grad, wd.grad, bd.grad]
+
+    ro, rg = run('cpu', lambda a, b_, c, d: fo.op_scaled_dot_attn(a, b_, c, d, False))
+    ho, hg = run(dev(), lambda a, b_, c, d: SdpaLnFn.apply(a, b_, c, d, 0.1, False))
+    assert_close_scaled('out', ho, ro)
+    for n, a, b_ in zip(['dx', 'dy', 'dln_w', 'dln_b'], hg, rg):
+        assert_close_scaled(n, a, b_, rel=2e-4)
+
+
+def _copy_params(dst_module, src_dict, prefix=''):
+    sd = dst_module.state_dict()
+    for k in sd:
+        sd[k] = src_dict[prefix + k].clone()
+    dst_module.load_state_dict(sd)
+
+
+@pytest.mark.parametrize('kind', ['glu', 'fc'])
+@pytest.mark.parametrize('b,C,L,training', [(4, 16, 8, True), (5, 16, 8, False), (3, 32, 16, True),
+                                            (6, 48, 4, True), (8, 192, 16, True), (9, 128, 8, True)])
+def test_conv_bn_act_modules(kind, b, C, L, training):
+    """LinearGLU / ConcatFC (x != y): conv GEMM + BN statistics + activation, fwd + bwd,
+    including the running-statistics update."""
+    from models.search.darts.node_operations import ConcatFC, LinearGLU
+    from oracle import synth
+    cfg = fo.make_cfg(N=2, C=C, L=L, drpt=0.0)
+    g = _gen(300 + b + C + L)
+    M = 2 * C if kind == 'glu' else C
+    shapes = {'conv.weight': (M, 2 * C, 1), 'conv.bias': (M,), 'bn.weight': (M,), 'bn.bias': (M,),
+              'bn.running_mean': (M,), 'bn.running_var': (M,), 'bn.num_batches_tracked': ()}
+    p = synth.make_params(cfg, 5 + b, shapes)
+    x, y, go = _rand(g, b, C, L), _rand(g, b, C, L), _rand(g, b, C, L)
+    # oracle
+    po = {k: (v.clone() if fo.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in p.items()}
+    xo, yo = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    fn = fo.op_linear_glu if kind == 'glu' else fo.op_concat_fc
+    pref = {'op.' + k: v for k, v in po.items()}
+    ref = fn(xo, yo, pref, 'op', training, 0.0)
+    ref.backward(go)
+    # HIP module
+    mod = (LinearGLU if kind == 'glu' else ConcatFC)(C, Args(cfg, 0.0))
+    _copy_params(mod, p)
+    mod.to(dev())
+    mod.train(training)
+    xd, yd = x.to(dev()).requires_grad_(True), y.to(dev()).requires_grad_(True)
+    out = mod(xd, yd)
+    out.backward(go.to(dev()))
+    assert_close_scaled('out', out, ref)
+    assert_close_scaled('dx', xd.grad, xo.grad)
+    assert_close_scaled('dy', yd.grad, yo.grad)
+    assert_close_scaled('dconv.weight', mod.conv.weight.grad, po['conv.weight'].grad)
+    assert_close_scaled('dbn.weight', mod.bn.weight.grad, po['bn.weight'].grad)
+    assert_close_scaled('dbn.bias', mod.bn.bias.grad, po['bn.bias'].grad)
+    if training:   # conv bias in front of train-mode BN: zero gradient up to round-off
+        assert float(mod.conv.bias.grad.abs().max()) < 1e-4
+        assert_close_scaled('running_mean', mod.bn.running_mean, po['bn.running_mean'])
+        assert_close_scaled('running_var', mod.bn.running_var, po['bn.running_var'])
+        assert int(mod.bn.num_batches_tracked) == 1
+    else:
+        assert_close_scaled('dconv.bias', mod.conv.bias.grad, po['conv.bias'].grad)
+
+
+@pytest.mark.parametrize('b,C,L,same,training', [(4, 16, 8, True, True), (5, 16, 8, False, True),
+                                                 (3, 32, 16, True, False), (6, 192, 16, True, True),
+                                                 (7, 128, 8, False, True)])
+def test_node_mixed_op(b, C, L, same, training):
+    from models.search.darts.node_operations import NodeMixedOp
+    from oracle import synth
+    cfg = fo.make_cfg(N=2, C=C, L=L, S=1, M=1, ns=1, nm=1, drpt=0.0)
+    g = _gen(400 + b + C)
+    prefix = 'cell._step_nodes.0.node_cell.node_ops.0._ops'
+    full = synth.make_params(cfg, 11)
+    p = {k: v for k, v in full.items() if k.startswith(prefix)}
+    x = _rand(g, b, C, L)
+    y = x if same else _rand(g, b, C, L)
+    gam = torch.softmax(_rand(g, 4), -1)
+    go = _rand(g, b, C, L)
+    # oracle
+    po = {k: (v.clone() if fo.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in p.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = xo if same else y.clone().requires_grad_(True)
+    go_ = gam.clone().requires_grad_(True)
+    ref = fo.node_mixed_op(xo, yo, go_, po, prefix, training, 0.0, attn_drop=0.0)
+    ref.backward(go)
+    # HIP
+    op = NodeMixedOp(C, L, Args(cfg, 0.0))
+    _copy_params(op, p, prefix[:-len('_ops')])
+    op.to(dev())
+    set_mode(op, 'train_nodrop' if training else 'eval')
+    xd = x.to(dev()).requires_grad_(True)
+    yd = xd if same else y.to(dev()).requires_grad_(True)
+    gd = gam.to(dev()).requires_grad_(True)
+    out = op(xd, yd, gd)
+    out.backward(go.to(dev()))
+    assert_close_scaled('out', out, ref)
+    assert_close_scaled('dgamma', gd.grad, go_.grad)
+    assert_close_scaled('dx', xd.grad, xo.grad, rel=2e-4)
+    if not same:
+        assert_close_scaled('dy', yd.grad, yo.grad, rel=2e-4)
+    for k, v in op.named_parameters():
+        want = po[prefix[:-len('_ops')] + k].grad
+        if k.endswith('conv.bias') and training:
+            assert float(v.grad.abs().max()) < 1e-4
+        else:
+            assert_close_scaled('d' + k, v.grad, want, rel=2e-4)
+    if training:
+        for k, v in op.state_dict().items():
+            if k.endswith('num_batches_tracked'):
+                assert int(v) == 1            # (the oracle bumps the counter one level up, in node_cell)
+            elif fo.is_buffer(k):
+                assert_close_scaled(k, v.float(), po[prefix[:-len('_ops')] + k].float())
+
+
+def test_dropout_mask_is_consistent_between_forward_and_backward():
+    """Philox dropout: keep fraction ~ 1-p, kept values scaled by 1/(1-p), and the backward
+    regenerates exactly the forward's mask."""
+    from models.search.darts.node_operations import ConcatFC
+    cfg = fo.make_cfg(N=2, C=64, L=16, drpt=0.25)
+    torch.manual_seed(0)
+    mod = ConcatFC(64, Args(cfg, 0.25)).to(dev()).train()
+    x = torch.randn(64, 64, 16, device=dev(), requires_grad=True)
+    y = torch.randn(64, 64, 16, device=dev())
+    out = mod(x, y)
+    dead_relu = 0.5                    # BN output is ~zero-mean: about half is clipped by ReLU
+    zero_frac = float((out == 0).float().mean())
+    assert abs(zero_frac - (dead_relu + (1 - dead_relu) * 0.25)) < 0.03, zero_frac
+    out2 = mod(x, y)
+    assert not torch.equal(out == 0, out2 == 0)            # a new mask every call
+    # eval mode: identity dropout
+    mod.eval()
+    oe = mod(x, y)
+    assert abs(float((oe == 0).float().mean()) - dead_relu) < 0.03

@@ -1,0 +1,201 @@
+"""-m gpu: the product modules (models.search.darts.*) on cuda:0 against (1) the golden
+vectors captured from the reference and (2) the CPU oracle, whole network fwd + bwd."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as fo
+from oracle import synth
+from gpu_util import (Args, assert_close_scaled, build_found_net, build_search_net, dev, set_mode)
+from util import case_id, cfg_of, golden_files, load_npz, summarize
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_search_case(meta):
+    cfg = cfg_of(meta)
+    seed, batch, nout = meta['seed'], meta['batch'], meta['num_outputs']
+    net = build_search_net(cfg, seed, meta['mode'])
+    cls = torch.nn.Linear(cfg.M * cfg.C * cfg.L, nout)
+    cw, cb = synth.make_classifier(cfg, nout, seed)
+    cls.weight.data.copy_(cw)
+    cls.bias.data.copy_(cb)
+    cls.to(dev())
+    xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, seed)]
+    y = synth.make_labels(meta['loss'], batch, nout, seed).to(dev())
+    crit = torch.nn.BCEWithLogitsLoss() if meta['loss'] == 'bce' else torch.nn.CrossEntropyLoss()
+    with torch.set_grad_enabled(meta['has_grads']):
+        feat = net(xs)
+        logits = cls(feat)
+        loss = crit(logits, y)
+    if meta['has_grads']:
+        loss.backward()
+    return net, cls, xs, feat, logits, loss
+
+
+@pytest.mark.parametrize('path', golden_files('hypernet_*.npz'), ids=case_id)
+def test_search_hypernet_matches_reference_golden(path):
+    meta, z = load_npz(path)
+    net, cls, xs, feat, logits, loss = _run_search_case(meta)
+    assert_close_scaled('logits', logits, z['logits'])
+    assert_close_scaled('loss', loss, z['loss'])
+    full = meta['full']
+    got = {}
+    if meta['has_grads']:
+        for k, v in net.named_parameters():
+            got['grad:' + k] = v.grad
+        got['grad:central_classifier.weight'] = cls.weight.grad
+        got['grad:central_classifier.bias'] = cls.bias.grad
+        for i, a in enumerate(net.arch_parameters()):
+            got[f'grad:arch.{i}'] = a.grad
+        for i, x in enumerate(xs):
+            got[f'grad:input.{i}'] = x.grad
+    for k, v in net.state_dict().items():
+        if fo.is_buffer(k):
+            got['buf:' + k] = v
+    got['feat'] = feat
+    for k in z.files:
+        if k in ('meta', 'logits', 'loss'):
+            continue
+        g = got[k]
+        assert g is not None, k
+        if k.endswith('conv.bias') and k.startswith('grad:') and meta['mode'] != 'eval':
+            assert float(g.abs().max()) < 1e-4, k     # mathematically zero (BN removes the mean)
+            continue
+        if full or k.startswith('grad:arch.') or g.dim() == 0:
+            assert_close_scaled(k, g.double() if g.dtype != torch.float32 else g, z[k], rel=2e-4)
+        else:
+            s = summarize(g)
+            want = z[k]
+            n = g.numel()
+            l2 = max(abs(float(want[1])), 1e-12)
+            assert abs(s[1] - want[1]) <= 2e-4 * l2 + 1e-7, (k, 'l2', s[1], want[1])
+            assert abs(s[0] - want[0]) <= 2e-4 * l2 * np.sqrt(n) + 1e-6, (k, 'sum', s[0], want[0])
+            assert np.all(np.abs(s[2:] - want[2:]) <= 2e-4 * (np.abs(want[2:]) + l2 / np.sqrt(n)) + 1e-7), \
+                (k, 'head', s[2:], want[2:])
+
+
+@pytest.mark.parametrize('name,batch,nout,loss_kind', [('mmimdb', 32, 23, 'bce'), ('ntu', 16, 60, 'ce'),
+                                                      ('ego', 7, 83, 'ce')])
+def test_search_hypernet_matches_oracle_real_configs(name, batch, nout, loss_kind):
+    """Full tensors (every gradient element) against the oracle at the three real configs,
+    train-mode BN, dropout identity; ragged batch for ego (odd batch with L=8 packs two
+    samples per MFMA tile)."""
+    cfg = fo.Cfg({**fo.CONFIGS[name], 'drpt': 0.0})
+    seed = 31
+    meta = dict(cfg=dict(cfg), seed=seed, batch=batch, num_outputs=nout, loss=loss_kind,
+                mode='train_nodrop', has_grads=True)
+    net, cls, xs, feat, logits, loss = _run_search_case(meta)
+    p = synth.make_params(cfg, seed)
+    arch = synth.make_arch(cfg, seed)
+    cw, cb = synth.make_classifier(cfg, nout, seed)
+    ologits, oloss, ograds = fo.search_step(synth.make_inputs(cfg, batch, seed),
+                                            synth.make_labels(loss_kind, batch, nout, seed), arch, p,
+                                            cw, cb, cfg, loss_kind, training=True, attn_drop=0.0)
+    assert_close_scaled('logits', logits, ologits)
+    assert_close_scaled('loss', loss, oloss)
+    for k, v in net.named_parameters():
+        if k.endswith('conv.bias'):
+            assert float(v.grad.abs().max()) < 1e-4, k
+        else:
+            assert_close_scaled('grad:' + k, v.grad, ograds[k], rel=3e-4)
+    for i, a in enumerate(net.arch_parameters()):
+        assert_close_scaled(f'grad:arch.{i}', a.grad, ograds[f'arch.{i}'], rel=3e-4)
+    for i, x in enumerate(xs):
+        assert_close_scaled(f'grad:input.{i}', x.grad, ograds[f'input.{i}'], rel=3e-4)
+    for k, v in net.state_dict().items():
+        if fo.is_buffer(k):
+            assert_close_scaled('buf:' + k, v.float(), p[k].float())
+    # genotype parity on the same arch parameters
+    got = fo.genotype_to_jsonable(net.genotype())
+    assert got == fo.genotype_to_jsonable(fo.network_genotype(arch, cfg))
+
+
+@pytest.mark.parametrize('path', golden_files('found_*.npz'), ids=case_id)
+def test_found_network_matches_reference_golden(path):
+    meta, z = load_npz(path)
+    cfg = cfg_of(meta)
+    g = fo.genotype_from_jsonable(meta['genotype'])
+    seed, batch = meta['seed'], meta['batch']
+    net = build_found_net(cfg, g, seed, meta['mode'])
+    xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, seed)]
+    with torch.set_grad_enabled(meta['has_grads']):
+        feat = net(xs)
+    assert_close_scaled('feat', feat, z['feat'])
+    if meta['has_grads']:
+        w = torch.from_numpy(np.random.Generator(np.random.PCG64(seed))
+                             .standard_normal(tuple(feat.shape)).astype(np.float32)).to(dev())
+        (feat * w).sum().backward()
+        params = dict(net.named_parameters())
+        for k in z.files:
+            if k.startswith('grad:input.'):
+                x = xs[int(k.split('.')[-1])]
+                got = x.grad if x.grad is not None else torch.zeros_like(x)
+                assert_close_scaled(k, got, z[k], rel=2e-4)
+            elif k.startswith('grad:'):
+                t = params[k[5:]]
+                got = t.grad if t.grad is not None else torch.zeros_like(t)
+                if k.endswith('conv.bias') and meta['mode'] != 'eval':
+                    assert float(got.abs().max()) < 1e-4, k
+                else:
+                    assert_close_scaled(k, got, z[k], rel=2e-4)
+    for k, v in net.state_dict().items():
+        if fo.is_buffer(k):
+            assert_close_scaled('buf:' + k, v.float(), z['buf:' + k])
+
+
+@pytest.mark.parametrize('path', golden_files('traj_*.npz'), ids=case_id)
+def test_search_trajectory_matches_reference_golden(path):
+    """3 iterations of w-step + Architect.step with stock torch.optim.Adam on the product
+    modules reproduce the reference's logits, arch parameters and weights."""
+    from models.search.darts.architect import Architect
+    from models.search.darts.model_search import FusionNetwork
+    meta, z = load_npz(path)
+    cfg = cfg_of(meta)
+    seed, batch, nout, iters = meta['seed'], meta['batch'], meta['num_outputs'], meta['iters']
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fusion_net = FusionNetwork(cfg.S, cfg.M, cfg.N, 2, Args(cfg), criterion=None)
+            self.central_classifier = torch.nn.Linear(cfg.M * cfg.C * cfg.L, nout)
+
+        def forward(self, xs):
+            return self.central_classifier(self.fusion_net(list(xs)))
+
+        def arch_parameters(self):
+            return self.fusion_net.arch_parameters()
+
+    model = Net()
+    model.fusion_net.load_state_dict(synth.make_params(cfg, seed))
+    for dst, src in zip(model.arch_parameters(), synth.make_arch(cfg, seed, 1e-3)):
+        dst.data.copy_(src)
+    cw, cb = synth.make_classifier(cfg, nout, seed)
+    model.central_classifier.weight.data.copy_(cw)
+    model.central_classifier.bias.data.copy_(cb)
+    crit = torch.nn.BCEWithLogitsLoss() if meta['loss'] == 'bce' else torch.nn.CrossEntropyLoss()
+    # optimizers created BEFORE .to(device), like the reference's train_darts_model
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    aopt = torch.optim.Adam(model.arch_parameters(), lr=3e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    model.to(dev())
+    set_mode(model, 'train_nodrop')
+    architect = Architect(model, Args(cfg), crit, aopt)
+    for it in range(iters):
+        xs = [x.to(dev()) for x in synth.make_inputs(cfg, batch, seed + 10 * it)]
+        y = synth.make_labels(meta['loss'], batch, nout, seed + 10 * it).to(dev())
+        opt.zero_grad()
+        logits = model(xs)
+        crit(logits, y).backward()
+        opt.step()
+        assert_close_scaled(f'train_logits.{it}', logits, z[f'train_logits.{it}'], rel=5e-4)
+        xv = [x.to(dev()) for x in synth.make_inputs(cfg, batch, seed + 10 * it + 5)]
+        yv = synth.make_labels(meta['loss'], batch, nout, seed + 10 * it + 5).to(dev())
+        architect.step(xv, yv, None)
+        with torch.no_grad():
+            assert_close_scaled(f'dev_logits.{it}', model(xv), z[f'dev_logits.{it}'], rel=5e-4)
+    for i, a in enumerate(model.arch_parameters()):
+        assert a.is_cuda
+        assert_close_scaled(f'arch.{i}', a, z[f'arch.{i}'], rel=5e-4)
+    assert fo.genotype_to_jsonable(model.fusion_net.genotype()) == json.loads(str(z['genotype']))
