@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""bench.py — search-steps/s of the BM-NAS fusion hypernet (fwd + bwd) on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + loss + backward of FusionNetwork + central_classifier on one batch of
+synthetic MM-IMDB-shaped features (6 x (128, 192, 16) fp32 = relu(N(0,1)), 23-way multi-hot
+labels, BCEWithLogits), gradients for every weight, alpha/beta/gamma and the 6 inputs, train
+mode, dropout on — BASELINE.json configs[1] (batch 128 on one MI355X).  Inputs are resident
+in HBM before the timed region.  With N > 1 every rank processes its own 128-sample batch
+(weak scaling, configs[2] = 1024 over 8 GPUs) and the timed step also averages the weight
+and architecture gradients with one flat RCCL all-reduce each; value = N*K / max-rank time.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, live HIP-event
+timing in an instrumented eager pass of the same steps), "roofline_kernels" (all kernels),
+"cpu_baseline" (the CPU oracle — a port of the reference — timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'bm-nas_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA
+
+CONFIGS = {
+    # N, C, L, steps, multiplier, node_steps, node_multiplier, drpt, num_outputs, loss
+    'mmimdb': dict(N=6, C=192, L=16, S=2, M=2, ns=1, nm=1, drpt=0.1, nout=23, loss='bce'),
+    'ntu': dict(N=8, C=128, L=8, S=2, M=2, ns=2, nm=2, drpt=0.2, nout=60, loss='ce'),
+    'ego': dict(N=8, C=128, L=8, S=2, M=2, ns=3, nm=3, drpt=0.0, nout=83, loss='ce'),
+}
+
+
+class Args:
+    pass
+
+
+def make_args(c):
+    a = Args()
+    a.C, a.L, a.drpt = c['C'], c['L'], c['drpt']
+    a.num_input_nodes, a.num_keep_edges = c['N'], 2
+    a.node_steps, a.node_multiplier = c['ns'], c['nm']
+    a.steps, a.multiplier = c['S'], c['M']
+    a.parallel = False
+    a.weight_decay = 1e-4
+    return a
+
+
+class HyperNet(torch.nn.Module):
+    """fusion_net + central_classifier, wired like Searchable_* minus backbones/reshape layers."""
+
+    def __init__(self, c):
+        super().__init__()
+        from models.search.darts.model_search import FusionNetwork
+        self.fusion_net = FusionNetwork(c['S'], c['M'], c['N'], 2, make_args(c), criterion=None)
+        self.central_classifier = torch.nn.Linear(c['M'] * c['C'] * c['L'], c['nout'])
+
+    def forward(self, xs):
+        return self.central_classifier(self.fusion_net(xs))
+
+    def arch_parameters(self):
+        return self.fusion_net.arch_parameters()
+
+
+def synth_batch(c, batch, device, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    xs = [torch.relu(torch.randn(batch, c['C'], c['L'], generator=g)).to(device).requires_grad_(True)
+          for _ in range(c['N'])]
+    if c['loss'] == 'bce':
+        y = (torch.rand(batch, c['nout'], generator=g) < 0.2).float().to(device)
+    else:
+        y = torch.randint(0, c['nout'], (batch,), generator=g).to(device)
+    return xs, y
+
+
+def algo_table(C, L):
+    """wrapper name -> (bound, algorithmic units of one launch); SURVEY.md section 8(d)."""
+    T = lambda t: t.numel() * 4
+    return {
+        'mixsum_fwd': lambda xs, w, ws, out: ('hbm', (len(xs) + 1) * T(out)),
+        'mixsum_bwd': lambda xs, dxs, w, ws, g, dw, m: ('hbm', (2 * len(xs) + 1) * T(g)),
+        'cat_ln_fwd': lambda srcs, resid, w, b_, out, st, b, Cc, L_, relu:
+            ('hbm', (len(srcs) + (1 if resid is not None else 0)) * T(srcs[0]) + T(out) + 2 * T(w)),
+        'cat_ln_bwd': lambda g, srcs, resid, w, b_, st, ds, dr, m, dw, db, b, Cc, L_, relu:
+            ('hbm', T(g) + (2 * len(srcs) + (2 if resid is not None else 0)) * T(srcs[0]) + 4 * T(w)),
+        'sdpa_ln_fwd': lambda x, y, w, b_, out, st, b, Cc, L_, d:
+            ('hbm', (2 if x.data_ptr() == y.data_ptr() else 3) * T(x) + 2 * T(w)),
+        'sdpa_ln_bwd': lambda g, gs, x, y, w, st, dx, dy, m, dw, db, b, Cc, L_, d:
+            ('hbm', (3 if dy is None else 5) * T(x) + 3 * T(w)),
+        'conv1x1_fwd': lambda srcs, Cs, W, ldw, bias, U, part, b, L_, M:
+            ('mfma', 2.0 * M * len(srcs) * Cs * b * L_),
+        'conv1x1_bwd_data': lambda dU, W, ldw, ds, Cs, m, b, L_, M:
+            ('mfma', 2.0 * M * len(ds) * Cs * b * L_),
+        'conv1x1_bwd_weight': lambda dU, srcs, Cs, dW, ldw, db, dup, b, L_, M:
+            ('mfma', 2.0 * M * len(srcs) * Cs * b * L_),
+        'node_mix_fwd': lambda x, y, p1, U, ch, gm, out, b, Cc, L_, d1, d2: ('hbm', T(U) + 3 * T(out)),
+        'node_mix_bwd': lambda g, x, y, p1, U, ch, gm, dg, dx, dy, m, dV, bg, b, Cc, L_, d1, d2:
+            ('hbm', 2 * T(U) + 4 * T(g)),
+        'bn_relu_fwd': lambda U, ch, out, b, M, L_, d: ('hbm', 2 * T(U)),
+        'bn_relu_bwd': lambda g, U, ch, dV, bg, b, M, L_, d: ('hbm', 3 * T(U)),
+        'bn_bwd_apply': lambda dV, U, ch, bg, b, M, L_, tr: ('hbm', 3 * T(U)),
+        'fold_weight': lambda W, We, M, Cc: ('hbm', T(W) + T(We)),
+    }
+
+
+def cpu_baseline(cname, c, batch, max_seconds=20.0):
+    """The CPU oracle (a port of the reference's path: same aten op sequence, pinned against
+    the reference by tests/golden) on this host's cores; same synthetic batch, dropout on."""
+    from oracle import fusion_oracle as fo, synth
+    cfg = fo.CONFIGS[cname]
+    torch.set_num_threads(os.cpu_count() or 1)
+    p = synth.make_params(cfg, 2)
+    arch = synth.make_arch(cfg, 2, 1e-3)
+    cw, cb = synth.make_classifier(cfg, c['nout'], 2)
+    xs = synth.make_inputs(cfg, batch, 0)
+    y = synth.make_labels(c['loss'], batch, c['nout'], 0)
+    times = []
+    t_start = time.time()
+    for i in range(45):
+        t0 = time.perf_counter()
+        fo.search_step(xs, y, arch, p, cw, cb, cfg, c['loss'], training=True)
+        times.append(time.perf_counter() - t0)
+        if time.time() - t_start > max_seconds and len(times) >= 8:
+            break
+    timed = times[5:] if len(times) > 8 else times[1:]
+    med = statistics.median(timed)
+    return {'value': round(1.0 / med, 3), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'ms_per_step': round(med * 1e3, 3),
+            'samples_per_s': round(batch / med, 1),
+            'sample': f'{len(timed)} timed fwd+bwd steps (after {len(times) - len(timed)} warm-up) of the '
+                      f'same {cname} batch-{batch} synthetic workload, torch CPU fp32, median'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', default='mmimdb', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
+    ap.add_argument('--mode', default='graph', choices=['graph', 'eager'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    from bmnas import dist as bdist
+    from bmnas import lib
+    rank, local, world = bdist.init_from_env('nccl')
+    if world != a.gpus and world > 1:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    lib.load()                                   # fail loudly if the HIP library is missing
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    c = CONFIGS[a.config]
+
+    torch.manual_seed(2)                         # the mains' default --seed 2
+    model = HyperNet(c).to(device).train()
+    crit = torch.nn.BCEWithLogitsLoss() if c['loss'] == 'bce' else torch.nn.CrossEntropyLoss()
+    xs, y = synth_batch(c, a.batch, device, seed=rank)
+    params = [p for p in model.parameters()]
+    arch = list(model.arch_parameters())
+    leaves = params + arch + xs
+
+    def log(msg):
+        if rank == 0:
+            print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        loss = crit(model(xs), y)
+        loss.backward()
+        return loss
+
+    def step_for_capture():
+        # same work as step(); gradients are taken with autograd.grad (no AccumulateGrad nodes,
+        # whose streams are pinned at creation and do not follow the capture stream) and then
+        # attached as .grad — the tensors are static, replays refresh them in place
+        loss = crit(model(xs), y)
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        for t, g in zip(leaves, grads):
+            t.grad = g
+        return loss
+
+    if world > 1:
+        bdist.broadcast_state(model, arch)
+        red_w = bdist.FlatGradAllReducer(params)
+        red_a = bdist.FlatGradAllReducer(arch)
+
+    eager_ms = None
+    if a.mode == 'graph':
+        # short eager measurement for reference, then capture
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / 10 * 1e3
+        from bmnas.graph import GraphedStep
+        log(f'eager {eager_ms:.3f} ms/step; capturing hipGraph')
+        graphed = GraphedStep(step_for_capture)
+        log('captured')
+        run_local = graphed.replay
+    else:
+        run_local = step
+
+    def run():
+        run_local()
+        if world > 1:
+            red_w()
+            red_a()
+
+    for _ in range(a.warmup):
+        run()
+    log('warm-up done')
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = {
+        'metric': 'search-steps/sec (fwd+bwd of fusion hypernet) on MM-IMDB synthetic'
+                  if a.config == 'mmimdb' else f'search-steps/sec (fwd+bwd of fusion hypernet) on {a.config} synthetic',
+        'value': round(world * a.steps / dt, 3),
+        'unit': 'steps/s',
+        'n_gpus': world,
+        'steps': a.steps,
+        'warmup': a.warmup,
+        'ms_per_step': round(dt / a.steps * 1e3, 4),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'{a.config} fusion search, batch {a.batch} per GPU x {world} GPU(s), '
+                               f'N{c["N"]} C{c["C"]} L{c["L"]} steps{c["S"]} node_steps{c["ns"]} '
+                               f'node_multiplier{c["nm"]}, train mode, dropout {c["drpt"]}/0.1(attn)',
+                   'global_batch': a.batch * world, 'per_gpu_batch': a.batch,
+                   'parallelism': f'dp{world}', 'mode': a.mode,
+                   'step': 'fwd+bwd (+ flat RCCL all-reduce of w- and arch-grads when n_gpus > 1)'},
+        'samples_per_s': round(world * a.steps * a.batch / dt, 1),
+    }
+    if eager_ms is not None:
+        result['eager_ms_per_step'] = round(eager_ms, 4)
+
+    log(f'timed region done: {dt / a.steps * 1e3:.4f} ms/step')
+    if rank == 0 and not a.no_roofline:
+        # instrumented eager pass: HIP events on the launch stream around every kernel call
+        n_prof = min(a.steps, 20)
+        for _ in range(2):
+            step()
+        lib.profile_begin(algo_table(c['C'], c['L']))
+        for _ in range(n_prof):
+            step()
+        recs = lib.profile_end()
+        rows = []
+        for name, rr in recs.items():
+            tot_ms = sum(r[0] for r in rr)
+            units = sum(r[2] for r in rr)
+            bound = rr[0][1]
+            per_launch_us = tot_ms / len(rr) * 1e3
+            if bound == 'hbm':
+                achieved = units / (tot_ms * 1e-3) / 1e9
+                peak, unit = HBM_PEAK_GBS, 'GB/s'
+            else:
+                achieved = units / (tot_ms * 1e-3) / 1e12
+                peak, unit = MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
+            rows.append({'kernel': name, 'bound': bound, 'achieved': round(achieved, 2), 'peak': peak,
+                         'unit': unit, 'frac': round(achieved / peak, 4), 'traffic': None,
+                         'launches_per_step': len(rr) / n_prof, 'avg_us': round(per_launch_us, 2),
+                         'us_per_step': round(tot_ms / n_prof * 1e3, 2)})
+        rows.sort(key=lambda r: -r['us_per_step'])
+        if rows:
+            top = dict(rows[0])
+            top['measured'] = (f'HIP events on the launch stream, instrumented eager pass of {n_prof} steps '
+                               'after the timed region; avg per launch')
+            result['roofline'] = top
+            result['roofline_kernels'] = rows
+    log('roofline pass done')
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        result['cpu_baseline'] = cpu_baseline(a.config, c, a.batch)
+        result['speedup_vs_cpu_baseline'] = round(result['value'] / result['cpu_baseline']['value'], 1)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -18,15 +18,20 @@ ATTN_DROP = 0.1     # ScaledDotAttn's hard-coded nn.Dropout(0.1) (node_operation
 # ------------------------------------------------------------------------ dropout state
 class _DropState:
     """Counter-based dropout bookkeeping: seed = torch.initial_seed(), offset advances with
-    every dropout site so masks never repeat; the backward reuses the saved descriptor."""
+    every dropout site so masks never repeat; the backward reuses the saved descriptor.
+    Under hipGraph capture (bmnas.graph) the offsets restart at 0 inside the captured
+    region and a DEVICE counter, advanced by the graph itself, is added at run time."""
 
     def __init__(self):
         self.offset = 0
+        self.device_counter = None       # int64 cuda tensor while capturing / replaying
 
     def make(self, p, numel, training):
         if not training or p <= 0.0:
             return lib.NO_DROP
-        d = lib.make_dropout(p, torch.initial_seed(), self.offset)
+        ctr = self.device_counter
+        d = lib.make_dropout(p, torch.initial_seed(), self.offset,
+                             None if ctr is None else ctr.data_ptr())
         self.offset += (numel + 3) // 4
         return d
 

@@ -22,10 +22,10 @@ class BmnasError(RuntimeError):
 class Dropout(C.Structure):
     """bmnas_dropout_t"""
     _fields_ = [('thr', C.c_uint32), ('scale', C.c_float), ('seed', C.c_uint64),
-                ('offset', C.c_uint64)]
+                ('offset', C.c_uint64), ('step', C.c_void_p)]
 
 
-NO_DROP = Dropout(0, 1.0, 0, 0)
+NO_DROP = Dropout(0, 1.0, 0, 0, None)
 
 _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
@@ -108,8 +108,9 @@ def version():
     return load().bmnas_version()
 
 
-def make_dropout(p, seed, offset):
-    """thr = p * 2^32; p == 0 (or eval) -> NO_DROP."""
+def make_dropout(p, seed, offset, step_ptr=None):
+    """thr = p * 2^32; p == 0 (or eval) -> NO_DROP.  step_ptr: device address of a uint64
+    counter added to the offset at run time (None: host-side offsets only)."""
     if p <= 0.0:
         return NO_DROP
     if p >= 1.0:
@@ -118,7 +119,7 @@ def make_dropout(p, seed, offset):
     if thr <= 0:
         return NO_DROP
     return Dropout(min(thr, 0xFFFFFFFF), 1.0 / (1.0 - p), seed & 0xFFFFFFFFFFFFFFFF,
-                   offset & 0xFFFFFFFFFFFFFFFF)
+                   offset & 0xFFFFFFFFFFFFFFFF, step_ptr)
 
 
 # ------------------------------------------------------------------------- wrappers
@@ -236,3 +237,51 @@ def arch_softmax_fwd(logits, w, rows, cols):
 def arch_softmax_bwd(w, dw, dlogits, rows, cols):
     _check(load().bmnas_arch_softmax_bwd(w.data_ptr(), dw.data_ptr(), dlogits.data_ptr(), rows, cols,
                                          _stream()), 'arch_softmax_bwd')
+
+
+# ----------------------------------------------------------------- optional kernel timing
+# bench.py brackets selected wrappers with HIP events on the launch stream (torch's current
+# stream, the one the kernels are enqueued on) to measure per-kernel durations live.
+_PROF = None
+
+
+def profile_begin(algo):
+    """algo: {wrapper name: fn(*args) -> (bound, units)} with bound in {'hbm', 'mfma'} and
+    units = algorithmic bytes / flops of that launch.  Only the named wrappers are timed."""
+    global _PROF
+    _PROF = {'algo': algo, 'records': {}}
+
+
+def profile_end():
+    """-> {name: [(ms, bound, units), ...]} (synchronises)."""
+    global _PROF
+    prof, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in prof['records'].items():
+        out[name] = [(s.elapsed_time(e), bound, units) for s, e, bound, units in recs]
+    return out
+
+
+def _timed(name, fn):
+    def wrapper(*a, **k):
+        prof = _PROF
+        if prof is None or name not in prof['algo']:
+            return fn(*a, **k)
+        bound, units = prof['algo'][name](*a, **k)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn(*a, **k)
+        e.record()
+        prof['records'].setdefault(name, []).append((s, e, bound, units))
+        return r
+    wrapper.__name__ = name
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
+for _n in ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'sdpa_ln_fwd', 'sdpa_ln_bwd',
+           'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight', 'fold_weight', 'bn_finalize',
+           'node_mix_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd', 'bn_relu_fwd', 'bn_relu_bwd',
+           'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd'):
+    globals()[_n] = _timed(_n, globals()[_n])

@@ -372,7 +372,7 @@ inline int stream_grid(int64_t total) {
 
 inline DropCfg to_cfg(const bmnas_dropout_t& d) {
   DropCfg c;
-  c.thr = d.thr; c.scale = d.scale; c.seed = d.seed; c.offset = d.offset;
+  c.thr = d.thr; c.scale = d.scale; c.seed = d.seed; c.offset = d.offset; c.step = d.step;
   return c;
 }
 

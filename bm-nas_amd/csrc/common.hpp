@@ -19,6 +19,7 @@ struct DropCfg {
   float scale;
   uint64_t seed;
   uint64_t offset;
+  const uint64_t* step;   // device counter added to offset (hipGraph replays), nullable
 };
 
 #define BMNAS_CHECK_LAUNCH()                         \
@@ -44,7 +45,8 @@ __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
 // mask*scale multipliers for the float4 starting at flat element index e (e % 4 == 0)
 __device__ __forceinline__ float4 drop_mult4(const DropCfg& d, uint64_t e) {
   if (d.thr == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);
-  uint4 r = philox4x32_10(d.offset + (e >> 2), d.seed);
+  const uint64_t base = (d.step != nullptr) ? d.step[0] : 0ull;
+  uint4 r = philox4x32_10(base + d.offset + (e >> 2), d.seed);
   return make_float4(r.x >= d.thr ? d.scale : 0.f, r.y >= d.thr ? d.scale : 0.f,
                      r.z >= d.thr ? d.scale : 0.f, r.w >= d.thr ? d.scale : 0.f);
 }

@@ -282,7 +282,7 @@ inline int geom(int b, int C, int L, SdpaGeom* G) {
 
 inline DropCfg to_cfg(const bmnas_dropout_t& d) {
   DropCfg c;
-  c.thr = d.thr; c.scale = d.scale; c.seed = d.seed; c.offset = d.offset;
+  c.thr = d.thr; c.scale = d.scale; c.seed = d.seed; c.offset = d.offset; c.step = d.step;
   return c;
 }
 

@@ -38,7 +38,9 @@ extern "C" {
 #define BMNAS_E_LIMIT (-3)    /* too many pointers / LDS budget exceeded                 */
 
 /* Dropout descriptor: Philox4x32-10 counter RNG, element e of a tensor is kept iff
- * philox(seed, offset + e/4)[e%4] >= thr (thr = p * 2^32), and scaled by `scale` = 1/(1-p).
+ * philox(seed, base + offset + e/4)[e%4] >= thr (thr = p * 2^32), and scaled by
+ * `scale` = 1/(1-p); base = *step if step != NULL else 0.  `step` is a DEVICE counter so a
+ * captured hipGraph draws fresh masks on every replay (the graph itself advances it).
  * thr == 0 means identity (eval mode, or p == 0).  The backward call passes the SAME
  * descriptor and regenerates the mask — no mask tensor is stored.  Replaces nn.Dropout
  * at node_operations.py:27,38 / :46,55 / :89,105 and node_search.py:42,64. */
@@ -47,6 +49,7 @@ typedef struct {
   float scale;
   uint64_t seed;
   uint64_t offset;
+  const uint64_t* step;
 } bmnas_dropout_t;
 
 int bmnas_version(void);
