@@ -130,9 +130,12 @@ def mixsum_fwd(xs, w_row0, w_stride=2):
     return out
 
 
-def mixsum_bwd(xs, slots, w_row0, g, dw_row0, w_stride=2):
+ARCH_SHARDS = 16    # copies of the arch-weight gradient buffers (atomic contention spreading)
+
+
+def mixsum_bwd(xs, slots, w_row0, g, dw_row0, w_stride=2, shards=1, shard_stride=0):
     bufs, mask = _write_group(slots)
-    lib.mixsum_bwd(xs, bufs, w_row0, w_stride, g, dw_row0, mask)
+    lib.mixsum_bwd(xs, bufs, w_row0, w_stride, g, dw_row0, mask, shards, shard_stride)
 
 
 # -------------------------------------------------------------------- conv + BatchNorm
@@ -205,8 +208,9 @@ def node_mixed_fwd(x, y, gamma_row, P, training):
     # attention branch
     sv.d_attn = DROP.make(P.attn_p, x.numel(), training)
     p1 = torch.empty_like(x)
+    sv.xhat1 = torch.empty_like(x)
     sv.stats1 = _empty(x, b * 2)
-    lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.stats1, b, C, L, sv.d_attn)
+    lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, b, C, L, sv.d_attn)
     sv.p1 = p1
     # stacked [LinearGLU | ConcatFC] conv + BN
     if same:
@@ -224,6 +228,12 @@ def node_mixed_fwd(x, y, gamma_row, P, training):
     return out, sv
 
 
+def _attn_affine_bwd(sv, g, G):
+    b, C, L = sv.x.shape
+    lib.ln_affine_bwd(g, sv.gamma[1:2], [sv.xhat1], None, None, None, None, G.dln_w, G.dln_b, b, C, L,
+                      False, True)
+
+
 def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G):
     """g: grad of the mixed output.  dgamma_row (4 floats, +=), x_slot / y_slot: GradSlots
     (y_slot None when x is y).  G: gradient pack (stack_dW, stack_dbias, stack_bn_grad,
@@ -238,16 +248,17 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G):
         lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
                          dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc)
         conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias)
-        lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.stats1, dxb, None, 1, G.dln_w, G.dln_b,
-                        b, C, L, sv.d_attn)
+        lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, None, 1, b, C, L,
+                        sv.d_attn)
     else:
         dxb, dyb = x_slot.buf(), y_slot.buf()
         acc = x_slot.acc_bit() | (y_slot.acc_bit() << 1)
         lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, dyb, acc,
                          dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc)
         conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot, y_slot], G.stack_dW, G.stack_dbias)
-        lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.stats1, dxb, dyb, 3, G.dln_w, G.dln_b,
-                        b, C, L, sv.d_attn)
+        lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, dyb, 3, b, C, L,
+                        sv.d_attn)
+    _attn_affine_bwd(sv, g, G)
 
 
 # ------------------------------------------------------------------- search-mode NodeCell
@@ -305,7 +316,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG):
         bufs, mask = _write_group([d_o])
         racc = x_slot.acc_bit()
         lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
-                       mask | (racc << 31), NG.dln_w, NG.dln_b, b, C, L, False)
+                       mask | (racc << 31), None, None, b, C, L, False)
         dV = _empty(x, b, C, L)
         lib.bn_relu_bwd(d_o.buf(), sv.oconv.U, sv.oconv.chan, dV, NG.bn_grad, b, C, L, sv.d_out)
         conv_bn_bwd(sv.oconv, dV, NG.bn_grad, [slots[j] for j in tail],
@@ -314,7 +325,9 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG):
         bufs, mask = _write_group([slots[tail[0]]])
         racc = x_slot.acc_bit()
         lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
-                       mask | (racc << 31), NG.dln_w, NG.dln_b, b, C, L, False)
+                       mask | (racc << 31), None, None, b, C, L, False)
+    lib.ln_affine_bwd(g, None, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, NG.dln_w, NG.dln_b, b, C, L,
+                      False, False)
     for t in reversed(range(ns)):
         gs = slots[2 + t].get()
         if gs is None:
@@ -324,7 +337,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG):
         off = sv.offsets[t]
         n_in = 2 + t
         mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.beta_w[off:, 1], z_slot.buf(),
-                   dbeta_w[off:, 1])
+                   dbeta_w[off:, 1], 2, NG.shards, NG.shard_stride)
 
 
 # ------------------------------------------------------------------- search-mode FusionCell
@@ -366,8 +379,10 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
     slots = [GradSlot(x0) if (j >= N or need_input_grads[j]) else None for j in range(N + S)]
     tail = slots[-M:]
     bufs, mask = _write_group(tail)
-    lib.cat_ln_bwd(g, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, bufs, None, mask, CG.dln_w,
-                   CG.dln_b, b, C, L, True)
+    lib.cat_ln_bwd(g, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, bufs, None, mask, None, None,
+                   b, C, L, True)
+    lib.ln_affine_bwd(g, None, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, CG.dln_w, CG.dln_b,
+                      b, C, L, True, False)
     for i in reversed(range(S)):
         gn = slots[N + i].get()
         if gn is None:
@@ -377,5 +392,5 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
         off = sv.offsets[i]
         n_in = N + i
         mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
-                   dalpha_w[off:, 1])
+                   dalpha_w[off:, 1], 2, CG.shards, CG.shard_stride)
     return [s.get() if s is not None else None for s in slots[:N]]

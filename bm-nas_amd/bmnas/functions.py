@@ -108,7 +108,9 @@ class CatLnFn(Function):
         dres = torch.empty_like(resid) if (resid is not None and ctx.needs_input_grad[3]) else None
         dw = torch.zeros_like(ctx.lw)
         db = torch.zeros_like(ctx.lb)
-        lib.cat_ln_bwd(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dsrcs, dres, 0, dw, db, b, C, L, ctx.relu)
+        lib.cat_ln_bwd(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dsrcs, dres, 0, None, None, b, C, L,
+                       ctx.relu)
+        lib.ln_affine_bwd(g, None, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, ctx.relu, False)
         return (None, dw, db, dres, *dsrcs)
 
 
@@ -125,8 +127,9 @@ class SdpaLnFn(Function):
         stats = torch.empty(b * 2, device=x.device, dtype=torch.float32)
         drop = K.DROP.make(p, x.numel(), training)
         lw, lb = _c(ln_w), _c(ln_b)
-        lib.sdpa_ln_fwd(x, y, lw, lb, out, stats, b, C, L, drop)
-        ctx.x, ctx.y, ctx.lw, ctx.stats, ctx.drop = x, y, lw, stats, drop
+        xhat = torch.empty_like(x)
+        lib.sdpa_ln_fwd(x, y, lw, lb, out, xhat, stats, b, C, L, drop)
+        ctx.x, ctx.y, ctx.lw, ctx.stats, ctx.drop, ctx.xhat = x, y, lw, stats, drop, xhat
         return out
 
     @staticmethod
@@ -135,7 +138,9 @@ class SdpaLnFn(Function):
         b, C, L = x.shape
         dx, dy = torch.empty_like(x), torch.empty_like(y)
         dw, db = torch.zeros_like(ctx.lw), torch.zeros_like(ctx.lw)
-        lib.sdpa_ln_bwd(_c(g), None, x, y, ctx.lw, ctx.stats, dx, dy, 0, dw, db, b, C, L, ctx.drop)
+        g = _c(g)
+        lib.sdpa_ln_bwd(g, None, x, y, ctx.lw, ctx.xhat, ctx.stats, dx, dy, 0, b, C, L, ctx.drop)
+        lib.ln_affine_bwd(g, None, [ctx.xhat], None, None, None, None, dw, db, b, C, L, False, True)
         return dx, dy, dw, db, None, None
 
 
@@ -228,22 +233,24 @@ class FusedCellFn(Function):
     the whole cell — mixed edges, step nodes, LayerNorm tail — as one autograd node."""
 
     @staticmethod
-    def forward(ctx, cell, training, alpha_w, *tensors):
+    def forward(ctx, cell, training, alpha_is_logits, alpha, *tensors):
         N, S = cell.num_input_nodes, cell._steps
         xs = [_c(_f32(t)) for t in tensors[:N]]
         _require_gpu(xs[0], 'FusionCell')
-        arch = tensors[N:N + 2 * S]
         dev = xs[0].device
-        beta_ws, gamma_ws = [], []
-        for i in range(S):
-            bt, gm = _c(arch[2 * i]), _c(arch[2 * i + 1])
-            bw, gw = torch.empty_like(bt), torch.empty_like(gm)
-            lib.arch_softmax_fwd(bt, bw, bt.shape[0], bt.shape[1])
-            lib.arch_softmax_fwd(gm, gw, gm.shape[0], gm.shape[1])
-            beta_ws.append(bw)
-            gamma_ws.append(gw)
+        logits = [_c(t) for t in tensors[N:N + 2 * S]]
+        if alpha_is_logits:
+            logits = [_c(alpha)] + logits
+        ws = [torch.empty_like(t) for t in logits]
+        lib.arch_softmax_multi(logits, None, ws, False)          # every arch tensor, one launch
+        if alpha_is_logits:
+            alpha_w, ws = ws[0], ws[1:]
+        else:
+            alpha_w = _c(alpha)
+        beta_ws, gamma_ws = ws[0::2], ws[1::2]
+        ctx.alpha_is_logits = alpha_is_logits
         CP = cell.pack()
-        out, sv = K.fusion_cell_fwd(xs, _c(alpha_w), beta_ws, gamma_ws, CP, training, S,
+        out, sv = K.fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S,
                                     cell._multiplier, cell.args.node_steps, cell.args.node_multiplier)
         ctx.cell, ctx.sv, ctx.beta_ws, ctx.gamma_ws, ctx.N, ctx.S = cell, sv, beta_ws, gamma_ws, N, S
         ctx.dev = dev
@@ -253,15 +260,20 @@ class FusedCellFn(Function):
     def backward(ctx, g):
         cell, sv, N, S = ctx.cell, ctx.sv, ctx.N, ctx.S
         dev = ctx.dev
-        need_in = [ctx.needs_input_grad[3 + j] for j in range(N)]
+        need_in = [ctx.needs_input_grad[4 + j] for j in range(N)]
         # one zero-filled arena for every gradient that is accumulated with atomics
         CG, dalpha_w, dbeta_ws, dgamma_ws = cell.grad_pack(dev, sv.alpha_w, ctx.beta_ws, ctx.gamma_ws)
         dxs = K.fusion_cell_bwd(sv, _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws, CG)
-        darch = []
+        ws, dws = [], []
         for i in range(S):
-            bw, gw = ctx.beta_ws[i], ctx.gamma_ws[i]
-            db, dg = torch.empty_like(bw), torch.empty_like(gw)
-            lib.arch_softmax_bwd(bw, dbeta_ws[i], db, bw.shape[0], bw.shape[1])
-            lib.arch_softmax_bwd(gw, dgamma_ws[i], dg, gw.shape[0], gw.shape[1])
-            darch += [db, dg]
-        return (None, None, dalpha_w, *dxs, *darch, *cell.grads_in_param_order(CG))
+            ws += [ctx.beta_ws[i], ctx.gamma_ws[i]]
+            dws += [dbeta_ws[i], dgamma_ws[i]]
+        if ctx.alpha_is_logits:
+            ws, dws = [sv.alpha_w] + ws, [dalpha_w] + dws
+        darch = [torch.empty_like(w) for w in ws]
+        lib.arch_softmax_multi(ws, dws, darch, True, CG.shards, CG.shard_stride)
+        if ctx.alpha_is_logits:
+            dalpha, darch = darch[0], darch[1:]
+        else:
+            dalpha = dalpha_w
+        return (None, None, None, dalpha, *dxs, *darch, *cell.grads_in_param_order(CG))

@@ -36,11 +36,12 @@ _U32 = C.c_uint32
 SIGNATURES = {
     'bmnas_version': ([], _I),
     'bmnas_mixsum_fwd': ([_PP, _I, _P, _I, _P, _I64, _P], _I),
-    'bmnas_mixsum_bwd': ([_PP, _PP, _I, _P, _I, _P, _P, _U32, _I64, _P], _I),
+    'bmnas_mixsum_bwd': ([_PP, _PP, _I, _P, _I, _P, _P, _I, _I64, _U32, _I64, _P], _I),
     'bmnas_cat_ln_fwd': ([_PP, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_cat_ln_bwd': ([_P, _PP, _I, _P, _P, _P, _P, _PP, _P, _U32, _P, _P, _I, _I, _I, _I, _P], _I),
-    'bmnas_sdpa_ln_fwd': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
-    'bmnas_sdpa_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_ln_affine_bwd': ([_P, _P, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    'bmnas_sdpa_ln_fwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_sdpa_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, _I, _I, Dropout, _P], _I),
     'bmnas_conv1x1_num_partials': ([_I, _I], _I),
     'bmnas_conv1x1_fwd': ([_PP, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P], _I),
     'bmnas_conv1x1_bwd_data': ([_P, _P, _I, _PP, _I, _I, _U32, _I, _I, _I, _P], _I),
@@ -57,6 +58,8 @@ SIGNATURES = {
     'bmnas_bn_bwd_apply': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
+    'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
+                                 _P], _I),
 }
 
 _lib = None
@@ -129,10 +132,10 @@ def mixsum_fwd(xs, w, w_stride, out):
                                    out.numel(), _stream()), 'mixsum_fwd')
 
 
-def mixsum_bwd(xs, dxs, w, w_stride, g, dw, acc_mask):
+def mixsum_bwd(xs, dxs, w, w_stride, g, dw, acc_mask, dw_shards=1, dw_shard_stride=0):
     _check(load().bmnas_mixsum_bwd(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, _ptr(g),
-                                   None if dw is None else dw.data_ptr(), acc_mask, g.numel(),
-                                   _stream()), 'mixsum_bwd')
+                                   None if dw is None else dw.data_ptr(), dw_shards, dw_shard_stride,
+                                   acc_mask, g.numel(), _stream()), 'mixsum_bwd')
 
 
 def cat_ln_fwd(srcs, resid, ln_w, ln_b, out, stats, b, Cc, L, relu):
@@ -146,15 +149,22 @@ def cat_ln_bwd(g, srcs, resid, ln_w, ln_b, stats, dsrcs, dresid, acc_mask, dln_w
                                    _ptr(dln_b), b, Cc, L, int(relu), _stream()), 'cat_ln_bwd')
 
 
-def sdpa_ln_fwd(x, y, ln_w, ln_b, out, stats, b, Cc, L, drop):
-    _check(load().bmnas_sdpa_ln_fwd(_ptr(x), _ptr(y), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(stats),
-                                    b, Cc, L, drop, _stream()), 'sdpa_ln_fwd')
+def ln_affine_bwd(g, gscale, srcs, resid, ln_w, ln_b, stats, dln_w, dln_b, b, Cc, L, relu, prenorm):
+    _check(load().bmnas_ln_affine_bwd(_ptr(g), None if gscale is None else gscale.data_ptr(), _ptrs(srcs),
+                                      len(srcs), _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(stats),
+                                      _ptr(dln_w), _ptr(dln_b), b, Cc, L, int(relu), int(prenorm),
+                                      _stream()), 'ln_affine_bwd')
 
 
-def sdpa_ln_bwd(g, gscale, x, y, ln_w, stats, dx, dy, acc_mask, dln_w, dln_b, b, Cc, L, drop):
+def sdpa_ln_fwd(x, y, ln_w, ln_b, out, xhat, stats, b, Cc, L, drop):
+    _check(load().bmnas_sdpa_ln_fwd(_ptr(x), _ptr(y), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(xhat),
+                                    _ptr(stats), b, Cc, L, drop, _stream()), 'sdpa_ln_fwd')
+
+
+def sdpa_ln_bwd(g, gscale, x, y, ln_w, xhat, stats, dx, dy, acc_mask, b, Cc, L, drop):
     _check(load().bmnas_sdpa_ln_bwd(_ptr(g), None if gscale is None else gscale.data_ptr(), _ptr(x),
-                                    _ptr(y), _ptr(ln_w), _ptr(stats), _ptr(dx), _ptr(dy), acc_mask,
-                                    _ptr(dln_w), _ptr(dln_b), b, Cc, L, drop, _stream()), 'sdpa_ln_bwd')
+                                    _ptr(y), _ptr(ln_w), _ptr(xhat), _ptr(stats), _ptr(dx), _ptr(dy),
+                                    acc_mask, b, Cc, L, drop, _stream()), 'sdpa_ln_bwd')
 
 
 def conv1x1_num_partials(b, L):
@@ -239,6 +249,19 @@ def arch_softmax_bwd(w, dw, dlogits, rows, cols):
                                          _stream()), 'arch_softmax_bwd')
 
 
+def arch_softmax_multi(a_list, dw_list, out_list, backward, n_shards=1, shard_stride=0):
+    """One launch for every architecture tensor (row softmax, or its backward)."""
+    n = len(a_list)
+    rows = (C.c_int * n)(*[t.shape[0] for t in a_list])
+    cols = (C.c_int * n)(*[t.shape[1] for t in a_list])
+    pa = (C.c_void_p * n)(*[t.data_ptr() for t in a_list])
+    po = (C.c_void_p * n)(*[t.data_ptr() for t in out_list])
+    pd = (C.c_void_p * n)(*[t.data_ptr() for t in dw_list]) if backward else None
+    _check(load().bmnas_arch_softmax_multi(pa, pd, po, rows, cols, n, int(backward), n_shards,
+                                           shard_stride, _stream()),
+           'arch_softmax_multi')
+
+
 # ----------------------------------------------------------------- optional kernel timing
 # bench.py brackets selected wrappers with HIP events on the launch stream (torch's current
 # stream, the one the kernels are enqueued on) to measure per-kernel durations live.
@@ -280,7 +303,7 @@ def _timed(name, fn):
     return wrapper
 
 
-for _n in ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'sdpa_ln_fwd', 'sdpa_ln_bwd',
+for _n in ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'sdpa_ln_fwd', 'sdpa_ln_bwd',
            'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight', 'fold_weight', 'bn_finalize',
            'node_mix_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd', 'bn_relu_fwd', 'bn_relu_bwd',
            'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd'):

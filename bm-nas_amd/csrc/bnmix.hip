@@ -19,39 +19,48 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
                                                      float* running_mean, float* running_var,
                                                      int64_t* nbt, int n_nbt, int training,
                                                      float* __restrict__ chan) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
+  // one wavefront per channel: lanes stride over that channel's partials (part[m][p][2]),
+  // Chan's parallel-variance combine, two wave reductions
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   float mean, rstd;
   if (training) {
     const int N = b * L;
+    const float* pm = part + (int64_t)m * n_part * 2;
     float tot = 0.f;
-    for (int p = 0; p < n_part; ++p) tot += part[((int64_t)p * M + m) * 2];
+    for (int p = lane; p < n_part; p += 64) tot += pm[2 * p];
+    tot = wave_sum(tot);
     mean = tot / (float)N;
     float m2 = 0.f;
-    for (int p = 0; p < n_part; ++p) {
+    for (int p = lane; p < n_part; p += 64) {
       int cnt = N - 32 * p;
       cnt = cnt > 32 ? 32 : cnt;
-      const float sp = part[((int64_t)p * M + m) * 2];
-      const float d = sp / (float)cnt - mean;
-      m2 += part[((int64_t)p * M + m) * 2 + 1] + (float)cnt * d * d;
+      const float d = pm[2 * p] / (float)cnt - mean;
+      m2 += pm[2 * p + 1] + (float)cnt * d * d;
     }
+    m2 = wave_sum(m2);
     const float var = m2 / (float)N;
     rstd = 1.f / sqrtf(var + kEps);
-    if (running_mean != nullptr) {
-      running_mean[m] = (1.f - kMomentum) * running_mean[m] + kMomentum * mean;
-      const float unbiased = m2 / (float)(N - 1);
-      running_var[m] = (1.f - kMomentum) * running_var[m] + kMomentum * unbiased;
+    if (lane == 0) {
+      if (running_mean != nullptr) {
+        running_mean[m] = (1.f - kMomentum) * running_mean[m] + kMomentum * mean;
+        const float unbiased = m2 / (float)(N - 1);
+        running_var[m] = (1.f - kMomentum) * running_var[m] + kMomentum * unbiased;
+      }
+      if (m < n_nbt && nbt != nullptr) nbt[m] += 1;
     }
-    if (m < n_nbt && nbt != nullptr) nbt[m] += 1;
   } else {
     mean = running_mean[m];
     rstd = 1.f / sqrtf(running_var[m] + kEps);
   }
-  const float scale = bn_w[m] * rstd;
-  chan[m] = mean;
-  chan[M + m] = rstd;
-  chan[2 * M + m] = scale;
-  chan[3 * M + m] = bn_b[m] - mean * scale;
+  if (lane == 0) {
+    const float scale = bn_w[m] * rstd;
+    chan[m] = mean;
+    chan[M + m] = rstd;
+    chan[2 * M + m] = scale;
+    chan[3 * M + m] = bn_b[m] - mean * scale;
+  }
 }
 
 __device__ __forceinline__ float4 affine4(float4 u, float sc, float sh) {
@@ -101,8 +110,10 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
     float* __restrict__ dV, float* bn_grad, int b, int C, int L, int chunk, DropCfg dglu,
     DropCfg dfc) {
   __shared__ float red[4];
+  __shared__ float csum[3][6][64];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
-  const int r = blockIdx.x * 256 + threadIdx.x;      // float4 slot inside one sample's (C, L) tile
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;   // 64 slots x 4 sample lanes
+  const int r = blockIdx.x * 64 + col;               // float4 slot inside one sample's (C, L) tile
   const bool active = r < cl4;
   const int c = active ? r / l4n : 0;
   const float g0 = gamma[0], g2 = gamma[2], g3 = gamma[3];
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
   int s_end = s_beg + chunk;
   if (s_end > b) s_end = b;
   if (active) {
-    for (int s = s_beg; s < s_end; ++s) {
+    for (int s = s_beg + sl; s < s_end; s += 4) {
       const int64_t e = ((int64_t)s * cl4 + r) * 4;
       const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
       const float4 ua = ld4(U + ub), ug = ld4(U + ub + (int64_t)C * L), uf = ld4(U + ub + (int64_t)2 * C * L);
@@ -167,13 +178,26 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
       }
     }
   }
-  // per-channel batch sums -> BatchNorm affine gradients
+  // per-channel batch sums -> BatchNorm affine gradients: reduce over the l4 lanes of a
+  // channel row (shuffles), over the 4 sample lanes (LDS), then one atomic per channel
+  float cs[6];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float w = row_sum(sw[k], l4n), bb = row_sum(sb[k], l4n);
-    if (active && (r % l4n) == 0) {
-      atomicAdd(bn_grad + k * C + c, w);
-      atomicAdd(bn_grad + M + k * C + c, bb);
+    cs[k] = row_sum(sw[k], l4n);
+    cs[3 + k] = row_sum(sb[k], l4n);
+  }
+  if (sl > 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) csum[sl - 1][k][col] = cs[k];
+  }
+  __syncthreads();
+  if (sl == 0 && active && (r % l4n) == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cs[k] += csum[0][k][col] + csum[1][k][col] + csum[2][k][col];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      atomicAdd(bn_grad + k * C + c, cs[k]);
+      atomicAdd(bn_grad + M + k * C + c, cs[3 + k]);
     }
   }
 #pragma unroll
@@ -209,8 +233,10 @@ __global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
                                                     const float* __restrict__ chan,
                                                     float* __restrict__ dV, float* bn_grad, int b,
                                                     int C, int L, int chunk, DropCfg d) {
+  __shared__ float csum[3][4][64];
   const int cl4 = C * L / 4, l4n = L / 4, M = 2 * C;
-  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + col;
   const bool active = r < cl4;
   const int c = active ? r / l4n : 0;
   float sc[2], sh[2], mu[2], rs[2];
@@ -226,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
   int s_end = s_beg + chunk;
   if (s_end > b) s_end = b;
   if (active) {
-    for (int s = s_beg; s < s_end; ++s) {
+    for (int s = s_beg + sl; s < s_end; s += 4) {
       const int64_t e = ((int64_t)s * cl4 + r) * 4;
       const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
       const float4 ua = ld4(U + ub), ug = ld4(U + ub + (int64_t)C * L), gv = ld4(g + e);
@@ -249,12 +275,24 @@ __global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
       st4(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
     }
   }
+  float cs[4];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const float w = row_sum(sw[k], l4n), bb = row_sum(sb[k], l4n);
-    if (active && (r % l4n) == 0) {
-      atomicAdd(bn_grad + k * C + c, w);
-      atomicAdd(bn_grad + M + k * C + c, bb);
+    cs[k] = row_sum(sw[k], l4n);
+    cs[2 + k] = row_sum(sb[k], l4n);
+  }
+  if (sl > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) csum[sl - 1][k][col] = cs[k];
+  }
+  __syncthreads();
+  if (sl == 0 && active && (r % l4n) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cs[k] += csum[0][k][col] + csum[1][k][col] + csum[2][k][col];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      atomicAdd(bn_grad + k * C + c, cs[k]);
+      atomicAdd(bn_grad + M + k * C + c, cs[2 + k]);
     }
   }
 }
@@ -280,8 +318,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g
                                                      const float* __restrict__ chan,
                                                      float* __restrict__ dV, float* bn_grad, int b,
                                                      int M, int L, int chunk, DropCfg d) {
+  __shared__ float csum[3][2][64];
   const int ml4 = M * L / 4, l4n = L / 4;
-  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + col;
   const bool active = r < ml4;
   const int c = active ? r / l4n : 0;
   const float mu = chan[c], rs = chan[M + c], sc = chan[2 * M + c], sh = chan[3 * M + c];
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g
   int s_end = s_beg + chunk;
   if (s_end > b) s_end = b;
   if (active) {
-    for (int s = s_beg; s < s_end; ++s) {
+    for (int s = s_beg + sl; s < s_end; s += 4) {
       const int64_t e = ((int64_t)s * ml4 + r) * 4;
       const float4 u = ld4(U + e), gv = ld4(g + e);
       const float4 m = drop_mult4(d, (uint64_t)e);
@@ -307,8 +347,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g
       st4(dV + e, make_float4(dv[0], dv[1], dv[2], dv[3]));
     }
   }
-  const float w = row_sum(sw, l4n), bb = row_sum(sb, l4n);
-  if (active && (r % l4n) == 0) {
+  float w = row_sum(sw, l4n), bb = row_sum(sb, l4n);
+  if (sl > 0) {
+    csum[sl - 1][0][col] = w;
+    csum[sl - 1][1][col] = bb;
+  }
+  __syncthreads();
+  if (sl == 0 && active && (r % l4n) == 0) {
+    w += csum[0][0][col] + csum[1][0][col] + csum[2][0][col];
+    bb += csum[0][1][col] + csum[1][1][col] + csum[2][1][col];
     atomicAdd(bn_grad + c, w);
     atomicAdd(bn_grad + M + c, bb);
   }
@@ -363,6 +410,46 @@ __global__ void arch_softmax_bwd_k(const float* __restrict__ w, const float* __r
   for (int p = 0; p < cols; ++p) da[r * cols + p] = w[r * cols + p] * (dw[r * cols + p] - dot);
 }
 
+struct ArchPack {
+  const float* a[BMNAS_MAX_PTRS];     // fwd: logits      bwd: softmax weights
+  const float* b[BMNAS_MAX_PTRS];     //                  bwd: dweights
+  float* o[BMNAS_MAX_PTRS];           // fwd: weights     bwd: dlogits
+  int rows[BMNAS_MAX_PTRS], cols[BMNAS_MAX_PTRS];
+  int n, n_shards;
+  int64_t shard_stride;               // bwd: dweights are summed over n_shards copies
+};
+
+// every row of every architecture tensor in ONE launch (<= 94 rows in total)
+__global__ void arch_softmax_multi_k(ArchPack P, int backward) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int t = 0; t < P.n; ++t) {
+    if (r < P.rows[t]) {
+      const int cols = P.cols[t];
+      const float* a = P.a[t] + r * cols;
+      float* o = P.o[t] + r * cols;
+      if (!backward) {
+        float mx = a[0];
+        for (int p = 1; p < cols; ++p) mx = fmaxf(mx, a[p]);
+        float den = 0.f;
+        for (int p = 0; p < cols; ++p) den += expf(a[p] - mx);
+        for (int p = 0; p < cols; ++p) o[p] = expf(a[p] - mx) / den;
+      } else {
+        const float* dwp = P.b[t] + r * cols;
+        float dw[4], dot = 0.f;
+        for (int p = 0; p < cols; ++p) {
+          float acc = 0.f;
+          for (int sh = 0; sh < P.n_shards; ++sh) acc += dwp[(int64_t)sh * P.shard_stride + p];
+          dw[p] = acc;
+          dot += a[p] * acc;
+        }
+        for (int p = 0; p < cols; ++p) o[p] = a[p] * (dw[p] - dot);
+      }
+      return;
+    }
+    r -= P.rows[t];
+  }
+}
+
 inline int stream_grid(int64_t total) {
   int64_t blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -378,11 +465,8 @@ inline DropCfg to_cfg(const bmnas_dropout_t& d) {
 
 // samples walked per workgroup in the backward reductions: keep >= ~512 workgroups
 inline int pick_chunk(int b, int slots4) {
-  const int xblocks = (slots4 + 255) / 256;
-  int chunk = (b * xblocks + 511) / 512;
-  if (chunk < 1) chunk = 1;
-  if (chunk > 16) chunk = 16;
-  return chunk;
+  (void)slots4;
+  return b >= 64 ? 16 : (b >= 16 ? 8 : 4);     // 4 sample lanes walk the chunk
 }
 
 }  // namespace
@@ -396,7 +480,7 @@ extern "C" int bmnas_bn_finalize(const float* part, int n_part, int b, int L, in
   if (!bn_w || !bn_b || !chan || M < 1 || b < 1 || L < 1) return BMNAS_E_ARG;
   if (training && (!part || n_part < 1 || b * L < 2)) return BMNAS_E_ARG;
   if (!training && (!running_mean || !running_var)) return BMNAS_E_ARG;
-  hipLaunchKernelGGL(bn_finalize_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, part,
+  hipLaunchKernelGGL(bn_finalize_k, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, part,
                      n_part, b, L, M, bn_w, bn_b, running_mean, running_var, num_batches_tracked,
                      n_nbt, training, chan);
   BMNAS_CHECK_LAUNCH();
@@ -428,7 +512,7 @@ extern "C" int bmnas_node_mix_bwd(const float* g, const float* x, const float* y
   if (b == 0) return 0;
   const int cl4 = C * L / 4;
   const int chunk = pick_chunk(b, cl4);
-  dim3 grid((cl4 + 255) / 256, (b + chunk - 1) / chunk);
+  dim3 grid((cl4 + 63) / 64, (b + chunk - 1) / chunk);
   hipLaunchKernelGGL(node_mix_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, x, y, p1, U, chan,
                      gamma, dgamma, dx, dy, accumulate_mask, dV, bn_grad, b, C, L, chunk,
                      to_cfg(drop_glu), to_cfg(drop_fc));
@@ -457,7 +541,7 @@ extern "C" int bmnas_bn_glu_bwd(const float* g, const float* U, const float* cha
   if (b == 0) return 0;
   const int cl4 = C * L / 4;
   const int chunk = pick_chunk(b, cl4);
-  dim3 grid((cl4 + 255) / 256, (b + chunk - 1) / chunk);
+  dim3 grid((cl4 + 63) / 64, (b + chunk - 1) / chunk);
   hipLaunchKernelGGL(bn_glu_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, U, chan, dV, bn_grad,
                      b, C, L, chunk, to_cfg(drop));
   BMNAS_CHECK_LAUNCH();
@@ -484,7 +568,7 @@ extern "C" int bmnas_bn_relu_bwd(const float* g, const float* U, const float* ch
   if (b == 0) return 0;
   const int ml4 = M * L / 4;
   const int chunk = pick_chunk(b, ml4);
-  dim3 grid((ml4 + 255) / 256, (b + chunk - 1) / chunk);
+  dim3 grid((ml4 + 63) / 64, (b + chunk - 1) / chunk);
   hipLaunchKernelGGL(bn_relu_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, U, chan, dV, bn_grad,
                      b, M, L, chunk, to_cfg(drop));
   BMNAS_CHECK_LAUNCH();
@@ -518,6 +602,33 @@ extern "C" int bmnas_arch_softmax_bwd(const float* w, const float* dw, float* dl
   if (!w || !dw || !dlogits || rows < 1 || cols < 1) return BMNAS_E_ARG;
   hipLaunchKernelGGL(arch_softmax_bwd_k, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, w,
                      dw, dlogits, rows, cols);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_arch_softmax_multi(const float* const* a, const float* const* dw,
+                                        float* const* out, const int* rows, const int* cols, int n,
+                                        int backward, int n_shards, int64_t shard_stride,
+                                        void* stream) {
+  if (!a || !out || !rows || !cols || n < 1 || (backward && !dw) || n_shards < 1) return BMNAS_E_ARG;
+  if (n > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
+  ArchPack P{};
+  int total = 0;
+  for (int t = 0; t < n; ++t) {
+    if (!a[t] || !out[t] || rows[t] < 1 || cols[t] < 1 || cols[t] > 4 || (backward && !dw[t]))
+      return BMNAS_E_ARG;
+    P.a[t] = a[t];
+    P.b[t] = backward ? dw[t] : nullptr;
+    P.o[t] = out[t];
+    P.rows[t] = rows[t];
+    P.cols[t] = cols[t];
+    total += rows[t];
+  }
+  P.n = n;
+  P.n_shards = n_shards;
+  P.shard_stride = shard_stride;
+  hipLaunchKernelGGL(arch_softmax_multi_k, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, P,
+                     backward);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

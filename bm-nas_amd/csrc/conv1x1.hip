@@ -21,7 +21,7 @@ struct ConvArgs {
   const float* bias;     // per output col (fwd), nullable
   float* part;           // BN partial stats (fwd, training), nullable
   int ldw, Ci, Cj, I, J;
-  int b, L, Lb, spw, n_groups;
+  int b, L, Lb, spw, n_groups, n_part;
   uint32_t acc_mask;
 };
 
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
       m2 += __shfl_xor(m2, 16, 64);
       m2 += __shfl_xor(m2, 32, 64);
       if (h == 0) {
-        float* pp = a.part + ((int64_t)prow * a.J + j) * 2;
+        float* pp = a.part + ((int64_t)j * a.n_part + prow) * 2;
         pp[0] = sum;
         pp[1] = m2;
       }
@@ -322,7 +322,7 @@ extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src,
   a.dst.p[0] = U;
   a.W = W; a.bias = bias; a.part = part; a.ldw = ldw;
   a.Ci = C_src; a.I = n_src * C_src; a.Cj = M; a.J = M;
-  a.b = b; a.L = L; a.acc_mask = 0;
+  a.b = b; a.L = L; a.acc_mask = 0; a.n_part = (a.n_groups + 1) / 2;
   dim3 grid((a.n_groups + 3) / 4, (M + 63) / 64);
   hipLaunchKernelGGL(conv_nj_k<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
   BMNAS_CHECK_LAUNCH();

@@ -156,6 +156,72 @@ __global__ __launch_bounds__(256) void cat_ln_bwd_k(const float* __restrict__ g,
   }
 }
 
+
+// LayerNorm affine gradients dln_w[e] = sum_s gy[s,e]*x_hat[s,e], dln_b[e] = sum_s gy[s,e]:
+// a reduction over SAMPLES per element.  Workgroup = 64 float4 columns x 4 sample lanes
+// (one wave per sample lane -> 1 KiB coalesced rows); each thread walks its share of the
+// sample chunk, the four lanes are summed through LDS, one atomic per element per chunk
+// (b/16 x fewer atomics than doing it per sample).  prenorm: srcs[0] already holds x_hat.
+__global__ __launch_bounds__(256) void ln_affine_bwd_k(const float* __restrict__ g,
+                                                       const float* __restrict__ gscale, LnSrc srcs,
+                                                       const float* __restrict__ resid,
+                                                       const float* __restrict__ ln_w,
+                                                       const float* __restrict__ ln_b,
+                                                       const float* __restrict__ stats,
+                                                       float* dln_w, float* dln_b, int b, int cl4,
+                                                       int d4, int relu, int prenorm, int chunk) {
+  __shared__ float4 red[2][3][64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  const bool active = i < d4;
+  const float gs = (gscale != nullptr) ? gscale[0] : 1.f;
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw;
+  if (active) {
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f), bb = w;
+    if (relu) {
+      w = ld4(ln_w + (int64_t)i * 4);
+      bb = ld4(ln_b + (int64_t)i * 4);
+    }
+    const int s_beg = blockIdx.y * chunk;
+    int s_end = s_beg + chunk;
+    if (s_end > b) s_end = b;
+    for (int s = s_beg + sl; s < s_end; s += 4) {
+      float4 x = ld4(src_ptr(srcs, i, cl4, s));
+      float4 gy = f4_scale(ld4(g + ((int64_t)s * d4 + i) * 4), gs);
+      float4 h = x;
+      if (!prenorm) {
+        if (resid != nullptr) x = f4_add(x, ld4(resid + ((int64_t)s * d4 + i) * 4));
+        const float mean = stats[2 * s], rstd = stats[2 * s + 1];
+        h = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+      }
+      if (relu) {
+        if (h.x * w.x + bb.x <= 0.f) gy.x = 0.f;
+        if (h.y * w.y + bb.y <= 0.f) gy.y = 0.f;
+        if (h.z * w.z + bb.z <= 0.f) gy.z = 0.f;
+        if (h.w * w.w + bb.w <= 0.f) gy.w = 0.f;
+      }
+      aw = f4_add(aw, f4_mul(gy, h));
+      ab = f4_add(ab, gy);
+    }
+  }
+  if (sl > 0) {
+    red[0][sl - 1][col] = aw;
+    red[1][sl - 1][col] = ab;
+  }
+  __syncthreads();
+  if (sl == 0 && active) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      aw = f4_add(aw, red[0][k][col]);
+      ab = f4_add(ab, red[1][k][col]);
+    }
+    float* pw = dln_w + (int64_t)i * 4;
+    float* pb = dln_b + (int64_t)i * 4;
+    atomicAdd(pw + 0, aw.x); atomicAdd(pw + 1, aw.y); atomicAdd(pw + 2, aw.z); atomicAdd(pw + 3, aw.w);
+    atomicAdd(pb + 0, ab.x); atomicAdd(pb + 1, ab.y); atomicAdd(pb + 2, ab.z); atomicAdd(pb + 3, ab.w);
+  }
+}
+
 inline int pick_vpt(int d4) {
   const int need = (d4 + 255) / 256;
   if (need <= 1) return 1;
@@ -227,6 +293,31 @@ extern "C" int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_
 #define CALL(V) hipLaunchKernelGGL(cat_ln_bwd_k<V>, dim3(b), dim3(256), 0, st, g, s, resid, ln_w, ln_b, stats, d, dresid, accumulate_mask, dln_w, dln_b, cl4, d4, relu)
   LN_DISPATCH(vpt, CALL)
 #undef CALL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_ln_affine_bwd(const float* g, const float* gscale, const float* const* srcs,
+                                   int n_src, const float* resid, const float* ln_w,
+                                   const float* ln_b, const float* stats, float* dln_w, float* dln_b,
+                                   int b, int C, int L, int relu, int prenorm, void* stream) {
+  if (!g || !srcs || !dln_w || !dln_b || n_src < 1 || b < 0 || C < 1 || L < 1) return BMNAS_E_ARG;
+  if (!prenorm && !stats) return BMNAS_E_ARG;
+  if (relu && (!ln_w || !ln_b)) return BMNAS_E_ARG;
+  if (n_src > 4) return BMNAS_E_LIMIT;
+  if (resid && n_src != 1) return BMNAS_E_ARG;
+  if ((C * L) % 4 != 0) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  LnSrc s{};
+  for (int q = 0; q < n_src; ++q) {
+    if (!srcs[q]) return BMNAS_E_ARG;
+    s.p[q] = srcs[q];
+  }
+  const int cl4 = C * L / 4, d4 = cl4 * n_src;
+  const int chunk = 16;
+  dim3 grid((d4 + 63) / 64, (b + chunk - 1) / chunk);
+  hipLaunchKernelGGL(ln_affine_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, gscale, s, resid, ln_w,
+                     ln_b, stats, dln_w, dln_b, b, cl4, d4, relu, prenorm, chunk);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

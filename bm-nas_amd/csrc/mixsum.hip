@@ -36,6 +36,7 @@ template <int NIN>
 __global__ __launch_bounds__(256) void mixsum_bwd_k(PtrsIn xs, PtrsOut dxs,
                                                     const float* __restrict__ w, int w_stride,
                                                     const float* __restrict__ g, float* dw,
+                                                    int dw_shards, int64_t dw_shard_stride,
                                                     uint32_t acc_mask, int64_t n4) {
   __shared__ float red[4 * NIN];
   float wj[NIN], part[NIN];
@@ -75,7 +76,10 @@ __global__ __launch_bounds__(256) void mixsum_bwd_k(PtrsIn xs, PtrsOut dxs,
   __syncthreads();
   if (threadIdx.x < NIN) {
     const int j = threadIdx.x;
-    atomicAdd(dw + j * w_stride, red[j] + red[NIN + j] + red[2 * NIN + j] + red[3 * NIN + j]);
+    // hundreds of workgroups adding into the same n_in scalars serialise on the atomics:
+    // spread them over dw_shards copies (summed by the arch-softmax backward)
+    float* d = dw + (int64_t)(blockIdx.x % dw_shards) * dw_shard_stride;
+    atomicAdd(d + j * w_stride, red[j] + red[NIN + j] + red[2 * NIN + j] + red[3 * NIN + j]);
   }
 }
 
@@ -131,8 +135,10 @@ extern "C" int bmnas_mixsum_fwd(const float* const* xs, int n_in, const float* w
 
 extern "C" int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n_in,
                                 const float* w, int w_stride, const float* g, float* dw,
-                                uint32_t accumulate_mask, int64_t n_elem, void* stream) {
-  if (!xs || !dxs || !w || !g || n_in < 1 || n_elem < 0 || w_stride < 1) return BMNAS_E_ARG;
+                                int dw_shards, int64_t dw_shard_stride, uint32_t accumulate_mask,
+                                int64_t n_elem, void* stream) {
+  if (!xs || !dxs || !w || !g || n_in < 1 || n_elem < 0 || w_stride < 1 || dw_shards < 1)
+    return BMNAS_E_ARG;
   if (n_in > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
   if (n_elem % 4 != 0) return BMNAS_E_SHAPE;
   if (n_elem == 0) return 0;
@@ -145,7 +151,7 @@ extern "C" int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n
   }
   const int64_t n4 = n_elem / 4;
   hipStream_t st = (hipStream_t)stream;
-#define CALL(N) hipLaunchKernelGGL(mixsum_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, g, dw, accumulate_mask, n4)
+#define CALL(N) hipLaunchKernelGGL(mixsum_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, g, dw, dw_shards, dw_shard_stride, accumulate_mask, n4)
   MIXSUM_DISPATCH(n_in, CALL)
 #undef CALL
   BMNAS_CHECK_LAUNCH();

@@ -58,15 +58,23 @@ class FusionCell(nn.Module):
     def grad_pack(self, device, alpha_w, beta_ws, gamma_ws):
         """One zero-filled arena holding every atomically accumulated gradient of the cell
         plus the gradients w.r.t. the softmaxed arch weights."""
+        from bmnas.cell import ARCH_SHARDS
         arena = Arena()
         hn = [n.node_cell.plan_grads(arena) for n in self._step_nodes]
         hl = (arena.ask(self.C * self._multiplier, self.L), arena.ask(self.C * self._multiplier, self.L))
+        # arch-weight gradients: ARCH_SHARDS copies of one section (shard 0 is handed out; the
+        # kernels spread their atomics over the copies, the softmax backward sums them)
+        base = arena.total
         ha = arena.ask(*alpha_w.shape)
         hb = [arena.ask(*t.shape) for t in beta_ws]
         hg = [arena.ask(*t.shape) for t in gamma_ws]
+        stride = arena.total - base
+        arena.total += stride * (ARCH_SHARDS - 1)
         arena.alloc(device)
         CG = Pack(nodes=[n.node_cell.bind_grads(arena, h) for n, h in zip(self._step_nodes, hn)],
-                  dln_w=arena.view(hl[0]), dln_b=arena.view(hl[1]))
+                  dln_w=arena.view(hl[0]), dln_b=arena.view(hl[1]), shards=ARCH_SHARDS, shard_stride=stride)
+        for g in CG.nodes:
+            g.shards, g.shard_stride = ARCH_SHARDS, stride
         return CG, arena.view(ha), [arena.view(i) for i in hb], [arena.view(i) for i in hg]
 
     def grads_in_param_order(self, CG):
@@ -75,7 +83,10 @@ class FusionCell(nn.Module):
             gs += n.node_cell.grads_in_param_order(g)
         return gs + [CG.dln_w, CG.dln_b]
 
-    def forward(self, input_features, weights):
+    def forward(self, input_features, weights, weights_are_logits=False):
+        """weights: the softmaxed alphas (k, 2), as in the reference; FusionNetwork passes the
+        raw alphas with weights_are_logits=True so that every arch softmax of the cell runs
+        in one kernel launch."""
         states = list(input_features)
         dev = states[0].device
         w = weights if weights.device == dev else weights.to(dev)
@@ -83,7 +94,10 @@ class FusionCell(nn.Module):
             arch = []
             for n in self._step_nodes:
                 arch += [t if t.device == dev else t.to(dev) for t in (n.betas, n.gammas)]
-            return FusedCellFn.apply(self, self.training, w, *states, *arch, *self.param_list())
+            return FusedCellFn.apply(self, self.training, weights_are_logits, w, *states, *arch,
+                                     *self.param_list())
+        if weights_are_logits:
+            w = arch_softmax(w, dev)
         # edited primitive lists: same dataflow, composed op by op
         offset = 0
         for i in range(self._steps):
@@ -129,8 +143,8 @@ class FusionNetwork(nn.Module):
 
     def forward(self, input_features):
         assert self._num_input_nodes == len(input_features)
-        weights = arch_softmax(self.alphas_edges, input_features[0].device)
-        return self.cell(input_features, weights)
+        # softmax(alphas_edges) (reference :95) is folded into the fused cell call
+        return self.cell(input_features, self.alphas_edges, weights_are_logits=True)
 
     def _loss(self, input_features, labels):
         return self._criterion(self(input_features), labels)

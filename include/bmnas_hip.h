@@ -64,10 +64,14 @@ int bmnas_version(void);
 int bmnas_mixsum_fwd(const float* const* xs, int n_in, const float* w, int w_stride,
                      float* out, int64_t n_elem, void* stream);
 /* dxs[j] (=|+=) w_j * g  (dxs[j] may be NULL to skip; bit j of accumulate_mask selects +=);
- * dw[j*w_stride] += <g, xs[j]> (atomic; dw may be NULL to skip the dot products). */
+ * dw[shard*dw_shard_stride + j*w_stride] += <g, xs[j]> (atomic; dw may be NULL to skip the dot
+ * products).  The adds of the workgroups are spread round-robin over dw_shards (>= 1) copies of
+ * the buffer so that they do not serialise on n_in addresses; the consumer sums the copies
+ * (bmnas_arch_softmax_multi does). */
 int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n_in, const float* w,
-                     int w_stride, const float* g, float* dw, uint32_t accumulate_mask,
-                     int64_t n_elem, void* stream);
+                     int w_stride, const float* g, float* dw, int dw_shards,
+                     int64_t dw_shard_stride, uint32_t accumulate_mask, int64_t n_elem,
+                     void* stream);
 
 /* ---- K6 / K7: channel-concat (+ residual) + LayerNorm (+ ReLU) -------------------------
  * x = cat(srcs[0..n_src), dim=1) (+ resid if non-NULL; n_src must be 1 then);
@@ -79,26 +83,38 @@ int bmnas_cat_ln_fwd(const float* const* srcs, int n_src, const float* resid, co
                      const float* ln_b, float* out, float* stats, int b, int C, int L, int relu,
                      void* stream);
 /* g: gradient of `out`.  dsrcs[q] (NULL to skip) / dresid (NULL to skip) receive the input
- * gradient (acc bits: bit q for dsrcs[q], bit 31 for dresid); dln_w / dln_b += (atomic). */
+ * gradient (acc bits: bit q for dsrcs[q], bit 31 for dresid); dln_w / dln_b += (atomic per
+ * sample; pass NULL and use bmnas_ln_affine_bwd, which needs 16x fewer atomics). */
 int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_src, const float* resid,
                      const float* ln_w, const float* ln_b, const float* stats,
                      float* const* dsrcs, float* dresid, uint32_t accumulate_mask,
                      float* dln_w, float* dln_b, int b, int C, int L, int relu, void* stream);
 
+/* LayerNorm affine gradients (a reduction over samples, kept out of the per-sample kernels):
+ * dln_w[e] += sum_s gy*x_hat, dln_b[e] += sum_s gy with gy = g * (*gscale) * relu-mask.
+ * prenorm != 0: srcs[0] already holds x_hat (the attention kernel saves it). */
+int bmnas_ln_affine_bwd(const float* g, const float* gscale, const float* const* srcs, int n_src,
+                        const float* resid, const float* ln_w, const float* ln_b,
+                        const float* stats, float* dln_w, float* dln_b, int b, int C, int L,
+                        int relu, int prenorm, void* stream);
+
 /* ---- K3: scaled-dot attention + dropout + LayerNorm -----------------------------------
  * ScaledDotAttn.forward node_operations.py:92-108: q = x^T, k = y, v = y^T,
  * scores = q@k / sqrt(C), softmax(-1), out = (attn@v)^T, Dropout, LayerNorm([C, L]).
- * One wavefront per 16 rows (= 16/L samples); QK^T and AV on v_mfma_f32_16x16x4_f32,
- * row softmax by in-lane + cross-lane (xor 16/32) reductions.  stats as in cat_ln. */
+ * One 4-wave workgroup per 16 rows (= 16/L samples), channels split over the waves; QK^T and
+ * AV on v_mfma_f32_16x16x4_f32, row softmax by in-lane + cross-lane (xor 16/32) reductions.
+ * xhat (b, C, L) receives the normalised pre-affine output (saved for backward);
+ * stats as in cat_ln.  C <= 512. */
 int bmnas_sdpa_ln_fwd(const float* x, const float* y, const float* ln_w, const float* ln_b,
-                      float* out, float* stats, int b, int C, int L, bmnas_dropout_t drop,
-                      void* stream);
+                      float* out, float* xhat, float* stats, int b, int C, int L,
+                      bmnas_dropout_t drop, void* stream);
 /* g: gradient of out, multiplied in-kernel by *gscale if gscale != NULL (the gamma weight
  * of the mixed op).  dx / dy (=|+=, bit0 / bit1 of accumulate_mask); if dy == NULL the
- * y-gradient is added into dx (search mode, x is y).  dln_w/dln_b += (atomic). */
+ * y-gradient is added into dx (search mode, x is y).  The LayerNorm affine gradients come
+ * from bmnas_ln_affine_bwd(g, gscale, {xhat}, prenorm = 1). */
 int bmnas_sdpa_ln_bwd(const float* g, const float* gscale, const float* x, const float* y,
-                      const float* ln_w, const float* stats, float* dx, float* dy,
-                      uint32_t accumulate_mask, float* dln_w, float* dln_b, int b, int C, int L,
+                      const float* ln_w, const float* xhat, const float* stats, float* dx,
+                      float* dy, uint32_t accumulate_mask, int b, int C, int L,
                       bmnas_dropout_t drop, void* stream);
 
 /* ---- K4 / K5 / out_conv: channel-concat + 1x1 Conv1d as an fp32-MFMA GEMM ----------------
@@ -106,8 +122,8 @@ int bmnas_sdpa_ln_bwd(const float* g, const float* gscale, const float* x, const
  * Replaces torch.cat + nn.Conv1d(k=1) at node_operations.py:32-33, :51-52 and
  * node_search.py:59-61 (several convs sharing the same input may be stacked along M).
  * If part != NULL (train-mode BatchNorm follows): per-channel partial batch statistics
- * part[(p*M + m)*2 + {0,1}] = (sum, M2 about the partial's own mean) over the p-th block
- * of 32 (sample,l) columns; p < bmnas_conv1x1_num_partials(b, L). */
+ * part[(m*P + p)*2 + {0,1}] = (sum, M2 about the partial's own mean) over the p-th block
+ * of 32 (sample,l) columns; p < P = bmnas_conv1x1_num_partials(b, L). */
 int bmnas_conv1x1_num_partials(int b, int L);
 int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const float* W, int ldw,
                       const float* bias, float* U, float* part, int b, int L, int M,
@@ -181,6 +197,12 @@ int bmnas_bn_bwd_apply(float* dV, const float* U, const float* chan, const float
 int bmnas_arch_softmax_fwd(const float* logits, float* w, int rows, int cols, void* stream);
 int bmnas_arch_softmax_bwd(const float* w, const float* dw, float* dlogits, int rows, int cols,
                            void* stream);
+/* All n (<= 16) architecture tensors in ONE launch.  backward == 0: out[t] = softmax(a[t]);
+ * backward != 0: a[t] = softmax weights, dw[t] = their gradient (summed over n_shards copies
+ * spaced shard_stride floats apart), out[t] = dlogits. */
+int bmnas_arch_softmax_multi(const float* const* a, const float* const* dw, float* const* out,
+                             const int* rows, const int* cols, int n, int backward, int n_shards,
+                             int64_t shard_stride, void* stream);
 
 #ifdef __cplusplus
 }
