@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
     mean = tot / (float)N;
     float m2 = 0.f;
     for (int p = lane; p < n_part; p += 64) {
-      int cnt = N - 32 * p;
-      cnt = cnt > 32 ? 32 : cnt;
+      int cnt = N - 16 * p;
+      cnt = cnt > 16 ? 16 : cnt;
       const float d = pm[2 * p] / (float)cnt - mean;
       m2 += pm[2 * p + 1] + (float)cnt * d * d;
     }

@@ -11,6 +11,7 @@
 // FLOPs: 2*M*K*b*L each; bound: fp32 MFMA (157 TFLOP/s dense).
 #include "common.hpp"
 #include "../../include/bmnas_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -23,125 +24,528 @@ struct ConvArgs {
   int ldw, Ci, Cj, I, J;
   int b, L, Lb, spw, n_groups, n_part;
   uint32_t acc_mask;
+  int probe;             // diagnostics only (BMNAS_CONV_PROBE): 1 = no MFMA, 2 = no loads
 };
 
 // OUT[n][j] = sum_i ACT[i][n] * MAT(i, j);  TRANS: MAT(i,j) = W[j*ldw + i] (forward conv),
-// else MAT(i,j) = W[i*ldw + j] (data gradient).  Workgroup = 4 waves as 2 (n) x 2 (j);
-// wave tile = 32 n x 32 j = 2x2 MFMA tiles.
-template <bool TRANS>
+// else MAT(i,j) = W[i*ldw + j] (data gradient).  A wave owns TN x TJ MFMA tiles
+// (16*TN columns n, 16*TJ columns j); a workgroup is 4 waves laid out WN x (4/WN).
+// The contraction runs in groups of KB blocks of 16 channels: all operand loads of group
+// g+1 are issued (into a second register set) before the MFMAs of group g, so at 1-2
+// waves per SIMD the L2 latency hides behind 16*KB*TN*TJ/4... MFMAs instead of being paid
+// per block.  No LDS, no barriers.
+template <bool TRANS, int TN, int TJ, int WN>
 __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
+  constexpr int KB = 4;
+  constexpr int WJ = 4 / WN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
-  const int wn = wave & 1, wj = wave >> 1;
-  const int prow = blockIdx.x * 2 + wn;       // index of this wave's 32-column block
-  const int g0 = prow * 2;
-  const int j0 = (blockIdx.y * 2 + wj) * 32;
-  if (g0 >= a.n_groups || j0 >= a.J) return;  // wave-uniform; no barriers below
+  const int wn = wave % WN, wj = wave / WN;
+  const int g0 = (blockIdx.x * WN + wn) * TN;            // first n-group of this wave
+  const int j0 = (blockIdx.y * WJ + wj) * (16 * TJ);
+  if (g0 >= a.n_groups || j0 >= a.J) return;             // wave-uniform; no barriers below
 
-  // A operand addressing: column n = lo of group g0+tn
-  bool va[2];
-  int64_t abase[2];
+  // Operand addresses are CLAMPED into range instead of predicating the loads (predicated
+  // loads compile to a branch per load and wreck the schedule): padded samples / tiles past
+  // the edge read a valid neighbour, their results are simply never stored.
+  int64_t abase[TN];
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int g = g0 + tn;
-    const int s = g * a.spw + (lo >> a.Lb);
-    va[tn] = (g < a.n_groups) && (s < a.b);
+  for (int tn = 0; tn < TN; ++tn) {
+    int g = g0 + tn;
+    g = g < a.n_groups ? g : a.n_groups - 1;
+    int s = g * a.spw + (lo >> a.Lb);
+    s = s < a.b ? s : a.b - 1;
     abase[tn] = ((int64_t)s * a.Ci) * a.L + (lo & (a.L - 1));
   }
-  bool vj[2];
+  bool vj[TJ];
+  int jcl[TJ];
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj) vj[tj] = (j0 + 16 * tj) < a.J;   // J % 16 == 0
+  for (int tj = 0; tj < TJ; ++tj) {
+    vj[tj] = (j0 + 16 * tj) < a.J;                       // J % 16 == 0
+    jcl[tj] = (vj[tj] ? j0 + 16 * tj : a.J - 16) + lo;
+  }
 
-  f32x4 acc[2][2];
+  f32x4 acc[TN][TJ];
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn)
+  for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tj = 0; tj < TJ; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int i0 = 0; i0 < a.I; i0 += 16) {
-    const int q = i0 / a.Ci;
+  const int nblk = a.I / 16;
+  const int ngrp = nblk / KB;                             // full groups; the tail runs unpipelined
+  float av[2][KB][TN][4], bv[2][KB][TJ][4];
+
+  auto load_block = [&](float (&A)[TN][4], float (&B)[TJ][4], int blk) {
+    const int i0 = blk * 16;
+    const int q = i0 / a.Ci;                              // wave-uniform
     const int ci = i0 - q * a.Ci + 4 * h;
     const float* src = a.act.p[q];
-    float av[2][4];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const float* p = src + abase[tn] + (int64_t)ci * a.L;
+    for (int tn = 0; tn < TN; ++tn) {
+      const float* pp = src + abase[tn] + (int64_t)ci * a.L;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) av[tn][r] = va[tn] ? p[(int64_t)r * a.L] : 0.f;
+      for (int r = 0; r < 4; ++r) A[tn][r] = pp[(int64_t)r * a.L];
     }
-    float bv[2][4];
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-      const int j = j0 + 16 * tj + lo;
-      if (!vj[tj]) {
-        bv[tj][0] = bv[tj][1] = bv[tj][2] = bv[tj][3] = 0.f;
-      } else if (TRANS) {
-        const float4 w4 = ld4(a.W + (int64_t)j * a.ldw + i0 + 4 * h);
-        bv[tj][0] = w4.x; bv[tj][1] = w4.y; bv[tj][2] = w4.z; bv[tj][3] = w4.w;
+    for (int tj = 0; tj < TJ; ++tj) {
+      if (TRANS) {
+        const float4 w4 = ld4(a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h);
+        B[tj][0] = w4.x; B[tj][1] = w4.y; B[tj][2] = w4.z; B[tj][3] = w4.w;
       } else {
-        const float* p = a.W + (int64_t)(i0 + 4 * h) * a.ldw + j;
+        const float* pp = a.W + (int64_t)(i0 + 4 * h) * a.ldw + jcl[tj];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[tj][r] = p[(int64_t)r * a.ldw];
+        for (int r = 0; r < 4; ++r) B[tj][r] = pp[(int64_t)r * a.ldw];
       }
     }
+  };
+  auto mma_block = [&](const float (&A)[TN][4], const float (&B)[TJ][4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][r], bv[tj][r], acc[tn][tj], 0, 0, 0);
+        for (int tj = 0; tj < TJ; ++tj)
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tn][r], B[tj][r], acc[tn][tj], 0, 0, 0);
+  };
+  auto load_group = [&](float (&A)[KB][TN][4], float (&B)[KB][TJ][4], int grp) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) load_block(A[kb], B[kb], grp * KB + kb);
+  };
+  auto mma_group = [&](const float (&A)[KB][TN][4], const float (&B)[KB][TJ][4]) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) mma_block(A[kb], B[kb]);
+  };
+
+  if (ngrp > 0) {
+    // software pipeline over two statically named register sets.  The steady-state body is
+    // straight-line (no conditionals), so hipcc's waits before each MFMA group are COUNTED
+    // vmcnt(N) that leave the next group's loads in flight (a branch join would force
+    // vmcnt(0) and serialise load -> compute).
+    load_group(av[0], bv[0], 0);
+    int grp = 0;
+    for (; grp + 2 < ngrp; grp += 2) {
+      load_group(av[1], bv[1], grp + 1);
+      mma_group(av[0], bv[0]);
+      load_group(av[0], bv[0], grp + 2);
+      mma_group(av[1], bv[1]);
+    }
+    if (grp + 1 < ngrp) {
+      load_group(av[1], bv[1], grp + 1);
+      mma_group(av[0], bv[0]);
+      mma_group(av[1], bv[1]);
+    } else {
+      mma_group(av[0], bv[0]);
+    }
+  }
+  for (int blk = ngrp * KB; blk < nblk; ++blk) {          // < KB leftover blocks
+    load_block(av[0][0], bv[0][0], blk);
+    mma_block(av[0][0], bv[0][0]);
   }
 
   // epilogue.  acc[tn][tj][r] = OUT[n = 16*(g0+tn) + 4h + r][j = j0 + 16*tj + lo]
-  bool vo[2];
-  int so[2];
+  bool vo[TN];
+  int so[TN];
   const int l0 = (4 * h) & (a.L - 1);
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
+  for (int tn = 0; tn < TN; ++tn) {
     const int g = g0 + tn;
     so[tn] = g * a.spw + ((4 * h) >> a.Lb);
     vo[tn] = (g < a.n_groups) && (so[tn] < a.b);
   }
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj) {
+  for (int tj = 0; tj < TJ; ++tj) {
     if (!vj[tj]) continue;
-    const int j = j0 + 16 * tj + lo;
-    const float bj = (a.bias != nullptr) ? a.bias[j] : 0.f;
-    const int q = j / a.Cj;
-    const int cj = j - q * a.Cj;
+    const int jj = j0 + 16 * tj + lo;
+    const float bj = (a.bias != nullptr) ? a.bias[jj] : 0.f;
+    const int q = jj / a.Cj;
+    const int cj = jj - q * a.Cj;
     float* d = a.dst.p[q];
-    float4 o[2];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      o[tn] = make_float4(acc[tn][tj][0] + bj, acc[tn][tj][1] + bj, acc[tn][tj][2] + bj,
-                          acc[tn][tj][3] + bj);
+    for (int tn = 0; tn < TN; ++tn) {
+      const float4 o = make_float4(acc[tn][tj][0] + bj, acc[tn][tj][1] + bj, acc[tn][tj][2] + bj,
+                                   acc[tn][tj][3] + bj);
       if (vo[tn] && d != nullptr) {
         float* pp = d + ((int64_t)so[tn] * a.Cj + cj) * a.L + l0;
-        st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o[tn], ld4(pp)) : o[tn]);
+        st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
+      }
+      if (a.part != nullptr) {
+        // per-channel partial statistics over this tile's (<= 16) valid columns (n-group g0+tn)
+        const int prow = g0 + tn;
+        if (prow < a.n_groups) {                         // wave-uniform
+          float sum = vo[tn] ? f4_hsum(o) : 0.f;
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          int cnt = a.b * a.L - 16 * prow;
+          cnt = cnt > 16 ? 16 : cnt;
+          const float mean = sum / (float)cnt;
+          float m2 = 0.f;
+          if (vo[tn]) {
+            const float4 c = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
+            m2 = f4_dot(c, c);
+          }
+          m2 += __shfl_xor(m2, 16, 64);
+          m2 += __shfl_xor(m2, 32, 64);
+          if (h == 0) {
+            float* pp = a.part + ((int64_t)jj * a.n_part + prow) * 2;
+            pp[0] = sum;
+            pp[1] = m2;
+          }
+        }
       }
     }
+  }
+}
+
+// ---- split-K variant: ONE memory round trip per wave ------------------------------------------
+// At these sizes (0.1-0.5 GFLOP per GEMM, every operand L2-resident) the kernels are bound
+// by exposed load latency, not by MFMA or bandwidth: a wave that alternates "load a slice /
+// multiply a slice" pays the (loaded) L2 latency once per slice.  Here the four waves of a
+// workgroup split the contraction dimension of ONE (16*TN x 16*TJ) output tile, each wave
+// issues ALL of its operand loads up front (KPW blocks of 16 channels = KPW*4*(TN+TJ) VGPRs),
+// waits once, runs its MFMAs back to back, and the four partial tiles are summed through
+// LDS.  Splitting K four ways also quadruples the number of waves, which is what hides the
+// latency at batch 128.
+template <bool TRANS, int TN, int TJ, int KPW>
+__global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
+  __shared__ float4 part[4][TN * TJ][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, h = lane >> 4;
+  const int g0 = blockIdx.x * TN;
+  const int j0 = blockIdx.y * (16 * TJ);
+
+  int64_t abase[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    int g = g0 + tn;
+    g = g < a.n_groups ? g : a.n_groups - 1;             // clamped, never stored
+    int s = g * a.spw + (lo >> a.Lb);
+    s = s < a.b ? s : a.b - 1;
+    abase[tn] = ((int64_t)s * a.Ci) * a.L + (lo & (a.L - 1));
+  }
+  int jcl[TJ];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    const int jt = j0 + 16 * tj;
+    jcl[tj] = (jt < a.J ? jt : a.J - 16) + lo;
+  }
+
+  const int nblk = a.I / 16;
+  float av[KPW][TN][4], bv[KPW][TJ][4];
+#pragma unroll
+  for (int kb = 0; kb < KPW; ++kb) {
+    const int blk = wave * KPW + kb;
+    const bool vb = blk < nblk;                          // wave-uniform
+    const int i0 = (vb ? blk : nblk - 1) * 16;
+    const int q = i0 / a.Ci;
+    const int ci = i0 - q * a.Ci + 4 * h;
+    const float* src = a.act.p[q];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const float* pp = src + abase[tn] + (int64_t)ci * a.L;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = (a.probe & 2) ? (float)lane : pp[(int64_t)r * a.L];
+        av[kb][tn][r] = vb ? t : 0.f;                    // blocks past the end contribute zero
+      }
+    }
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      if (a.probe & 2) {
+        bv[kb][tj][0] = bv[kb][tj][1] = bv[kb][tj][2] = bv[kb][tj][3] = (float)lo;
+      } else if (TRANS) {
+        const float4 w4 = ld4(a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h);
+        bv[kb][tj][0] = w4.x; bv[kb][tj][1] = w4.y; bv[kb][tj][2] = w4.z; bv[kb][tj][3] = w4.w;
+      } else {
+        const float* pp = a.W + (int64_t)(i0 + 4 * h) * a.ldw + jcl[tj];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[kb][tj][r] = pp[(int64_t)r * a.ldw];
+      }
+    }
+  }
+  // keep every load above this line: without the fence hipcc sinks the loads next to their
+  // MFMAs to save registers, which re-serialises load -> wait -> multiply per block
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[TN][TJ];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (a.probe & 1) {
+#pragma unroll
+    for (int kb = 0; kb < KPW; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj) acc[tn][tj][r] += av[kb][tn][r] + bv[kb][tj][r];
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < KPW; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+            acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][r], bv[kb][tj][r], acc[tn][tj], 0, 0, 0);
+  }
+
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+      part[wave][tn * TJ + tj][lane] = make_float4(acc[tn][tj][0], acc[tn][tj][1], acc[tn][tj][2], acc[tn][tj][3]);
+  __syncthreads();
+
+  // wave w finishes the tiles t = w, w + 4, ...:  o[r] = OUT[n = 16*g + 4h + r][j]
+  const int l0 = (4 * h) & (a.L - 1);
+  for (int t = wave; t < TN * TJ; t += 4) {
+    const int tn = t / TJ, tj = t - tn * TJ;
+    const int g = g0 + tn, jt = j0 + 16 * tj;
+    if (g >= a.n_groups || jt >= a.J) continue;          // wave-uniform
+    const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
+    const int jj = jt + lo;
+    const float bj = (a.bias != nullptr) ? a.bias[jj] : 0.f;
+    const float4 o = make_float4((p0.x + p1.x) + (p2.x + p3.x) + bj, (p0.y + p1.y) + (p2.y + p3.y) + bj,
+                                 (p0.z + p1.z) + (p2.z + p3.z) + bj, (p0.w + p1.w) + (p2.w + p3.w) + bj);
+    const int q = jj / a.Cj;
+    const int cj = jj - q * a.Cj;
+    float* d = a.dst.p[0];
+#pragma unroll
+    for (int qq = 1; qq < BMNAS_MAX_PTRS; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
+    const int so = g * a.spw + ((4 * h) >> a.Lb);
+    const bool vo = so < a.b;
+    if (vo && d != nullptr) {
+      float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
+      st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
+    }
     if (a.part != nullptr) {
-      // per-channel partial statistics over this wave's (<= 32) valid columns
-      float sum = (vo[0] ? f4_hsum(o[0]) : 0.f) + (vo[1] ? f4_hsum(o[1]) : 0.f);
+      float sum = vo ? f4_hsum(o) : 0.f;
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
-      int cnt = a.b * a.L - 32 * prow;
-      cnt = cnt > 32 ? 32 : cnt;
+      int cnt = a.b * a.L - 16 * g;
+      cnt = cnt > 16 ? 16 : cnt;
       const float mean = sum / (float)cnt;
       float m2 = 0.f;
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-        if (vo[tn]) {
-          const float4 c = make_float4(o[tn].x - mean, o[tn].y - mean, o[tn].z - mean, o[tn].w - mean);
-          m2 += f4_dot(c, c);
-        }
+      if (vo) {
+        const float4 c = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
+        m2 = f4_dot(c, c);
+      }
       m2 += __shfl_xor(m2, 16, 64);
       m2 += __shfl_xor(m2, 32, 64);
       if (h == 0) {
-        float* pp = a.part + ((int64_t)j * a.n_part + prow) * 2;
+        float* pp = a.part + ((int64_t)jj * a.n_part + g) * 2;
         pp[0] = sum;
         pp[1] = m2;
+      }
+    }
+  }
+}
+
+// ---- LDS-staged variant (the one launched at production sizes) ------------------------------
+// Operand fetch straight from global costs one VMEM instruction per 256 B (the activation
+// rows are only L*4 = 32-64 B long), and at ~300 loads per wave the kernel is bound by VMEM
+// issue, not by the matrix cores.  Here a workgroup stages a 32-deep slice of both operands
+// with 1-KiB float4 loads, shares it between its four waves through LDS, and overlaps the
+// next slice's global loads (held in registers) with the current slice's MFMAs:
+//   sA[k][n]  activation slice, k-major, rows padded to BN+4 floats (conflict-free b32 reads:
+//             the four k-slots of a wave read rows 4 apart -> banks 16 apart);
+//   sB        TRANS: W[j][i] slice stored [j][k] (k contiguous, row BK+4) and read as ONE b128
+//             per tile per 16 k (k-permuted: step r <-> k = kb + 4*slot + r, same permutation
+//             on the A side);  !TRANS: W[i][j] slice stored [k][j] like sA.
+template <bool TRANS, int BN, int BJ>
+__global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
+  constexpr int BK = 32;
+  constexpr int TN = BN / 32, TJ = BJ / 32;              // 16x16 tiles per wave (waves are 2 x 2)
+  constexpr int LDA = BN + 4;
+  constexpr int LDB = TRANS ? (BK + 4) : (BJ + 4);
+  constexpr int SB_ROWS = TRANS ? BJ : BK;
+  constexpr int NA = BK * BN / 4 / 256;                  // float4 per thread per stage (1 or 2)
+  constexpr int NB = BK * BJ / 4 / 256;
+  __shared__ __attribute__((aligned(16))) float sA[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float sB[2][SB_ROWS * LDB];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, h = lane >> 4;
+  const int wn = wave & 1, wj = wave >> 1;
+  const int gbase = blockIdx.x * (BN / 16);              // first n-group of the workgroup
+  const int jbase = blockIdx.y * BJ;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- staging: slot v of a thread is float4 number threadIdx.x + 256*v of the slice; the
+  // registers are individually named (arrays indexed in unrolled lambdas ended up in scratch)
+  auto a_coord = [&](int v, int& k, int& n, int64_t& off) __attribute__((always_inline)) {
+    const int idx = threadIdx.x + 256 * v;
+    k = idx / (BN / 4);
+    n = (idx % (BN / 4)) * 4;
+    int g = gbase + n / 16;
+    g = g < a.n_groups ? g : a.n_groups - 1;
+    const int u = n & 15;
+    int smp = g * a.spw + (u >> a.Lb);
+    smp = smp < a.b ? smp : a.b - 1;                     // clamped: padded columns are never stored
+    off = ((int64_t)smp * a.Ci) * a.L + (u & (a.L - 1));
+  };
+  auto b_coord = [&](int v, int& r, int& c) __attribute__((always_inline)) {
+    const int idx = threadIdx.x + 256 * v;
+    if (TRANS) {                                         // (j, 4*i4)
+      r = idx / (BK / 4);
+      c = (idx % (BK / 4)) * 4;
+    } else {                                             // (k, 4*j4)
+      r = idx / (BJ / 4);
+      c = (idx % (BJ / 4)) * 4;
+    }
+  };
+  auto gload_a = [&](int v, int i0) __attribute__((always_inline)) -> float4 {
+    int k, n;
+    int64_t off;
+    a_coord(v, k, n, off);
+    const int i = i0 + k;
+    const int ic = i < a.I ? i : a.I - 1;
+    const int q = ic / a.Ci;
+    const float* sp = a.act.p[0];
+#pragma unroll
+    for (int qq = 1; qq < BMNAS_MAX_PTRS; ++qq) sp = (q == qq) ? a.act.p[qq] : sp;
+    const float4 t = ld4(sp + off + (int64_t)(ic - q * a.Ci) * a.L);
+    return i < a.I ? t : z4;
+  };
+  auto gload_b = [&](int v, int i0) __attribute__((always_inline)) -> float4 {
+    int r, c;
+    b_coord(v, r, c);
+    if (TRANS) {
+      int j = jbase + r;
+      j = j < a.J ? j : a.J - 1;
+      const int i = i0 + c;                              // I % 16 == 0: a float4 is all in or all out
+      const int ic = i < a.I ? i : a.I - 4;
+      const float4 t = ld4(a.W + (int64_t)j * a.ldw + ic);
+      return i < a.I ? t : z4;
+    } else {
+      const int i = i0 + r;
+      const int ic = i < a.I ? i : a.I - 1;
+      int j = jbase + c;                                 // J % 16 == 0
+      j = j < a.J ? j : a.J - 4;
+      const float4 t = ld4(a.W + (int64_t)ic * a.ldw + j);
+      return i < a.I ? t : z4;
+    }
+  };
+  auto lstore_a = [&](int v, int buf, float4 val) __attribute__((always_inline)) {
+    int k, n;
+    int64_t off;
+    a_coord(v, k, n, off);
+    *reinterpret_cast<float4*>(&sA[buf][k * LDA + n]) = val;
+  };
+  auto lstore_b = [&](int v, int buf, float4 val) __attribute__((always_inline)) {
+    int r, c;
+    b_coord(v, r, c);
+    *reinterpret_cast<float4*>(&sB[buf][r * LDB + c]) = val;
+  };
+  float4 ra0 = z4, ra1 = z4, rb0 = z4, rb1 = z4;
+  auto gload = [&](int i0) __attribute__((always_inline)) {
+    ra0 = gload_a(0, i0);
+    if (NA > 1) ra1 = gload_a(1, i0);
+    rb0 = gload_b(0, i0);
+    if (NB > 1) rb1 = gload_b(1, i0);
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+    lstore_a(0, buf, ra0);
+    if (NA > 1) lstore_a(1, buf, ra1);
+    lstore_b(0, buf, rb0);
+    if (NB > 1) lstore_b(1, buf, rb1);
+  };
+
+  f32x4 acc[TN][TJ];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const float* A = sA[buf];
+    const float* B = sB[buf];
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 16) {
+      float av[TN][4], bv[TJ][4];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[tn][r] = A[(kb + 4 * h + r) * LDA + (wn * TN + tn) * 16 + lo];
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const int jl = (wj * TJ + tj) * 16 + lo;
+        if (TRANS) {
+          const float4 t = *reinterpret_cast<const float4*>(&B[jl * LDB + kb + 4 * h]);
+          bv[tj][0] = t.x; bv[tj][1] = t.y; bv[tj][2] = t.z; bv[tj][3] = t.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[tj][r] = B[(kb + 4 * h + r) * LDB + jl];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+            acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][r], bv[tj][r], acc[tn][tj], 0, 0, 0);
+    }
+  };
+
+  const int nstage = (a.I + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) gload((st + 1) * BK);           // in flight during the MFMAs below
+    compute(buf);
+    if (st + 1 < nstage) lstore(buf ^ 1);                // other buffer: last read one barrier ago
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[tn][tj][r] = OUT[n = 16*g + 4h + r][j] ----
+  const int l0 = (4 * h) & (a.L - 1);
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    const int jt = jbase + (wj * TJ + tj) * 16;
+    if (jt >= a.J) continue;                             // wave-uniform
+    const int jj = jt + lo;
+    const float bj = (a.bias != nullptr) ? a.bias[jj] : 0.f;
+    const int q = jj / a.Cj;
+    const int cj = jj - q * a.Cj;
+    float* d = a.dst.p[0];
+#pragma unroll
+    for (int qq = 1; qq < BMNAS_MAX_PTRS; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int g = gbase + wn * TN + tn;
+      if (g >= a.n_groups) continue;                     // wave-uniform
+      const int so = g * a.spw + ((4 * h) >> a.Lb);
+      const bool vo = so < a.b;
+      const float4 o = make_float4(acc[tn][tj][0] + bj, acc[tn][tj][1] + bj, acc[tn][tj][2] + bj,
+                                   acc[tn][tj][3] + bj);
+      if (vo && d != nullptr) {
+        float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
+        st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
+      }
+      if (a.part != nullptr) {
+        float sum = vo ? f4_hsum(o) : 0.f;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        int cnt = a.b * a.L - 16 * g;
+        cnt = cnt > 16 ? 16 : cnt;
+        const float mean = sum / (float)cnt;
+        float m2 = 0.f;
+        if (vo) {
+          const float4 c = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
+          m2 = f4_dot(c, c);
+        }
+        m2 += __shfl_xor(m2, 16, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        if (h == 0) {
+          float* pp = a.part + ((int64_t)jj * a.n_part + g) * 2;
+          pp[0] = sum;
+          pp[1] = m2;
+        }
       }
     }
   }
@@ -157,124 +561,135 @@ struct ConvWArgs {
   int use_atomic;
 };
 
-// dW[m][k] += sum_n dU[m][n] * X[k][n].  Workgroup = 8 waves on ONE 64(m) x 32(k) output
-// tile, each wave striding over the n-groups of the workgroup's split; partial tiles are
-// summed through LDS in wave order (deterministic inside the workgroup), then written
-// with coalesced stores (single split) or fp32 atomics (several splits).
+// dW[m][k] += sum_n dU[m][n] * X[k][n].  Workgroup = 8 waves on ONE 32(m) x 32(k) output
+// tile; wave w takes the n-groups gbeg + w, + 8, ... of the workgroup's split.  Both
+// operands are float4 along l (next group's loads issued before this group's 16 MFMAs), the
+// eight partial tiles meet in LDS and leave with coalesced stores (single split) or
+// well-shaped fp32 atomics (128-B runs along k).
 __global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
-  __shared__ float tile[64 * 33];
-  __shared__ float brow[64];
+  __shared__ float tile[8][32 * 33];
+  __shared__ float brow[8][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
-  const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 32;
+  const int m0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
   const int gbeg = blockIdx.z * a.groups_per_split;
   int gend = gbeg + a.groups_per_split;
   if (gend > a.n_groups) gend = a.n_groups;
   const bool want_bias = (a.dbias != nullptr) && (blockIdx.y == 0);
 
-  bool vm[4], vk[2];
+  // tiles past the edge are clamped (their results are never stored)
+  auto a_row = [&](int t) __attribute__((always_inline)) -> int64_t {
+    const int mt = m0 + 16 * t;
+    return (int64_t)((mt < a.M ? mt : a.M - 16) + lo) * a.L;
+  };
+  auto b_row = [&](int t, const float*& sp) __attribute__((always_inline)) -> int64_t {
+    const int kt = k0 + 16 * t;
+    const int k = (kt < a.K ? kt : a.K - 16) + lo;
+    const int q = k / a.C_src;
+    sp = a.src.p[0];                                     // q differs per lane: selects, not an indexed load
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) vm[tm] = (m0 + 16 * tm) < a.M;
-#pragma unroll
-  for (int tk = 0; tk < 2; ++tk) vk[tk] = (k0 + 16 * tk) < a.K;
-  // per-lane row offsets (in floats, without the sample term)
-  int64_t aoff[4], boff[2];
-  const float* bsrc[2];
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm) aoff[tm] = (int64_t)(m0 + 16 * tm + lo) * a.L;
-#pragma unroll
-  for (int tk = 0; tk < 2; ++tk) {
-    const int k = k0 + 16 * tk + lo;
-    const int q = vk[tk] ? k / a.C_src : 0;
-    bsrc[tk] = a.src.p[q];
-    boff[tk] = (int64_t)(k - q * a.C_src) * a.L;
-  }
+    for (int qq = 1; qq < BMNAS_MAX_PTRS; ++qq) sp = (q == qq) ? a.src.p[qq] : sp;
+    return (int64_t)(k - q * a.C_src) * a.L;
+  };
+  const float *bsrc0, *bsrc1;
+  const int64_t aoff0 = a_row(0), aoff1 = a_row(1);
+  const int64_t boff0 = b_row(0, bsrc0), boff1 = b_row(1, bsrc1);
   const int l0 = (4 * h) & (a.L - 1);
   const int sh = (4 * h) >> a.Lb;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  f32x4 acc[4][2];
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+  for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int tk = 0; tk < 2; ++tk) acc[tm][tk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
 
-  for (int g = gbeg + wave; g < gend; g += 8) {
-    const int s = g * a.spw + sh;
-    const bool vs = s < a.b;
-    float4 av[4], bv[2];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-      av[tm] = (vs && vm[tm]) ? ld4(a.dU + (int64_t)s * a.M * a.L + aoff[tm] + l0)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int tk = 0; tk < 2; ++tk)
-      bv[tk] = (vs && vk[tk]) ? ld4(bsrc[tk] + (int64_t)s * a.C_src * a.L + boff[tk] + l0)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+  // loads are unconditional from clamped addresses; what must not contribute to the sum over
+  // n (padded samples, groups past the split) is zeroed in the dU operand by a select
+  float4 a0[2], b0[2], a1[2], b1[2];           // two statically named operand sets
+  auto load_ops = [&](float4 (&A)[2], float4 (&B)[2], int g) __attribute__((always_inline)) {
+    const int gc = g < gend ? g : gend - 1;
+    const int s = gc * a.spw + sh;
+    const int sc = s < a.b ? s : a.b - 1;
+    const bool vs = (g < gend) && (s < a.b);
+    const float* ub = a.dU + (int64_t)sc * a.M * a.L + l0;
+    const int64_t xb = (int64_t)sc * a.C_src * a.L + l0;
+    const float4 u0 = ld4(ub + aoff0), u1 = ld4(ub + aoff1);
+    A[0] = vs ? u0 : z4;
+    A[1] = vs ? u1 : z4;
+    B[0] = ld4(bsrc0 + xb + boff0);
+    B[1] = ld4(bsrc1 + xb + boff1);
+  };
+  auto mma_ops = [&](const float4 (&A)[2], const float4 (&B)[2]) __attribute__((always_inline)) {
     if (want_bias) {
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) bsum[tm] += f4_hsum(av[tm]);
+      bsum[0] += f4_hsum(A[0]);
+      bsum[1] += f4_hsum(A[1]);
     }
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int tk = 0; tk < 2; ++tk) {
-        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm].x, bv[tk].x, acc[tm][tk], 0, 0, 0);
-        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm].y, bv[tk].y, acc[tm][tk], 0, 0, 0);
-        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm].z, bv[tk].z, acc[tm][tk], 0, 0, 0);
-        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm].w, bv[tk].w, acc[tm][tk], 0, 0, 0);
+        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].x, B[tk].x, acc[tm][tk], 0, 0, 0);
+        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].y, B[tk].y, acc[tm][tk], 0, 0, 0);
+        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].z, B[tk].z, acc[tm][tk], 0, 0, 0);
+        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].w, B[tk].w, acc[tm][tk], 0, 0, 0);
       }
+  };
+  // two-set software pipeline, straight-line steady state (groups past the split are clamped +
+  // zeroed by load_ops, so running one extra masked group is harmless).  Measured: 12.5 us vs
+  // 15.9 us for issuing all of a wave's loads up front.
+  int g = gbeg + wave;
+  load_ops(a0, b0, g);
+  for (; g + 8 < gend; g += 16) {
+    load_ops(a1, b1, g + 8);
+    mma_ops(a0, b0);
+    load_ops(a0, b0, g + 16);
+    mma_ops(a1, b1);
   }
+  if (g < gend) mma_ops(a0, b0);
 
-  // cross-wave reduction: acc[tm][tk][r] = dW[m0 + 16tm + 4h + r][k0 + 16tk + lo]
+  // acc[tm][tk][r] = dW[m0 + 16tm + 4h + r][k0 + 16tk + lo]
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[wave][(16 * tm + 4 * h + r) * 33 + 16 * tk + lo] = acc[tm][tk][r];
   if (want_bias) {
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
+    for (int tm = 0; tm < 2; ++tm) {
       bsum[tm] += __shfl_xor(bsum[tm], 16, 64);
       bsum[tm] += __shfl_xor(bsum[tm], 32, 64);
+      if (h == 0) brow[wave][16 * tm + lo] = bsum[tm];
     }
   }
-  for (int w = 0; w < 8; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* t = &tile[(16 * tm + 4 * h + r) * 33 + 16 * tk + lo];
-            *t = (w == 0) ? acc[tm][tk][r] : (*t + acc[tm][tk][r]);
-          }
-      if (want_bias && h == 0) {
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
-          float* t = &brow[16 * tm + lo];
-          *t = (w == 0) ? bsum[tm] : (*t + bsum[tm]);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  for (int e = threadIdx.x; e < 64 * 32; e += 512) {
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += 512) {
     const int mm = e >> 5, kk = e & 31;
     const int m = m0 + mm, k = k0 + kk;
     if (m < a.M && k < a.K) {
-      const float v = tile[mm * 33 + kk];
-      float* p = a.dW + (int64_t)m * a.ldw + k;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += tile[w][mm * 33 + kk];
+      float* pp = a.dW + (int64_t)m * a.ldw + k;
       if (a.use_atomic) {
-        atomicAdd(p, v);
-        if (a.dup_cols > 0) atomicAdd(p + a.dup_cols, v);
+        atomicAdd(pp, v);
+        if (a.dup_cols > 0) atomicAdd(pp + a.dup_cols, v);
       } else {
-        *p += v;
-        if (a.dup_cols > 0) p[a.dup_cols] += v;
+        *pp += v;
+        if (a.dup_cols > 0) pp[a.dup_cols] += v;
       }
     }
   }
-  if (want_bias && threadIdx.x < 64) {
+  if (want_bias && threadIdx.x < 32) {
     const int m = m0 + threadIdx.x;
     if (m < a.M) {
-      if (a.use_atomic) atomicAdd(a.dbias + m, brow[threadIdx.x]);
-      else a.dbias[m] += brow[threadIdx.x];
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += brow[w][threadIdx.x];
+      if (a.use_atomic) atomicAdd(a.dbias + m, v);
+      else a.dbias[m] += v;
     }
   }
 }
@@ -290,6 +705,11 @@ __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W
   }
 }
 
+inline int conv_probe() {
+  static const int v = []() { const char* e = getenv("BMNAS_CONV_PROBE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 inline int check_shape(int b, int L, int* Lb, int* spw, int* n_groups) {
   if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
   *Lb = ilog2_exact(L);
@@ -303,8 +723,71 @@ inline int check_shape(int b, int L, int* Lb, int* spw, int* n_groups) {
 extern "C" int bmnas_conv1x1_num_partials(int b, int L) {
   int Lb, spw, ng;
   if (b < 1 || check_shape(b, L, &Lb, &spw, &ng)) return BMNAS_E_SHAPE;
-  return (ng + 1) / 2;
+  return ng;                                   // one partial per 16-column n-group
 }
+
+namespace {
+// wave tile = (16*TN) x (16*TJ); pick the largest tile that still gives >= ~1500 waves
+template <bool TRANS, int TN, int TJ>
+bool launch_ksplit(const ConvArgs& a, hipStream_t st) {
+  const int nblk = a.I / 16;
+  const int kpw = (nblk + 3) / 4;
+  if (kpw * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;       // operand + accumulator VGPRs
+  dim3 grid((unsigned)((a.n_groups + TN - 1) / TN), (unsigned)((a.J / 16 + TJ - 1) / TJ));
+#define KS_CASE(K)                                                                                   \
+  if (kpw <= K) {                                                                                    \
+    hipLaunchKernelGGL((conv_ksplit_k<TRANS, TN, TJ, K>), grid, dim3(256), 0, st, a);                 \
+    return true;                                                                                     \
+  }
+  KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(6) KS_CASE(9) KS_CASE(12)
+#undef KS_CASE
+  return false;
+}
+
+template <bool TRANS>
+void launch_nj(const ConvArgs& a, hipStream_t st) {
+  const long jt = a.J / 16, ng = a.n_groups;
+  {
+    // split-K kernel.  Measured on MI355X: what costs time at batch 128 is the number of
+    // ROUNDS of workgroups a CU has to run (each round pays launch + one memory round trip +
+    // the store drain, ~3 us), not MFMA or bytes.  So: the largest output tile that still
+    // gives every CU a workgroup (>= 256), all of them resident at once.
+    // Tile choice is empirical (MI355X, batch 128, K = 192 / 576): 2x2 tiles with >= 1024
+    // workgroups 14.4 us, 1x1 tiles 14.6 us; fewer, fatter workgroups were SLOWER (4x4: 22-26 us,
+    // 2x2 with 384 workgroups: 18-22 us) — more waves in flight beat operand reuse here.
+    auto wgs = [&](long tn, long tj) { return ((ng + tn - 1) / tn) * ((jt + tj - 1) / tj); };
+    if (wgs(2, 2) >= 1024 && launch_ksplit<TRANS, 2, 2>(a, st)) return;
+    if (launch_ksplit<TRANS, 1, 1>(a, st)) return;
+  }
+  if (a.I >= 64 && ng * jt >= 256) {
+    // production sizes: LDS-staged kernel; biggest tile that still yields >= ~400 workgroups
+    const long wg64 = ((ng + 3) / 4) * ((jt + 3) / 4), wg3264 = ((ng + 1) / 2) * ((jt + 3) / 4);
+    if (wg64 >= 400) {
+      hipLaunchKernelGGL((conv_lds_k<TRANS, 64, 64>), dim3((unsigned)((ng + 3) / 4), (unsigned)((jt + 3) / 4)),
+                         dim3(256), 0, st, a);
+    } else if (wg3264 >= 400) {
+      hipLaunchKernelGGL((conv_lds_k<TRANS, 32, 64>), dim3((unsigned)((ng + 1) / 2), (unsigned)((jt + 3) / 4)),
+                         dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((conv_lds_k<TRANS, 32, 32>), dim3((unsigned)((ng + 1) / 2), (unsigned)((jt + 1) / 2)),
+                         dim3(256), 0, st, a);
+    }
+    return;
+  }
+  const long waves22 = ((ng + 1) / 2) * ((jt + 1) / 2);
+  const long waves12 = ng * ((jt + 1) / 2);
+  if (waves22 >= 2048) {
+    dim3 grid((unsigned)((ng + 3) / 4), (unsigned)((jt + 3) / 4));            // WG = 2x2 waves of 2x2 tiles
+    hipLaunchKernelGGL((conv_nj_k<TRANS, 2, 2, 2>), grid, dim3(256), 0, st, a);
+  } else if (waves12 >= 2048) {
+    dim3 grid((unsigned)((ng + 1) / 2), (unsigned)((jt + 3) / 4));            // WG = 2x2 waves of 1x2 tiles
+    hipLaunchKernelGGL((conv_nj_k<TRANS, 1, 2, 2>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid((unsigned)ng, (unsigned)((jt + 3) / 4));                        // WG = 1x4 waves of 1x1 tiles
+    hipLaunchKernelGGL((conv_nj_k<TRANS, 1, 1, 1>), grid, dim3(256), 0, st, a);
+  }
+}
+}  // namespace
 
 extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const float* W,
                                  int ldw, const float* bias, float* U, float* part, int b, int L,
@@ -322,9 +805,8 @@ extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src,
   a.dst.p[0] = U;
   a.W = W; a.bias = bias; a.part = part; a.ldw = ldw;
   a.Ci = C_src; a.I = n_src * C_src; a.Cj = M; a.J = M;
-  a.b = b; a.L = L; a.acc_mask = 0; a.n_part = (a.n_groups + 1) / 2;
-  dim3 grid((a.n_groups + 3) / 4, (M + 63) / 64);
-  hipLaunchKernelGGL(conv_nj_k<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = conv_probe();
+  launch_nj<true>(a, (hipStream_t)stream);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
@@ -342,9 +824,8 @@ extern "C" int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw,
   for (int q = 0; q < n_src; ++q) a.dst.p[q] = dsrcs[q];
   a.W = W; a.bias = nullptr; a.part = nullptr; a.ldw = ldw;
   a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
-  a.b = b; a.L = L; a.acc_mask = accumulate_mask;
-  dim3 grid((a.n_groups + 3) / 4, (a.J + 63) / 64);
-  hipLaunchKernelGGL(conv_nj_k<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = conv_probe();
+  launch_nj<false>(a, (hipStream_t)stream);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
@@ -365,16 +846,17 @@ extern "C" int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* src
   }
   a.dU = dU; a.dW = dW; a.dbias = dbias; a.ldw = ldw; a.C_src = C_src; a.M = M;
   a.K = n_src * C_src; a.dup_cols = dup_cols; a.b = b; a.L = L;
-  const int tiles = ((M + 63) / 64) * ((a.K + 31) / 32);
-  // enough workgroups to cover the chip about twice, never fewer than 8 groups per split
-  int splits = (512 + tiles - 1) / tiles;
+  const int tiles = ((M + 31) / 32) * ((a.K + 31) / 32);
+  // about one 8-wave workgroup per CU (all resident at once), at most 8 n-groups per wave
+  // (64 per split), never fewer than one group per wave
+  int splits = (256 + tiles - 1) / tiles;
   const int max_splits = (a.n_groups + 7) / 8;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   a.groups_per_split = (a.n_groups + splits - 1) / splits;
   splits = (a.n_groups + a.groups_per_split - 1) / a.groups_per_split;
   a.use_atomic = splits > 1;
-  dim3 grid((M + 63) / 64, (a.K + 31) / 32, splits);
+  dim3 grid((M + 31) / 32, (a.K + 31) / 32, splits);
   hipLaunchKernelGGL(conv_w_k, grid, dim3(512), 0, (hipStream_t)stream, a);
   BMNAS_CHECK_LAUNCH();
   return 0;

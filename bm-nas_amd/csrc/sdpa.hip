@@ -60,8 +60,11 @@ __device__ __forceinline__ void attn_probs(const float* __restrict__ x, const fl
                                            const SdpaGeom& G, int g, int wave, int lane, float4* ldsS,
                                            float p[4]) {
   const int lo = lane & 15, h = lane >> 4;
-  const int s_lo = g * G.spw + (lo >> G.Lb);
-  const bool v_lo = s_lo < G.b;
+  // padded samples read the last valid sample (clamped address, no predicated loads); the
+  // block-diagonal mask keeps them away from real rows and nothing of theirs is stored
+  int s_lo = g * G.spw + (lo >> G.Lb);
+  s_lo = s_lo < G.b ? s_lo : G.b - 1;
+  const bool v_lo = true;
   const int64_t base = ((int64_t)s_lo * G.C) * G.L + (lo & (G.L - 1));
   const float* xb = x + base;
   const float* yb = y + base;
@@ -261,8 +264,9 @@ __global__ __launch_bounds__(256) void sdpa_ln_bwd_k(
   // dP[i = lo][j = 4h + r] = sum_c dO[c][i] * y[c][j]: each wave contracts its quarter of C
   float ds[4];
   {
-    const int s_lo = g * G.spw + (lo >> G.Lb);
-    const bool v_lo = s_lo < G.b;
+    int s_lo = g * G.spw + (lo >> G.Lb);
+    s_lo = s_lo < G.b ? s_lo : G.b - 1;                  // clamped; dO of padded samples is zero
+    const bool v_lo = true;
     const float* yb = y + ((int64_t)s_lo * G.C) * G.L + (lo & (G.L - 1));
     const int per = G.C / 16;
     const int t0 = wave * per, t1 = t0 + per;

@@ -123,7 +123,7 @@ int bmnas_sdpa_ln_bwd(const float* g, const float* gscale, const float* x, const
  * node_search.py:59-61 (several convs sharing the same input may be stacked along M).
  * If part != NULL (train-mode BatchNorm follows): per-channel partial batch statistics
  * part[(m*P + p)*2 + {0,1}] = (sum, M2 about the partial's own mean) over the p-th block
- * of 32 (sample,l) columns; p < P = bmnas_conv1x1_num_partials(b, L). */
+ * of 16 (sample,l) columns; p < P = bmnas_conv1x1_num_partials(b, L). */
 int bmnas_conv1x1_num_partials(int b, int L);
 int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const float* W, int ldw,
                       const float* bias, float* U, float* part, int b, int L, int M,
