@@ -32,8 +32,11 @@ def init_from_env(backend=None):
     local = int(os.environ.get('LOCAL_RANK', rank))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    backend = os.environ.get('BMNAS_DIST_BACKEND', backend)       # testing hook (gloo on one GPU)
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if 'BMNAS_FORCE_DEVICE' in os.environ:                        # testing hook: all ranks on one GPU
+        local = int(os.environ['BMNAS_FORCE_DEVICE'])
     if backend == 'nccl':
         torch.cuda.set_device(local)
     if not dist.is_initialized():

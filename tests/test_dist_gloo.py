@@ -1,0 +1,106 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing that replaces nn.DataParallel
+(bmnas.dist).  The model here is a plain torch stand-in (the HIP hypernet needs a GPU); what is
+under test is the sharding, the flat gradient all-reduce riding on optimizer.step pre-hooks for
+BOTH the weight and the architecture optimizer, and that replicas stay identical."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Toy(torch.nn.Module):
+    """weights + unregistered 'arch' tensors, like FusionNetwork."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.l1 = torch.nn.Linear(6, 5)
+        self.l2 = torch.nn.Linear(5, 3)
+        self.alpha = (1e-3 * torch.randn(4, 2)).requires_grad_(True)
+
+    def arch_parameters(self):
+        return [self.alpha]
+
+    def forward(self, x):
+        w = torch.softmax(self.alpha, -1)[:, 1].sum()
+        return self.l2(torch.relu(self.l1(x))) * w
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bm-nas_amd'))
+    from bmnas import dist as bdist
+    r, l, w = bdist.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(1)
+    X, Y = torch.randn(8, 6), torch.randn(8, 3)
+    model = Toy()
+    if rank == 1:                      # start different on purpose; broadcast_state must fix it
+        with torch.no_grad():
+            model.l1.weight.add_(1.0)
+            model.alpha.add_(1.0)
+    bdist.broadcast_state(model, model.arch_parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    aopt = torch.optim.Adam(model.arch_parameters(), lr=1e-2, betas=(0.5, 0.999))
+    bdist.attach(opt)
+    bdist.attach(aopt)
+    # single-process reference on the FULL batch
+    ref = Toy()
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    raopt = torch.optim.Adam(ref.arch_parameters(), lr=1e-2, betas=(0.5, 0.999))
+    crit = torch.nn.MSELoss()
+    for it in range(3):
+        xs, ys = bdist.shard(X, rank, world), bdist.shard(Y, rank, world)
+        assert xs.shape[0] == 4
+        opt.zero_grad()
+        crit(model(xs), ys).backward()
+        opt.step()                     # pre-hook averages the shard gradients
+        aopt.zero_grad()
+        crit(model(xs), ys).backward()
+        aopt.step()
+        ropt.zero_grad()
+        crit(ref(X), Y).backward()
+        ropt.step()
+        raopt.zero_grad()
+        crit(ref(X), Y).backward()
+        raopt.step()
+    for a, b in zip(list(model.parameters()) + model.arch_parameters(),
+                    list(ref.parameters()) + ref.arch_parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
+    # replicas identical
+    flat = torch.cat([p.detach().reshape(-1) for p in list(model.parameters()) + model.arch_parameters()])
+    other = flat.clone()
+    dist.broadcast(other, src=0)
+    assert torch.equal(flat, other)
+    with pytest.raises(ValueError):
+        bdist.shard(torch.zeros(7, 2), rank, world)
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
+
+
+def test_two_rank_gradient_averaging_matches_full_batch(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def test_single_process_is_a_no_op():
+    import sys
+    from bmnas import dist as bdist
+    assert bdist.env_world() == int(os.environ.get('WORLD_SIZE', '1'))
+    m = Toy()
+    red = bdist.FlatGradAllReducer(list(m.parameters()))
+    red()                              # world 1: nothing to do, must not need a process group

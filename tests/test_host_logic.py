@@ -1,0 +1,154 @@
+"""CPU: host-side behaviour of the nn.Module mirror that needs no kernel — genotype() against
+the reference's golden answers, state_dict / pickle compatibility, arch-parameter handling,
+the stacked parameter storage of NodeMixedOp, scheduler arithmetic."""
+import copy
+import io
+import json
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as fo
+from oracle import synth
+from util import golden_files
+
+
+class Args:
+    def __init__(self, cfg):
+        self.C, self.L, self.drpt = cfg.C, cfg.L, cfg.drpt
+        self.num_input_nodes, self.num_keep_edges = cfg.N, 2
+        self.node_steps, self.node_multiplier = cfg.ns, cfg.nm
+        self.steps, self.multiplier = cfg.S, cfg.M
+        self.parallel, self.weight_decay = False, 1e-4
+
+
+def make_net(cfg):
+    from models.search.darts.model_search import FusionNetwork
+    return FusionNetwork(cfg.S, cfg.M, cfg.N, 2, Args(cfg))
+
+
+def test_genotype_matches_reference_golden():
+    with open(golden_files('genotypes.json')[0]) as f:
+        cases = json.load(f)
+    for c in cases:
+        cfg = fo.Cfg({**c['cfg'], 'C': 16, 'L': 8})
+        net = make_net(cfg)
+        for dst, src in zip(net.arch_parameters(), c['arch']):
+            dst.data.copy_(torch.tensor(src))
+        got = fo.genotype_to_jsonable(net.genotype())
+        assert got == c['genotype'], (c['kind'], c['seed'])
+
+
+def test_genotype_exhausted_pairs_raises_like_reference():
+    net = make_net(fo.make_cfg(N=2, C=16, L=8, S=2, M=2))
+    with pytest.raises(IndexError):
+        net.genotype()
+
+
+@pytest.mark.parametrize('name', ['mmimdb', 'ntu', 'ego'])
+def test_state_dict_keys_shapes_and_param_counts(name):
+    cfg = fo.CONFIGS[name]
+    net = make_net(cfg)
+    sd, want = net.state_dict(), fo.param_shapes(cfg)
+    assert set(sd) == set(want)
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(want[k]), k
+    n_params = sum(p.numel() for p in net.parameters())
+    assert n_params == {'mmimdb': 482688, 'ntu': 480512, 'ego': 716288}[name]
+    assert [tuple(a.shape) for a in net.arch_parameters()] == fo.arch_shapes(cfg)
+    # alphas/betas/gammas are NOT parameters / state (reference: unregistered leaf tensors)
+    ids = {id(p) for p in net.parameters()}
+    assert all(id(a) not in ids and a.requires_grad and a.is_leaf for a in net.arch_parameters())
+    assert float(net.alphas_edges.abs().max()) < 0.01                                # 1e-3 * randn init
+
+
+def test_load_state_dict_roundtrip_and_stacked_storage():
+    """NodeMixedOp keeps LinearGLU/ConcatFC conv+BN tensors as views of stacked buffers; this
+    must be invisible: load_state_dict, deepcopy and optimizers see ordinary parameters."""
+    cfg = fo.make_cfg(N=3, C=16, L=8, ns=2, nm=2)
+    net = make_net(cfg)
+    p = synth.make_params(cfg, 3)
+    net.load_state_dict(p)
+    op = net.cell._step_nodes[0].node_cell.node_ops[1]
+    pk = op.pack()
+    C = cfg.C
+    glu, cfc = op._ops[2], op._ops[3]
+    assert glu.conv.weight.data_ptr() == pk.stack_W.data_ptr()
+    assert cfc.conv.weight.data_ptr() == pk.stack_W[2 * C:].data_ptr()
+    key = 'cell._step_nodes.0.node_cell.node_ops.1._ops'
+    assert torch.equal(pk.stack_W[:2 * C].view(2 * C, 2 * C, 1), p[f'{key}.2.conv.weight'])
+    assert torch.equal(pk.stack_W[2 * C:].view(C, 2 * C, 1), p[f'{key}.3.conv.weight'])
+    assert torch.equal(pk.stack_rv[2 * C:], p[f'{key}.3.bn.running_var'])
+    # in-place optimizer-style updates go through the views
+    with torch.no_grad():
+        cfc.conv.weight.add_(1.0)
+    assert torch.equal(op.pack().stack_W[2 * C:].view(C, 2 * C, 1), p[f'{key}.3.conv.weight'] + 1.0)
+    # state_dict round trip through a fresh network
+    buf = io.BytesIO()
+    torch.save(net.state_dict(), buf)
+    buf.seek(0)
+    net2 = make_net(cfg)
+    net2.load_state_dict(torch.load(buf))
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, net2.state_dict()[k]), k
+    # deepcopy breaks the sharing; pack() re-establishes it without changing values
+    net3 = copy.deepcopy(net)
+    op3 = net3.cell._step_nodes[0].node_cell.node_ops[1]
+    pk3 = op3.pack()
+    assert op3._ops[2].conv.weight.data_ptr() == pk3.stack_W.data_ptr() != pk.stack_W.data_ptr()
+    assert torch.equal(pk3.stack_W, op.pack().stack_W)
+
+
+def test_genotype_pickle_uses_reference_module_path():
+    net = make_net(fo.make_cfg(N=3, C=16, L=8))
+    g = net.genotype()
+    blob = pickle.dumps(g)
+    assert b'models.search.darts.genotypes' in blob
+    g2 = pickle.loads(blob)
+    assert g2 == g and type(g2).__name__ == 'Genotype' and g2._fields == ('edges', 'steps', 'concat')
+    assert g2.steps[0]._fields == ('inner_edges', 'inner_steps', 'inner_concat')
+
+
+def test_arch_tensors_follow_module_apply_and_keep_identity():
+    """The reference creates the arch optimizer BEFORE model.to(device): tensor identity must
+    survive .to()/.double() so the optimizer keeps stepping the live tensors."""
+    net = make_net(fo.make_cfg(N=3, C=16, L=8))
+    arch = list(net.arch_parameters())
+    opt = torch.optim.Adam(arch, lr=3e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    net.double()
+    assert all(a is b for a, b in zip(arch, net.arch_parameters()))
+    assert all(a.dtype == torch.float64 for a in arch)
+    net.float()
+    for a in arch:
+        a.grad = torch.ones_like(a)
+    before = [a.detach().clone() for a in arch]
+    opt.step()
+    assert all(not torch.equal(a, b) for a, b in zip(arch, before))
+
+
+def test_registries_and_public_names():
+    from models.search.darts import genotypes, node_operations, operations
+    assert genotypes.PRIMITIVES == ['none', 'skip'] == genotypes.STEP_EDGE_PRIMITIVES
+    assert genotypes.STEP_STEP_PRIMITIVES == ['Sum', 'ScaleDotAttn', 'LinearGLU', 'ConcatFC']
+    assert set(operations.OPS) == {'none', 'fc_relu', 'fc_mish', 'skip'}
+    assert set(node_operations.STEP_STEP_OPS) == {'Sum', 'ScaleDotAttn', 'LinearGLU', 'ConcatFC'}
+    from models.search.darts.architect import Architect        # noqa: F401
+    from models.search.darts.model import Found_FusionNetwork   # noqa: F401
+    from models.search.darts.node import Found_FusionNode, Found_NodeCell   # noqa: F401
+    from models.search.darts.utils import (count_parameters, create_exp_dir, load, load_pickle,   # noqa: F401
+                                           save, save_pickle)
+
+
+def test_found_network_state_dict_keys():
+    from models.search.darts.model import Found_FusionNetwork
+    cfg = fo.make_cfg(N=4, C=16, L=8, ns=3, nm=2)
+    net = make_net(cfg)
+    for a in net.arch_parameters():
+        a.data.normal_()
+    g = net.genotype()
+    f = Found_FusionNetwork(cfg.S, cfg.M, cfg.N, 2, Args(cfg), None, g)
+    og = fo.genotype_from_jsonable(fo.genotype_to_jsonable(g))
+    assert set(f.state_dict()) == set(fo.found_param_shapes(cfg, og))
+    assert f.get_genotype() is g
