@@ -1,0 +1,177 @@
+"""The epoch / phase loop shared by the three dataset trainers.
+
+Behaviour follows the reference's train_searchable/{mmimdb,ntu,ego}.py: phase order, model.train()
+in BOTH the train and dev phases of a search, Architect.step on every dev batch followed by a
+no-grad forward for the metric, per-batch cosine schedule, best-dev checkpoint + genotype pickle.
+Differences, all on the host side of the hot path:
+  * the per-batch .item() / .cpu() syncs are gone: loss and metric statistics accumulate on the
+    device and are read once per phase (same numbers, no stall per batch);
+  * `parallel` means one process per GPU (bmnas.dist); statistics are summed over ranks and only
+    rank 0 writes checkpoints — there is no `.module` indirection.
+"""
+import copy
+import os
+
+import torch
+import torch.distributed as dist
+
+import models.auxiliary.scheduler as sc
+from models.search.darts.utils import count_parameters, save, save_pickle
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _all_sum(t):
+    if _world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+class AccuracyMeter:
+    name = 'Acc'
+
+    def reset(self, device):
+        self.correct = torch.zeros((), device=device, dtype=torch.float64)
+
+    def update(self, output, labels):
+        self.correct += (output.argmax(1) == labels).sum()
+
+    def compute(self, n):
+        return float(_all_sum(self.correct.clone())) / n
+
+
+class F1Meter:
+    """weighted / macro / ... F1 of sigmoid(output) > threshold, like the reference's sklearn call."""
+
+    def __init__(self, f1_type='weighted', th=0.3):
+        self.f1_type, self.th = f1_type, th
+        self.name = f'{f1_type} F1'
+
+    def reset(self, device):
+        self.preds, self.labels = [], []
+
+    def update(self, output, labels):
+        self.preds.append(torch.sigmoid(output) > self.th)
+        self.labels.append(labels)
+
+    def compute(self, n):
+        from sklearn.metrics import f1_score
+        y_pred = torch.cat(self.preds).cpu().numpy()
+        y_true = torch.cat(self.labels).cpu().numpy()
+        if _world() > 1:                       # gather every rank's shard on every rank
+            objs = [None] * _world()
+            dist.all_gather_object(objs, (y_pred, y_true))
+            import numpy as np
+            y_pred = np.concatenate([o[0] for o in objs])
+            y_true = np.concatenate([o[1] for o in objs])
+        return float(f1_score(y_true, y_pred, average=self.f1_type, zero_division=1))
+
+
+def fusion_params(model):
+    n = sum(count_parameters(layer) for layer in model.reshape_layers)
+    return n + count_parameters(model.fusion_net)
+
+
+def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_sizes, device,
+        num_epochs, logger, plotter, args, status, unpack, meter, eval_phases, better, task=None,
+        nan_escape=False):
+    """-> dict(best_dev, best_dev_genotype, best_test, best_test_genotype, last_genotype, nan_abort)."""
+    cosine = isinstance(scheduler, sc.LRCosineAnnealingScheduler)
+    best = dict(best_dev=None, best_dev_genotype=None, best_dev_epoch=0, best_test=None,
+                best_test_genotype=None, best_test_epoch=0, last_genotype=None, nan_abort=False)
+    for epoch in range(num_epochs):
+        logger.info('Epoch: {}'.format(epoch))
+        logger.info('EXP: {}'.format(args.save))
+        phases = ['train', 'dev'] if status == 'search' else eval_phases
+        for phase in phases:
+            if phase == 'train':
+                if not cosine:
+                    scheduler.step()
+                if architect is not None:
+                    architect.log_learning_rate(logger)
+                model.train()
+            elif phase == 'dev':
+                if status == 'eval' and not cosine:
+                    scheduler.step()
+                model.train()                  # the reference keeps BN/dropout in train mode here
+            else:
+                model.eval()
+            meter.reset(device)
+            loss_sum = torch.zeros((), device=device, dtype=torch.float64)
+            learn = phase == 'train' or (phase == 'dev' and status == 'eval')
+            for data in dataloaders[phase]:
+                inputs, labels = unpack(data, device)
+                if status == 'search' and phase in ('dev', 'test') and architect is not None:
+                    architect.step(inputs, labels, logger)
+                optimizer.zero_grad()
+                with torch.set_grad_enabled(learn):
+                    output = model(inputs)
+                    if isinstance(output, tuple):
+                        output = output[-1]
+                    loss = criterion(output, labels)
+                    if learn:
+                        if cosine:
+                            scheduler.step()
+                            scheduler.update_optimizer(optimizer)
+                        loss.backward()
+                        optimizer.step()
+                loss_sum += loss.detach().double() * labels.size(0)
+                meter.update(output.detach(), labels)
+            n = dataset_sizes[phase]
+            epoch_loss = float(_all_sum(loss_sum)) / n
+            epoch_metric = meter.compute(n)
+            logger.info('{} Loss: {:.4f}, {}: {:.4f}'.format(phase, epoch_loss, meter.name, epoch_metric))
+            logger.info('Fusion Model Params: {}'.format(fusion_params(model)))
+            genotype = model.genotype()
+            best['last_genotype'] = genotype
+            logger.info(str(genotype))
+            if nan_escape and phase == 'train' and epoch_loss != epoch_loss:
+                logger.info('Nan loss during training, escaping')
+                model.eval()
+                best['nan_abort'] = True
+                return best
+            for which, fname in (('dev', 'best_model.pt'), ('test', 'best_test_model.pt')):
+                if phase != which or (which == 'dev' and status != 'search' and eval_phases[-1] != 'dev'):
+                    continue
+                key = 'best_' + which
+                if best[key] is None or better(epoch_metric, best[key]):
+                    best[key] = epoch_metric
+                    best[key + '_genotype'] = copy.deepcopy(genotype)
+                    best[key + '_epoch'] = epoch
+                    if _rank() == 0:
+                        save(model, os.path.join(args.save, 'best', fname))
+                        save_pickle(best[key + '_genotype'],
+                                    os.path.join(args.save, 'best', fname.replace('model.pt', 'genotype.pkl')))
+        plotter.plot(best['last_genotype'], os.path.join(args.save, 'architectures', 'epoch_{}'.format(epoch)),
+                     task=task)
+        logger.info('Current best dev {}: {}, at training epoch: {}'.format(meter.name, best['best_dev'],
+                                                                          best['best_dev_epoch']))
+        logger.info('Current best test {}: {}, at training epoch: {}'.format(meter.name, best['best_test'],
+                                                                           best['best_test_epoch']))
+    return best
+
+
+@torch.no_grad()
+def evaluate(model, criterion, loader, n, device, logger, args, unpack, meter, phase='test'):
+    model.eval()
+    logger.info('EXP: {}'.format(args.save))
+    meter.reset(device)
+    loss_sum = torch.zeros((), device=device, dtype=torch.float64)
+    for data in loader:
+        inputs, labels = unpack(data, device)
+        output = model(inputs)
+        if isinstance(output, tuple):
+            output = output[-1]
+        loss_sum += criterion(output, labels).double() * labels.size(0)
+        meter.update(output, labels)
+    epoch_loss = float(_all_sum(loss_sum)) / n
+    metric = meter.compute(n)
+    logger.info('{} Loss: {:.4f}, {}: {:.4f}'.format(phase, epoch_loss, meter.name, metric))
+    logger.info('Fusion Model Params: {}'.format(fusion_params(model)))
+    return metric

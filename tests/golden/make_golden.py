@@ -322,6 +322,53 @@ def make_trajectory(ms, architect_mod):
         print('wrote', path, os.path.getsize(path))
 
 
+# ------------------------------------------------ reshape layers + scheduler ("next" rows)
+def make_aux():
+    import models.auxiliary.aux_models as aux_ref
+    import models.auxiliary.scheduler as sc_ref
+    out = {}
+    cases = [('mm_vec', 'ReshapeInputLayer_MMIMDB', 64, 32, 16, (5, 64)),
+             ('mm_map', 'ReshapeInputLayer_MMIMDB', 128, 32, 16, (3, 128, 10, 12)),
+             ('nt_vec', 'ReshapeInputLayer', 256, 32, 8, (4, 256)),
+             ('nt_vid', 'ReshapeInputLayer', 64, 16, 8, (3, 64, 6, 5, 5)),
+             ('nt_ske', 'ReshapeInputLayer', 128, 16, 8, (4, 128, 4, 4))]
+    meta = []
+    for name, cls, c_in, C, L, shape in cases:
+        for mode in ('eval', 'train_nodrop'):
+            a = Args()
+            a.drpt = 1e-12 if mode == 'train_nodrop' else 0.1
+            layer = getattr(aux_ref, cls)(c_in, C, L, a)
+            rng = np.random.Generator(np.random.PCG64(77))
+            sd = {'conv.weight': (rng.uniform(-1, 1, (C, c_in, 1)) / np.sqrt(c_in)).astype(np.float32),
+                  'conv.bias': (0.1 * rng.standard_normal(C)).astype(np.float32),
+                  'bn.weight': (1 + 0.1 * rng.standard_normal(C)).astype(np.float32),
+                  'bn.bias': (0.1 * rng.standard_normal(C)).astype(np.float32),
+                  'bn.running_mean': (0.1 * rng.standard_normal(C)).astype(np.float32),
+                  'bn.running_var': (1 + 0.2 * np.abs(rng.standard_normal(C))).astype(np.float32),
+                  'bn.num_batches_tracked': np.zeros((), np.int64)}
+            layer.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            layer.train(mode != 'eval')
+            x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).requires_grad_(True)
+            y = layer(x)
+            w = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+            (y * w).sum().backward()
+            key = f'{name}_{mode}'
+            out[key + ':y'] = y.detach().numpy()
+            out[key + ':dx'] = x.grad.numpy()
+            out[key + ':dconv_w'] = layer.conv.weight.grad.numpy()
+            out[key + ':dbn_w'] = layer.bn.weight.grad.numpy()
+            out[key + ':dbn_b'] = layer.bn.bias.grad.numpy()
+            out[key + ':rm'] = layer.bn.running_mean.numpy().copy()
+            out[key + ':rv'] = layer.bn.running_var.numpy().copy()
+            meta.append(dict(key=key, cls=cls, c_in=c_in, C=C, L=L, shape=list(shape), mode=mode))
+    sched = sc_ref.LRCosineAnnealingScheduler(1e-3, 1e-6, 1, 2, 7.5)
+    out['sched'] = np.array([sched.step() for _ in range(60)], dtype=np.float64)
+    out['meta'] = json.dumps(meta)
+    path = os.path.join(HERE, 'aux_layers.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -330,6 +377,7 @@ def main():
     make_genotypes(ms)
     make_found(ms, mf, gt)
     make_trajectory(ms, architect_mod)
+    make_aux()
 
 
 if __name__ == '__main__':
