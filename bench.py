@@ -215,8 +215,9 @@ def main():
 
     if world > 1:
         bdist.broadcast_state(model, arch)
-        red_w = bdist.FlatGradAllReducer(params)
-        red_a = bdist.FlatGradAllReducer(arch)
+        # weights AND architecture gradients in ONE flat bucket: both are produced by every
+        # fwd+bwd, and a second (42-float) all-reduce would cost a full collective latency
+        red_all = bdist.FlatGradAllReducer(params + arch)
 
     eager_ms = None
     if a.mode == 'graph':
@@ -240,8 +241,7 @@ def main():
     def run():
         run_local()
         if world > 1:
-            red_w()
-            red_a()
+            red_all()
 
     for _ in range(a.warmup):
         run()

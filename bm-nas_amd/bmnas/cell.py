@@ -234,7 +234,7 @@ def _attn_affine_bwd(sv, g, G):
                       False, True)
 
 
-def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G):
+def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=0):
     """g: grad of the mixed output.  dgamma_row (4 floats, +=), x_slot / y_slot: GradSlots
     (y_slot None when x is y).  G: gradient pack (stack_dW, stack_dbias, stack_bn_grad,
     dln_w, dln_b), all += ."""
@@ -246,7 +246,7 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G):
     if sv.same:
         dxb, acc = x_slot.buf(), x_slot.acc_bit()
         lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
-                         dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc)
+                         dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
         conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias)
         lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, None, 1, b, C, L,
                         sv.d_attn)
@@ -254,7 +254,7 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G):
         dxb, dyb = x_slot.buf(), y_slot.buf()
         acc = x_slot.acc_bit() | (y_slot.acc_bit() << 1)
         lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, dyb, acc,
-                         dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc)
+                         dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
         conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot, y_slot], G.stack_dW, G.stack_dbias)
         lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, dyb, 3, b, C, L,
                         sv.d_attn)
@@ -333,7 +333,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG):
         if gs is None:
             continue                                    # this inner state feeds nothing
         z_slot = GradSlot(x)
-        node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t])
+        node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t], NG.shards, NG.shard_stride)
         off = sv.offsets[t]
         n_in = 2 + t
         mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.beta_w[off:, 1], z_slot.buf(),

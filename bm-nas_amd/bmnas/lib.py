@@ -49,7 +49,7 @@ SIGNATURES = {
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
-    'bmnas_node_mix_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _I, _I, _I,
+    'bmnas_node_mix_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32, _P, _P, _I, _I, _I,
                             Dropout, Dropout, _P], _I),
     'bmnas_bn_glu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_glu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
@@ -209,11 +209,12 @@ def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc):
                                      _ptr(out), b, Cc, L, dglu, dfc, _stream()), 'node_mix_fwd')
 
 
-def node_mix_bwd(g, x, y, p1, U, chan, gamma, dgamma, dx, dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc):
+def node_mix_bwd(g, x, y, p1, U, chan, gamma, dgamma, dx, dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc,
+                 dg_shards=1, dg_stride=0):
     _check(load().bmnas_node_mix_bwd(_ptr(g), _ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan),
                                      gamma.data_ptr(), None if dgamma is None else dgamma.data_ptr(),
-                                     _ptr(dx), _ptr(dy), acc_mask, _ptr(dV), _ptr(bn_grad), b, Cc, L,
-                                     dglu, dfc, _stream()), 'node_mix_bwd')
+                                     dg_shards, dg_stride, _ptr(dx), _ptr(dy), acc_mask, _ptr(dV),
+                                     _ptr(bn_grad), b, Cc, L, dglu, dfc, _stream()), 'node_mix_bwd')
 
 
 def bn_glu_fwd(U, chan, out, b, Cc, L, drop):

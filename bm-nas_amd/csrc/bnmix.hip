@@ -106,9 +106,9 @@ __device__ __forceinline__ float row_sum(float v, int l4n) {
 __global__ __launch_bounds__(256) void node_mix_bwd_k(
     const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ p1, const float* __restrict__ U, const float* __restrict__ chan,
-    const float* __restrict__ gamma, float* dgamma, float* dx, float* dy, uint32_t acc_mask,
-    float* __restrict__ dV, float* bn_grad, int b, int C, int L, int chunk, DropCfg dglu,
-    DropCfg dfc) {
+    const float* __restrict__ gamma, float* dgamma, int dg_shards, int64_t dg_stride, float* dx,
+    float* dy, uint32_t acc_mask, float* __restrict__ dV, float* bn_grad, int b, int C, int L,
+    int chunk, DropCfg dglu, DropCfg dfc) {
   __shared__ float red[4];
   __shared__ float csum[3][6][64];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float t = block_sum256(dgam[q], red);
-    if (threadIdx.x == 0 && dgamma != nullptr) atomicAdd(dgamma + q, t);
+    // every workgroup adds into the same 4 scalars: same-address atomics serialise (~25 ns
+    // each), so spread them over dg_shards copies (summed by the arch-softmax backward)
+    if (threadIdx.x == 0 && dgamma != nullptr)
+      atomicAdd(dgamma + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % dg_shards) * dg_stride + q, t);
   }
 }
 
@@ -419,6 +422,34 @@ struct ArchPack {
   int64_t shard_stride;               // bwd: dweights are summed over n_shards copies
 };
 
+// backward of the above with the shard sum spread over a wavefront: block = one row, lane =
+// (shard group, column); shards beyond 16 are walked by the same lane
+__global__ __launch_bounds__(64) void arch_softmax_multi_bwd_k(ArchPack P) {
+  int r = blockIdx.x;
+  const int lane = threadIdx.x, col = lane & 3, sg = lane >> 2;
+  for (int t = 0; t < P.n; ++t) {
+    if (r < P.rows[t]) {
+      const int cols = P.cols[t];
+      float dw = 0.f, w = 0.f;
+      if (col < cols) {
+        const float* dwp = P.b[t] + r * cols + col;
+        for (int sh = sg; sh < P.n_shards; sh += 16) dw += dwp[(int64_t)sh * P.shard_stride];
+        w = P.a[t][r * cols + col];
+      }
+      dw += __shfl_xor(dw, 4, 64);
+      dw += __shfl_xor(dw, 8, 64);
+      dw += __shfl_xor(dw, 16, 64);
+      dw += __shfl_xor(dw, 32, 64);                      // every lane: total of its column
+      float dot = w * dw;
+      dot += __shfl_xor(dot, 1, 64);
+      dot += __shfl_xor(dot, 2, 64);                     // sum over the 4 columns
+      if (sg == 0 && col < cols) P.o[t][r * cols + col] = w * (dw - dot);
+      return;
+    }
+    r -= P.rows[t];
+  }
+}
+
 // every row of every architecture tensor in ONE launch (<= 94 rows in total)
 __global__ void arch_softmax_multi_k(ArchPack P, int backward) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -465,8 +496,11 @@ inline DropCfg to_cfg(const bmnas_dropout_t& d) {
 
 // samples walked per workgroup in the backward reductions: keep >= ~512 workgroups
 inline int pick_chunk(int b, int slots4) {
+  // 4 sample lanes walk the chunk.  Measured: 4-sample chunks (4x the workgroups, 4x the
+  // atomics) took 26 us against 15 us for 16-sample chunks — the atomics, not the
+  // parallelism, set the time.
   (void)slots4;
-  return b >= 64 ? 16 : (b >= 16 ? 8 : 4);     // 4 sample lanes walk the chunk
+  return b >= 64 ? 16 : (b >= 16 ? 8 : 4);
 }
 
 }  // namespace
@@ -503,10 +537,12 @@ extern "C" int bmnas_node_mix_fwd(const float* x, const float* y, const float* p
 
 extern "C" int bmnas_node_mix_bwd(const float* g, const float* x, const float* y, const float* p1,
                                   const float* U, const float* chan, const float* gamma,
-                                  float* dgamma, float* dx, float* dy, uint32_t accumulate_mask,
-                                  float* dV, float* bn_grad, int b, int C, int L,
-                                  bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream) {
-  if (!g || !x || !y || !p1 || !U || !chan || !gamma || !dV || !bn_grad || b < 0 || C < 1)
+                                  float* dgamma, int dgamma_shards, int64_t dgamma_shard_stride,
+                                  float* dx, float* dy, uint32_t accumulate_mask, float* dV,
+                                  float* bn_grad, int b, int C, int L, bmnas_dropout_t drop_glu,
+                                  bmnas_dropout_t drop_fc, void* stream) {
+  if (!g || !x || !y || !p1 || !U || !chan || !gamma || !dV || !bn_grad || b < 0 || C < 1 ||
+      dgamma_shards < 1)
     return BMNAS_E_ARG;
   if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
   if (b == 0) return 0;
@@ -514,7 +550,8 @@ extern "C" int bmnas_node_mix_bwd(const float* g, const float* x, const float* y
   const int chunk = pick_chunk(b, cl4);
   dim3 grid((cl4 + 63) / 64, (b + chunk - 1) / chunk);
   hipLaunchKernelGGL(node_mix_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, x, y, p1, U, chan,
-                     gamma, dgamma, dx, dy, accumulate_mask, dV, bn_grad, b, C, L, chunk,
+                     gamma, dgamma, dgamma_shards, dgamma_shard_stride, dx, dy, accumulate_mask, dV, bn_grad, b, C,
+                     L, chunk,
                      to_cfg(drop_glu), to_cfg(drop_fc));
   BMNAS_CHECK_LAUNCH();
   return 0;
@@ -627,6 +664,11 @@ extern "C" int bmnas_arch_softmax_multi(const float* const* a, const float* cons
   P.n = n;
   P.n_shards = n_shards;
   P.shard_stride = shard_stride;
+  if (backward) {
+    hipLaunchKernelGGL(arch_softmax_multi_bwd_k, dim3(total), dim3(64), 0, (hipStream_t)stream, P);
+    BMNAS_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(arch_softmax_multi_k, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, P,
                      backward);
   BMNAS_CHECK_LAUNCH();

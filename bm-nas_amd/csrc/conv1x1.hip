@@ -15,9 +15,16 @@
 
 namespace {
 
+// At most 4 tensors are ever concatenated in front of a conv (x, y | node_multiplier <= 4
+// states); the pointer lists are kept that short on purpose — the kernel-argument block is
+// fetched by every wave, and a 2 x 16-pointer block measurably slowed the launches.
+constexpr int kConvPtrs = 4;
+struct ConvIn { const float* p[kConvPtrs]; };
+struct ConvOut { float* p[kConvPtrs]; };
+
 struct ConvArgs {
-  PtrsIn act;            // n_act sources, each (b, Ci, L): contraction rows i = q*Ci + ci
-  PtrsOut dst;           // n_dst destinations, each (b, Cj, L): output cols j = q*Cj + cj
+  ConvIn act;            // n_act sources, each (b, Ci, L): contraction rows i = q*Ci + ci
+  ConvOut dst;           // n_dst destinations, each (b, Cj, L): output cols j = q*Cj + cj
   const float* W;
   const float* bias;     // per output col (fwd), nullable
   float* part;           // BN partial stats (fwd, training), nullable
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj)
       part[wave][tn * TJ + tj][lane] = make_float4(acc[tn][tj][0], acc[tn][tj][1], acc[tn][tj][2], acc[tn][tj][3]);
-  __syncthreads();
+  if (!(a.probe & 8)) __syncthreads();
 
   // wave w finishes the tiles t = w, w + 4, ...:  o[r] = OUT[n = 16*g + 4h + r][j]
   const int l0 = (4 * h) & (a.L - 1);
@@ -313,10 +320,10 @@ __global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
     const int cj = jj - q * a.Cj;
     float* d = a.dst.p[0];
 #pragma unroll
-    for (int qq = 1; qq < BMNAS_MAX_PTRS; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
+    for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
     const int so = g * a.spw + ((4 * h) >> a.Lb);
     const bool vo = so < a.b;
-    if (vo && d != nullptr) {
+    if (vo && d != nullptr && (!(a.probe & 4) || o.x == 12345.f)) {
       float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
       st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
     }
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
     const int q = ic / a.Ci;
     const float* sp = a.act.p[0];
 #pragma unroll
-    for (int qq = 1; qq < BMNAS_MAX_PTRS; ++qq) sp = (q == qq) ? a.act.p[qq] : sp;
+    for (int qq = 1; qq < kConvPtrs; ++qq) sp = (q == qq) ? a.act.p[qq] : sp;
     const float4 t = ld4(sp + off + (int64_t)(ic - q * a.Ci) * a.L);
     return i < a.I ? t : z4;
   };
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
     const int cj = jj - q * a.Cj;
     float* d = a.dst.p[0];
 #pragma unroll
-    for (int qq = 1; qq < BMNAS_MAX_PTRS; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
+    for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int g = gbase + wn * TN + tn;
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
 
 struct ConvWArgs {
   const float* dU;       // (b, M, L)
-  PtrsIn src;            // n_src sources (b, C_src, L); K = n_src * C_src
+  ConvIn src;            // n_src sources (b, C_src, L); K = n_src * C_src
   float* dW;
   float* dbias;          // nullable
   int ldw, C_src, M, K, dup_cols;
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
     const int q = k / a.C_src;
     sp = a.src.p[0];                                     // q differs per lane: selects, not an indexed load
 #pragma unroll
-    for (int qq = 1; qq < BMNAS_MAX_PTRS; ++qq) sp = (q == qq) ? a.src.p[qq] : sp;
+    for (int qq = 1; qq < kConvPtrs; ++qq) sp = (q == qq) ? a.src.p[qq] : sp;
     return (int64_t)(k - q * a.C_src) * a.L;
   };
   const float *bsrc0, *bsrc1;
@@ -793,7 +800,7 @@ extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src,
                                  int ldw, const float* bias, float* U, float* part, int b, int L,
                                  int M, void* stream) {
   if (!srcs || !W || !U || n_src < 1 || C_src < 1 || b < 0 || M < 1) return BMNAS_E_ARG;
-  if (n_src > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
+  if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
   if (C_src % 16 || M % 16 || ldw % 4 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
   ConvArgs a{};
   if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
@@ -815,7 +822,7 @@ extern "C" int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw,
                                       float* const* dsrcs, int n_src, int C_src,
                                       uint32_t accumulate_mask, int b, int L, int M, void* stream) {
   if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1) return BMNAS_E_ARG;
-  if (n_src > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
+  if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
   if (C_src % 16 || M % 16 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
   ConvArgs a{};
   if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
@@ -835,7 +842,7 @@ extern "C" int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* src
                                         int b, int L, int M, void* stream) {
   if (!dU || !srcs || !dW || n_src < 1 || C_src < 1 || b < 0 || M < 1 || dup_cols < 0)
     return BMNAS_E_ARG;
-  if (n_src > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
+  if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
   if (C_src % 16 || M % 16 || ldw < n_src * C_src + dup_cols) return BMNAS_E_SHAPE;
   ConvWArgs a{};
   if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;

@@ -314,7 +314,7 @@ extern "C" int bmnas_ln_affine_bwd(const float* g, const float* gscale, const fl
     s.p[q] = srcs[q];
   }
   const int cl4 = C * L / 4, d4 = cl4 * n_src;
-  const int chunk = 16;
+  const int chunk = 16;      // (smaller chunks = more atomics: measured slower, 6.5 vs 4.6 us)
   dim3 grid((d4 + 63) / 64, (b + chunk - 1) / chunk);
   hipLaunchKernelGGL(ln_affine_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, gscale, s, resid, ln_w,
                      ln_b, stats, dln_w, dln_b, b, cl4, d4, relu, prenorm, chunk);

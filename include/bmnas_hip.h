@@ -163,14 +163,15 @@ int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const fl
                        const float* chan, const float* gamma, float* out, int b, int C, int L,
                        bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
 /* Backward, phase A (elementwise + reductions):  g = grad of s.
- *   dgamma[q] += <g, p_q>;  dx / dy (=|+=) g0*g (dy NULL: both into dx);
+ *   dgamma[shard*dgamma_shard_stride + q] += <g, p_q> (shards as in bmnas_mixsum_bwd);
+ *   dx / dy (=|+=) g0*g (dy NULL: both into dx);
  *   dV[s, m, l] = gradient w.r.t. the BatchNorm OUTPUT (b, 3C, L);
  *   bn_grad[m] += sum dV*u_hat (= dBN.weight), bn_grad[3C + m] += sum dV (= dBN.bias). */
 int bmnas_node_mix_bwd(const float* g, const float* x, const float* y, const float* p1,
                        const float* U, const float* chan, const float* gamma, float* dgamma,
-                       float* dx, float* dy, uint32_t accumulate_mask, float* dV, float* bn_grad,
-                       int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
-                       void* stream);
+                       int dgamma_shards, int64_t dgamma_shard_stride, float* dx, float* dy,
+                       uint32_t accumulate_mask, float* dV, float* bn_grad, int b, int C, int L,
+                       bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
 
 /* ---- standalone LinearGLU tail (Found nets): out = drop(glu(BN(U))), U (b, 2C, L) --------
  * node_operations.py:34-38.  Backward phase A like bmnas_node_mix_bwd (M = 2C). */

@@ -17,9 +17,15 @@ dz = torch.empty(b, C, L, device=dev)
 dW = torch.zeros(3 * C, 2 * C, device=dev)
 db = torch.zeros(3 * C, device=dev)
 
+_blk = torch.randn(8192, 8192, device=dev)
+
 def timeit(fn, n=50):
+    # queue the calls behind ~30 ms of GEMMs so the GPU runs them back to back (the Python/ctypes
+    # launch path costs ~8 us per call and would otherwise be what is measured)
     for _ in range(5): fn()
     torch.cuda.synchronize()
+    b = _blk
+    for _ in range(4): b = (b @ b) * 1e-4
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n): fn()
