@@ -304,6 +304,13 @@ def main():
         for _ in range(n_prof):
             step()
         recs = lib.profile_end()
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE with
+        # the gfx950 read-side correction; tools/traffic_from_pmc.py); null if not collected
+        traffic = {}
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if a.config == 'mmimdb' and a.batch == 128 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = {k: v['traffic_bytes'] for k, v in json.load(f).items()}
         rows = []
         for name, rr in recs.items():
             tot_ms = sum(r[0] for r in rr)
@@ -317,7 +324,8 @@ def main():
                 achieved = units / (tot_ms * 1e-3) / 1e12
                 peak, unit = MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
             rows.append({'kernel': name, 'bound': bound, 'achieved': round(achieved, 2), 'peak': peak,
-                         'unit': unit, 'frac': round(achieved / peak, 4), 'traffic': None,
+                         'unit': unit, 'frac': round(achieved / peak, 4), 'traffic': traffic.get(name),
+                         'algorithmic_units_per_launch': round(units / len(rr)),
                          'launches_per_step': len(rr) / n_prof, 'avg_us': round(per_launch_us, 2),
                          'us_per_step': round(tot_ms / n_prof * 1e3, 2)})
         rows.sort(key=lambda r: -r['us_per_step'])
