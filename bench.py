@@ -64,7 +64,8 @@ class HyperNet(torch.nn.Module):
         super().__init__()
         from models.search.darts.model_search import FusionNetwork
         self.fusion_net = FusionNetwork(c['S'], c['M'], c['N'], 2, make_args(c), criterion=None)
-        self.central_classifier = torch.nn.Linear(c['M'] * c['C'] * c['L'], c['nout'])
+        from bmnas import nn as bnn
+        self.central_classifier = bnn.Linear(c['M'] * c['C'] * c['L'], c['nout'])
 
     def forward(self, xs):
         return self.central_classifier(self.fusion_net(xs))
@@ -112,6 +113,8 @@ def algo_table(C, L):
         'bn_relu_bwd': lambda g, U, *_: ('hbm', 3 * T(U)),
         'bn_bwd_apply': lambda dV, U, *_: ('hbm', 3 * T(U)),
         'fold_weight': lambda W, We, *_: ('hbm', T(W) + T(We)),
+        'linear_fwd': lambda feat, W, bias, out, b, O, Kd: ('mfma', 2.0 * b * O * Kd),
+        'linear_bwd': lambda g, gs, feat, W, df, dW, db, b, O, Kd: ('mfma', 4.0 * b * O * Kd),
     }
 
 
@@ -186,7 +189,8 @@ def main():
 
     torch.manual_seed(2)                         # the mains' default --seed 2
     model = HyperNet(c).to(device).train()
-    crit = torch.nn.BCEWithLogitsLoss() if c['loss'] == 'bce' else torch.nn.CrossEntropyLoss()
+    from bmnas import nn as bnn
+    crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
     xs, y = synth_batch(c, a.batch, device, seed=rank)
     params = [p for p in model.parameters()]
     arch = list(model.arch_parameters())

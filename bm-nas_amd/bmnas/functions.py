@@ -277,3 +277,69 @@ class FusedCellFn(Function):
         else:
             dalpha = dalpha_w
         return (None, None, None, dalpha, *dxs, *darch, *cell.grads_in_param_order(CG))
+
+
+# ------------------------------------------------------- classifier + criterion epilogue
+class LinearFn(Function):
+    """F.linear(feat, W, bias) for the skinny central classifier (classes <= 128)."""
+
+    @staticmethod
+    def forward(ctx, feat, W, bias):
+        _require_gpu(feat, 'central classifier')
+        feat, W, bias = _c(_f32(feat)), _c(_f32(W)), _c(bias)
+        b, Kd = feat.shape
+        O = W.shape[0]
+        out = torch.empty((b, O), device=feat.device, dtype=torch.float32)
+        lib.linear_fwd(feat, W, bias, out, b, O, Kd)
+        ctx.save_for_backward(feat, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, W = ctx.saved_tensors
+        b, Kd = feat.shape
+        O = W.shape[0]
+        need = ctx.needs_input_grad
+        dfeat = torch.empty_like(feat) if need[0] else None
+        dW = torch.empty_like(W) if need[1] else None
+        db = torch.empty(O, device=feat.device, dtype=torch.float32) if need[2] else None
+        lib.linear_bwd(_c(g), None, feat, W, dfeat, dW, db, b, O, Kd)
+        return dfeat, dW, db
+
+
+class _LossFn(Function):
+    """mean loss with dloss/dlogits produced in the forward pass."""
+
+    @staticmethod
+    def _finish(ctx, loss, dz):
+        ctx.save_for_backward(dz)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        (dz,) = ctx.saved_tensors
+        return dz * gl, None
+
+
+class BCEWithLogitsFn(_LossFn):
+    @staticmethod
+    def forward(ctx, z, y):
+        _require_gpu(z, 'BCEWithLogits loss')
+        z, y = _c(_f32(z)), _c(_f32(y))
+        loss = torch.empty(1, device=z.device, dtype=torch.float32)
+        dz = torch.empty_like(z)
+        lib.bce_logits(z, y, loss, dz)
+        return _LossFn._finish(ctx, loss, dz)
+
+
+class CrossEntropyFn(_LossFn):
+    @staticmethod
+    def forward(ctx, z, label):
+        _require_gpu(z, 'CrossEntropy loss')
+        z = _c(_f32(z))
+        b, O = z.shape
+        loss = torch.empty(1, device=z.device, dtype=torch.float32)
+        dz = torch.empty_like(z)
+        rows = torch.empty(b, device=z.device, dtype=torch.float32)
+        lib.cross_entropy(z, label.contiguous(), loss, dz, rows, b, O)
+        return _LossFn._finish(ctx, loss, dz)

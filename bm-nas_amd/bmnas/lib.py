@@ -56,6 +56,10 @@ SIGNATURES = {
     'bmnas_bn_relu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_bwd_apply': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_linear_fwd': ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
+    'bmnas_linear_bwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
+    'bmnas_bce_logits': ([_P, _P, _P, _P, _I, _P], _I),
+    'bmnas_cross_entropy': ([_P, _P, _P, _P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
@@ -250,6 +254,27 @@ def arch_softmax_bwd(w, dw, dlogits, rows, cols):
                                          _stream()), 'arch_softmax_bwd')
 
 
+def linear_fwd(feat, W, bias, out, b, O, Kd):
+    _check(load().bmnas_linear_fwd(_ptr(feat), _ptr(W), _ptr(bias), _ptr(out), b, O, Kd, _stream()),
+           'linear_fwd')
+
+
+def linear_bwd(g, gscale, feat, W, dfeat, dW, dbias, b, O, Kd):
+    _check(load().bmnas_linear_bwd(_ptr(g), None if gscale is None else gscale.data_ptr(), _ptr(feat),
+                                   _ptr(W), _ptr(dfeat), _ptr(dW), _ptr(dbias), b, O, Kd, _stream()),
+           'linear_bwd')
+
+
+def bce_logits(z, y, loss, dz):
+    _check(load().bmnas_bce_logits(_ptr(z), _ptr(y), _ptr(loss), _ptr(dz), z.numel(), _stream()),
+           'bce_logits')
+
+
+def cross_entropy(z, label, loss, dz, row_loss, b, O):
+    _check(load().bmnas_cross_entropy(_ptr(z), label.data_ptr(), _ptr(loss), _ptr(dz), _ptr(row_loss), b, O,
+                                      _stream()), 'cross_entropy')
+
+
 def arch_softmax_multi(a_list, dw_list, out_list, backward, n_shards=1, shard_stride=0):
     """One launch for every architecture tensor (row softmax, or its backward)."""
     n = len(a_list)
@@ -307,5 +332,6 @@ def _timed(name, fn):
 for _n in ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'sdpa_ln_fwd', 'sdpa_ln_bwd',
            'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight', 'fold_weight', 'bn_finalize',
            'node_mix_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd', 'bn_relu_fwd', 'bn_relu_bwd',
-           'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd'):
+           'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd', 'linear_fwd', 'linear_bwd',
+           'bce_logits', 'cross_entropy'):
     globals()[_n] = _timed(_n, globals()[_n])

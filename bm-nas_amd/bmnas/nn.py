@@ -1,0 +1,38 @@
+"""Drop-in nn.Module replacements for the two callers right after the fusion cell: the
+central classifier (nn.Linear) and the criterion, both on the gfx950 kernels of
+csrc/linear.hip.  Same constructor signatures, parameter names and state_dict keys as the torch
+classes they subclass; option combinations the kernels do not cover defer to the torch parent
+(the reference never uses them)."""
+import torch
+import torch.nn as nn
+
+from .functions import BCEWithLogitsFn, CrossEntropyFn, LinearFn
+
+
+class Linear(nn.Linear):
+    """nn.Linear whose forward/backward run on the MFMA kernels when out_features <= 128,
+    in_features % 16 == 0 and a bias is present (the central_classifier shapes)."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and self.bias is not None and self.out_features <= 128
+                and self.in_features % 16 == 0 and x.dtype == torch.float32):
+            return LinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
+class BCEWithLogitsLoss(nn.BCEWithLogitsLoss):
+    def forward(self, input, target):
+        if (input.is_cuda and self.weight is None and self.pos_weight is None and self.reduction == 'mean'
+                and input.dtype == torch.float32 and target.dtype == torch.float32
+                and input.shape == target.shape):
+            return BCEWithLogitsFn.apply(input, target)
+        return super().forward(input, target)
+
+
+class CrossEntropyLoss(nn.CrossEntropyLoss):
+    def forward(self, input, target):
+        if (input.is_cuda and input.dim() == 2 and self.weight is None and self.reduction == 'mean'
+                and self.label_smoothing == 0.0 and self.ignore_index == -100
+                and target.dtype == torch.int64 and target.dim() == 1 and input.dtype == torch.float32):
+            return CrossEntropyFn.apply(input, target)
+        return super().forward(input, target)

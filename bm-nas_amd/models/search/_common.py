@@ -6,6 +6,7 @@ import torch.optim as op
 
 import models.auxiliary.scheduler as sc
 from bmnas import dist as bdist
+from bmnas import nn as bnn
 
 from .darts.architect import Architect
 from .darts.model import Found_FusionNetwork
@@ -46,7 +47,8 @@ class HyperNetBase(nn.Module):
                                                   num_input_nodes=num_input_nodes,
                                                   num_keep_edges=num_keep_edges, args=args,
                                                   criterion=criterion, genotype=genotype)
-        self.central_classifier = nn.Linear(args.C * args.L * self.multiplier, args.num_outputs)
+        # nn.Linear subclass (same parameters / state_dict keys) running on the MFMA kernels
+        self.central_classifier = bnn.Linear(args.C * args.L * self.multiplier, args.num_outputs)
 
     @staticmethod
     def make_reshape_layers(layer_cls, C_ins, args, genotype=None):

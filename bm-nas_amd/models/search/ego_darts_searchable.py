@@ -7,6 +7,8 @@ import torch
 import models.auxiliary.aux_models as aux
 import models.search.train_searchable.ego as tr
 
+from bmnas import nn as bnn
+
 from ._common import HyperNetBase, parallel_flag, search_setup
 
 C_INS = [512, 1024, 2048, 2048, 512, 1024, 2048, 2048]
@@ -15,7 +17,7 @@ C_INS = [512, 1024, 2048, 2048, 512, 1024, 2048, 2048]
 def train_darts_model(dataloaders, args, opt, device, logger):
     dataset_sizes = {x: len(dataloaders[x].dataset) for x in ['train', 'dev', 'test']}
     num_batches_per_epoch = dataset_sizes['train'] / args.batchsize
-    criterion = torch.nn.CrossEntropyLoss()
+    criterion = bnn.CrossEntropyLoss()          # torch criterion subclass on the HIP loss kernel
     model = Searchable_RGB_Depth_Net(args, opt, criterion)
     rgb_path = os.path.join(args.checkpointdir, args.rgb_cp)
     depth_path = os.path.join(args.checkpointdir, args.depth_cp)

@@ -7,6 +7,8 @@ import torch
 import models.auxiliary.aux_models as aux
 import models.search.train_searchable.mmimdb as tr
 
+from bmnas import nn as bnn
+
 from ._common import HyperNetBase, parallel_flag, search_setup
 
 C_INS = [512, 512, 512, 512, 64, 128]
@@ -15,7 +17,7 @@ C_INS = [512, 512, 512, 512, 64, 128]
 def train_darts_model(dataloaders, args, device, logger):
     dataset_sizes = {x: len(dataloaders[x].dataset) for x in ['train', 'dev', 'test']}
     num_batches_per_epoch = dataset_sizes['train'] / args.batchsize
-    criterion = torch.nn.BCEWithLogitsLoss()
+    criterion = bnn.BCEWithLogitsLoss()          # torch criterion subclass on the HIP loss kernel
     model = Searchable_Image_Text_Net(args, criterion)
     optimizer, scheduler, architect, plotter = search_setup(model, args, criterion, device,
                                                             num_batches_per_epoch, args.weight_decay)

@@ -8,6 +8,8 @@ import torch
 import models.auxiliary.aux_models as aux
 import models.search.train_searchable.ntu as tr
 
+from bmnas import nn as bnn
+
 from ._common import HyperNetBase, parallel_flag, search_setup
 
 C_INS = [512, 1024, 2048, 2048, 128, 256, 1024, 512]
@@ -16,7 +18,7 @@ C_INS = [512, 1024, 2048, 2048, 128, 256, 1024, 512]
 def train_darts_model(dataloaders, args, device, logger):
     dataset_sizes = {x: len(dataloaders[x].dataset) for x in ['train', 'dev', 'test']}
     num_batches_per_epoch = dataset_sizes['train'] / args.batchsize
-    criterion = torch.nn.CrossEntropyLoss()
+    criterion = bnn.CrossEntropyLoss()          # torch criterion subclass on the HIP loss kernel
     model = Searchable_Skeleton_Image_Net(args, criterion, logger)
     model.skenet.load_state_dict(torch.load(os.path.join(args.checkpointdir, args.ske_cp)))
     model.rgbnet.load_state_dict(torch.load(os.path.join(args.checkpointdir, args.rgb_cp)))

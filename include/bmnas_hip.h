@@ -205,6 +205,23 @@ int bmnas_arch_softmax_multi(const float* const* a, const float* const* dw, floa
                              const int* rows, const int* cols, int n, int backward, int n_shards,
                              int64_t shard_stride, void* stream);
 
+/* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
+ * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at
+ * mmimdb_darts_searchable.py:82-83,114 (O <= 128, K % 16 == 0). */
+int bmnas_linear_fwd(const float* feat, const float* W, const float* bias, float* out, int b, int O,
+                     int K, void* stream);
+/* g: gradient of out, times *gscale if gscale != NULL.  dfeat (b, K), dW (O, K), dbias (O) are
+ * OVERWRITTEN; any of them may be NULL. */
+int bmnas_linear_bwd(const float* g, const float* gscale, const float* feat, const float* W,
+                     float* dfeat, float* dW, float* dbias, int b, int O, int K, void* stream);
+/* BCEWithLogitsLoss(reduction='mean') (mmimdb_darts_searchable.py:22) over n = b*O elements:
+ * loss[0] and, if dz != NULL, dz = dloss/dz. */
+int bmnas_bce_logits(const float* z, const float* y, float* loss, float* dz, int n, void* stream);
+/* CrossEntropyLoss(reduction='mean') over int64 class labels (ntu_darts_searchable.py:25,
+ * ego_darts_searchable.py:24); row_loss: (b) scratch. */
+int bmnas_cross_entropy(const float* z, const int64_t* label, float* loss, float* dz,
+                        float* row_loss, int b, int O, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

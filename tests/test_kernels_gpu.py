@@ -236,3 +236,58 @@ def test_dropout_mask_is_consistent_between_forward_and_backward():
     mod.eval()
     oe = mod(x, y)
     assert abs(float((oe == 0).float().mean()) - dead_relu) < 0.03
+
+
+@pytest.mark.parametrize('b,O,K', [(128, 23, 6144), (7, 60, 2048), (5, 83, 2048), (3, 5, 256), (33, 128, 64)])
+def test_linear_classifier_fwd_bwd(b, O, K):
+    from bmnas import nn as bnn
+    g = _gen(500 + b + O)
+    x, go = _rand(g, b, K), _rand(g, b, O)
+    ref = torch.nn.Linear(K, O)
+    mod = bnn.Linear(K, O)
+    mod.load_state_dict(ref.state_dict())
+    mod.to(dev())
+    xo = x.clone().requires_grad_(True)
+    ro = ref(xo)
+    ro.backward(go)
+    xd = x.to(dev()).requires_grad_(True)
+    out = mod(xd)
+    out.backward(go.to(dev()))
+    assert_close_scaled('out', out, ro)
+    assert_close_scaled('dx', xd.grad, xo.grad)
+    assert_close_scaled('dW', mod.weight.grad, ref.weight.grad)
+    assert_close_scaled('db', mod.bias.grad, ref.bias.grad)
+    assert list(mod.state_dict()) == list(ref.state_dict())
+
+
+@pytest.mark.parametrize('b,O', [(128, 23), (5, 7), (1, 3)])
+def test_bce_with_logits_loss(b, O):
+    from bmnas import nn as bnn
+    g = _gen(600 + b)
+    z = 3 * _rand(g, b, O)
+    y = (torch.from_numpy(g.uniform(size=(b, O))) < 0.3).float()
+    zo = z.clone().requires_grad_(True)
+    lo = torch.nn.BCEWithLogitsLoss()(zo, y)
+    (lo * 1.7).backward()
+    zd = z.to(dev()).requires_grad_(True)
+    ld = bnn.BCEWithLogitsLoss()(zd, y.to(dev()))
+    (ld * 1.7).backward()
+    assert ld.shape == lo.shape
+    assert_close_scaled('loss', ld, lo)
+    assert_close_scaled('dz', zd.grad, zo.grad)
+
+
+@pytest.mark.parametrize('b,O', [(64, 60), (48, 83), (5, 3), (1, 100)])
+def test_cross_entropy_loss(b, O):
+    from bmnas import nn as bnn
+    g = _gen(700 + b)
+    z = 3 * _rand(g, b, O)
+    y = torch.from_numpy(g.integers(0, O, size=(b,)).astype(np.int64))
+    zo = z.clone().requires_grad_(True)
+    lo = torch.nn.CrossEntropyLoss()(zo, y)
+    lo.backward()
+    zd = z.to(dev()).requires_grad_(True)
+    ld = bnn.CrossEntropyLoss()(zd, y.to(dev()))
+    ld.backward()
+    assert_close_scaled('loss', ld, lo)
+    assert_close_scaled('dz', zd.grad, zo.grad)
