@@ -97,15 +97,17 @@ def algo_table(C, L):
             ('hbm', T(g) + (2 * len(srcs) + (2 if resid is not None else 0)) * T(srcs[0]) + 2 * T(w)),
         'ln_affine_bwd': lambda g, gs, srcs, resid, *_:
             ('hbm', T(g) + (len(srcs) + (1 if resid is not None else 0)) * T(srcs[0])),
+        'ln_affine_bwd_multi': lambda probs, b, L_: ('hbm', sum(
+            T(p['g']) + (len(p['srcs']) + (1 if p['resid'] is not None else 0)) * T(p['srcs'][0]) for p in probs)),
         'sdpa_ln_fwd': lambda x, y, w, b_, out, *_:
             ('hbm', (3 if x.data_ptr() == y.data_ptr() else 4) * T(x) + 2 * T(w)),
         'sdpa_ln_bwd': lambda g, gs, x, y, w, xhat, st, dx, dy, *_:
             ('hbm', (4 if dy is None else 6) * T(x) + T(w)),
-        'conv1x1_fwd': lambda srcs, Cs, W, ldw, bias, U, part, b, L_, M:
+        'conv1x1_fwd': lambda srcs, Cs, W, ldw, bias, U, part, b, L_, M, *_:
             ('mfma', 2.0 * M * len(srcs) * Cs * b * L_),
-        'conv1x1_bwd_data': lambda dU, W, ldw, ds, Cs, m, b, L_, M:
+        'conv1x1_bwd_data': lambda dU, W, ldw, ds, Cs, m, b, L_, M, *_:
             ('mfma', 2.0 * M * len(ds) * Cs * b * L_),
-        'conv1x1_bwd_weight': lambda dU, srcs, Cs, dW, ldw, db, dup, b, L_, M:
+        'conv1x1_bwd_weight': lambda dU, srcs, Cs, dW, ldw, db, dup, b, L_, M, *_:
             ('mfma', 2.0 * M * len(srcs) * Cs * b * L_),
         'node_mix_fwd': lambda x, y, p1, U, ch, gm, out, *_: ('hbm', T(U) + 3 * T(out)),
         'node_mix_bwd': lambda g, x, y, p1, U, *_: ('hbm', 2 * T(U) + 4 * T(g)),

@@ -140,10 +140,10 @@ def mixsum_bwd(xs, slots, w_row0, g, dw_row0, w_stride=2, shards=1, shard_stride
 
 # -------------------------------------------------------------------- conv + BatchNorm
 class ConvBnSaved:
-    __slots__ = ('srcs', 'C_src', 'W', 'ldw', 'U', 'chan', 'M', 'training', 'dup')
+    __slots__ = ('srcs', 'C_src', 'W', 'ldw', 'U', 'chan', 'M', 'training', 'dup', 'fold')
 
 
-def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, dup=0):
+def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, dup=0, fold=0):
     """U = conv1x1(cat(srcs)) (+ batch statistics) and the fused BN affine `chan`.
     W is (M, ldw) row-major with the first len(srcs)*C_src columns used."""
     x0 = srcs[0]
@@ -157,12 +157,12 @@ def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, du
                              f'{[b, M, L]}')            # same refusal as nn.BatchNorm1d
         n_part = lib.conv1x1_num_partials(b, L)
         part = _empty(x0, n_part * M * 2)
-    lib.conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M)
+    lib.conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold)
     chan = _empty(x0, 4 * M)
     lib.bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan)
     sv = ConvBnSaved()
     sv.srcs, sv.C_src, sv.W, sv.ldw, sv.U, sv.chan, sv.M = list(srcs), C_src, W, ldw, U, chan, M
-    sv.training, sv.dup = training, dup
+    sv.training, sv.dup, sv.fold = training, dup, fold
     return U, chan, sv
 
 
@@ -186,7 +186,7 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias):
             slots.append(s)
     bufs, mask = _write_group(slots)
     if any(x is not None for x in bufs):
-        lib.conv1x1_bwd_data(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M)
+        lib.conv1x1_bwd_data(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold)
     for s, tmp in extra:
         s.buf().add_(tmp.buf())
     if dW is not None:
@@ -214,6 +214,9 @@ def node_mixed_fwd(x, y, gamma_row, P, training):
     sv.p1 = p1
     # stacked [LinearGLU | ConcatFC] conv + BN
     if same:
+        # conv(cat[z, z]) = (W[:, :C] + W[:, C:]) z: K is C instead of 2C.  The halves are added once
+        # into a folded copy (2.3 us); letting the GEMMs add them while fetching their operand
+        # (fold_cols of the C ABI) was measured slower: +4 us per GEMM for the doubled weight loads.
         Weff = _empty(x, 3 * C, C)
         lib.fold_weight(P.stack_W, Weff, 3 * C, C)
         U, chan, sv.conv = conv_bn_fwd([x], C, Weff, C, P.stack_bias, P.stack_bn_w, P.stack_bn_b,
@@ -228,13 +231,37 @@ def node_mixed_fwd(x, y, gamma_row, P, training):
     return out, sv
 
 
-def _attn_affine_bwd(sv, g, G):
+class Deferred:
+    """LayerNorm affine-gradient problems collected during a backward pass and flushed in
+    ONE launch at its end (they feed nothing downstream)."""
+
+    def __init__(self):
+        self.probs = []
+
+    def add(self, **p):
+        self.probs.append(p)
+
+    def flush(self, b, L):
+        for i in range(0, len(self.probs), 8):
+            lib.ln_affine_bwd_multi(self.probs[i:i + 8], b, L)
+        self.probs = []
+
+
+def _ln_affine(deferred, g, gscale, srcs, resid, ln_w, ln_b, stats, dln_w, dln_b, b, C, L, relu, prenorm):
+    if deferred is None:
+        lib.ln_affine_bwd(g, gscale, srcs, resid, ln_w, ln_b, stats, dln_w, dln_b, b, C, L, relu, prenorm)
+    else:
+        deferred.add(g=g, gscale=gscale, srcs=list(srcs), resid=resid, ln_w=ln_w, ln_b=ln_b, stats=stats,
+                     dln_w=dln_w, dln_b=dln_b, C=C, relu=relu, prenorm=prenorm)
+
+
+def _attn_affine_bwd(sv, g, G, deferred=None):
     b, C, L = sv.x.shape
-    lib.ln_affine_bwd(g, sv.gamma[1:2], [sv.xhat1], None, None, None, None, G.dln_w, G.dln_b, b, C, L,
-                      False, True)
+    _ln_affine(deferred, g, sv.gamma[1:2], [sv.xhat1], None, None, None, None, G.dln_w, G.dln_b, b, C, L,
+               False, True)
 
 
-def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=0):
+def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=0, deferred=None):
     """g: grad of the mixed output.  dgamma_row (4 floats, +=), x_slot / y_slot: GradSlots
     (y_slot None when x is y).  G: gradient pack (stack_dW, stack_dbias, stack_bn_grad,
     dln_w, dln_b), all += ."""
@@ -258,7 +285,7 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
         conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot, y_slot], G.stack_dW, G.stack_dbias)
         lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, dyb, 3, b, C, L,
                         sv.d_attn)
-    _attn_affine_bwd(sv, g, G)
+    _attn_affine_bwd(sv, g, G, deferred)
 
 
 # ------------------------------------------------------------------- search-mode NodeCell
@@ -302,7 +329,7 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm):
     return out, sv
 
 
-def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG):
+def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None):
     """g: grad of the node output.  x_slot / y_slot: GradSlots of the two inputs (the same
     object in search mode).  dbeta_w / dgamma_w: zero-initialised (k_in,2)/(ns,4) buffers
     receiving the gradients w.r.t. the SOFTMAXED weights.  NG: gradient pack."""
@@ -326,14 +353,15 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG):
         racc = x_slot.acc_bit()
         lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
                        mask | (racc << 31), None, None, b, C, L, False)
-    lib.ln_affine_bwd(g, None, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, NG.dln_w, NG.dln_b, b, C, L,
-                      False, False)
+    _ln_affine(deferred, g, None, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, NG.dln_w, NG.dln_b, b, C, L,
+               False, False)
     for t in reversed(range(ns)):
         gs = slots[2 + t].get()
         if gs is None:
             continue                                    # this inner state feeds nothing
         z_slot = GradSlot(x)
-        node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t], NG.shards, NG.shard_stride)
+        node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t], NG.shards, NG.shard_stride,
+                       deferred)
         off = sv.offsets[t]
         n_in = 2 + t
         mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.beta_w[off:, 1], z_slot.buf(),
@@ -381,16 +409,18 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
     bufs, mask = _write_group(tail)
     lib.cat_ln_bwd(g, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, bufs, None, mask, None, None,
                    b, C, L, True)
-    lib.ln_affine_bwd(g, None, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, CG.dln_w, CG.dln_b,
-                      b, C, L, True, False)
+    deferred = Deferred()
+    _ln_affine(deferred, g, None, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, CG.dln_w, CG.dln_b,
+               b, C, L, True, False)
     for i in reversed(range(S)):
         gn = slots[N + i].get()
         if gn is None:
             continue
         sif_slot = GradSlot(x0)
-        node_cell_bwd(sv.nodes[i], gn, sif_slot, sif_slot, dbeta_ws[i], dgamma_ws[i], CG.nodes[i])
+        node_cell_bwd(sv.nodes[i], gn, sif_slot, sif_slot, dbeta_ws[i], dgamma_ws[i], CG.nodes[i], deferred)
         off = sv.offsets[i]
         n_in = N + i
         mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
                    dalpha_w[off:, 1], 2, CG.shards, CG.shard_stride)
+    deferred.flush(b, L)
     return [s.get() if s is not None else None for s in slots[:N]]

@@ -40,11 +40,14 @@ SIGNATURES = {
     'bmnas_cat_ln_fwd': ([_PP, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_cat_ln_bwd': ([_P, _PP, _I, _P, _P, _P, _P, _PP, _P, _U32, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_ln_affine_bwd': ([_P, _P, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    'bmnas_ln_affine_bwd_multi': ([_I, _PP, _PP, C.POINTER(_PP), C.POINTER(C.c_int), _PP, _PP, _PP, _PP, _PP,
+                                  _PP, _I, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _P],
+                                 _I),
     'bmnas_sdpa_ln_fwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_sdpa_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, _I, _I, Dropout, _P], _I),
     'bmnas_conv1x1_num_partials': ([_I, _I], _I),
-    'bmnas_conv1x1_fwd': ([_PP, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P], _I),
-    'bmnas_conv1x1_bwd_data': ([_P, _P, _I, _PP, _I, _I, _U32, _I, _I, _I, _P], _I),
+    'bmnas_conv1x1_fwd': ([_PP, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P], _I),
+    'bmnas_conv1x1_bwd_data': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _P], _I),
     'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
@@ -160,6 +163,23 @@ def ln_affine_bwd(g, gscale, srcs, resid, ln_w, ln_b, stats, dln_w, dln_b, b, Cc
                                       _stream()), 'ln_affine_bwd')
 
 
+def ln_affine_bwd_multi(probs, b, L):
+    """probs: list of dicts(g, gscale, srcs, resid, ln_w, ln_b, stats, dln_w, dln_b, C, relu, prenorm)."""
+    n = len(probs)
+
+    def parr(key):
+        return (C.c_void_p * n)(*[None if p[key] is None else p[key].data_ptr() for p in probs])
+
+    src_arrays = [_ptrs(p['srcs']) for p in probs]
+    srcs = (_PP * n)(*[C.cast(a, _PP) for a in src_arrays])
+    ints = lambda key: (C.c_int * n)(*[int(p[key]) for p in probs])
+    n_src = (C.c_int * n)(*[len(p['srcs']) for p in probs])
+    _check(load().bmnas_ln_affine_bwd_multi(n, parr('g'), parr('gscale'), srcs, n_src, parr('resid'),
+                                            parr('ln_w'), parr('ln_b'), parr('stats'), parr('dln_w'),
+                                            parr('dln_b'), b, ints('C'), L, ints('relu'), ints('prenorm'),
+                                            _stream()), 'ln_affine_bwd_multi')
+
+
 def sdpa_ln_fwd(x, y, ln_w, ln_b, out, xhat, stats, b, Cc, L, drop):
     _check(load().bmnas_sdpa_ln_fwd(_ptr(x), _ptr(y), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(xhat),
                                     _ptr(stats), b, Cc, L, drop, _stream()), 'sdpa_ln_fwd')
@@ -178,14 +198,14 @@ def conv1x1_num_partials(b, L):
     return n
 
 
-def conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M):
-    _check(load().bmnas_conv1x1_fwd(_ptrs(srcs), len(srcs), C_src, W.data_ptr(), ldw, _ptr(bias),
+def conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold=0):
+    _check(load().bmnas_conv1x1_fwd(_ptrs(srcs), len(srcs), C_src, W.data_ptr(), ldw, fold, _ptr(bias),
                                     _ptr(U), _ptr(part), b, L, M, _stream()), 'conv1x1_fwd')
 
 
-def conv1x1_bwd_data(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M):
-    _check(load().bmnas_conv1x1_bwd_data(_ptr(dU), W.data_ptr(), ldw, _ptrs(dsrcs), len(dsrcs), C_src,
-                                         acc_mask, b, L, M, _stream()), 'conv1x1_bwd_data')
+def conv1x1_bwd_data(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold=0):
+    _check(load().bmnas_conv1x1_bwd_data(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs),
+                                         C_src, acc_mask, b, L, M, _stream()), 'conv1x1_bwd_data')
 
 
 def conv1x1_bwd_weight(dU, srcs, C_src, dW, ldw, dbias, dup_cols, b, L, M):
@@ -329,7 +349,7 @@ def _timed(name, fn):
     return wrapper
 
 
-for _n in ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'sdpa_ln_fwd', 'sdpa_ln_bwd',
+for _n in ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'sdpa_ln_fwd', 'sdpa_ln_bwd',
            'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight', 'fold_weight', 'bn_finalize',
            'node_mix_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd', 'bn_relu_fwd', 'bn_relu_bwd',
            'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd', 'linear_fwd', 'linear_bwd',

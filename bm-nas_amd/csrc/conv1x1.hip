@@ -31,6 +31,8 @@ struct ConvArgs {
   int ldw, Ci, Cj, I, J;
   int b, L, Lb, spw, n_groups, n_part;
   uint32_t acc_mask;
+  int fold;              // > 0: effective weight = W[.] + W[. + fold] along its column index
+                         // (conv applied to cat[z, z], search mode: no separate folded copy)
   int probe;             // diagnostics only (BMNAS_CONV_PROBE): 1 = no MFMA, 2 = no loads
 };
 
@@ -96,12 +98,15 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       if (TRANS) {
-        const float4 w4 = ld4(a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h);
+        const float* pp = a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h;
+        float4 w4 = ld4(pp);
+        if (a.fold > 0) w4 = f4_add(w4, ld4(pp + a.fold));
         B[tj][0] = w4.x; B[tj][1] = w4.y; B[tj][2] = w4.z; B[tj][3] = w4.w;
       } else {
         const float* pp = a.W + (int64_t)(i0 + 4 * h) * a.ldw + jcl[tj];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) B[tj][r] = pp[(int64_t)r * a.ldw];
+        for (int r = 0; r < 4; ++r)
+          B[tj][r] = pp[(int64_t)r * a.ldw] + (a.fold > 0 ? pp[(int64_t)r * a.ldw + a.fold] : 0.f);
       }
     }
   };
@@ -260,12 +265,19 @@ __global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
       if (a.probe & 2) {
         bv[kb][tj][0] = bv[kb][tj][1] = bv[kb][tj][2] = bv[kb][tj][3] = (float)lo;
       } else if (TRANS) {
-        const float4 w4 = ld4(a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h);
+        const float* pp = a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h;
+        float4 w4 = ld4(pp);
+        if (a.fold > 0) w4 = f4_add(w4, ld4(pp + a.fold));   // wave-uniform; W is L2-resident
         bv[kb][tj][0] = w4.x; bv[kb][tj][1] = w4.y; bv[kb][tj][2] = w4.z; bv[kb][tj][3] = w4.w;
       } else {
         const float* pp = a.W + (int64_t)(i0 + 4 * h) * a.ldw + jcl[tj];
+        if (a.fold > 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[kb][tj][r] = pp[(int64_t)r * a.ldw];
+          for (int r = 0; r < 4; ++r) bv[kb][tj][r] = pp[(int64_t)r * a.ldw] + pp[(int64_t)r * a.ldw + a.fold];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[kb][tj][r] = pp[(int64_t)r * a.ldw];
+        }
       }
     }
   }
@@ -424,14 +436,16 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
       j = j < a.J ? j : a.J - 1;
       const int i = i0 + c;                              // I % 16 == 0: a float4 is all in or all out
       const int ic = i < a.I ? i : a.I - 4;
-      const float4 t = ld4(a.W + (int64_t)j * a.ldw + ic);
+      float4 t = ld4(a.W + (int64_t)j * a.ldw + ic);
+      if (a.fold > 0) t = f4_add(t, ld4(a.W + (int64_t)j * a.ldw + ic + a.fold));
       return i < a.I ? t : z4;
     } else {
       const int i = i0 + r;
       const int ic = i < a.I ? i : a.I - 1;
       int j = jbase + c;                                 // J % 16 == 0
       j = j < a.J ? j : a.J - 4;
-      const float4 t = ld4(a.W + (int64_t)ic * a.ldw + j);
+      float4 t = ld4(a.W + (int64_t)ic * a.ldw + j);
+      if (a.fold > 0) t = f4_add(t, ld4(a.W + (int64_t)ic * a.ldw + j + a.fold));
       return i < a.I ? t : z4;
     }
   };
@@ -797,9 +811,10 @@ void launch_nj(const ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const float* W,
-                                 int ldw, const float* bias, float* U, float* part, int b, int L,
-                                 int M, void* stream) {
-  if (!srcs || !W || !U || n_src < 1 || C_src < 1 || b < 0 || M < 1) return BMNAS_E_ARG;
+                                 int ldw, int fold_cols, const float* bias, float* U, float* part,
+                                 int b, int L, int M, void* stream) {
+  if (!srcs || !W || !U || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
+  if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
   if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
   if (C_src % 16 || M % 16 || ldw % 4 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
   ConvArgs a{};
@@ -812,16 +827,17 @@ extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src,
   a.dst.p[0] = U;
   a.W = W; a.bias = bias; a.part = part; a.ldw = ldw;
   a.Ci = C_src; a.I = n_src * C_src; a.Cj = M; a.J = M;
-  a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = conv_probe();
+  a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = conv_probe(); a.fold = fold_cols;
   launch_nj<true>(a, (hipStream_t)stream);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw,
+extern "C" int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, int fold_cols,
                                       float* const* dsrcs, int n_src, int C_src,
                                       uint32_t accumulate_mask, int b, int L, int M, void* stream) {
-  if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1) return BMNAS_E_ARG;
+  if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
+  if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
   if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
   if (C_src % 16 || M % 16 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
   ConvArgs a{};
@@ -831,7 +847,7 @@ extern "C" int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw,
   for (int q = 0; q < n_src; ++q) a.dst.p[q] = dsrcs[q];
   a.W = W; a.bias = nullptr; a.part = nullptr; a.ldw = ldw;
   a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
-  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = conv_probe();
+  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = conv_probe(); a.fold = fold_cols;
   launch_nj<false>(a, (hipStream_t)stream);
   BMNAS_CHECK_LAUNCH();
   return 0;

@@ -162,39 +162,50 @@ __global__ __launch_bounds__(256) void cat_ln_bwd_k(const float* __restrict__ g,
 // (one wave per sample lane -> 1 KiB coalesced rows); each thread walks its share of the
 // sample chunk, the four lanes are summed through LDS, one atomic per element per chunk
 // (b/16 x fewer atomics than doing it per sample).  prenorm: srcs[0] already holds x_hat.
-__global__ __launch_bounds__(256) void ln_affine_bwd_k(const float* __restrict__ g,
-                                                       const float* __restrict__ gscale, LnSrc srcs,
-                                                       const float* __restrict__ resid,
-                                                       const float* __restrict__ ln_w,
-                                                       const float* __restrict__ ln_b,
-                                                       const float* __restrict__ stats,
-                                                       float* dln_w, float* dln_b, int b, int cl4,
-                                                       int d4, int relu, int prenorm, int chunk) {
-  __shared__ float4 red[2][3][64];
+struct LnAffineProb {
+  const float* g;
+  const float* gscale;
+  LnSrc srcs;
+  const float* resid;
+  const float* ln_w;
+  const float* ln_b;
+  const float* stats;
+  float* dln_w;
+  float* dln_b;
+  int cl4, d4, relu, prenorm;
+};
+
+constexpr int kMaxLnProbs = 8;
+struct LnAffineBatch {
+  LnAffineProb p[kMaxLnProbs];
+  int n, b, chunk;
+};
+
+__device__ __forceinline__ void ln_affine_body(const LnAffineProb& P, int b, int chunk, float4 (*red)[3][64]) {
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + col;
-  const bool active = i < d4;
-  const float gs = (gscale != nullptr) ? gscale[0] : 1.f;
+  const bool active = i < P.d4;
+  const float gs = (P.gscale != nullptr) ? P.gscale[0] : 1.f;
   float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw;
   if (active) {
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f), bb = w;
-    if (relu) {
-      w = ld4(ln_w + (int64_t)i * 4);
-      bb = ld4(ln_b + (int64_t)i * 4);
+    if (P.relu) {
+      w = ld4(P.ln_w + (int64_t)i * 4);
+      bb = ld4(P.ln_b + (int64_t)i * 4);
     }
     const int s_beg = blockIdx.y * chunk;
     int s_end = s_beg + chunk;
     if (s_end > b) s_end = b;
     for (int s = s_beg + sl; s < s_end; s += 4) {
-      float4 x = ld4(src_ptr(srcs, i, cl4, s));
-      float4 gy = f4_scale(ld4(g + ((int64_t)s * d4 + i) * 4), gs);
+      float4 x = ld4(src_ptr(P.srcs, i, P.cl4, s));
+      float4 gy = f4_scale(ld4(P.g + ((int64_t)s * P.d4 + i) * 4), gs);
       float4 h = x;
-      if (!prenorm) {
-        if (resid != nullptr) x = f4_add(x, ld4(resid + ((int64_t)s * d4 + i) * 4));
-        const float mean = stats[2 * s], rstd = stats[2 * s + 1];
+      if (!P.prenorm) {
+        if (P.resid != nullptr) x = f4_add(x, ld4(P.resid + ((int64_t)s * P.d4 + i) * 4));
+        const float mean = P.stats[2 * s], rstd = P.stats[2 * s + 1];
         h = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
       }
-      if (relu) {
+      if (P.relu) {
         if (h.x * w.x + bb.x <= 0.f) gy.x = 0.f;
         if (h.y * w.y + bb.y <= 0.f) gy.y = 0.f;
         if (h.z * w.z + bb.z <= 0.f) gy.z = 0.f;
@@ -215,11 +226,20 @@ __global__ __launch_bounds__(256) void ln_affine_bwd_k(const float* __restrict__
       aw = f4_add(aw, red[0][k][col]);
       ab = f4_add(ab, red[1][k][col]);
     }
-    float* pw = dln_w + (int64_t)i * 4;
-    float* pb = dln_b + (int64_t)i * 4;
+    float* pw = P.dln_w + (int64_t)i * 4;
+    float* pb = P.dln_b + (int64_t)i * 4;
     atomicAdd(pw + 0, aw.x); atomicAdd(pw + 1, aw.y); atomicAdd(pw + 2, aw.z); atomicAdd(pw + 3, aw.w);
     atomicAdd(pb + 0, ab.x); atomicAdd(pb + 1, ab.y); atomicAdd(pb + 2, ab.z); atomicAdd(pb + 3, ab.w);
   }
+}
+
+// blockIdx.z selects the problem: every LayerNorm of a backward pass (K7, the K6 of each step
+// node, the attention LNs) in ONE launch at the end of the pass instead of five ~4.5 us ones.
+__global__ __launch_bounds__(256) void ln_affine_bwd_k(LnAffineBatch B) {
+  __shared__ float4 red[2][3][64];
+  const LnAffineProb& P = B.p[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= P.d4) return;              // block-uniform: this problem is narrower
+  ln_affine_body(P, B.b, B.chunk, red);
 }
 
 inline int pick_vpt(int d4) {
@@ -297,27 +317,70 @@ extern "C" int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_
   return 0;
 }
 
-extern "C" int bmnas_ln_affine_bwd(const float* g, const float* gscale, const float* const* srcs,
-                                   int n_src, const float* resid, const float* ln_w,
-                                   const float* ln_b, const float* stats, float* dln_w, float* dln_b,
-                                   int b, int C, int L, int relu, int prenorm, void* stream) {
-  if (!g || !srcs || !dln_w || !dln_b || n_src < 1 || b < 0 || C < 1 || L < 1) return BMNAS_E_ARG;
+namespace {
+int fill_prob(LnAffineProb& P, const float* g, const float* gscale, const float* const* srcs, int n_src,
+              const float* resid, const float* ln_w, const float* ln_b, const float* stats, float* dln_w,
+              float* dln_b, int C, int L, int relu, int prenorm) {
+  if (!g || !srcs || !dln_w || !dln_b || n_src < 1 || C < 1 || L < 1) return BMNAS_E_ARG;
   if (!prenorm && !stats) return BMNAS_E_ARG;
   if (relu && (!ln_w || !ln_b)) return BMNAS_E_ARG;
   if (n_src > 4) return BMNAS_E_LIMIT;
   if (resid && n_src != 1) return BMNAS_E_ARG;
   if ((C * L) % 4 != 0) return BMNAS_E_SHAPE;
-  if (b == 0) return 0;
-  LnSrc s{};
+  P = LnAffineProb{};
   for (int q = 0; q < n_src; ++q) {
     if (!srcs[q]) return BMNAS_E_ARG;
-    s.p[q] = srcs[q];
+    P.srcs.p[q] = srcs[q];
   }
-  const int cl4 = C * L / 4, d4 = cl4 * n_src;
-  const int chunk = 16;      // (smaller chunks = more atomics: measured slower, 6.5 vs 4.6 us)
-  dim3 grid((d4 + 63) / 64, (b + chunk - 1) / chunk);
-  hipLaunchKernelGGL(ln_affine_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, gscale, s, resid, ln_w,
-                     ln_b, stats, dln_w, dln_b, b, cl4, d4, relu, prenorm, chunk);
+  P.g = g; P.gscale = gscale; P.resid = resid; P.ln_w = ln_w; P.ln_b = ln_b; P.stats = stats;
+  P.dln_w = dln_w; P.dln_b = dln_b;
+  P.cl4 = C * L / 4; P.d4 = P.cl4 * n_src; P.relu = relu; P.prenorm = prenorm;
+  return 0;
+}
+
+int launch_ln_affine(LnAffineBatch& B, hipStream_t st) {
+  B.chunk = 16;      // (smaller chunks = more atomics: measured slower, 6.5 vs 4.6 us)
+  int maxd4 = 0;
+  for (int i = 0; i < B.n; ++i) maxd4 = B.p[i].d4 > maxd4 ? B.p[i].d4 : maxd4;
+  dim3 grid((maxd4 + 63) / 64, (B.b + B.chunk - 1) / B.chunk, B.n);
+  hipLaunchKernelGGL(ln_affine_bwd_k, grid, dim3(256), 0, st, B);
   BMNAS_CHECK_LAUNCH();
   return 0;
+}
+}  // namespace
+
+extern "C" int bmnas_ln_affine_bwd(const float* g, const float* gscale, const float* const* srcs,
+                                   int n_src, const float* resid, const float* ln_w,
+                                   const float* ln_b, const float* stats, float* dln_w, float* dln_b,
+                                   int b, int C, int L, int relu, int prenorm, void* stream) {
+  if (b < 0) return BMNAS_E_ARG;
+  LnAffineBatch B{};
+  if (int e = fill_prob(B.p[0], g, gscale, srcs, n_src, resid, ln_w, ln_b, stats, dln_w, dln_b, C, L, relu,
+                        prenorm))
+    return e;
+  if (b == 0) return 0;
+  B.n = 1;
+  B.b = b;
+  return launch_ln_affine(B, (hipStream_t)stream);
+}
+
+extern "C" int bmnas_ln_affine_bwd_multi(int n_prob, const float* const* g, const float* const* gscale,
+                                         const float* const* const* srcs, const int* n_src,
+                                         const float* const* resid, const float* const* ln_w,
+                                         const float* const* ln_b, const float* const* stats,
+                                         float* const* dln_w, float* const* dln_b, int b, const int* C,
+                                         int L, const int* relu, const int* prenorm, void* stream) {
+  if (n_prob < 1 || b < 0 || !g || !srcs || !n_src || !dln_w || !dln_b || !C || !relu || !prenorm)
+    return BMNAS_E_ARG;
+  if (n_prob > kMaxLnProbs) return BMNAS_E_LIMIT;
+  LnAffineBatch B{};
+  for (int i = 0; i < n_prob; ++i)
+    if (int e = fill_prob(B.p[i], g[i], gscale ? gscale[i] : nullptr, srcs[i], n_src[i],
+                          resid ? resid[i] : nullptr, ln_w ? ln_w[i] : nullptr, ln_b ? ln_b[i] : nullptr,
+                          stats ? stats[i] : nullptr, dln_w[i], dln_b[i], C[i], L, relu[i], prenorm[i]))
+      return e;
+  if (b == 0) return 0;
+  B.n = n_prob;
+  B.b = b;
+  return launch_ln_affine(B, (hipStream_t)stream);
 }

@@ -98,6 +98,16 @@ int bmnas_ln_affine_bwd(const float* g, const float* gscale, const float* const*
                         const float* stats, float* dln_w, float* dln_b, int b, int C, int L,
                         int relu, int prenorm, void* stream);
 
+/* The same for up to 8 LayerNorms at once (all with batch b and length L): arrays of n_prob
+ * entries, C[i] = channels per source of problem i.  Used at the end of a backward pass: the
+ * affine gradients feed nothing downstream, so five ~4.5 us launches collapse into one. */
+int bmnas_ln_affine_bwd_multi(int n_prob, const float* const* g, const float* const* gscale,
+                              const float* const* const* srcs, const int* n_src,
+                              const float* const* resid, const float* const* ln_w,
+                              const float* const* ln_b, const float* const* stats,
+                              float* const* dln_w, float* const* dln_b, int b, const int* C, int L,
+                              const int* relu, const int* prenorm, void* stream);
+
 /* ---- K3: scaled-dot attention + dropout + LayerNorm -----------------------------------
  * ScaledDotAttn.forward node_operations.py:92-108: q = x^T, k = y, v = y^T,
  * scores = q@k / sqrt(C), softmax(-1), out = (attn@v)^T, Dropout, LayerNorm([C, L]).
@@ -125,13 +135,16 @@ int bmnas_sdpa_ln_bwd(const float* g, const float* gscale, const float* x, const
  * part[(m*P + p)*2 + {0,1}] = (sum, M2 about the partial's own mean) over the p-th block
  * of 16 (sample,l) columns; p < P = bmnas_conv1x1_num_partials(b, L). */
 int bmnas_conv1x1_num_partials(int b, int L);
+/* fold_cols > 0: the weight actually applied is W[m, k] + W[m, k + fold_cols] — the conv of
+ * cat[z, z] (search mode, NodeMixedOp(z, z) at node_search.py:55) with n_src = 1. */
 int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const float* W, int ldw,
-                      const float* bias, float* U, float* part, int b, int L, int M,
+                      int fold_cols, const float* bias, float* U, float* part, int b, int L, int M,
                       void* stream);
-/* dsrcs[q][s, c, l] (=|+=) sum_m W[m*ldw + q*C_src + c] * dU[s, m, l]   (dsrcs[q] NULL: skip) */
-int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, float* const* dsrcs,
-                           int n_src, int C_src, uint32_t accumulate_mask, int b, int L, int M,
-                           void* stream);
+/* dsrcs[q][s, c, l] (=|+=) sum_m Weff[m, q*C_src + c] * dU[s, m, l]   (dsrcs[q] NULL: skip;
+ * Weff as above) */
+int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, int fold_cols,
+                           float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
+                           int b, int L, int M, void* stream);
 /* dW[m*ldw + k] += sum_{s,l} dU[s,m,l] * cat(srcs)[s,k,l];  dbias[m] += sum_{s,l} dU[s,m,l]
  * (atomic adds: caller zeroes; dbias may be NULL).  If dup_cols > 0 the same value is also
  * added at column k + dup_cols (folded x-is-y weights, see bmnas_fold_weight). */
