@@ -6,6 +6,7 @@
 // atomic per channel per workgroup.
 #include "common.hpp"
 #include "../../include/bmnas_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -496,11 +497,13 @@ inline DropCfg to_cfg(const bmnas_dropout_t& d) {
 
 // samples walked per workgroup in the backward reductions: keep >= ~512 workgroups
 inline int pick_chunk(int b, int slots4) {
-  // 4 sample lanes walk the chunk.  Measured: 4-sample chunks (4x the workgroups, 4x the
-  // atomics) took 26 us against 15 us for 16-sample chunks — the atomics, not the
-  // parallelism, set the time.
+  // 4 sample lanes walk the chunk.  Measured (MM-IMDB b = 128, dgamma atomics sharded):
+  // chunk 4: 10.2 us, 8: 10.2 us, 16: 12.8 us, 32: 16.5 us.  (Before the dgamma adds were
+  // sharded, small chunks were much WORSE: every extra workgroup queued on the same 4 scalars.)
   (void)slots4;
-  return b >= 64 ? 16 : (b >= 16 ? 8 : 4);
+  static const int forced = []() { const char* e = getenv("BMNAS_MIX_CHUNK"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return forced;           // tuning hook
+  return b >= 32 ? 8 : 4;
 }
 
 }  // namespace

@@ -127,21 +127,26 @@ __global__ __launch_bounds__(256) void sdpa_ln_fwd_k(const float* __restrict__ x
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int g = blockIdx.x;
-  float p[4];
-  attn_probs(x, y, G, g, wave, lane, ldsS, p);
-
   const int sh = g * G.spw + ((4 * h) >> G.Lb);
   const int l0 = (4 * h) & (G.L - 1);
   const bool v_h = sh < G.b;
+  const int shc = v_h ? sh : G.b - 1;                    // clamped: padded samples are never stored
   const int nch = G.C / 16;
-  // this wave's 16-channel chunks: wave, wave + 4, ...  (all loads first, then the MFMAs)
-  float4 yv[kMaxCh], od[kMaxCh];
+  // Everything this wave will need later (its y chunks, the LayerNorm affine rows) is requested
+  // BEFORE the score computation: one memory round trip for the whole kernel instead of three
+  // dependent ones (the kernel is latency bound: 128 workgroups, ~40 KB each).
+  float4 yv[kMaxCh], od[kMaxCh], lw[kMaxCh], lb[kMaxCh];
 #pragma unroll
   for (int k = 0; k < kMaxCh; ++k) {
     const int ch = wave + 4 * k;
-    yv[k] = (ch < nch && v_h) ? ld4(y + ((int64_t)sh * G.C + ch * 16 + lo) * G.L + l0)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int chc = ch < nch ? ch : nch - 1;
+    const int64_t pe = (int64_t)(chc * 16 + lo) * G.L + l0;
+    yv[k] = ld4(y + (int64_t)shc * G.C * G.L + pe);
+    lw[k] = ld4(ln_w + pe);
+    lb[k] = ld4(ln_b + pe);
   }
+  float p[4];
+  attn_probs(x, y, G, g, wave, lane, ldsS, p);
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < kMaxCh; ++k) {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void sdpa_ln_fwd_k(const float* __restrict__ x
     if (ch < nch) {
       const int64_t pe = (int64_t)(ch * 16 + lo) * G.L + l0;
       const int64_t e = (int64_t)sh * G.C * G.L + pe;
-      const float4 w = ld4(ln_w + pe), bb = ld4(ln_b + pe);
+      const float4 w = lw[k], bb = lb[k];
       const float4 hh = make_float4((od[k].x - mean) * rstd, (od[k].y - mean) * rstd,
                                     (od[k].z - mean) * rstd, (od[k].w - mean) * rstd);
       st4(xhat + e, hh);
@@ -206,6 +211,23 @@ __global__ __launch_bounds__(256) void sdpa_ln_bwd_k(
   const int lo = lane & 15, h = lane >> 4;
   const int g = blockIdx.x;
   const int nch = G.C / 16;
+  const int sh = g * G.spw + ((4 * h) >> G.Lb);
+  const int l0 = (4 * h) & (G.L - 1);
+  const bool v_h = sh < G.b;
+  const int shc = v_h ? sh : G.b - 1;
+  // all of this wave's streaming operands are requested up front (one round trip, see forward)
+  float4 xh[kMaxCh], dv[kMaxCh], yv[kMaxCh], xv[kMaxCh];
+#pragma unroll
+  for (int k = 0; k < kMaxCh; ++k) {
+    const int ch = wave + 4 * k;
+    const int chc = ch < nch ? ch : nch - 1;
+    const int64_t pe = (int64_t)(chc * 16 + lo) * G.L + l0;
+    const int64_t e = (int64_t)shc * G.C * G.L + pe;
+    xh[k] = ld4(xhat + e);
+    dv[k] = f4_mul(ld4(gout + e), ld4(ln_w + pe));               // g * w (the gamma scale comes later)
+    yv[k] = ld4(y + e);
+    xv[k] = ld4(x + e);
+  }
   float p[4];
   attn_probs(x, y, G, g, wave, lane, ldsS, p);                   // P[i = lo][j = 4h + r]
 #pragma unroll
@@ -215,27 +237,21 @@ __global__ __launch_bounds__(256) void sdpa_ln_bwd_k(
 #pragma unroll
   for (int r = 0; r < 4; ++r) pw[r] = tP[wave][(4 * h + r) * 17 + lo];
 
-  const int sh = g * G.spw + ((4 * h) >> G.Lb);
-  const int l0 = (4 * h) & (G.L - 1);
-  const bool v_h = sh < G.b;
-  const float rstd = v_h ? stats[2 * sh + 1] : 1.f;
+  const float rstd = stats[2 * shc + 1];
   const float gs = (gscale != nullptr) ? gscale[0] : 1.f;
 
   // pass A: dx_hat = g * w and the two LayerNorm-backward reductions
-  float4 xh[kMaxCh], dv[kMaxCh];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < kMaxCh; ++k) {
     const int ch = wave + 4 * k;
-    xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    dv[k] = xh[k];
     if (ch < nch && v_h) {
-      const int64_t pe = (int64_t)(ch * 16 + lo) * G.L + l0;
-      const int64_t e = (int64_t)sh * G.C * G.L + pe;
-      xh[k] = ld4(xhat + e);
-      dv[k] = f4_mul(f4_scale(ld4(gout + e), gs), ld4(ln_w + pe));
+      dv[k] = f4_scale(dv[k], gs);
       s1 += f4_hsum(dv[k]);
       s2 += f4_dot(dv[k], xh[k]);
+    } else {
+      xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dv[k] = xh[k];
     }
   }
   const float inv_d = 1.f / (float)(G.C * G.L);
@@ -307,16 +323,7 @@ __global__ __launch_bounds__(256) void sdpa_ln_bwd_k(
 #pragma unroll
   for (int r = 0; r < 4; ++r) dsw[r] = tS[wave][(4 * h + r) * 17 + lo];
 
-  // outputs, per 16-channel chunk, float4 along l
-  float4 yv[kMaxCh], xv[kMaxCh];
-#pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
-    const int ch = wave + 4 * k;
-    const bool ok = (ch < nch) && v_h;
-    const int64_t e = ((int64_t)sh * G.C + ch * 16 + lo) * G.L + l0;
-    yv[k] = ok ? ld4(y + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-    xv[k] = ok ? ld4(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  // outputs, per 16-channel chunk, float4 along l (operands were loaded at the top)
 #pragma unroll
   for (int k = 0; k < kMaxCh; ++k) {
     const int ch = wave + 4 * k;
