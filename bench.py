@@ -209,21 +209,41 @@ def main():
         loss.backward()
         return loss
 
+    # N > 1: every gradient that is averaged across ranks (weights + alpha/beta/gamma) lives in ONE
+    # flat fp32 bucket; the captured step writes into it and scales the loss by 1/world, so the
+    # per-step communication is a single RCCL all-reduce(sum) on that bucket and nothing else
+    # (no flatten / unflatten / scale kernels on the host path).
+    shared = params + arch
+    flat = torch.zeros(sum(t.numel() for t in shared), device=device) if world > 1 else None
+    flat_views = []
+    if world > 1:
+        off = 0
+        for t in shared:
+            flat_views.append(flat[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+    loss_scale = 1.0 / world
+
     def step_for_capture():
         # same work as step(); gradients are taken with autograd.grad (no AccumulateGrad nodes,
         # whose streams are pinned at creation and do not follow the capture stream) and then
         # attached as .grad — the tensors are static, replays refresh them in place
         loss = crit(model(xs), y)
-        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
-        for t, g in zip(leaves, grads):
-            t.grad = g
+        if world > 1:
+            grads = torch.autograd.grad(loss * loss_scale, leaves, allow_unused=True)
+            torch._foreach_copy_(flat_views, list(grads[:len(shared)]))
+            for t, v in zip(shared, flat_views):
+                t.grad = v
+            for t, g in zip(xs, grads[len(shared):]):
+                t.grad = g
+        else:
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+            for t, g in zip(leaves, grads):
+                t.grad = g
         return loss
 
     if world > 1:
         bdist.broadcast_state(model, arch)
-        # weights AND architecture gradients in ONE flat bucket: both are produced by every
-        # fwd+bwd, and a second (42-float) all-reduce would cost a full collective latency
-        red_all = bdist.FlatGradAllReducer(params + arch)
+        red_all = bdist.FlatGradAllReducer(shared)          # eager mode: flatten -> all-reduce -> copy back
 
     eager_ms = None
     if a.mode == 'graph':
@@ -247,7 +267,10 @@ def main():
     def run():
         run_local()
         if world > 1:
-            red_all()
+            if a.mode == 'graph':
+                torch.distributed.all_reduce(flat)           # grads already carry the 1/world factor
+            else:
+                red_all()
 
     for _ in range(a.warmup):
         run()
@@ -309,7 +332,7 @@ def main():
         lib.profile_begin(algo_table(c['C'], c['L']))
         for _ in range(n_prof):
             step()
-        recs = lib.profile_end()
+        recs, ev_ms = lib.profile_end()
         # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE with
         # the gfx950 read-side correction; tools/traffic_from_pmc.py); null if not collected
         traffic = {}
@@ -319,7 +342,7 @@ def main():
                 traffic = {k: v['traffic_bytes'] for k, v in json.load(f).items()}
         rows = []
         for name, rr in recs.items():
-            tot_ms = sum(r[0] for r in rr)
+            tot_ms = sum(max(r[0] - ev_ms, 1e-4) for r in rr)      # minus the empty-bracket time
             units = sum(r[2] for r in rr)
             bound = rr[0][1]
             per_launch_us = tot_ms / len(rr) * 1e3
@@ -339,7 +362,8 @@ def main():
             top = dict(rows[0])
             top['measured'] = (f'HIP events on the launch stream around every launch, instrumented pass of '
                                f'{n_prof} steps queued behind a GPU-side blocker (back-to-back execution), '
-                               'after the timed region; avg per launch; cross-check: profiles/ rocprofv3 stats')
+                               'after the timed region; avg per launch minus the elapsed time of an empty '
+                               f'event bracket ({ev_ms * 1e3:.2f} us); cross-check: profiles/ rocprofv3 stats')
             result['roofline'] = top
             result['roofline_kernels'] = rows
     log('roofline pass done')
