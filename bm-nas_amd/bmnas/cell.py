@@ -14,6 +14,50 @@ from . import lib
 
 ATTN_DROP = 0.1     # ScaledDotAttn's hard-coded nn.Dropout(0.1) (node_operations.py:89)
 
+# Independent kernels of a NodeMixedOp CAN run on a second HIP stream (attention next to the conv
+# GEMM in the forward, the weight-gradient GEMM next to the attention backward); the fork / join
+# are stream waits, which a hipGraph capture turns into parallel branches.  Measured on MI355X
+# (MM-IMDB b = 128): with the four fork/join pairs per step the replayed graph got SLOWER
+# (0.364 vs 0.308 ms/step; eager 1.69 vs 1.38 ms) — the cross-stream dependencies cost more than
+# the ~10 us kernels they overlap.  Off by default.
+OVERLAP = False
+_SIDE = {}
+
+
+class _Fork:
+    """with _Fork(device) as f: ... f.side(lambda: kernel launches) ...; joins on exit."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        if OVERLAP:
+            key = (device.index, self.main.cuda_stream)
+            s = _SIDE.get(key)
+            if s is None:
+                s = torch.cuda.Stream(device)
+                _SIDE[key] = s
+            self.stream = s
+        else:
+            self.stream = None
+        self.used = False
+
+    def __enter__(self):
+        return self
+
+    def side(self, fn):
+        if self.stream is None:
+            fn()
+            return
+        if not self.used:
+            self.stream.wait_stream(self.main)
+            self.used = True
+        with torch.cuda.stream(self.stream):
+            fn()
+
+    def __exit__(self, *exc):
+        if self.used:
+            self.main.wait_stream(self.stream)
+        return False
+
 
 # ------------------------------------------------------------------------ dropout state
 class _DropState:
@@ -166,7 +210,7 @@ def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, du
     return U, chan, sv
 
 
-def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias):
+def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None):
     """dV (gradient w.r.t. the BN output, with bn_grad already reduced) -> in place dU;
     then data gradient into src_slots and weight/bias gradient (+=) into dW / dbias."""
     b, L = sv.U.shape[0], sv.U.shape[2]
@@ -190,7 +234,12 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias):
     for s, tmp in extra:
         s.buf().add_(tmp.buf())
     if dW is not None:
-        lib.conv1x1_bwd_weight(dV, sv.srcs, sv.C_src, dW, dW.shape[1], dbias, sv.dup, b, L, sv.M)
+        def weight_grad():
+            lib.conv1x1_bwd_weight(dV, sv.srcs, sv.C_src, dW, dW.shape[1], dbias, sv.dup, b, L, sv.M)
+        if fork is not None:
+            fork.side(weight_grad)           # independent of everything that follows on the main stream
+        else:
+            weight_grad()
 
 
 # -------------------------------------------------------------- search-mode NodeMixedOp
@@ -210,8 +259,18 @@ def node_mixed_fwd(x, y, gamma_row, P, training):
     p1 = torch.empty_like(x)
     sv.xhat1 = torch.empty_like(x)
     sv.stats1 = _empty(x, b * 2)
-    lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, b, C, L, sv.d_attn)
     sv.p1 = p1
+    sv.d_glu = DROP.make(P.glu_p, x.numel(), training)
+    sv.d_fc = DROP.make(P.fc_p, x.numel(), training)
+    with _Fork(x.device) as fork:
+        fork.side(lambda: lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, b, C, L, sv.d_attn))
+        U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C)
+    out = torch.empty_like(x)
+    lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc)
+    return out, sv
+
+
+def _mixed_conv_fwd(sv, x, y, same, P, training, C):
     # stacked [LinearGLU | ConcatFC] conv + BN
     if same:
         # conv(cat[z, z]) = (W[:, :C] + W[:, C:]) z: K is C instead of 2C.  The halves are added once
@@ -224,11 +283,7 @@ def node_mixed_fwd(x, y, gamma_row, P, training):
     else:
         U, chan, sv.conv = conv_bn_fwd([x, y], C, P.stack_W, 2 * C, P.stack_bias, P.stack_bn_w,
                                        P.stack_bn_b, P.stack_rm, P.stack_rv, P.stack_nbt, training)
-    sv.d_glu = DROP.make(P.glu_p, x.numel(), training)
-    sv.d_fc = DROP.make(P.fc_p, x.numel(), training)
-    out = torch.empty_like(x)
-    lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc)
-    return out, sv
+    return U, chan
 
 
 class Deferred:
@@ -270,21 +325,22 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
     M = 3 * C
     dV = _empty(x, b, M, L)
     bn_grad = G.stack_bn_grad            # [dW_bn (3C) | dB_bn (3C)], zero-initialised by caller
-    if sv.same:
-        dxb, acc = x_slot.buf(), x_slot.acc_bit()
-        lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
-                         dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
-        conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias)
-        lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, None, 1, b, C, L,
-                        sv.d_attn)
-    else:
-        dxb, dyb = x_slot.buf(), y_slot.buf()
-        acc = x_slot.acc_bit() | (y_slot.acc_bit() << 1)
-        lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, dyb, acc,
-                         dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
-        conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot, y_slot], G.stack_dW, G.stack_dbias)
-        lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, dyb, 3, b, C, L,
-                        sv.d_attn)
+    with _Fork(x.device) as fork:
+        if sv.same:
+            dxb, acc = x_slot.buf(), x_slot.acc_bit()
+            lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
+                             dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
+            conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias, fork)
+            lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, None, 1, b, C, L,
+                            sv.d_attn)
+        else:
+            dxb, dyb = x_slot.buf(), y_slot.buf()
+            acc = x_slot.acc_bit() | (y_slot.acc_bit() << 1)
+            lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, dyb, acc,
+                             dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
+            conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot, y_slot], G.stack_dW, G.stack_dbias, fork)
+            lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, dyb, 3, b, C, L,
+                            sv.d_attn)
     _attn_affine_bwd(sv, g, G, deferred)
 
 
