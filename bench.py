@@ -371,8 +371,9 @@ def main():
         result['cpu_baseline'] = cpu_baseline(a.config, c, a.batch)
         result['speedup_vs_cpu_baseline'] = round(result['value'] / result['cpu_baseline']['value'], 1)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        torch.distributed.barrier()          # ranks leave together (rank 0 ran the roofline pass)
         torch.distributed.destroy_process_group()
 
 

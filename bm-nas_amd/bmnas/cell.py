@@ -247,9 +247,11 @@ class MixedSaved:
     pass
 
 
-def node_mixed_fwd(x, y, gamma_row, P, training):
+def node_mixed_fwd(x, y, gamma_row, P, training, ln=None):
     """NodeMixedOp.forward (node_operations.py:118-120).  P: parameter pack of one NodeMixedOp
-    (see models.search.darts.node_operations.NodeMixedOp.pack()).  x may be y (search)."""
+    (see models.search.darts.node_operations.NodeMixedOp.pack()).  x may be y (search).
+    ln = (resid, ln_w, ln_b, stats): fuse the NodeCell tail `out += x; ln(out)` (node_search.py:67-68)
+    into the mix kernel; returns LN(mix + resid) and keeps the pre-norm sum in sv.pre."""
     b, C, L = x.shape
     same = x is y or x.data_ptr() == y.data_ptr()
     sv = MixedSaved()
@@ -266,7 +268,13 @@ def node_mixed_fwd(x, y, gamma_row, P, training):
         fork.side(lambda: lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, b, C, L, sv.d_attn))
         U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C)
     out = torch.empty_like(x)
-    lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc)
+    if ln is None:
+        lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc)
+    else:
+        resid, ln_w, ln_b, stats = ln
+        sv.pre = torch.empty_like(x)
+        lib.node_mix_ln_fwd(x, y, p1, U, chan, gamma_row, resid, ln_w, ln_b, sv.pre, out, stats, b, C, L,
+                            sv.d_glu, sv.d_fc)
     return out, sv
 
 
@@ -349,6 +357,9 @@ class NodeCellSaved:
     pass
 
 
+FUSE_TAIL = True   # node_multiplier == 1: NodeMixedOp + residual + LayerNorm in one launch
+
+
 def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm):
     """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
     device tensors.  NP: parameter pack of the NodeCell."""
@@ -359,15 +370,22 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm):
     states = [x, y]
     sv.zs, sv.mixed, sv.offsets = [], [], []
     offset = 0
+    sv.fused_tail = nm == 1 and FUSE_TAIL
+    sv.stats = _empty(x, b * 2)
     for t in range(ns):
         z = mixsum_fwd(states, beta_w[offset:, 1])
-        s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training)
+        last = sv.fused_tail and t == ns - 1
+        s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
+                                (x, NP.ln_w, NP.ln_b, sv.stats) if last else None)
         sv.zs.append(z)
         sv.mixed.append(msv)
         sv.offsets.append(offset)
         offset += len(states)
         states.append(s)
     sv.states = states
+    if sv.fused_tail:
+        sv.o = sv.mixed[-1].pre                          # pre-norm sum o + x; states[-1] is LN(o + x)
+        return states[-1], sv
     tail = states[-nm:]
     if nm != 1:
         Wo = NP.out_conv_w.view(C, nm * C)
@@ -380,7 +398,6 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm):
         o = tail[0]
     sv.o = o
     out = torch.empty_like(x)
-    sv.stats = _empty(x, b * 2)
     lib.cat_ln_fwd([o], x, NP.ln_w, NP.ln_b, out, sv.stats, b, C, L, False)
     return out, sv
 
@@ -394,6 +411,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None):
     ns, nm, NP = sv.ns, sv.nm, sv.NP
     slots = [x_slot, y_slot] + [GradSlot(x) for _ in range(ns)]
     tail = list(range(2 + ns - nm, 2 + ns))
+    resid = None if sv.fused_tail else x                 # fused: sv.o already holds o + x
     if nm != 1:
         d_o = GradSlot(x)
         bufs, mask = _write_group([d_o])
@@ -407,9 +425,9 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None):
     else:
         bufs, mask = _write_group([slots[tail[0]]])
         racc = x_slot.acc_bit()
-        lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
+        lib.cat_ln_bwd(g, [sv.o], resid, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
                        mask | (racc << 31), None, None, b, C, L, False)
-    _ln_affine(deferred, g, None, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, NG.dln_w, NG.dln_b, b, C, L,
+    _ln_affine(deferred, g, None, [sv.o], resid, NP.ln_w, NP.ln_b, sv.stats, NG.dln_w, NG.dln_b, b, C, L,
                False, False)
     for t in reversed(range(ns)):
         gs = slots[2 + t].get()

@@ -52,6 +52,8 @@ SIGNATURES = {
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
+    'bmnas_node_mix_ln_fwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, _P],
+                              _I),
     'bmnas_node_mix_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32, _P, _P, _I, _I, _I,
                             Dropout, Dropout, _P], _I),
     'bmnas_bn_glu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
@@ -233,6 +235,12 @@ def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc):
                                      _ptr(out), b, Cc, L, dglu, dfc, _stream()), 'node_mix_fwd')
 
 
+def node_mix_ln_fwd(x, y, p1, U, chan, gamma, resid, ln_w, ln_b, pre, out, stats, b, Cc, L, dglu, dfc):
+    _check(load().bmnas_node_mix_ln_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), gamma.data_ptr(),
+                                        _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(pre), _ptr(out),
+                                        _ptr(stats), b, Cc, L, dglu, dfc, _stream()), 'node_mix_ln_fwd')
+
+
 def node_mix_bwd(g, x, y, p1, U, chan, gamma, dgamma, dx, dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc,
                  dg_shards=1, dg_stride=0):
     _check(load().bmnas_node_mix_bwd(_ptr(g), _ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan),
@@ -319,6 +327,11 @@ def profile_begin(algo):
     units = algorithmic bytes / flops of that launch.  Only the named wrappers are timed."""
     global _PROF
     _PROF = {'algo': algo, 'records': {}}
+    g = globals()
+    for n in _TIMED_NAMES:
+        if n in algo and n not in _PLAIN:
+            _PLAIN[n] = g[n]
+            g[n] = _timed(n, g[n])
 
 
 def profile_end():
@@ -328,6 +341,10 @@ def profile_end():
     from every bracket by the caller."""
     global _PROF
     prof, _PROF = _PROF, None
+    g = globals()
+    for n, fn in list(_PLAIN.items()):
+        g[n] = fn
+    _PLAIN.clear()
     empties = []
     for _ in range(32):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -340,6 +357,14 @@ def profile_end():
         out[name] = [(s.elapsed_time(e), bound, units) for s, e, bound, units in recs]
     overhead = sorted(s.elapsed_time(e) for s, e in empties)[len(empties) // 2]
     return out, overhead
+
+
+_TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi',
+                'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
+                'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
+                'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',
+                'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy')
+_PLAIN = {}
 
 
 def _timed(name, fn):
@@ -357,11 +382,3 @@ def _timed(name, fn):
     wrapper.__name__ = name
     wrapper.__doc__ = fn.__doc__
     return wrapper
-
-
-for _n in ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'sdpa_ln_fwd', 'sdpa_ln_bwd',
-           'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight', 'fold_weight', 'bn_finalize',
-           'node_mix_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd', 'bn_relu_fwd', 'bn_relu_bwd',
-           'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd', 'linear_fwd', 'linear_bwd',
-           'bce_logits', 'cross_entropy'):
-    globals()[_n] = _timed(_n, globals()[_n])

@@ -97,6 +97,76 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
   }
 }
 
+
+// K2 + K6 fused (node_multiplier == 1, last inner step): the gamma-mix result never goes to
+// memory on its own — one workgroup per sample forms s, adds the residual X, keeps the sample
+// in registers for the two LayerNorm reductions and writes pre = s + X (saved for backward)
+// and out = LN(pre).  Saves one launch and 3 T of traffic per step node.
+template <int VPT>
+__global__ __launch_bounds__(256) void node_mix_ln_fwd_k(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ p1,
+    const float* __restrict__ U, const float* __restrict__ chan, const float* __restrict__ gamma,
+    const float* __restrict__ resid, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+    float* __restrict__ pre, float* __restrict__ out, float* __restrict__ stats, int C, int L,
+    DropCfg dglu, DropCfg dfc) {
+  __shared__ float red[4];
+  const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
+  const int smp = blockIdx.x;
+  const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
+  float4 v[VPT];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * 256;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < cl4) {
+      const int c = r / l4n;
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      const int64_t ub = ((int64_t)smp * M) * L + (int64_t)r * 4;
+      const float4 va = affine4(ld4(U + ub), chan[2 * M + c], chan[3 * M + c]);
+      const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), chan[2 * M + C + c], chan[3 * M + C + c]);
+      const float4 vf = affine4(ld4(U + ub + (int64_t)2 * C * L), chan[2 * M + 2 * C + c], chan[3 * M + 2 * C + c]);
+      const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
+      const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e), rv = ld4(resid + e);
+      float4 o;
+      o.x = g0 * (xv.x + yv.x) + g1 * pv.x + g2 * (va.x * sigmoidf(vg.x) * m2.x) + g3 * (fmaxf(vf.x, 0.f) * m3.x);
+      o.y = g0 * (xv.y + yv.y) + g1 * pv.y + g2 * (va.y * sigmoidf(vg.y) * m2.y) + g3 * (fmaxf(vf.y, 0.f) * m3.y);
+      o.z = g0 * (xv.z + yv.z) + g1 * pv.z + g2 * (va.z * sigmoidf(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
+      o.w = g0 * (xv.w + yv.w) + g1 * pv.w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
+      v[k] = f4_add(o, rv);
+      st4(pre + e, v[k]);
+      sum += f4_hsum(v[k]);
+    }
+  }
+  const float inv_d = 1.f / (float)(cl4 * 4);
+  const float mean = block_sum256(sum, red) * inv_d;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * 256;
+    if (r < cl4) {
+      const float4 cdev = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
+      sq += f4_dot(cdev, cdev);
+    }
+  }
+  const float var = block_sum256(sq, red) * inv_d;
+  const float rstd = 1.f / sqrtf(var + kEps);
+  if (threadIdx.x == 0) {
+    stats[2 * smp] = mean;
+    stats[2 * smp + 1] = rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * 256;
+    if (r < cl4) {
+      const float4 w = ld4(ln_w + (int64_t)r * 4), bb = ld4(ln_b + (int64_t)r * 4);
+      st4(out + ((int64_t)smp * cl4 + r) * 4,
+          make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
+                      (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w));
+    }
+  }
+}
+
 // reduce v over the l4n adjacent lanes that share a channel row (l4n in {1, 2, 4})
 __device__ __forceinline__ float row_sum(float v, int l4n) {
   if (l4n >= 2) v += __shfl_xor(v, 1, 64);
@@ -534,6 +604,32 @@ extern "C" int bmnas_node_mix_fwd(const float* x, const float* y, const float* p
   const int64_t total = (int64_t)b * C * L / 4;
   hipLaunchKernelGGL(node_mix_fwd_k, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x,
                      y, p1, U, chan, gamma, out, b, C, L, to_cfg(drop_glu), to_cfg(drop_fc));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+
+extern "C" int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float* p1, const float* U,
+                                     const float* chan, const float* gamma, const float* resid,
+                                     const float* ln_w, const float* ln_b, float* pre, float* out,
+                                     float* stats, int b, int C, int L, bmnas_dropout_t drop_glu,
+                                     bmnas_dropout_t drop_fc, void* stream) {
+  if (!x || !y || !p1 || !U || !chan || !gamma || !resid || !ln_w || !ln_b || !pre || !out || !stats ||
+      b < 0 || C < 1)
+    return BMNAS_E_ARG;
+  if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  const int need = (C * L / 4 + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+#define NML(V)                                                                                         \
+  hipLaunchKernelGGL(node_mix_ln_fwd_k<V>, dim3(b), dim3(256), 0, st, x, y, p1, U, chan, gamma, resid, \
+                     ln_w, ln_b, pre, out, stats, C, L, to_cfg(drop_glu), to_cfg(drop_fc))
+  if (need <= 1) NML(1);
+  else if (need <= 2) NML(2);
+  else if (need <= 4) NML(4);
+  else if (need <= 8) NML(8);
+  else return BMNAS_E_LIMIT;
+#undef NML
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

@@ -175,6 +175,15 @@ int bmnas_bn_finalize(const float* part, int n_part, int b, int L, int M, const 
 int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const float* U,
                        const float* chan, const float* gamma, float* out, int b, int C, int L,
                        bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
+/* K2 + K6 in one launch (node_multiplier == 1, last inner step; node_search.py:55,67-68):
+ * pre = NodeMixedOp(...) + resid (saved for backward), out = LayerNorm_[C, L](pre), stats as in
+ * cat_ln.  The backward is bmnas_cat_ln_bwd(srcs = {pre}, resid = NULL) with its input gradient
+ * routed to both the mix and the residual, then bmnas_node_mix_bwd. */
+int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float* p1, const float* U,
+                          const float* chan, const float* gamma, const float* resid,
+                          const float* ln_w, const float* ln_b, float* pre, float* out, float* stats,
+                          int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
+                          void* stream);
 /* Backward, phase A (elementwise + reductions):  g = grad of s.
  *   dgamma[shard*dgamma_shard_stride + q] += <g, p_q> (shards as in bmnas_mixsum_bwd);
  *   dx / dy (=|+=) g0*g (dy NULL: both into dx);
