@@ -91,6 +91,9 @@ def algo_table(C, L):
     return {
         'mixsum_fwd': lambda xs, w, ws, out, *_: ('hbm', (len(xs) + 1) * T(out)),
         'mixsum_bwd': lambda xs, dxs, w, ws, g, *_: ('hbm', (2 * len(xs) + 1) * T(g)),
+        'mixsum_pair_fwd': lambda xs, w, ws, w2, ws2, out, *_: ('hbm', (len(xs) + 2) * T(out)),
+        'mixsum_pair_bwd': lambda xs, dxs, w, ws, w2, ws2, h, gh, gz, *_:
+            ('hbm', (2 * len(xs) + 2 + (1 if gh is not None else 0)) * T(gz)),
         'cat_ln_fwd': lambda srcs, resid, w, b_, out, *_:
             ('hbm', (len(srcs) + (1 if resid is not None else 0)) * T(srcs[0]) + T(out) + 2 * T(w)),
         'cat_ln_bwd': lambda g, srcs, resid, w, *_:
@@ -110,6 +113,8 @@ def algo_table(C, L):
         'conv1x1_bwd_weight': lambda dU, srcs, Cs, dW, ldw, db, dup, b, L_, M, *_:
             ('mfma', 2.0 * M * len(srcs) * Cs * b * L_),
         'node_mix_fwd': lambda x, y, p1, U, ch, gm, out, *_: ('hbm', T(U) + 3 * T(out)),
+        'node_mix_ln_fwd': lambda x, y, p1, U, ch, gm, resid, w, b_, pre, out, *_:
+            ('hbm', T(U) + 5 * T(out) + 2 * T(w)),
         'node_mix_bwd': lambda g, x, y, p1, U, *_: ('hbm', 2 * T(U) + 4 * T(g)),
         'bn_relu_fwd': lambda U, *_: ('hbm', 2 * T(U)),
         'bn_relu_bwd': lambda g, U, *_: ('hbm', 3 * T(U)),

@@ -360,9 +360,13 @@ class NodeCellSaved:
 FUSE_TAIL = True   # node_multiplier == 1: NodeMixedOp + residual + LayerNorm in one launch
 
 
-def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm):
+FUSE_PAIR = True   # search mode: cell-level mixed sum + the node's first inner sum in one launch
+
+
+def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None):
     """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
-    device tensors.  NP: parameter pack of the NodeCell."""
+    device tensors.  NP: parameter pack of the NodeCell.  z0: the first inner mixed sum when the
+    caller already formed it (bmnas_mixsum_pair_fwd)."""
     b, C, L = x.shape
     sv = NodeCellSaved()
     sv.x, sv.ns, sv.nm, sv.NP, sv.training = x, ns, nm, NP, training
@@ -373,7 +377,7 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm):
     sv.fused_tail = nm == 1 and FUSE_TAIL
     sv.stats = _empty(x, b * 2)
     for t in range(ns):
-        z = mixsum_fwd(states, beta_w[offset:, 1])
+        z = z0 if (t == 0 and z0 is not None) else mixsum_fwd(states, beta_w[offset:, 1])
         last = sv.fused_tail and t == ns - 1
         s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
                                 (x, NP.ln_w, NP.ln_b, sv.stats) if last else None)
@@ -402,10 +406,12 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm):
     return out, sv
 
 
-def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None):
+def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, defer_first=False):
     """g: grad of the node output.  x_slot / y_slot: GradSlots of the two inputs (the same
     object in search mode).  dbeta_w / dgamma_w: zero-initialised (k_in,2)/(ns,4) buffers
-    receiving the gradients w.r.t. the SOFTMAXED weights.  NG: gradient pack."""
+    receiving the gradients w.r.t. the SOFTMAXED weights.  NG: gradient pack.
+    defer_first: do not run the backward of the first inner mixed sum; return the gradient of
+    z0 instead (the caller folds it into bmnas_mixsum_pair_bwd)."""
     x = sv.x
     b, C, L = x.shape
     ns, nm, NP = sv.ns, sv.nm, sv.NP
@@ -436,10 +442,13 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None):
         z_slot = GradSlot(x)
         node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t], NG.shards, NG.shard_stride,
                        deferred)
+        if t == 0 and defer_first:
+            return z_slot.buf()
         off = sv.offsets[t]
         n_in = 2 + t
         mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.beta_w[off:, 1], z_slot.buf(),
                    dbeta_w[off:, 1], 2, NG.shards, NG.shard_stride)
+    return None
 
 
 # ------------------------------------------------------------------- search-mode FusionCell
@@ -458,8 +467,13 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm):
     sv.sifs, sv.nodes, sv.offsets = [], [], []
     offset = 0
     for i in range(S):
-        sif = mixsum_fwd(states, alpha_w[offset:, 1])
-        out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm)
+        if FUSE_PAIR and len(states) <= 15:
+            sif, z0 = torch.empty_like(xs[0]), torch.empty_like(xs[0])
+            lib.mixsum_pair_fwd(states, alpha_w[offset:, 1], 2, beta_ws[i][:, 1], 2, sif, z0)
+        else:
+            sif, z0 = mixsum_fwd(states, alpha_w[offset:, 1]), None
+        out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm, z0)
+        nsv.paired = z0 is not None
         sv.sifs.append(sif)
         sv.nodes.append(nsv)
         sv.offsets.append(offset)
@@ -491,10 +505,18 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
         if gn is None:
             continue
         sif_slot = GradSlot(x0)
-        node_cell_bwd(sv.nodes[i], gn, sif_slot, sif_slot, dbeta_ws[i], dgamma_ws[i], CG.nodes[i], deferred)
+        nsv = sv.nodes[i]
+        gz = node_cell_bwd(nsv, gn, sif_slot, sif_slot, dbeta_ws[i], dgamma_ws[i], CG.nodes[i], deferred,
+                           defer_first=nsv.paired)
         off = sv.offsets[i]
         n_in = N + i
-        mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
-                   dalpha_w[off:, 1], 2, CG.shards, CG.shard_stride)
+        if gz is not None:
+            bufs, mask = _write_group(slots[:n_in])
+            lib.mixsum_pair_bwd(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
+                                sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1],
+                                mask, CG.shards, CG.shard_stride)
+        else:
+            mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
+                       dalpha_w[off:, 1], 2, CG.shards, CG.shard_stride)
     deferred.flush(b, L)
     return [s.get() if s is not None else None for s in slots[:N]]

@@ -275,7 +275,10 @@ class FusedCellFn(Function):
         if ctx.alpha_is_logits:
             dalpha, darch = darch[0], darch[1:]
         else:
-            dalpha = dalpha_w
+            # the caller owns the alpha softmax: hand back the sum of the atomic shards
+            dalpha = torch.as_strided(dalpha_w, (CG.shards, *dalpha_w.shape),
+                                      (CG.shard_stride, *dalpha_w.stride()),
+                                      dalpha_w.storage_offset()).sum(0)
         return (None, None, None, dalpha, *dxs, *darch, *cell.grads_in_param_order(CG))
 
 

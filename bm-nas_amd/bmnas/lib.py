@@ -37,6 +37,8 @@ SIGNATURES = {
     'bmnas_version': ([], _I),
     'bmnas_mixsum_fwd': ([_PP, _I, _P, _I, _P, _I64, _P], _I),
     'bmnas_mixsum_bwd': ([_PP, _PP, _I, _P, _I, _P, _P, _I, _I64, _U32, _I64, _P], _I),
+    'bmnas_mixsum_pair_fwd': ([_PP, _I, _P, _I, _P, _I, _P, _P, _I64, _P], _I),
+    'bmnas_mixsum_pair_bwd': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I64, _U32, _I64, _P], _I),
     'bmnas_cat_ln_fwd': ([_PP, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_cat_ln_bwd': ([_P, _PP, _I, _P, _P, _P, _P, _PP, _P, _U32, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_ln_affine_bwd': ([_P, _P, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
@@ -145,6 +147,19 @@ def mixsum_bwd(xs, dxs, w, w_stride, g, dw, acc_mask, dw_shards=1, dw_shard_stri
     _check(load().bmnas_mixsum_bwd(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, _ptr(g),
                                    None if dw is None else dw.data_ptr(), dw_shards, dw_shard_stride,
                                    acc_mask, g.numel(), _stream()), 'mixsum_bwd')
+
+
+def mixsum_pair_fwd(xs, w, w_stride, w2, w2_stride, out, out2):
+    _check(load().bmnas_mixsum_pair_fwd(_ptrs(xs), len(xs), w.data_ptr(), w_stride, w2.data_ptr(), w2_stride,
+                                        _ptr(out), _ptr(out2), out.numel(), _stream()), 'mixsum_pair_fwd')
+
+
+def mixsum_pair_bwd(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, acc_mask, dw_shards=1,
+                    dw_shard_stride=0):
+    _check(load().bmnas_mixsum_pair_bwd(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride,
+                                        w2.data_ptr(), w2_stride, _ptr(h), _ptr(gh), _ptr(gz),
+                                        dw.data_ptr(), dw2.data_ptr(), dw_shards, dw_shard_stride, acc_mask,
+                                        gz.numel(), _stream()), 'mixsum_pair_bwd')
 
 
 def cat_ln_fwd(srcs, resid, ln_w, ln_b, out, stats, b, Cc, L, relu):
@@ -359,7 +374,7 @@ def profile_end():
     return out, overhead
 
 
-_TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi',
+_TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',

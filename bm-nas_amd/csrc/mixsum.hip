@@ -83,6 +83,97 @@ __global__ __launch_bounds__(256) void mixsum_bwd_k(PtrsIn xs, PtrsOut dxs,
   }
 }
 
+
+// K1 pair — the cell-level sum h = sum_j w_j x_j together with the first inner-cell sum of the
+// step node it feeds.  In search mode FusionNode is called as node(h, h) (model_search.py:59), so
+// NodeCell's first mixed sum (node_search.py:54) is z = (w2_0 + w2_1) * h: written from the same
+// registers instead of a second launch that re-reads h twice.
+template <int NIN>
+__global__ __launch_bounds__(256) void mixsum_pair_fwd_k(PtrsIn xs, const float* __restrict__ w,
+                                                         int w_stride, const float* __restrict__ w2,
+                                                         int w2_stride, float* __restrict__ out,
+                                                         float* __restrict__ out2, int64_t n4) {
+  float wj[NIN];
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) wj[j] = w[j * w_stride];
+  const float s2 = w2[0] + w2[w2_stride];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 v[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+    float4 acc = f4_scale(v[0], wj[0]);
+#pragma unroll
+    for (int j = 1; j < NIN; ++j) {
+      acc.x = fmaf(wj[j], v[j].x, acc.x);
+      acc.y = fmaf(wj[j], v[j].y, acc.y);
+      acc.z = fmaf(wj[j], v[j].z, acc.z);
+      acc.w = fmaf(wj[j], v[j].w, acc.w);
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+    reinterpret_cast<float4*>(out2)[i] = f4_scale(acc, s2);
+  }
+}
+
+// backward of the pair: G = gh + (w2_0 + w2_1) * gz is the full gradient of h (gh: what the other
+// consumers of h already accumulated, may be null); dx_j (+)= w_j G, dw_j += <G, x_j>,
+// dw2_0 += <gz, h>, dw2_1 += <gz, h>.
+template <int NIN>
+__global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
+                                                         const float* __restrict__ w, int w_stride,
+                                                         const float* __restrict__ w2, int w2_stride,
+                                                         const float* __restrict__ h,
+                                                         const float* __restrict__ gh,
+                                                         const float* __restrict__ gz, float* dw,
+                                                         float* dw2, int dw_shards,
+                                                         int64_t dw_shard_stride, uint32_t acc_mask,
+                                                         int64_t n4) {
+  __shared__ float red[4 * (NIN + 1)];
+  float wj[NIN], part[NIN + 1];
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) {
+    wj[j] = w[j * w_stride];
+    part[j] = 0.f;
+  }
+  part[NIN] = 0.f;
+  const float s2 = w2[0] + w2[w2_stride];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 z4 = reinterpret_cast<const float4*>(gz)[i];
+    const float4 h4 = reinterpret_cast<const float4*>(h)[i];
+    float4 g4 = f4_scale(z4, s2);
+    if (gh != nullptr) g4 = f4_add(g4, reinterpret_cast<const float4*>(gh)[i]);
+    float4 v[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) part[j] += f4_dot(g4, v[j]);
+    part[NIN] += f4_dot(z4, h4);
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+      float* d = dxs.p[j];
+      if (d == nullptr) continue;
+      float4 r = f4_scale(g4, wj[j]);
+      if (acc_mask & (1u << j)) r = f4_add(r, reinterpret_cast<float4*>(d)[i]);
+      reinterpret_cast<float4*>(d)[i] = r;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j <= NIN; ++j) {
+    float s = wave_sum(part[j]);
+    if (lane == 0) red[wave * (NIN + 1) + j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x <= NIN + 1) {
+    const int j = threadIdx.x < NIN ? threadIdx.x : NIN;
+    const float v = red[j] + red[NIN + 1 + j] + red[2 * (NIN + 1) + j] + red[3 * (NIN + 1) + j];
+    const int64_t sh = (int64_t)(blockIdx.x % dw_shards) * dw_shard_stride;
+    if (threadIdx.x < NIN) atomicAdd(dw + sh + j * w_stride, v);
+    else atomicAdd(dw2 + sh + (threadIdx.x - NIN) * w2_stride, v);
+  }
+}
+
 inline int grid_for(int64_t n4) {
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -153,6 +244,62 @@ extern "C" int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n
   hipStream_t st = (hipStream_t)stream;
 #define CALL(N) hipLaunchKernelGGL(mixsum_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, g, dw, dw_shards, dw_shard_stride, accumulate_mask, n4)
   MIXSUM_DISPATCH(n_in, CALL)
+#undef CALL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_mixsum_pair_fwd(const float* const* xs, int n_in, const float* w, int w_stride,
+                                     const float* w2, int w2_stride, float* out, float* out2,
+                                     int64_t n_elem, void* stream) {
+  if (!xs || !w || !w2 || !out || !out2 || n_in < 1 || n_elem < 0 || w_stride < 1 || w2_stride < 1)
+    return BMNAS_E_ARG;
+  if (n_in > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
+  if (n_elem % 4 != 0) return BMNAS_E_SHAPE;
+  if (n_elem == 0) return 0;
+  PtrsIn p{};
+  for (int j = 0; j < n_in; ++j) {
+    if (!xs[j]) return BMNAS_E_ARG;
+    p.p[j] = xs[j];
+  }
+  const int64_t n4 = n_elem / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(N) hipLaunchKernelGGL(mixsum_pair_fwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, w, w_stride, w2, w2_stride, out, out2, n4)
+  MIXSUM_DISPATCH(n_in, CALL)
+#undef CALL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, int n_in,
+                                     const float* w, int w_stride, const float* w2, int w2_stride,
+                                     const float* h, const float* gh, const float* gz, float* dw,
+                                     float* dw2, int dw_shards, int64_t dw_shard_stride,
+                                     uint32_t accumulate_mask, int64_t n_elem, void* stream) {
+  if (!xs || !dxs || !w || !w2 || !h || !gz || !dw || !dw2 || n_in < 1 || n_elem < 0 || w_stride < 1 ||
+      w2_stride < 1 || dw_shards < 1)
+    return BMNAS_E_ARG;
+  if (n_in > BMNAS_MAX_PTRS - 1) return BMNAS_E_LIMIT;
+  if (n_elem % 4 != 0) return BMNAS_E_SHAPE;
+  if (n_elem == 0) return 0;
+  PtrsIn p{};
+  PtrsOut d{};
+  for (int j = 0; j < n_in; ++j) {
+    if (!xs[j]) return BMNAS_E_ARG;
+    p.p[j] = xs[j];
+    d.p[j] = dxs[j];
+  }
+  const int64_t n4 = n_elem / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(N) hipLaunchKernelGGL(mixsum_pair_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, dw_shards, dw_shard_stride, accumulate_mask, n4)
+  switch (n_in) {
+    case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;
+    case 4: CALL(4); break;   case 5: CALL(5); break;   case 6: CALL(6); break;
+    case 7: CALL(7); break;   case 8: CALL(8); break;   case 9: CALL(9); break;
+    case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break;
+    case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break;
+    default: return BMNAS_E_LIMIT;
+  }
 #undef CALL
   BMNAS_CHECK_LAUNCH();
   return 0;

@@ -73,6 +73,22 @@ int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n_in, const 
                      int64_t dw_shard_stride, uint32_t accumulate_mask, int64_t n_elem,
                      void* stream);
 
+/* K1 pair (search mode): out = sum_j w_j xs[j] and, from the same registers, the first inner sum
+ * of the step node that consumes it, out2 = (w2[0] + w2[w2_stride]) * out — FusionNode(h, h) at
+ * model_search.py:59 makes NodeCell's states [h, h] (node_search.py:52-54). */
+int bmnas_mixsum_pair_fwd(const float* const* xs, int n_in, const float* w, int w_stride,
+                          const float* w2, int w2_stride, float* out, float* out2, int64_t n_elem,
+                          void* stream);
+/* Backward of the pair.  h = the saved `out`; gz = gradient of out2; gh = gradient `out` received
+ * from its other consumers (NULL if none).  G = gh + (w2_0 + w2_1) gz;  dxs[j] (=|+=) w_j G;
+ * dw[j] += <G, xs[j]>;  dw2[0], dw2[w2_stride] += <gz, h>  (n_in <= 15; shards as above, dw and dw2
+ * share dw_shard_stride). */
+int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, int n_in, const float* w,
+                          int w_stride, const float* w2, int w2_stride, const float* h,
+                          const float* gh, const float* gz, float* dw, float* dw2, int dw_shards,
+                          int64_t dw_shard_stride, uint32_t accumulate_mask, int64_t n_elem,
+                          void* stream);
+
 /* ---- K6 / K7: channel-concat (+ residual) + LayerNorm (+ ReLU) -------------------------
  * x = cat(srcs[0..n_src), dim=1) (+ resid if non-NULL; n_src must be 1 then);
  * out = LayerNorm_[n_src*C, L](x; ln_w, ln_b) (eps 1e-5, biased variance), optional ReLU.

@@ -199,3 +199,27 @@ def test_search_trajectory_matches_reference_golden(path):
         assert a.is_cuda
         assert_close_scaled(f'arch.{i}', a, z[f'arch.{i}'], rel=5e-4)
     assert fo.genotype_to_jsonable(model.fusion_net.genotype()) == json.loads(str(z['genotype']))
+
+
+@pytest.mark.parametrize('name,batch', [('mmimdb', 16), ('ntu', 8)])
+def test_cell_called_with_softmaxed_weights(name, batch):
+    """FusionCell.forward(input_features, weights) with weights = softmax(alphas), the
+    reference's own call (model_search.py:95-96): same output and the same alpha gradient as
+    the one-launch path that hands the cell the raw alphas."""
+    cfg = fo.Cfg({**fo.CONFIGS[name], 'drpt': 0.0})
+    net = build_search_net(cfg, 5, 'train_nodrop')
+    xs = [x.to(dev()) for x in synth.make_inputs(cfg, batch, 5)]
+    feat = net(xs)
+    w = torch.randn_like(feat)
+    (feat * w).sum().backward()
+    want_alpha = net.alphas_edges.grad.clone()
+    want_beta = net.arch_parameters()[1].grad.clone()
+    for a in net.arch_parameters():
+        a.grad = None
+    net2 = build_search_net(cfg, 5, 'train_nodrop')
+    weights = torch.softmax(net2.alphas_edges, dim=-1)
+    feat2 = net2.cell(xs, weights)
+    (feat2 * w).sum().backward()
+    assert_close_scaled('feat', feat2, feat.detach().cpu())
+    assert_close_scaled('alpha grad', net2.alphas_edges.grad, want_alpha.cpu(), rel=3e-4)
+    assert_close_scaled('beta grad', net2.arch_parameters()[1].grad, want_beta.cpu(), rel=3e-4)
