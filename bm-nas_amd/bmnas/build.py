@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
 LIB = os.path.join(HERE, 'libbmnas_hip.so')
-SOURCES = ['mixsum.hip', 'layernorm.hip', 'sdpa.hip', 'conv1x1.hip', 'bnmix.hip', 'linear.hip']
+SOURCES = ['mixsum.hip', 'layernorm.hip', 'sdpa.hip', 'conv1x1.hip', 'bnmix.hip', 'linear.hip', 'adam.hip']
 
 
 def hipcc_path():

@@ -65,7 +65,28 @@ class FlatGradAllReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
+    # -- persistent bucket: gradients are PRODUCED in the flat buffer (GraphedTrainStep writes them
+    # there inside the captured step, pre-scaled by 1/world), so a step's communication is one
+    # all-reduce(sum) and nothing else: no flatten, no scale, no copy back
+    def ensure_bucket(self):
+        if getattr(self, 'flat', None) is None:
+            dev = self.tensors[0].device
+            self.flat = torch.zeros(sum(t.numel() for t in self.tensors), device=dev, dtype=torch.float32)
+            self.views, off = [], 0
+            for t in self.tensors:
+                self.views.append(self.flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+        return self.views
+
+    def all_reduce_bucket(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.reduced = True                      # the optimizer pre-hook must not average again
+
     def __call__(self):
+        if getattr(self, 'reduced', False):
+            self.reduced = False
+            return
         if self.world <= 1:
             return
         grads = [t.grad for t in self.tensors if t.grad is not None]
@@ -85,6 +106,7 @@ def attach(optimizer, tensors=None, group=None):
         tensors = [p for g in optimizer.param_groups for p in g['params']]
     reducer = FlatGradAllReducer(tensors, group)
     handle = optimizer.register_step_pre_hook(lambda opt, args, kwargs: reducer())
+    optimizer._bmnas_reducer = reducer           # GraphedTrainStep writes gradients into its bucket
     return reducer, handle
 
 

@@ -43,3 +43,95 @@ class GraphedStep:
     def replay(self):
         self.graph.replay()
         return self.outputs
+
+
+class GraphedTrainStep:
+    """One optimisation step of the search loop — forward, criterion, backward and the Adam
+    update — as ONE hipGraph replay ("HIP-graph capture of the whole
+    fwd+bwd+allreduce+Adam step").  The reference's loops issue the same work eagerly
+    (train_searchable/mmimdb.py:85-101 for the weights, architect.py:21-29 for alpha).
+
+        step = GraphedTrainStep(model, criterion, optimizer, inputs, labels)
+        loss, logits = step(inputs, labels)          # copies the batch in, replays, returns statics
+
+    * The tensors differentiated are the optimizer's own (central_params for the weight phase,
+      arch_parameters for the alpha phase); their gradients come from torch.autograd.grad, so no
+      other leaf's .grad is touched — the stepped tensors end up exactly as after
+      zero_grad + backward + step.
+    * `optimizer`: a bmnas.optim.Adam (its step is capturable: the scalars travel through a pinned
+      staging buffer, so per-batch learning rates and bias corrections stay exact).
+    * Data parallel (optimizer passed through bmnas.dist.attach, world size > 1): the captured step
+      writes the gradients straight into the reducer's flat bucket with the loss pre-scaled by
+      1/world; the replay is followed by one RCCL all-reduce(sum) of the bucket and the one-launch
+      Adam step (outside the graph: collectives are not captured).
+    * The batch shape is fixed at capture: check `matches(inputs, labels)` and run a ragged last
+      batch through the eager path.
+    Returned `loss` / `logits` are static tensors that the next call overwrites."""
+
+    def __init__(self, model, criterion, optimizer, inputs, labels, warmup=2):
+        self.optimizer = optimizer
+        self.targets = [p for g in optimizer.param_groups for p in g['params']]
+        reducer = getattr(optimizer, '_bmnas_reducer', None)
+        if reducer is not None and reducer.world <= 1:
+            reducer = None
+        self.reducer = reducer
+        self.inputs = [x.detach().clone() for x in inputs]
+        self.labels = labels.detach().clone()
+        self.in_graph_step = reducer is None
+        scale = 1.0 / reducer.world if reducer is not None else 1.0
+        views = reducer.ensure_bucket() if reducer is not None else None
+        armed = [False]
+
+        def fn():
+            logits = model(self.inputs)
+            loss = criterion(logits, self.labels)
+            grads = torch.autograd.grad(loss * scale if reducer is not None else loss, self.targets,
+                                        allow_unused=True)
+            if reducer is not None:
+                have = [(v, g) for v, g in zip(views, grads) if g is not None]
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+                for t, v, g in zip(self.targets, views, grads):
+                    t.grad = v if g is not None else None
+            else:
+                for t, g in zip(self.targets, grads):
+                    t.grad = g
+            if self.in_graph_step and armed[0]:
+                optimizer.step()
+            return loss, logits
+
+        # The warm-up passes run WITHOUT the update (they settle allocations and lazy
+        # initialisation; extra optimizer steps on the example batch would change training) and
+        # their BatchNorm running-statistics updates are undone afterwards.
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if self.in_graph_step:
+            optimizer.capture_safe()
+        armed[0] = True
+        self._g = GraphedStep(fn, warmup=0)
+        model.load_state_dict(state)
+
+    def matches(self, inputs, labels):
+        return (len(inputs) == len(self.inputs) and labels.shape == self.labels.shape and
+                all(a.shape == b.shape for a, b in zip(inputs, self.inputs)))
+
+    def __call__(self, inputs, labels):
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        opt = self.optimizer
+        if self.in_graph_step:
+            opt.wait_staging()
+            opt.prepare_replay()
+            loss, logits = self._g.replay()
+            opt.mark_launched()
+        else:
+            loss, logits = self._g.replay()
+            self.reducer.all_reduce_bucket()
+            opt.step()
+        return loss, logits

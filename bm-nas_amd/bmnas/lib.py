@@ -67,6 +67,8 @@ SIGNATURES = {
     'bmnas_linear_bwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
     'bmnas_bce_logits': ([_P, _P, _P, _P, _I, _P], _I),
     'bmnas_cross_entropy': ([_P, _P, _P, _P, _P, _I, _I, _P], _I),
+    'bmnas_adam_chunk_elems': ([], _I),
+    'bmnas_adam_multi': ([_P, _P, _I, _P, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
@@ -318,6 +320,17 @@ def cross_entropy(z, label, loss, dz, row_loss, b, O):
                                       _stream()), 'cross_entropy')
 
 
+def adam_chunk_elems():
+    return load().bmnas_adam_chunk_elems()
+
+
+def adam_multi(table, chunks, n_chunks, hyp):
+    """table: uint8 device tensor holding bmnas_adam_tensor_t[]; chunks: int32 device (n_chunks, 2);
+    hyp: float32 device (rows, 8)."""
+    _check(load().bmnas_adam_multi(table.data_ptr(), chunks.data_ptr(), n_chunks, hyp.data_ptr(), _stream()),
+           'adam_multi')
+
+
 def arch_softmax_multi(a_list, dw_list, out_list, backward, n_shards=1, shard_stride=0):
     """One launch for every architecture tensor (row softmax, or its backward)."""
     n = len(a_list)
@@ -378,7 +391,7 @@ _TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd'
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',
-                'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy')
+                'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy', 'adam_multi')
 _PLAIN = {}
 
 

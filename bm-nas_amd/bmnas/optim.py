@@ -1,0 +1,179 @@
+"""torch.optim.Adam with the update of every tensor in one HIP launch.
+
+Drop-in for the two optimizers of the search loop (reference mmimdb_darts_searchable.py:28-33:
+`Adam(central_params, lr=eta_max, weight_decay=wd)` and `Adam(arch_parameters, betas=(0.5, 0.999),
+weight_decay=arch_wd)`): same constructor, same `param_groups`, same `state` layout (`step`,
+`exp_avg`, `exp_avg_sq` per parameter, so `state_dict()` / `load_state_dict()` interoperate with
+torch.optim.Adam checkpoints), same arithmetic operation by operation.  What changes is the
+execution: the step-dependent scalars are computed on the host in double (as torch does), written
+with the tensor descriptors into ONE pinned staging buffer, copied to the device with one async
+H2D copy, and one `bmnas_adam_multi` launch updates every tensor (torch's foreach path: ~10
+launches per parameter group).  Because all per-step values travel through the staging buffer,
+a step captured in a hipGraph replays correctly: `prepare_replay()` before each replay.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib
+
+# bmnas_adam_tensor_t (include/bmnas_hip.h)
+_DESC = np.dtype([('param', '<u8'), ('grad', '<u8'), ('exp_avg', '<u8'), ('exp_avg_sq', '<u8'),
+                  ('numel', '<i8'), ('hyp_row', '<i4'), ('reserved', '<i4')])
+assert _DESC.itemsize == 48
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if amsgrad:
+            raise lib.BmnasError('bmnas.optim.Adam: amsgrad is not on the reference path')
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False)
+        self._plan = None
+
+    # ------------------------------------------------------------------ plan
+    def _active(self):
+        return [(p, gi) for gi, g in enumerate(self.param_groups) for p in g['params'] if p.grad is not None]
+
+    def _init_state(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st['step'] = torch.tensor(0.0, dtype=torch.float32)
+            st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
+
+    def _flush_counts(self):
+        """Write the plan's step counts back into the per-parameter `step` tensors."""
+        pl = self._plan
+        if pl is not None:
+            for (p, _), r in zip(pl['active'], pl['row_of']):
+                self.state[p]['step'].fill_(pl['count'][r])
+
+    def _build(self, active):
+        self._flush_counts()
+        dev = active[0][0].device
+        E = lib.adam_chunk_elems()
+        rows, row_idx, row_of, chunks = [], {}, [], []
+        for i, (p, gi) in enumerate(active):
+            if not p.is_cuda:
+                raise lib.BmnasError('bmnas.optim.Adam needs parameters on the GPU (HIP kernel, no CPU path)')
+            st = self._init_state(p)
+            for name, t in (('parameter', p), ('exp_avg', st['exp_avg']), ('exp_avg_sq', st['exp_avg_sq'])):
+                if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise lib.BmnasError(f'bmnas.optim.Adam: {name} must be contiguous fp32 on {dev}')
+            # parameters of one group with the same step count share a row of scalars
+            key = (gi, float(st['step']))
+            if key not in row_idx:
+                row_idx[key] = len(rows)
+                rows.append(key)
+            row_of.append(row_idx[key])
+            chunks += [(i, c) for c in range((p.numel() + E - 1) // E)]
+        hyp_bytes = (len(rows) * 32 + 63) // 64 * 64
+        nbytes = hyp_bytes + len(active) * _DESC.itemsize
+        pin = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        host = pin.numpy()
+        tab = host[hyp_bytes:].view(_DESC)
+        tab['exp_avg'] = [self.state[p]['exp_avg'].data_ptr() for p, _ in active]
+        tab['exp_avg_sq'] = [self.state[p]['exp_avg_sq'].data_ptr() for p, _ in active]
+        tab['numel'] = [p.numel() for p, _ in active]
+        tab['hyp_row'] = row_of
+        devbuf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self._plan = dict(ids=tuple(id(p) for p, _ in active), active=active, row_of=row_of,
+                          groups=[gi for gi, _ in rows], count=[t for _, t in rows],
+                          pin=pin, hyp=host[:len(rows) * 32].view(np.float32).reshape(len(rows), 8), tab=tab,
+                          dev=devbuf, dev_hyp=devbuf[:hyp_bytes], dev_tab=devbuf[hyp_bytes:],
+                          chunks=torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev),
+                          n_chunks=len(chunks))
+
+    def _stage(self, active):
+        """Advance the step counts; write this step's scalars and pointers into the staging buffer."""
+        self.prepare_replay()
+        self._write_ptrs(active)
+
+    def _write_ptrs(self, active):
+        grads = [p.grad for p, _ in active]
+        for gr, (p, _) in zip(grads, active):
+            if gr.dtype != torch.float32 or not gr.is_contiguous() or gr.device != p.device:
+                raise lib.BmnasError('bmnas.optim.Adam: gradients must be contiguous fp32 on the parameter device')
+        pl = self._plan
+        pl['tab']['param'] = [p.data_ptr() for p, _ in active]
+        pl['tab']['grad'] = [gr.data_ptr() for gr in grads]
+
+    def _launch(self):
+        pl = self._plan
+        pl['dev'].copy_(pl['pin'], non_blocking=True)
+        lib.adam_multi(pl['dev_tab'], pl['chunks'], pl['n_chunks'], pl['dev_hyp'])
+
+    def wait_staging(self):
+        """Block until the last launch has consumed the pinned staging buffer (the host may run
+        ahead of the GPU; rewriting the buffer earlier would change a step still in flight)."""
+        if self._plan is not None and self._plan.get('event') is not None:
+            self._plan['event'].synchronize()
+
+    def mark_launched(self):
+        """Record, on the current stream, that everything queued so far (a step() or a graph
+        replay that contains one) has read the staging buffer."""
+        pl = self._plan
+        if pl.get('event') is None:
+            pl['event'] = torch.cuda.Event()
+        pl['event'].record()
+
+    # ------------------------------------------------------------------ torch.optim API
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        active = self._active()
+        if not active:
+            return loss
+        if torch.cuda.is_current_stream_capturing():
+            if self._plan is None or self._plan['ids'] != tuple(id(p) for p, _ in active):
+                raise lib.BmnasError('bmnas.optim.Adam: call capture_safe() before capturing step() in a graph')
+            self._write_ptrs(active)            # the capture's static gradient tensors
+            self._plan['active'] = active
+            self._launch()                      # scalars are refreshed by prepare_replay()
+            return loss
+        if self._plan is None or self._plan['ids'] != tuple(id(p) for p, _ in active):
+            self._build(active)
+        self.wait_staging()
+        self._stage(active)
+        self._launch()
+        self.mark_launched()
+        return loss
+
+    def state_dict(self):
+        self._flush_counts()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if torch.is_tensor(st.get('step')) and st['step'].is_cuda:
+                st['step'] = st['step'].cpu()
+        self._plan = None
+
+    # ------------------------------------------------------------------ hipGraph support
+    def capture_safe(self):
+        """Build the plan from the gradients that exist NOW (static tensors of the step being
+        captured) so that step() inside `torch.cuda.graph` issues only stream work: one pinned
+        H2D copy and one launch.  Before every replay call prepare_replay()."""
+        active = self._active()
+        self.wait_staging()
+        self._build(active)
+        self._write_ptrs(active)
+
+    def prepare_replay(self):
+        """Advance the step count and publish the current learning rates for the next replay
+        (call wait_staging() first and mark_launched() after the replay; GraphedTrainStep does)."""
+        pl = self._plan
+        h = pl['hyp']
+        for r, gi in enumerate(pl['groups']):
+            g = self.param_groups[gi]
+            pl['count'][r] += 1.0
+            t = pl['count'][r]
+            b1, b2 = g['betas']
+            h[r] = (-(g['lr'] / (1 - b1 ** t)), math.sqrt(1 - b2 ** t), b1, b2, g['eps'], g['weight_decay'],
+                    1 - b1, 1 - b2)

@@ -3,6 +3,7 @@
 import torch
 import torch.nn as nn
 import torch.optim as op
+from bmnas.optim import Adam          # torch.optim.Adam semantics, one HIP launch per step
 
 import models.auxiliary.scheduler as sc
 from bmnas import dist as bdist
@@ -90,10 +91,10 @@ def search_setup(model, args, criterion, device, num_batches_per_epoch, weight_d
     the reference's train_darts_model between model construction and the trainer call
     (mmimdb_darts_searchable.py:26-40).  nn.DataParallel is replaced by per-process replicas
     whose optimizers average gradients over RCCL right before step() (bmnas.dist)."""
-    optimizer = op.Adam(model.central_params(), lr=args.eta_max, weight_decay=weight_decay)
+    optimizer = Adam(model.central_params(), lr=args.eta_max, weight_decay=weight_decay)
     scheduler = sc.LRCosineAnnealingScheduler(args.eta_max, args.eta_min, args.Ti, args.Tm,
                                               num_batches_per_epoch)
-    arch_optimizer = op.Adam(model.arch_parameters(), lr=args.arch_learning_rate, betas=(0.5, 0.999),
+    arch_optimizer = Adam(model.arch_parameters(), lr=args.arch_learning_rate, betas=(0.5, 0.999),
                              weight_decay=args.arch_weight_decay)
     model.to(device)
     if parallel_flag(args) and bdist.env_world() > 1:

@@ -260,6 +260,30 @@ int bmnas_bce_logits(const float* z, const float* y, float* loss, float* dz, int
 int bmnas_cross_entropy(const float* z, const int64_t* label, float* loss, float* dz,
                         float* row_loss, int b, int O, void* stream);
 
+/* ---- multi-tensor Adam (row f2) ----------------------------------------------------------
+ * One launch applies torch.optim.Adam's update (amsgrad off; L2 weight decay added to the
+ * gradient) to every tensor of an optimizer — the w-step at train_searchable/mmimdb.py:101 and the
+ * alpha-step at architect.py:24, optimizers built at mmimdb_darts_searchable.py:28-33.
+ *   tensors: DEVICE array of descriptors (device pointers, fp32; any alignment, any numel);
+ *   chunks:  DEVICE array of n_chunks (tensor index, chunk index) int32 pairs, one workgroup each,
+ *            chunk c of a tensor covers elements [c*E, (c+1)*E), E = bmnas_adam_chunk_elems();
+ *   hyp:     DEVICE array of 8-float rows, tensor -> row by hyp_row:
+ *            { -(lr / (1 - beta1^t)), sqrt(1 - beta2^t), beta1, beta2, eps, weight_decay,
+ *              1 - beta1, 1 - beta2 }  computed by the host in double (as torch does) and refreshed
+ *            before each launch, so a captured graph replays with new rates / step counts. */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+  int32_t hyp_row;
+  int32_t reserved;
+} bmnas_adam_tensor_t;
+int bmnas_adam_chunk_elems(void);
+int bmnas_adam_multi(const bmnas_adam_tensor_t* tensors, const int32_t* chunks, int n_chunks,
+                     const float* hyp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,10 +146,16 @@ def test_found_network_matches_reference_golden(path):
             assert_close_scaled('buf:' + k, v.float(), z['buf:' + k])
 
 
+@pytest.mark.parametrize('optim', ['torch', 'bmnas', 'graph'])
 @pytest.mark.parametrize('path', golden_files('traj_*.npz'), ids=case_id)
-def test_search_trajectory_matches_reference_golden(path):
-    """3 iterations of w-step + Architect.step with stock torch.optim.Adam on the product
-    modules reproduce the reference's logits, arch parameters and weights."""
+def test_search_trajectory_matches_reference_golden(path, optim):
+    """3 iterations of w-step + Architect.step on the product modules reproduce the reference's
+    logits, arch parameters and weights — with stock torch.optim.Adam and with the one-launch
+    bmnas.optim.Adam that search_setup installs, and with both phases replayed as hipGraphs
+    (bmnas.graph.GraphedTrainStep: fwd + criterion + bwd + Adam in one launch)."""
+    import bmnas.optim
+    Adam = torch.optim.Adam if optim == 'torch' else bmnas.optim.Adam
+    from gpu_util import dev
     from models.search.darts.architect import Architect
     from models.search.darts.model_search import FusionNetwork
     meta, z = load_npz(path)
@@ -177,22 +183,33 @@ def test_search_trajectory_matches_reference_golden(path):
     model.central_classifier.bias.data.copy_(cb)
     crit = torch.nn.BCEWithLogitsLoss() if meta['loss'] == 'bce' else torch.nn.CrossEntropyLoss()
     # optimizers created BEFORE .to(device), like the reference's train_darts_model
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-    aopt = torch.optim.Adam(model.arch_parameters(), lr=3e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    aopt = Adam(model.arch_parameters(), lr=3e-4, betas=(0.5, 0.999), weight_decay=1e-3)
     model.to(dev())
     set_mode(model, 'train_nodrop')
     architect = Architect(model, Args(cfg), crit, aopt)
+    w_graph = a_graph = None
     for it in range(iters):
         xs = [x.to(dev()) for x in synth.make_inputs(cfg, batch, seed + 10 * it)]
         y = synth.make_labels(meta['loss'], batch, nout, seed + 10 * it).to(dev())
-        opt.zero_grad()
-        logits = model(xs)
-        crit(logits, y).backward()
-        opt.step()
-        assert_close_scaled(f'train_logits.{it}', logits, z[f'train_logits.{it}'], rel=5e-4)
         xv = [x.to(dev()) for x in synth.make_inputs(cfg, batch, seed + 10 * it + 5)]
         yv = synth.make_labels(meta['loss'], batch, nout, seed + 10 * it + 5).to(dev())
-        architect.step(xv, yv, None)
+        if optim == 'graph':
+            from bmnas.graph import GraphedTrainStep
+            if w_graph is None:
+                w_graph = GraphedTrainStep(model, crit, opt, xs, y)
+                a_graph = GraphedTrainStep(model, crit, aopt, xv, yv)
+            assert w_graph.matches(xs, y)
+            _, logits = w_graph(xs, y)
+            assert_close_scaled(f'train_logits.{it}', logits, z[f'train_logits.{it}'], rel=5e-4)
+            a_graph(xv, yv)
+        else:
+            opt.zero_grad()
+            logits = model(xs)
+            crit(logits, y).backward()
+            opt.step()
+            assert_close_scaled(f'train_logits.{it}', logits, z[f'train_logits.{it}'], rel=5e-4)
+            architect.step(xv, yv, None)
         with torch.no_grad():
             assert_close_scaled(f'dev_logits.{it}', model(xv), z[f'dev_logits.{it}'], rel=5e-4)
     for i, a in enumerate(model.arch_parameters()):

@@ -1,0 +1,116 @@
+"""-m gpu: bmnas.optim.Adam (one HIP launch) against torch.optim.Adam on the CPU — the
+optimizer the reference builds at mmimdb_darts_searchable.py:28-33 — same state layout, same
+arithmetic.  Tolerance: 2e-6 relative to the parameter scale after 6 steps (fp32, the only
+differences are fused-multiply-add contractions)."""
+import copy
+
+import pytest
+import torch
+
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(seed, shapes):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(*s, generator=g) for s in shapes]
+
+
+SHAPES = [(384, 384, 1), (384,), (7,), (1,), (13, 2), (3, 5, 11), (4099,), (192, 16)]
+
+
+@pytest.mark.parametrize('betas,wd', [((0.9, 0.999), 1e-4), ((0.5, 0.999), 1e-3), ((0.9, 0.999), 0.0)])
+def test_adam_matches_torch(betas, wd):
+    from bmnas.optim import Adam
+    init = _make(1, SHAPES)
+    cpu = [t.clone().requires_grad_(True) for t in init]
+    gpu = [t.clone().to(dev()).requires_grad_(True) for t in init]
+    groups = lambda ps: [{'params': ps[:3]}, {'params': ps[3:], 'lr': 3e-3}]
+    ref = torch.optim.Adam(groups(cpu), lr=1e-2, betas=betas, weight_decay=wd)
+    opt = Adam(groups(gpu), lr=1e-2, betas=betas, weight_decay=wd)
+    for step in range(6):
+        grads = _make(100 + step, SHAPES)
+        for i, (c, g_, gr) in enumerate(zip(cpu, gpu, grads)):
+            if i == 2 and step < 2:
+                c.grad, g_.grad = None, None          # joins later: its own step count
+                continue
+            c.grad, g_.grad = gr.clone(), gr.clone().to(dev())
+        for grp_c, grp_g in zip(ref.param_groups, opt.param_groups):
+            grp_c['lr'] = grp_g['lr'] = grp_c['lr'] * 0.9       # per-batch schedule
+        ref.step()
+        opt.step()
+    for c, g_ in zip(cpu, gpu):
+        scale = float(c.detach().abs().max()) + 1e-3
+        assert float((g_.detach().cpu() - c.detach()).abs().max()) <= 2e-6 * scale + 1e-7
+    sd_ref, sd = ref.state_dict(), opt.state_dict()
+    for k in sd_ref['state']:
+        assert float(sd['state'][k]['step']) == float(sd_ref['state'][k]['step'])
+        a, b = sd['state'][k]['exp_avg_sq'].cpu(), sd_ref['state'][k]['exp_avg_sq']
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12
+
+
+def test_adam_state_dict_roundtrip_with_torch():
+    """A torch.optim.Adam checkpoint loads into bmnas.optim.Adam and training continues identically."""
+    from bmnas.optim import Adam
+    init = _make(2, SHAPES[:4])
+    cpu = [t.clone().requires_grad_(True) for t in init]
+    ref = torch.optim.Adam(cpu, lr=1e-2, weight_decay=1e-4)
+    for step in range(3):
+        for c, gr in zip(cpu, _make(50 + step, SHAPES[:4])):
+            c.grad = gr
+        ref.step()
+    gpu = [c.detach().clone().to(dev()).requires_grad_(True) for c in cpu]
+    opt = Adam(gpu, lr=1e-2, weight_decay=1e-4)
+    opt.load_state_dict(copy.deepcopy(ref.state_dict()))
+    for step in range(3, 6):
+        for c, g_, gr in zip(cpu, gpu, _make(50 + step, SHAPES[:4])):
+            c.grad, g_.grad = gr.clone(), gr.clone().to(dev())
+        ref.step()
+        opt.step()
+    for c, g_ in zip(cpu, gpu):
+        assert float((g_.detach().cpu() - c.detach()).abs().max()) <= 2e-6 * (float(c.detach().abs().max()) + 1e-3)
+    assert float(opt.state_dict()['state'][0]['step']) == 6.0
+
+
+def test_adam_in_graph_replays_with_new_rates():
+    from bmnas.optim import Adam
+    init = _make(3, SHAPES)
+    cpu = [t.clone().requires_grad_(True) for t in init]
+    gpu = [t.clone().to(dev()).requires_grad_(True) for t in init]
+    ref = torch.optim.Adam(cpu, lr=1e-2, betas=(0.5, 0.999), weight_decay=1e-3)
+    opt = Adam(gpu, lr=1e-2, betas=(0.5, 0.999), weight_decay=1e-3)
+    for g_ in gpu:
+        g_.grad = torch.zeros_like(g_)
+    opt.capture_safe()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.cuda.graph(graph, stream=s):
+        opt.step()
+    torch.cuda.current_stream().wait_stream(s)
+    for step in range(5):
+        lr = 1e-2 * (0.8 ** step)
+        for grp in list(ref.param_groups) + list(opt.param_groups):
+            grp['lr'] = lr
+        for c, g_, gr in zip(cpu, gpu, _make(70 + step, SHAPES)):
+            c.grad = gr.clone()
+            g_.grad.copy_(gr)
+        ref.step()
+        opt.wait_staging()
+        opt.prepare_replay()
+        graph.replay()
+        opt.mark_launched()
+    torch.cuda.synchronize()
+    for c, g_ in zip(cpu, gpu):
+        assert float((g_.detach().cpu() - c.detach()).abs().max()) <= 2e-6 * (float(c.detach().abs().max()) + 1e-3)
+    assert float(opt.state_dict()['state'][0]['step']) == 5.0
+
+
+def test_adam_refuses_cpu_parameters():
+    from bmnas import lib
+    from bmnas.optim import Adam
+    p = torch.zeros(4, requires_grad=True)
+    p.grad = torch.ones(4)
+    with pytest.raises(lib.BmnasError):
+        Adam([p]).step()
