@@ -125,6 +125,59 @@ def algo_table(C, L):
     }
 
 
+def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log, pairs=100):
+    """SURVEY.md section 8(d) secondary figure: the search loop's two optimisation steps with
+    everything in them — weight phase (fwd + criterion + bwd + [RCCL all-reduce] + Adam on w,
+    train_searchable/mmimdb.py:85-101) and architecture phase (the same for alpha/beta/gamma,
+    architect.py:21-29) — each one hipGraph replay (bmnas.graph.GraphedTrainStep,
+    bmnas.optim.Adam).  Not the headline metric; reported next to it."""
+    from bmnas import dist as bdist
+    from bmnas.graph import GraphedTrainStep
+    from bmnas.optim import Adam
+    w_opt = Adam(params, lr=1e-3, weight_decay=1e-4)
+    a_opt = Adam(arch, lr=3e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    if world > 1:
+        bdist.attach(w_opt)
+        bdist.attach(a_opt)
+    xv, yv = synth_batch(c, a.batch, device, seed=1000 + (torch.distributed.get_rank() if world > 1 else 0))
+    gw = GraphedTrainStep(model, crit, w_opt, xs, y)
+    ga = GraphedTrainStep(model, crit, a_opt, xv, yv)
+
+    def timed(fn, n):
+        for _ in range(5):
+            fn()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / n * 1e3
+
+    def pair():
+        for g in w_opt.param_groups:
+            g['lr'] *= 0.999                      # a per-batch schedule, as the cosine rule applies
+        gw(xs, y)
+        ga(xv, yv)
+
+    ms_pair = timed(pair, pairs)
+    ms_w = timed(lambda: gw(xs, y), pairs)
+    ms_a = timed(lambda: ga(xv, yv), pairs)
+    log(f'full search step: {ms_pair:.4f} ms per (w-step + alpha-step) pair')
+    return {'ms_per_pair': round(ms_pair, 4), 'w_step_ms': round(ms_w, 4), 'alpha_step_ms': round(ms_a, 4),
+            'pairs_per_s': round(world * 1e3 / ms_pair, 1), 'pairs_timed': pairs,
+            'includes': 'w-step: fwd + criterion + bwd (weights, arch and input grads) + Adam(w, wd 1e-4); '
+                        'alpha-step: the same with Adam(alpha/beta/gamma, betas (0.5, 0.999), wd 1e-3); '
+                        + ('each step = one hipGraph replay' if world == 1 else
+                           'hipGraph replay + one flat RCCL all-reduce + one-launch Adam per step')}
+
+
 def cpu_baseline(cname, c, batch, max_seconds=20.0):
     """The CPU oracle (a port of the reference's path: same aten op sequence, pinned against
     the reference by tests/golden) on this host's cores; same synthetic batch, dropout on."""
@@ -182,6 +235,7 @@ def main():
     ap.add_argument('--mode', default='graph', choices=['graph', 'eager'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-full-step', action='store_true')
     a = ap.parse_args()
 
     from bmnas import dist as bdist
@@ -321,6 +375,8 @@ def main():
         result['eager_ms_per_step'] = round(eager_ms, 4)
 
     log(f'timed region done: {dt / a.steps * 1e3:.4f} ms/step')
+    if not a.no_full_step:
+        result['full_search_step'] = full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log)
     if rank == 0 and not a.no_roofline:
         # instrumented eager pass: HIP events on the launch stream around every kernel call
         n_prof = min(a.steps, 10)

@@ -17,6 +17,9 @@ class GraphedStep:
     stay referenced (they become static graph outputs)."""
 
     def __init__(self, fn, warmup=3):
+        quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if quiet is not None:
+            quiet(False)         # leaves outside the differentiated set keep nodes from the warm-up stream
         dev = torch.cuda.current_device()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -75,7 +78,7 @@ class GraphedTrainStep:
         if reducer is not None and reducer.world <= 1:
             reducer = None
         self.reducer = reducer
-        self.inputs = [x.detach().clone() for x in inputs]
+        self.inputs = [x.detach().clone().requires_grad_(x.requires_grad) for x in inputs]
         self.labels = labels.detach().clone()
         self.in_graph_step = reducer is None
         scale = 1.0 / reducer.world if reducer is not None else 1.0
@@ -84,6 +87,8 @@ class GraphedTrainStep:
 
         def fn():
             logits = model(self.inputs)
+            if isinstance(logits, tuple):
+                logits = logits[-1]
             loss = criterion(logits, self.labels)
             grads = torch.autograd.grad(loss * scale if reducer is not None else loss, self.targets,
                                         allow_unused=True)
@@ -116,14 +121,32 @@ class GraphedTrainStep:
         self._g = GraphedStep(fn, warmup=0)
         model.load_state_dict(state)
 
+    @staticmethod
+    def try_build(model, criterion, optimizer, inputs, labels, logger=None):
+        """-> a GraphedTrainStep, or False when this step cannot be captured (inputs that are not a
+        flat list of tensors, a module that synchronises with the host, ...); callers then keep
+        the eager path."""
+        if not (isinstance(inputs, (list, tuple)) and all(torch.is_tensor(x) for x in inputs)
+                and torch.is_tensor(labels)):
+            return False
+        try:
+            return GraphedTrainStep(model, criterion, optimizer, inputs, labels)
+        except Exception as e:                       # noqa: BLE001 — capture errors are of many types
+            torch.cuda.synchronize()
+            if logger is not None:
+                logger.info('hipGraph capture of the step failed ({}: {}); staying eager'.format(
+                    type(e).__name__, e))
+            return False
+
     def matches(self, inputs, labels):
         return (len(inputs) == len(self.inputs) and labels.shape == self.labels.shape and
                 all(a.shape == b.shape for a, b in zip(inputs, self.inputs)))
 
     def __call__(self, inputs, labels):
-        for dst, src in zip(self.inputs, inputs):
-            dst.copy_(src, non_blocking=True)
-        self.labels.copy_(labels, non_blocking=True)
+        with torch.no_grad():
+            for dst, src in zip(self.inputs, inputs):
+                dst.copy_(src, non_blocking=True)
+            self.labels.copy_(labels, non_blocking=True)
         opt = self.optimizer
         if self.in_graph_step:
             opt.wait_staging()

@@ -7,7 +7,11 @@ Differences, all on the host side of the hot path:
   * the per-batch .item() / .cpu() syncs are gone: loss and metric statistics accumulate on the
     device and are read once per phase (same numbers, no stall per batch);
   * `parallel` means one process per GPU (bmnas.dist); statistics are summed over ranks and only
-    rank 0 writes checkpoints — there is no `.module` indirection.
+    rank 0 writes checkpoints — there is no `.module` indirection;
+  * opt-in `args.hip_graph`: the weight step (forward + criterion + backward + Adam) and the
+    Architect step are captured once and replayed as one hipGraph launch per batch
+    (bmnas.graph.GraphedTrainStep); a ragged last batch, or a model that cannot be captured,
+    runs the eager path.
 """
 import copy
 import os
@@ -83,6 +87,9 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
         nan_escape=False):
     """-> dict(best_dev, best_dev_genotype, best_test, best_test_genotype, last_genotype, nan_abort)."""
     cosine = isinstance(scheduler, sc.LRCosineAnnealingScheduler)
+    use_graph = bool(getattr(args, 'hip_graph', False))
+    w_graph = None
+    stats = run.stats = dict(graph_replays=0, eager_steps=0)
     best = dict(best_dev=None, best_dev_genotype=None, best_dev_epoch=0, best_test=None,
                 best_test_genotype=None, best_test_epoch=0, last_genotype=None, nan_abort=False)
     for epoch in range(num_epochs):
@@ -109,6 +116,20 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 inputs, labels = unpack(data, device)
                 if status == 'search' and phase in ('dev', 'test') and architect is not None:
                     architect.step(inputs, labels, logger)
+                if learn and use_graph:
+                    if w_graph is None:
+                        from bmnas.graph import GraphedTrainStep
+                        w_graph = GraphedTrainStep.try_build(model, criterion, optimizer, inputs, labels, logger)
+                    if w_graph and w_graph.matches(inputs, labels):
+                        if cosine:
+                            scheduler.step()
+                            scheduler.update_optimizer(optimizer)
+                        loss, output = w_graph(inputs, labels)
+                        loss_sum += loss.detach().double() * labels.size(0)
+                        meter.update(output.detach(), labels)
+                        stats['graph_replays'] += 1
+                        continue
+                stats['eager_steps'] += 1
                 optimizer.zero_grad()
                 with torch.set_grad_enabled(learn):
                     output = model(inputs)

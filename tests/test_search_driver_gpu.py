@@ -84,3 +84,57 @@ def test_mmimdb_search_driver_runs_end_to_end(tmp_path, monkeypatch):
     sd = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
     assert 'fusion_net.cell.ln.weight' in sd and 'reshape_layers.0.conv.weight' in sd
     assert not any('alphas' in k or 'betas' in k or 'gammas' in k for k in sd)
+
+
+class _CapturableVGG(torch.nn.Module):
+    """Stand-in backbone without host synchronisation (the real GP_VGG is a plain conv stack)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.proj = torch.nn.Linear(3 * 16 * 16, 512)
+
+    def forward(self, image):
+        f = self.proj(image.flatten(1)).relu()                       # (b, 512)
+        mk = lambda h, w: f[:, :, None, None].expand(-1, -1, h, w) * torch.linspace(
+            0.5, 1.5, h * w, device=f.device).view(1, 1, h, w)
+        return [mk(20, 32), mk(20, 32), mk(10, 16), mk(5, 8), f[:, :23]]
+
+
+def test_mmimdb_search_driver_with_hip_graph_steps(tmp_path, monkeypatch):
+    """args.hip_graph: every full batch of both phases is one graph replay; the ragged last
+    batches take the eager path; results are written as usual."""
+    central = types.ModuleType('models.central')
+    fake = types.ModuleType('models.central.mmimdb')
+    fake.GP_VGG, fake.MaxOut_MLP = _CapturableVGG, _FakeMLP
+    central.mmimdb = fake
+    monkeypatch.setitem(sys.modules, 'models.central', central)
+    monkeypatch.setitem(sys.modules, 'models.central.mmimdb', fake)
+    import models.search.mmimdb_darts_searchable as drv
+    import models.search.train_searchable._loop as loop
+    from models.search.darts.utils import create_exp_dir
+
+    class Args:
+        pass
+
+    a = Args()
+    a.C, a.L, a.drpt = 32, 16, 0.1
+    a.num_input_nodes, a.num_keep_edges, a.steps, a.multiplier = 6, 2, 2, 2
+    a.node_steps, a.node_multiplier, a.num_outputs = 1, 1, 23
+    a.batchsize, a.epochs = 8, 2
+    a.eta_max, a.eta_min, a.Ti, a.Tm = 1e-3, 1e-6, 1, 2
+    a.arch_learning_rate, a.arch_weight_decay, a.weight_decay = 3e-4, 1e-3, 1e-4
+    a.f1_type = 'weighted'
+    a.use_dataparallel = False
+    a.hip_graph = True
+    a.save = str(tmp_path / 'exp')
+    create_exp_dir(a.save)
+    loaders = {k: DataLoader(_DS(n, s), batch_size=a.batchsize, shuffle=True, drop_last=False)
+               for k, n, s in (('train', 20, 1), ('dev', 12, 2), ('test', 8, 3))}
+    logger = logging.getLogger('bmnas-test')
+    best_f1, genotype = drv.train_darts_model(loaders, a, torch.device('cuda:0'), logger)
+    assert 0.0 <= best_f1 <= 1.0
+    assert len(genotype.edges) == 4 and len(genotype.steps) == 2
+    # 2 epochs x (2 full + 1 ragged) train batches
+    assert loop.run.stats['graph_replays'] == 4, loop.run.stats
+    sd = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
