@@ -127,12 +127,13 @@ class Pack:
 class GradSlot:
     """A lazily allocated gradient buffer that remembers whether it has been written
     (first writer overwrites, later writers accumulate)."""
-    __slots__ = ('t', 'like', 'written')
+    __slots__ = ('t', 'like', 'written', 'extra')
 
     def __init__(self, like):
         self.like = like
         self.t = None
         self.written = False
+        self.extra = None     # a second addend of this gradient, produced concurrently (merged launches)
 
     def buf(self):
         if self.t is None:
@@ -177,9 +178,9 @@ def mixsum_fwd(xs, w_row0, w_stride=2):
 ARCH_SHARDS = 16    # copies of the arch-weight gradient buffers (atomic contention spreading)
 
 
-def mixsum_bwd(xs, slots, w_row0, g, dw_row0, w_stride=2, shards=1, shard_stride=0):
+def mixsum_bwd(xs, slots, w_row0, g, dw_row0, w_stride=2, shards=1, shard_stride=0, g2=None):
     bufs, mask = _write_group(slots)
-    lib.mixsum_bwd(xs, bufs, w_row0, w_stride, g, dw_row0, mask, shards, shard_stride)
+    lib.mixsum_bwd(xs, bufs, w_row0, w_stride, g, dw_row0, mask, shards, shard_stride, g2)
 
 
 # -------------------------------------------------------------------- conv + BatchNorm
@@ -187,7 +188,7 @@ class ConvBnSaved:
     __slots__ = ('srcs', 'C_src', 'W', 'ldw', 'U', 'chan', 'M', 'training', 'dup', 'fold')
 
 
-def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, dup=0, fold=0):
+def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, dup=0, fold=0, attn=None):
     """U = conv1x1(cat(srcs)) (+ batch statistics) and the fused BN affine `chan`.
     W is (M, ldw) row-major with the first len(srcs)*C_src columns used."""
     x0 = srcs[0]
@@ -201,7 +202,10 @@ def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, du
                              f'{[b, M, L]}')            # same refusal as nn.BatchNorm1d
         n_part = lib.conv1x1_num_partials(b, L)
         part = _empty(x0, n_part * M * 2)
-    lib.conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold)
+    if attn is None:
+        lib.conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold)
+    else:                                    # the attention branch rides in the same launch
+        lib.conv1x1_fwd_sdpa(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold, *attn)
     chan = _empty(x0, 4 * M)
     lib.bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan)
     sv = ConvBnSaved()
@@ -210,7 +214,7 @@ def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, du
     return U, chan, sv
 
 
-def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None):
+def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
     """dV (gradient w.r.t. the BN output, with bn_grad already reduced) -> in place dU;
     then data gradient into src_slots and weight/bias gradient (+=) into dW / dbias."""
     b, L = sv.U.shape[0], sv.U.shape[2]
@@ -229,7 +233,9 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None):
                 seen[id(s)] = q
             slots.append(s)
     bufs, mask = _write_group(slots)
-    if any(x is not None for x in bufs):
+    if attn is not None:
+        lib.conv1x1_bwd_data_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, *attn)
+    elif any(x is not None for x in bufs):
         lib.conv1x1_bwd_data(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold)
     for s, tmp in extra:
         s.buf().add_(tmp.buf())
@@ -264,9 +270,14 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None):
     sv.p1 = p1
     sv.d_glu = DROP.make(P.glu_p, x.numel(), training)
     sv.d_fc = DROP.make(P.fc_p, x.numel(), training)
-    with _Fork(x.device) as fork:
-        fork.side(lambda: lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, b, C, L, sv.d_attn))
-        U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C)
+    sv.merged = same and FUSE_ATTN_GEMM
+    if sv.merged:
+        U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C,
+                                  attn=(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, C, sv.d_attn))
+    else:
+        with _Fork(x.device) as fork:
+            fork.side(lambda: lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, b, C, L, sv.d_attn))
+            U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C)
     out = torch.empty_like(x)
     if ln is None:
         lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc)
@@ -278,7 +289,10 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None):
     return out, sv
 
 
-def _mixed_conv_fwd(sv, x, y, same, P, training, C):
+FUSE_ATTN_GEMM = True   # search mode: attention branch and conv GEMM share a launch (fwd and bwd)
+
+
+def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None):
     # stacked [LinearGLU | ConcatFC] conv + BN
     if same:
         # conv(cat[z, z]) = (W[:, :C] + W[:, C:]) z: K is C instead of 2C.  The halves are added once
@@ -287,7 +301,7 @@ def _mixed_conv_fwd(sv, x, y, same, P, training, C):
         Weff = _empty(x, 3 * C, C)
         lib.fold_weight(P.stack_W, Weff, 3 * C, C)
         U, chan, sv.conv = conv_bn_fwd([x], C, Weff, C, P.stack_bias, P.stack_bn_w, P.stack_bn_b,
-                                       P.stack_rm, P.stack_rv, P.stack_nbt, training, dup=C)
+                                       P.stack_rm, P.stack_rv, P.stack_nbt, training, dup=C, attn=attn)
     else:
         U, chan, sv.conv = conv_bn_fwd([x, y], C, P.stack_W, 2 * C, P.stack_bias, P.stack_bn_w,
                                        P.stack_bn_b, P.stack_rm, P.stack_rv, P.stack_nbt, training)
@@ -338,9 +352,17 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
             dxb, acc = x_slot.buf(), x_slot.acc_bit()
             lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
                              dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
-            conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias, fork)
-            lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, None, 1, b, C, L,
-                            sv.d_attn)
+            if sv.merged and x_slot.extra is None:
+                # the attention gradient is produced next to the data-gradient GEMM, into its own
+                # buffer; whoever consumes x_slot adds the two parts (g2 / gz2 of the K1 backward)
+                x_slot.extra = torch.empty_like(x)
+                conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias, fork,
+                            attn=(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, x_slot.extra, None,
+                                  0, C, sv.d_attn))
+            else:
+                conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias, fork)
+                lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, None, 1, b, C, L,
+                                sv.d_attn)
         else:
             dxb, dyb = x_slot.buf(), y_slot.buf()
             acc = x_slot.acc_bit() | (y_slot.acc_bit() << 1)
@@ -443,11 +465,11 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
         node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t], NG.shards, NG.shard_stride,
                        deferred)
         if t == 0 and defer_first:
-            return z_slot.buf()
+            return z_slot.buf(), z_slot.extra
         off = sv.offsets[t]
         n_in = 2 + t
         mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.beta_w[off:, 1], z_slot.buf(),
-                   dbeta_w[off:, 1], 2, NG.shards, NG.shard_stride)
+                   dbeta_w[off:, 1], 2, NG.shards, NG.shard_stride, g2=z_slot.extra)
     return None
 
 
@@ -511,10 +533,11 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
         off = sv.offsets[i]
         n_in = N + i
         if gz is not None:
+            gz, gz2 = gz
             bufs, mask = _write_group(slots[:n_in])
             lib.mixsum_pair_bwd(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
                                 sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1],
-                                mask, CG.shards, CG.shard_stride)
+                                mask, CG.shards, CG.shard_stride, gz2)
         else:
             mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
                        dalpha_w[off:, 1], 2, CG.shards, CG.shard_stride)

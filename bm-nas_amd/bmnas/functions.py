@@ -219,6 +219,8 @@ class NodeMixedFn(Function):
         ys = None if sv.same else K.GradSlot(sv.y)
         K.node_mixed_bwd(sv, _c(g), dgamma, xs, ys, G)
         dx = xs.get()
+        if xs.extra is not None:                 # attention part produced next to the GEMM
+            dx = dx.add_(xs.extra)
         if sv.same:
             # x and y are the same tensor object: autograd adds both returned halves
             dx_half, dy = dx, torch.zeros_like(dx)

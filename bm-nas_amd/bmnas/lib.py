@@ -36,9 +36,10 @@ _U32 = C.c_uint32
 SIGNATURES = {
     'bmnas_version': ([], _I),
     'bmnas_mixsum_fwd': ([_PP, _I, _P, _I, _P, _I64, _P], _I),
-    'bmnas_mixsum_bwd': ([_PP, _PP, _I, _P, _I, _P, _P, _I, _I64, _U32, _I64, _P], _I),
+    'bmnas_mixsum_bwd': ([_PP, _PP, _I, _P, _I, _P, _P, _P, _I, _I64, _U32, _I64, _P], _I),
     'bmnas_mixsum_pair_fwd': ([_PP, _I, _P, _I, _P, _I, _P, _P, _I64, _P], _I),
-    'bmnas_mixsum_pair_bwd': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I64, _U32, _I64, _P], _I),
+    'bmnas_mixsum_pair_bwd': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _U32, _I64, _P],
+                              _I),
     'bmnas_cat_ln_fwd': ([_PP, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_cat_ln_bwd': ([_P, _PP, _I, _P, _P, _P, _P, _PP, _P, _U32, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_ln_affine_bwd': ([_P, _P, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
@@ -50,6 +51,10 @@ SIGNATURES = {
     'bmnas_conv1x1_num_partials': ([_I, _I], _I),
     'bmnas_conv1x1_fwd': ([_PP, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P], _I),
     'bmnas_conv1x1_bwd_data': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _P], _I),
+    'bmnas_conv1x1_fwd_sdpa': ([_PP, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I,
+                                _P, _P, _P, _P, _P, _P, _P, _I, Dropout, _P], _I),
+    'bmnas_conv1x1_bwd_data_sdpa': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P], _I),
     'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
@@ -145,8 +150,8 @@ def mixsum_fwd(xs, w, w_stride, out):
                                    out.numel(), _stream()), 'mixsum_fwd')
 
 
-def mixsum_bwd(xs, dxs, w, w_stride, g, dw, acc_mask, dw_shards=1, dw_shard_stride=0):
-    _check(load().bmnas_mixsum_bwd(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, _ptr(g),
+def mixsum_bwd(xs, dxs, w, w_stride, g, dw, acc_mask, dw_shards=1, dw_shard_stride=0, g2=None):
+    _check(load().bmnas_mixsum_bwd(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, _ptr(g), _ptr(g2),
                                    None if dw is None else dw.data_ptr(), dw_shards, dw_shard_stride,
                                    acc_mask, g.numel(), _stream()), 'mixsum_bwd')
 
@@ -157,9 +162,9 @@ def mixsum_pair_fwd(xs, w, w_stride, w2, w2_stride, out, out2):
 
 
 def mixsum_pair_bwd(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, acc_mask, dw_shards=1,
-                    dw_shard_stride=0):
+                    dw_shard_stride=0, gz2=None):
     _check(load().bmnas_mixsum_pair_bwd(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride,
-                                        w2.data_ptr(), w2_stride, _ptr(h), _ptr(gh), _ptr(gz),
+                                        w2.data_ptr(), w2_stride, _ptr(h), _ptr(gh), _ptr(gz), _ptr(gz2),
                                         dw.data_ptr(), dw2.data_ptr(), dw_shards, dw_shard_stride, acc_mask,
                                         gz.numel(), _stream()), 'mixsum_pair_bwd')
 
@@ -225,6 +230,23 @@ def conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold=0):
 def conv1x1_bwd_data(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold=0):
     _check(load().bmnas_conv1x1_bwd_data(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs),
                                          C_src, acc_mask, b, L, M, _stream()), 'conv1x1_bwd_data')
+
+
+def conv1x1_fwd_sdpa(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold, x, y, ln_w, ln_b, out, xhat, stats, Cc,
+                     drop):
+    _check(load().bmnas_conv1x1_fwd_sdpa(_ptrs(srcs), len(srcs), C_src, W.data_ptr(), ldw, fold, _ptr(bias),
+                                         _ptr(U), _ptr(part), b, L, M, _ptr(x), _ptr(y), _ptr(ln_w),
+                                         _ptr(ln_b), _ptr(out), _ptr(xhat), _ptr(stats), Cc, drop, _stream()),
+           'conv1x1_fwd_sdpa')
+
+
+def conv1x1_bwd_data_sdpa(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, g, gscale, x, y, ln_w, xhat, stats,
+                          dx, dy, sdpa_acc_mask, Cc, drop):
+    _check(load().bmnas_conv1x1_bwd_data_sdpa(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs),
+                                              C_src, acc_mask, b, L, M, _ptr(g),
+                                              None if gscale is None else gscale.data_ptr(), _ptr(x), _ptr(y),
+                                              _ptr(ln_w), _ptr(xhat), _ptr(stats), _ptr(dx), _ptr(dy),
+                                              sdpa_acc_mask, Cc, drop, _stream()), 'conv1x1_bwd_data_sdpa')
 
 
 def conv1x1_bwd_weight(dU, srcs, C_src, dW, ldw, dbias, dup_cols, b, L, M):
@@ -389,6 +411,7 @@ def profile_end():
 
 _TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
+                'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',
                 'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy', 'adam_multi')

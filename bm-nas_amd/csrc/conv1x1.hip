@@ -9,8 +9,7 @@
 //   * weight-gradient GEMM contracts over n, where BOTH operands are float4 along l.
 // The k-permutation is legal because A and B use the same one.
 // FLOPs: 2*M*K*b*L each; bound: fp32 MFMA (157 TFLOP/s dense).
-#include "common.hpp"
-#include "../../include/bmnas_hip.h"
+#include "sdpa_body.hpp"
 #include <cstdlib>
 
 namespace {
@@ -218,12 +217,12 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
 // LDS.  Splitting K four ways also quadruples the number of waves, which is what hides the
 // latency at batch 128.
 template <bool TRANS, int TN, int TJ, int KPW>
-__global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
+__device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx, const int by) {
   __shared__ float4 part[4][TN * TJ][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
-  const int g0 = blockIdx.x * TN;
-  const int j0 = blockIdx.y * (16 * TJ);
+  const int g0 = bx * TN;
+  const int j0 = by * (16 * TJ);
 
   int64_t abase[TN];
 #pragma unroll
@@ -359,6 +358,55 @@ __global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
         pp[1] = m2;
       }
     }
+  }
+}
+
+template <bool TRANS, int TN, int TJ, int KPW>
+__global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
+  conv_ksplit_body<TRANS, TN, TJ, KPW>(a, blockIdx.x, blockIdx.y);
+}
+
+// ---- GEMM + attention in one launch ---------------------------------------------------------
+// In a NodeMixedOp the attention branch and the stacked LinearGLU/ConcatFC conv read the same
+// input and do not depend on each other.  K3 is 16/L samples per workgroup = 128 workgroups at
+// batch 128: half of the 256 CUs idle for its 7-11 us.  Here one grid carries both: the first
+// `groups` workgroups run the attention body (they are the long dependent chains, so they start
+// first), the rest are the GEMM's tiles.  Forward: conv + sdpa_ln_fwd.  Backward: data-gradient
+// GEMM + sdpa_ln_bwd (the attention gradient goes to its own buffer; the consumer adds the two).
+struct SdpaFwdArgs {
+  const float *x, *y, *ln_w, *ln_b;
+  float *out, *xhat, *stats;
+  SdpaGeom G;
+  DropCfg drop;
+  int groups;
+};
+struct SdpaBwdArgs {
+  const float *g, *gscale, *x, *y, *ln_w, *xhat, *stats;
+  float *dx, *dy;
+  uint32_t acc_mask;
+  SdpaGeom G;
+  DropCfg drop;
+  int groups;
+};
+
+template <int TN, int TJ, int KPW>
+__global__ __launch_bounds__(256) void conv_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s, int gx) {
+  if ((int)blockIdx.x < s.groups) {
+    sdpa_fwd_body(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop);
+  } else {
+    const int t = blockIdx.x - s.groups;
+    conv_ksplit_body<true, TN, TJ, KPW>(a, t % gx, t / gx);
+  }
+}
+
+template <int TN, int TJ, int KPW>
+__global__ __launch_bounds__(256) void conv_bwd_sdpa_k(ConvArgs a, SdpaBwdArgs s, int gx) {
+  if ((int)blockIdx.x < s.groups) {
+    sdpa_bwd_body(blockIdx.x, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask,
+                  s.G, s.drop);
+  } else {
+    const int t = blockIdx.x - s.groups;
+    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx);
   }
 }
 
@@ -765,6 +813,41 @@ bool launch_ksplit(const ConvArgs& a, hipStream_t st) {
   return false;
 }
 
+// merged launch; false when the split-K kernel does not cover this shape (caller launches the
+// two kernels separately)
+template <int TN, int TJ>
+bool launch_ksplit_sdpa_fwd(const ConvArgs& a, const SdpaFwdArgs& s, hipStream_t st) {
+  const int kpw = (a.I / 16 + 3) / 4;
+  if (kpw * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;
+  const int gx = (a.n_groups + TN - 1) / TN, gy = (a.J / 16 + TJ - 1) / TJ;
+  dim3 grid((unsigned)(s.groups + gx * gy));
+#define KS_CASE(K)                                                                                   \
+  if (kpw <= K) {                                                                                    \
+    hipLaunchKernelGGL((conv_fwd_sdpa_k<TN, TJ, K>), grid, dim3(256), 0, st, a, s, gx);              \
+    return true;                                                                                     \
+  }
+  KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(6) KS_CASE(9) KS_CASE(12)
+#undef KS_CASE
+  return false;
+}
+
+template <int TN, int TJ>
+bool launch_ksplit_sdpa_bwd(const ConvArgs& a, const SdpaBwdArgs& s, hipStream_t st) {
+  const int kpw = (a.I / 16 + 3) / 4;
+  if (kpw * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;
+  const int gx = (a.n_groups + TN - 1) / TN, gy = (a.J / 16 + TJ - 1) / TJ;
+  dim3 grid((unsigned)(s.groups + gx * gy));
+  const size_t lds = sdpa_bwd_lds(s.G.C);
+#define KS_CASE(K)                                                                                   \
+  if (kpw <= K) {                                                                                    \
+    hipLaunchKernelGGL((conv_bwd_sdpa_k<TN, TJ, K>), grid, dim3(256), lds, st, a, s, gx);            \
+    return true;                                                                                     \
+  }
+  KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(6) KS_CASE(9) KS_CASE(12)
+#undef KS_CASE
+  return false;
+}
+
 template <bool TRANS>
 void launch_nj(const ConvArgs& a, hipStream_t st) {
   const long jt = a.J / 16, ng = a.n_groups;
@@ -849,6 +932,89 @@ extern "C" int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, 
   a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
   a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = conv_probe(); a.fold = fold_cols;
   launch_nj<false>(a, (hipStream_t)stream);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C_src, const float* W,
+                                      int ldw, int fold_cols, const float* bias, float* U, float* part,
+                                      int b, int L, int M, const float* x, const float* y,
+                                      const float* ln_w, const float* ln_b, float* out, float* xhat,
+                                      float* stats, int C, bmnas_dropout_t drop, void* stream) {
+  if (!srcs || !W || !U || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
+  if (!x || !y || !ln_w || !ln_b || !out || !xhat || !stats) return BMNAS_E_ARG;
+  if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
+  if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
+  if (C_src % 16 || M % 16 || ldw % 4 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
+  ConvArgs a{};
+  if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
+  SdpaFwdArgs s{};
+  if (int e = geom(b, C, L, &s.G)) return e;
+  if (b == 0) return 0;
+  for (int q = 0; q < n_src; ++q) {
+    if (!srcs[q]) return BMNAS_E_ARG;
+    a.act.p[q] = srcs[q];
+  }
+  a.dst.p[0] = U;
+  a.W = W; a.bias = bias; a.part = part; a.ldw = ldw;
+  a.Ci = C_src; a.I = n_src * C_src; a.Cj = M; a.J = M;
+  a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = 0; a.fold = fold_cols;
+  s.x = x; s.y = y; s.ln_w = ln_w; s.ln_b = ln_b; s.out = out; s.xhat = xhat; s.stats = stats;
+  s.drop = to_cfg(drop);
+  s.groups = (b + s.G.spw - 1) / s.G.spw;
+  hipStream_t st = (hipStream_t)stream;
+  const long jt = a.J / 16, ng = a.n_groups;
+  bool done = false;
+  if (((ng + 1) / 2) * ((jt + 1) / 2) >= 1024) done = launch_ksplit_sdpa_fwd<2, 2>(a, s, st);
+  if (!done) done = launch_ksplit_sdpa_fwd<1, 1>(a, s, st);
+  if (!done) {
+    launch_nj<true>(a, st);
+    BMNAS_CHECK_LAUNCH();
+    return bmnas_sdpa_ln_fwd(x, y, ln_w, ln_b, out, xhat, stats, b, C, L, drop, stream);
+  }
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_conv1x1_bwd_data_sdpa(const float* dU, const float* W, int ldw, int fold_cols,
+                                           float* const* dsrcs, int n_src, int C_src,
+                                           uint32_t accumulate_mask, int b, int L, int M,
+                                           const float* g, const float* gscale, const float* x,
+                                           const float* y, const float* ln_w, const float* xhat,
+                                           const float* stats, float* dx, float* dy,
+                                           uint32_t sdpa_accumulate_mask, int C, bmnas_dropout_t drop,
+                                           void* stream) {
+  if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
+  if (!g || !x || !y || !ln_w || !xhat || !stats || !dx) return BMNAS_E_ARG;
+  if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
+  if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
+  if (C_src % 16 || M % 16 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
+  for (int q = 0; q < n_src; ++q)                    // the two halves run concurrently: no shared output
+    if (dsrcs[q] == dx || (dy && dsrcs[q] == dy)) return BMNAS_E_ARG;
+  ConvArgs a{};
+  if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
+  SdpaBwdArgs s{};
+  if (int e = geom(b, C, L, &s.G)) return e;
+  if (b == 0) return 0;
+  a.act.p[0] = dU;
+  for (int q = 0; q < n_src; ++q) a.dst.p[q] = dsrcs[q];
+  a.W = W; a.bias = nullptr; a.part = nullptr; a.ldw = ldw;
+  a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
+  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = 0; a.fold = fold_cols;
+  s.g = g; s.gscale = gscale; s.x = x; s.y = y; s.ln_w = ln_w; s.xhat = xhat; s.stats = stats;
+  s.dx = dx; s.dy = dy; s.acc_mask = sdpa_accumulate_mask; s.drop = to_cfg(drop);
+  s.groups = (b + s.G.spw - 1) / s.G.spw;
+  hipStream_t st = (hipStream_t)stream;
+  const long jt = a.J / 16, ng = a.n_groups;
+  bool done = false;
+  if (((ng + 1) / 2) * ((jt + 1) / 2) >= 1024) done = launch_ksplit_sdpa_bwd<2, 2>(a, s, st);
+  if (!done) done = launch_ksplit_sdpa_bwd<1, 1>(a, s, st);
+  if (!done) {
+    launch_nj<false>(a, st);
+    BMNAS_CHECK_LAUNCH();
+    return bmnas_sdpa_ln_bwd(g, gscale, x, y, ln_w, xhat, stats, dx, dy, sdpa_accumulate_mask, b, C, L,
+                             drop, stream);
+  }
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void mixsum_fwd_k(PtrsIn xs, const float* __re
 template <int NIN>
 __global__ __launch_bounds__(256) void mixsum_bwd_k(PtrsIn xs, PtrsOut dxs,
                                                     const float* __restrict__ w, int w_stride,
-                                                    const float* __restrict__ g, float* dw,
+                                                    const float* __restrict__ g,
+                                                    const float* __restrict__ g2, float* dw,
                                                     int dw_shards, int64_t dw_shard_stride,
                                                     uint32_t acc_mask, int64_t n4) {
   __shared__ float red[4 * NIN];
@@ -47,7 +48,8 @@ __global__ __launch_bounds__(256) void mixsum_bwd_k(PtrsIn xs, PtrsOut dxs,
   }
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    if (g2 != nullptr) g4 = f4_add(g4, reinterpret_cast<const float4*>(g2)[i]);
     if (dw != nullptr) {
       float4 v[NIN];
 #pragma unroll
@@ -124,7 +126,8 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
                                                          const float* __restrict__ w2, int w2_stride,
                                                          const float* __restrict__ h,
                                                          const float* __restrict__ gh,
-                                                         const float* __restrict__ gz, float* dw,
+                                                         const float* __restrict__ gz,
+                                                         const float* __restrict__ gz2, float* dw,
                                                          float* dw2, int dw_shards,
                                                          int64_t dw_shard_stride, uint32_t acc_mask,
                                                          int64_t n4) {
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
   const float s2 = w2[0] + w2[w2_stride];
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const float4 z4 = reinterpret_cast<const float4*>(gz)[i];
+    float4 z4 = reinterpret_cast<const float4*>(gz)[i];
+    if (gz2 != nullptr) z4 = f4_add(z4, reinterpret_cast<const float4*>(gz2)[i]);
     const float4 h4 = reinterpret_cast<const float4*>(h)[i];
     float4 g4 = f4_scale(z4, s2);
     if (gh != nullptr) g4 = f4_add(g4, reinterpret_cast<const float4*>(gh)[i]);
@@ -225,9 +229,9 @@ extern "C" int bmnas_mixsum_fwd(const float* const* xs, int n_in, const float* w
 }
 
 extern "C" int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n_in,
-                                const float* w, int w_stride, const float* g, float* dw,
-                                int dw_shards, int64_t dw_shard_stride, uint32_t accumulate_mask,
-                                int64_t n_elem, void* stream) {
+                                const float* w, int w_stride, const float* g, const float* g2,
+                                float* dw, int dw_shards, int64_t dw_shard_stride,
+                                uint32_t accumulate_mask, int64_t n_elem, void* stream) {
   if (!xs || !dxs || !w || !g || n_in < 1 || n_elem < 0 || w_stride < 1 || dw_shards < 1)
     return BMNAS_E_ARG;
   if (n_in > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
@@ -242,7 +246,7 @@ extern "C" int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n
   }
   const int64_t n4 = n_elem / 4;
   hipStream_t st = (hipStream_t)stream;
-#define CALL(N) hipLaunchKernelGGL(mixsum_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, g, dw, dw_shards, dw_shard_stride, accumulate_mask, n4)
+#define CALL(N) hipLaunchKernelGGL(mixsum_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, g, g2, dw, dw_shards, dw_shard_stride, accumulate_mask, n4)
   MIXSUM_DISPATCH(n_in, CALL)
 #undef CALL
   BMNAS_CHECK_LAUNCH();
@@ -273,8 +277,9 @@ extern "C" int bmnas_mixsum_pair_fwd(const float* const* xs, int n_in, const flo
 
 extern "C" int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, int n_in,
                                      const float* w, int w_stride, const float* w2, int w2_stride,
-                                     const float* h, const float* gh, const float* gz, float* dw,
-                                     float* dw2, int dw_shards, int64_t dw_shard_stride,
+                                     const float* h, const float* gh, const float* gz,
+                                     const float* gz2, float* dw, float* dw2, int dw_shards,
+                                     int64_t dw_shard_stride,
                                      uint32_t accumulate_mask, int64_t n_elem, void* stream) {
   if (!xs || !dxs || !w || !w2 || !h || !gz || !dw || !dw2 || n_in < 1 || n_elem < 0 || w_stride < 1 ||
       w2_stride < 1 || dw_shards < 1)
@@ -291,7 +296,7 @@ extern "C" int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, 
   }
   const int64_t n4 = n_elem / 4;
   hipStream_t st = (hipStream_t)stream;
-#define CALL(N) hipLaunchKernelGGL(mixsum_pair_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, dw_shards, dw_shard_stride, accumulate_mask, n4)
+#define CALL(N) hipLaunchKernelGGL(mixsum_pair_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards, dw_shard_stride, accumulate_mask, n4)
   switch (n_in) {
     case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;
     case 4: CALL(4); break;   case 5: CALL(5); break;   case 6: CALL(6); break;

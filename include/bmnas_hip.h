@@ -67,9 +67,10 @@ int bmnas_mixsum_fwd(const float* const* xs, int n_in, const float* w, int w_str
  * dw[shard*dw_shard_stride + j*w_stride] += <g, xs[j]> (atomic; dw may be NULL to skip the dot
  * products).  The adds of the workgroups are spread round-robin over dw_shards (>= 1) copies of
  * the buffer so that they do not serialise on n_in addresses; the consumer sums the copies
- * (bmnas_arch_softmax_multi does). */
+ * (bmnas_arch_softmax_multi does).  g2 (nullable): a second tensor added to g on load — the
+ * gradient of the summed state arrives in two parts when bmnas_conv1x1_bwd_data_sdpa produced it. */
 int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n_in, const float* w,
-                     int w_stride, const float* g, float* dw, int dw_shards,
+                     int w_stride, const float* g, const float* g2, float* dw, int dw_shards,
                      int64_t dw_shard_stride, uint32_t accumulate_mask, int64_t n_elem,
                      void* stream);
 
@@ -82,12 +83,12 @@ int bmnas_mixsum_pair_fwd(const float* const* xs, int n_in, const float* w, int 
 /* Backward of the pair.  h = the saved `out`; gz = gradient of out2; gh = gradient `out` received
  * from its other consumers (NULL if none).  G = gh + (w2_0 + w2_1) gz;  dxs[j] (=|+=) w_j G;
  * dw[j] += <G, xs[j]>;  dw2[0], dw2[w2_stride] += <gz, h>  (n_in <= 15; shards as above, dw and dw2
- * share dw_shard_stride). */
+ * share dw_shard_stride).  gz2 (nullable) is added to gz on load, as g2 above. */
 int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, int n_in, const float* w,
                           int w_stride, const float* w2, int w2_stride, const float* h,
-                          const float* gh, const float* gz, float* dw, float* dw2, int dw_shards,
-                          int64_t dw_shard_stride, uint32_t accumulate_mask, int64_t n_elem,
-                          void* stream);
+                          const float* gh, const float* gz, const float* gz2, float* dw, float* dw2,
+                          int dw_shards, int64_t dw_shard_stride, uint32_t accumulate_mask,
+                          int64_t n_elem, void* stream);
 
 /* ---- K6 / K7: channel-concat (+ residual) + LayerNorm (+ ReLU) -------------------------
  * x = cat(srcs[0..n_src), dim=1) (+ resid if non-NULL; n_src must be 1 then);
@@ -161,6 +162,25 @@ int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const floa
 int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, int fold_cols,
                            float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
                            int b, int L, int M, void* stream);
+/* bmnas_conv1x1_fwd and bmnas_sdpa_ln_fwd in ONE launch: the attention branch and the stacked
+ * LinearGLU/ConcatFC conv of a NodeMixedOp (node_operations.py:118-120) read the same input and are
+ * independent; K3's b*L/16 workgroups leave half the CUs idle, the GEMM tiles fill them.
+ * Arguments = those of the two functions (same b, L). */
+int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C_src, const float* W, int ldw,
+                           int fold_cols, const float* bias, float* U, float* part, int b, int L,
+                           int M, const float* x, const float* y, const float* ln_w,
+                           const float* ln_b, float* out, float* xhat, float* stats, int C,
+                           bmnas_dropout_t drop, void* stream);
+/* bmnas_conv1x1_bwd_data and bmnas_sdpa_ln_bwd in ONE launch.  The two halves run concurrently, so
+ * dx / dy must not be among dsrcs: the attention gradient goes to its own buffer and the consumer
+ * adds the parts (g2 of bmnas_mixsum_bwd / gz2 of bmnas_mixsum_pair_bwd). */
+int bmnas_conv1x1_bwd_data_sdpa(const float* dU, const float* W, int ldw, int fold_cols,
+                                float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
+                                int b, int L, int M, const float* g, const float* gscale,
+                                const float* x, const float* y, const float* ln_w, const float* xhat,
+                                const float* stats, float* dx, float* dy,
+                                uint32_t sdpa_accumulate_mask, int C, bmnas_dropout_t drop,
+                                void* stream);
 /* dW[m*ldw + k] += sum_{s,l} dU[s,m,l] * cat(srcs)[s,k,l];  dbias[m] += sum_{s,l} dU[s,m,l]
  * (atomic adds: caller zeroes; dbias may be NULL).  If dup_cols > 0 the same value is also
  * added at column k + dup_cols (folded x-is-y weights, see bmnas_fold_weight). */
