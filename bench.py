@@ -391,13 +391,29 @@ def main():
         # instrumented steps are then all queued before the GPU reaches them and run back to
         # back, and start->end event deltas are kernel durations (+ the event records).
         torch.cuda.synchronize()
-        blk = torch.randn(8192, 8192, device=device)
-        for _ in range(6):
-            blk = (blk @ blk) * 1e-4
-        lib.profile_begin(algo_table(c['C'], c['L']))
-        for _ in range(n_prof):
-            step()
-        recs, ev_ms = lib.profile_end()
+        # the blocker: a one-thread spin kernel (torch.cuda._sleep) on the launch stream, calibrated
+        # in wall time first.  (A stack of big GEMMs was used before; on some boxes the instrumented
+        # kernels then ran 1.5-2x slow, as if next to it.)  The pass is only accepted if the blocker
+        # was still running when the host finished queueing: otherwise brackets contain host gaps.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(20_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        cycles_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+        recs, ev_ms, park_ms = {}, 0.0, 0
+        for park_ms in (80, 200, 500):
+            torch.cuda._sleep(int(cycles_per_ms * park_ms))
+            guard = torch.cuda.Event()
+            guard.record()
+            lib.profile_begin(algo_table(c['C'], c['L']))
+            for _ in range(n_prof):
+                step()
+            queued_in_time = not guard.query()
+            recs, ev_ms = lib.profile_end()
+            if queued_in_time:
+                break
+            log(f'roofline pass: host needed more than the {park_ms} ms blocker to queue {n_prof} steps; retrying')
         # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE with
         # the gfx950 read-side correction; tools/traffic_from_pmc.py); null if not collected
         traffic = {}
@@ -426,7 +442,7 @@ def main():
         if rows:
             top = dict(rows[0])
             top['measured'] = (f'HIP events on the launch stream around every launch, instrumented pass of '
-                               f'{n_prof} steps queued behind a GPU-side blocker (back-to-back execution), '
+                               f'{n_prof} steps queued behind a {park_ms} ms GPU-side spin blocker (back-to-back execution), '
                                'after the timed region; avg per launch minus the elapsed time of an empty '
                                f'event bracket ({ev_ms * 1e3:.2f} us); cross-check: profiles/ rocprofv3 stats')
             result['roofline'] = top

@@ -389,20 +389,25 @@ struct SdpaBwdArgs {
   int groups;
 };
 
-template <int TN, int TJ, int KPW>
+// KCH = 16-channel chunks per wave of the attention body = ceil(C / 64); the merged launches exist
+// for the NodeMixedOp shapes only (conv input = the attention input, K = C, M = 3C), where the
+// GEMM's blocks-per-wave are KCH (forward) and 3 KCH (data gradient).
+template <int TN, int TJ, int KCH>
 __global__ __launch_bounds__(256) void conv_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s, int gx) {
+  constexpr int KPW = KCH;
   if ((int)blockIdx.x < s.groups) {
-    sdpa_fwd_body(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop);
+    sdpa_fwd_body<KCH>(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop);
   } else {
     const int t = blockIdx.x - s.groups;
     conv_ksplit_body<true, TN, TJ, KPW>(a, t % gx, t / gx);
   }
 }
 
-template <int TN, int TJ, int KPW>
+template <int TN, int TJ, int KCH>
 __global__ __launch_bounds__(256) void conv_bwd_sdpa_k(ConvArgs a, SdpaBwdArgs s, int gx) {
+  constexpr int KPW = 3 * KCH;
   if ((int)blockIdx.x < s.groups) {
-    sdpa_bwd_body(blockIdx.x, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask,
+    sdpa_bwd_body<KCH>(blockIdx.x, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask,
                   s.G, s.drop);
   } else {
     const int t = blockIdx.x - s.groups;
@@ -817,33 +822,35 @@ bool launch_ksplit(const ConvArgs& a, hipStream_t st) {
 // two kernels separately)
 template <int TN, int TJ>
 bool launch_ksplit_sdpa_fwd(const ConvArgs& a, const SdpaFwdArgs& s, hipStream_t st) {
-  const int kpw = (a.I / 16 + 3) / 4;
-  if (kpw * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;
+  const int kch = sdpa_kch(s.G.C);
+  if (a.I != s.G.C || kch > 4) return false;                     // NodeMixedOp shape only
+  if (kch * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;
   const int gx = (a.n_groups + TN - 1) / TN, gy = (a.J / 16 + TJ - 1) / TJ;
   dim3 grid((unsigned)(s.groups + gx * gy));
 #define KS_CASE(K)                                                                                   \
-  if (kpw <= K) {                                                                                    \
+  if (kch == K) {                                                                                    \
     hipLaunchKernelGGL((conv_fwd_sdpa_k<TN, TJ, K>), grid, dim3(256), 0, st, a, s, gx);              \
     return true;                                                                                     \
   }
-  KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(6) KS_CASE(9) KS_CASE(12)
+  KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4)
 #undef KS_CASE
   return false;
 }
 
 template <int TN, int TJ>
 bool launch_ksplit_sdpa_bwd(const ConvArgs& a, const SdpaBwdArgs& s, hipStream_t st) {
-  const int kpw = (a.I / 16 + 3) / 4;
-  if (kpw * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;
+  const int kch = sdpa_kch(s.G.C);
+  if (a.I != 3 * s.G.C || s.G.C % 64 != 0 || kch > 4) return false;   // K = 3C = 4 waves x 3 KCH blocks
+  if (3 * kch * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;
   const int gx = (a.n_groups + TN - 1) / TN, gy = (a.J / 16 + TJ - 1) / TJ;
   dim3 grid((unsigned)(s.groups + gx * gy));
   const size_t lds = sdpa_bwd_lds(s.G.C);
 #define KS_CASE(K)                                                                                   \
-  if (kpw <= K) {                                                                                    \
+  if (kch == K) {                                                                                    \
     hipLaunchKernelGGL((conv_bwd_sdpa_k<TN, TJ, K>), grid, dim3(256), lds, st, a, s, gx);            \
     return true;                                                                                     \
   }
-  KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(6) KS_CASE(9) KS_CASE(12)
+  KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4)
 #undef KS_CASE
   return false;
 }

@@ -17,6 +17,7 @@
 
 namespace {
 
+template <int KCH>
 __global__ __launch_bounds__(256) void sdpa_ln_fwd_k(const float* __restrict__ x,
                                                      const float* __restrict__ y,
                                                      const float* __restrict__ ln_w,
@@ -25,17 +26,29 @@ __global__ __launch_bounds__(256) void sdpa_ln_fwd_k(const float* __restrict__ x
                                                      float* __restrict__ xhat,
                                                      float* __restrict__ stats, SdpaGeom G,
                                                      DropCfg drop) {
-  sdpa_fwd_body(blockIdx.x, x, y, ln_w, ln_b, out, xhat, stats, G, drop);
+  sdpa_fwd_body<KCH>(blockIdx.x, x, y, ln_w, ln_b, out, xhat, stats, G, drop);
 }
 
+template <int KCH>
 __global__ __launch_bounds__(256) void sdpa_ln_bwd_k(
     const float* __restrict__ gout, const float* __restrict__ gscale, const float* __restrict__ x,
     const float* __restrict__ y, const float* __restrict__ ln_w, const float* __restrict__ xhat,
     const float* __restrict__ stats, float* dx, float* dy, uint32_t acc_mask, SdpaGeom G, DropCfg drop) {
-  sdpa_bwd_body(blockIdx.x, gout, gscale, x, y, ln_w, xhat, stats, dx, dy, acc_mask, G, drop);
+  sdpa_bwd_body<KCH>(blockIdx.x, gout, gscale, x, y, ln_w, xhat, stats, dx, dy, acc_mask, G, drop);
 }
 
 }  // namespace
+
+#define SDPA_KCH_DISPATCH(KCH, CALL) \
+  do {                               \
+    const int k__ = (KCH);           \
+    if (k__ <= 1) CALL(1);           \
+    else if (k__ <= 2) CALL(2);      \
+    else if (k__ <= 3) CALL(3);      \
+    else if (k__ <= 4) CALL(4);      \
+    else if (k__ <= 6) CALL(6);      \
+    else CALL(8);                    \
+  } while (0)
 
 extern "C" int bmnas_sdpa_ln_fwd(const float* x, const float* y, const float* ln_w,
                                  const float* ln_b, float* out, float* xhat, float* stats, int b,
@@ -45,8 +58,11 @@ extern "C" int bmnas_sdpa_ln_fwd(const float* x, const float* y, const float* ln
   if (int e = geom(b, C, L, &G)) return e;
   if (b == 0) return 0;
   const int groups = (b + G.spw - 1) / G.spw;
-  hipLaunchKernelGGL(sdpa_ln_fwd_k, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, y, ln_w, ln_b,
-                     out, xhat, stats, G, to_cfg(drop));
+#define SDPA_F(K)                                                                                     \
+  hipLaunchKernelGGL(sdpa_ln_fwd_k<K>, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, y, ln_w, ln_b, \
+                     out, xhat, stats, G, to_cfg(drop))
+  SDPA_KCH_DISPATCH(sdpa_kch(C), SDPA_F);
+#undef SDPA_F
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
@@ -61,8 +77,11 @@ extern "C" int bmnas_sdpa_ln_bwd(const float* g, const float* gscale, const floa
   if (b == 0) return 0;
   const size_t lds = sdpa_bwd_lds(C);
   const int groups = (b + G.spw - 1) / G.spw;
-  hipLaunchKernelGGL(sdpa_ln_bwd_k, dim3(groups), dim3(256), lds, (hipStream_t)stream, g, gscale, x, y,
-                     ln_w, xhat, stats, dx, dy, accumulate_mask, G, to_cfg(drop));
+#define SDPA_B(K)                                                                                      \
+  hipLaunchKernelGGL(sdpa_ln_bwd_k<K>, dim3(groups), dim3(256), lds, (hipStream_t)stream, g, gscale, x, y, \
+                     ln_w, xhat, stats, dx, dy, accumulate_mask, G, to_cfg(drop))
+  SDPA_KCH_DISPATCH(sdpa_kch(C), SDPA_B);
+#undef SDPA_B
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

@@ -10,6 +10,10 @@ namespace {
 
 constexpr float kEps = 1e-5f;
 constexpr int kMaxCh = 8;          // 16-channel chunks per wave: C <= 4 * 8 * 16 = 512
+// The bodies are templated on KCH = chunks per wave actually needed (ceil(C / 64)): the operand
+// prefetch arrays are sized by it, and a fixed size of 8 cost 212 VGPRs and 5 redundant (clamped)
+// loads per array at C = 192.
+inline int sdpa_kch(int C) { return (C / 16 + 3) / 4; }
 
 struct SdpaGeom {
   int b, C, L, Lb, spw;
@@ -105,6 +109,7 @@ __device__ __forceinline__ void attn_probs(const float* __restrict__ x, const fl
 }
 
 // g = tile group (one workgroup of 256 threads each)
+template <int KCH>
 __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restrict__ x,
                                               const float* __restrict__ y,
                                               const float* __restrict__ ln_w,
@@ -123,9 +128,9 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
   // Everything this wave will need later (its y chunks, the LayerNorm affine rows) is requested
   // BEFORE the score computation: one memory round trip for the whole kernel instead of three
   // dependent ones (the kernel is latency bound: 128 workgroups, ~40 KB each).
-  float4 yv[kMaxCh], od[kMaxCh], lw[kMaxCh], lb[kMaxCh];
+  float4 yv[KCH], od[KCH], lw[KCH], lb[KCH];
 #pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
+  for (int k = 0; k < KCH; ++k) {
     const int ch = wave + 4 * k;
     const int chc = ch < nch ? ch : nch - 1;
     const int64_t pe = (int64_t)(chc * 16 + lo) * G.L + l0;
@@ -137,7 +142,7 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
   attn_probs(x, y, G, g, wave, lane, ldsS, p);
   float sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
+  for (int k = 0; k < KCH; ++k) {
     const int ch = wave + 4 * k;
     od[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ch < nch) {                                      // wave-uniform
@@ -156,7 +161,7 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
   const float mean = wg_sample_sum(sum, G.L, G.Lb, red, wave, lo, h) * inv_d;
   float sq = 0.f;
 #pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
+  for (int k = 0; k < KCH; ++k) {
     if (wave + 4 * k < nch) {
       const float4 c = make_float4(od[k].x - mean, od[k].y - mean, od[k].z - mean, od[k].w - mean);
       sq += f4_dot(c, c);
@@ -170,7 +175,7 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
     stats[2 * sh + 1] = rstd;
   }
 #pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
+  for (int k = 0; k < KCH; ++k) {
     const int ch = wave + 4 * k;
     if (ch < nch) {
       const int64_t pe = (int64_t)(ch * 16 + lo) * G.L + l0;
@@ -184,6 +189,7 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
   }
 }
 
+template <int KCH>
 __device__ __forceinline__ void sdpa_bwd_body(
     const int g, const float* __restrict__ gout, const float* __restrict__ gscale,
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ ln_w,
@@ -204,9 +210,9 @@ __device__ __forceinline__ void sdpa_bwd_body(
   const bool v_h = sh < G.b;
   const int shc = v_h ? sh : G.b - 1;
   // all of this wave's streaming operands are requested up front (one round trip, see forward)
-  float4 xh[kMaxCh], dv[kMaxCh], yv[kMaxCh], xv[kMaxCh];
+  float4 xh[KCH], dv[KCH], yv[KCH], xv[KCH];
 #pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
+  for (int k = 0; k < KCH; ++k) {
     const int ch = wave + 4 * k;
     const int chc = ch < nch ? ch : nch - 1;
     const int64_t pe = (int64_t)(chc * 16 + lo) * G.L + l0;
@@ -231,7 +237,7 @@ __device__ __forceinline__ void sdpa_bwd_body(
   // pass A: dx_hat = g * w and the two LayerNorm-backward reductions
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
+  for (int k = 0; k < KCH; ++k) {
     const int ch = wave + 4 * k;
     if (ch < nch && v_h) {
       dv[k] = f4_scale(dv[k], gs);
@@ -249,7 +255,7 @@ __device__ __forceinline__ void sdpa_bwd_body(
   // pass B: dO = rstd * (dx_hat - m1 - x_hat * m2) * dropout mask, kept in registers (lane =
   // channel, regs = rows i) and transposed into LDS for the contraction over channels
 #pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
+  for (int k = 0; k < KCH; ++k) {
     const int ch = wave + 4 * k;
     if (ch < nch) {
       const int64_t e = ((int64_t)sh * G.C + ch * 16 + lo) * G.L + l0;
@@ -313,7 +319,7 @@ __device__ __forceinline__ void sdpa_bwd_body(
 
   // outputs, per 16-channel chunk, float4 along l (operands were loaded at the top)
 #pragma unroll
-  for (int k = 0; k < kMaxCh; ++k) {
+  for (int k = 0; k < KCH; ++k) {
     const int ch = wave + 4 * k;
     if (ch >= nch) continue;                                     // wave-uniform
     const int64_t e = ((int64_t)sh * G.C + ch * 16 + lo) * G.L + l0;
