@@ -8,6 +8,8 @@ Math and reference citations: SURVEY.md Appendix A; kernel contracts: include/bm
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import lib
@@ -289,7 +291,8 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None):
     return out, sv
 
 
-FUSE_ATTN_GEMM = True   # search mode: attention branch and conv GEMM share a launch (fwd and bwd)
+# search mode: attention branch and conv GEMM share a launch (fwd and bwd); BMNAS_FUSE_ATTN_GEMM=0 for A/B runs
+FUSE_ATTN_GEMM = os.environ.get('BMNAS_FUSE_ATTN_GEMM', '1') != '0'
 
 
 def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None):

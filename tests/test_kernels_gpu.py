@@ -291,3 +291,55 @@ def test_cross_entropy_loss(b, O):
     ld.backward()
     assert_close_scaled('loss', ld, lo)
     assert_close_scaled('dz', zd.grad, zo.grad)
+
+
+@pytest.mark.parametrize('b,C,L,M,bias,stats', [(128, 192, 16, 576, True, True), (100, 192, 16, 576, False, True),
+                                              (250, 128, 8, 384, True, True), (509, 64, 4, 208, True, False),
+                                              (128, 192, 16, 80, True, True)])
+def test_conv1x1_fwd_large_single_source(b, C, L, M, bias, stats):
+    """The production-size forward GEMM through the C ABI: U = W x + bias and the per-16-column
+    BatchNorm partials (sum, centred second moment), against float64 on the CPU.  Ragged batches
+    and output-channel counts that are not a multiple of the workgroup tile included."""
+    from bmnas import lib
+    g = _gen(900 + b + C)
+    x = _rand(g, b, C, L)
+    W = _rand(g, M, C) * 0.1
+    bv = _rand(g, M)
+    xd, Wd, bd = x.to(dev()), W.to(dev()), bv.to(dev())
+    U = torch.full((b, M, L), float('nan'), device=dev())
+    n_part = lib.conv1x1_num_partials(b, L)
+    part = torch.full((M * n_part * 2,), float('nan'), device=dev()) if stats else None
+    lib.conv1x1_fwd([xd], C, Wd, C, bd if bias else None, U, part, b, L, M)
+    ref = torch.einsum('mc,bcl->bml', W.double(), x.double())
+    if bias:
+        ref = ref + bv.double()[None, :, None]
+    assert_close_scaled('U', U, ref.float(), rel=2e-5)
+    if stats:
+        cols = ref.permute(1, 0, 2).reshape(M, b * L)                  # (M, n) in (sample, l) order
+        got = part.view(M, n_part, 2).cpu().double()
+        for gi in (0, n_part // 2, n_part - 1):
+            seg = cols[:, 16 * gi:16 * gi + 16]
+            assert_close_scaled(f'sum[{gi}]', got[:, gi, 0].float(), seg.sum(1).float(), rel=5e-5)
+            m2 = ((seg - seg.mean(1, keepdim=True)) ** 2).sum(1)
+            assert_close_scaled(f'm2[{gi}]', got[:, gi, 1].float(), m2.float(), rel=2e-4)
+
+
+@pytest.mark.parametrize('b,C,L,M,n_dst,acc', [(128, 192, 16, 576, 1, 1), (100, 192, 16, 576, 1, 1),
+                                              (128, 192, 16, 576, 1, 0), (250, 128, 8, 384, 2, 3),
+                                              (509, 64, 4, 192, 1, 1), (128, 128, 16, 128, 2, 0)])
+def test_conv1x1_bwd_data_large(b, C, L, M, n_dst, acc):
+    """The production-size data-gradient GEMM through the C ABI, overwrite and accumulate,
+    one and two destinations: d src_q (=|+=) W[:, qC:(q+1)C]^T dU."""
+    from bmnas import lib
+    g = _gen(950 + b + C)
+    dU = _rand(g, b, M, L)
+    W = _rand(g, M, n_dst * C) * 0.1
+    prev = [_rand(g, b, C, L) for _ in range(n_dst)]
+    dst = [p.clone().to(dev()) for p in prev]
+    lib.conv1x1_bwd_data(dU.to(dev()), W.to(dev()), n_dst * C, dst, C, acc, b, L, M)
+    ref = torch.einsum('mc,bml->bcl', W.double(), dU.double())
+    for q in range(n_dst):
+        want = ref[:, q * C:(q + 1) * C]
+        if acc & (1 << q):
+            want = want + prev[q].double()
+        assert_close_scaled(f'dsrc{q}', dst[q], want.float(), rel=3e-5)
