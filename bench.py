@@ -90,10 +90,14 @@ def algo_table(C, L):
     T = lambda t: t.numel() * 4
     return {
         'mixsum_fwd': lambda xs, w, ws, out, *_: ('hbm', (len(xs) + 1) * T(out)),
-        'mixsum_bwd': lambda xs, dxs, w, ws, g, *_: ('hbm', (2 * len(xs) + 1) * T(g)),
+        # reads: g (+ g2) + the n_in inputs + the destinations that accumulate; writes: the destinations
+        'mixsum_bwd': lambda xs, dxs, w, ws, g, dw, acc, sh=1, st=0, g2=None:
+            ('hbm', (1 + (g2 is not None) + len(xs) + bin(acc).count('1')
+                     + sum(d is not None for d in dxs)) * T(g)),
         'mixsum_pair_fwd': lambda xs, w, ws, w2, ws2, out, *_: ('hbm', (len(xs) + 2) * T(out)),
-        'mixsum_pair_bwd': lambda xs, dxs, w, ws, w2, ws2, h, gh, gz, *_:
-            ('hbm', (2 * len(xs) + 2 + (1 if gh is not None else 0)) * T(gz)),
+        'mixsum_pair_bwd': lambda xs, dxs, w, ws, w2, ws2, h, gh, gz, dw, dw2, acc, sh=1, st=0, gz2=None:
+            ('hbm', (2 + (gh is not None) + (gz2 is not None) + len(xs) + bin(acc).count('1')
+                     + sum(d is not None for d in dxs)) * T(gz)),
         'cat_ln_fwd': lambda srcs, resid, w, b_, out, *_:
             ('hbm', (len(srcs) + (1 if resid is not None else 0)) * T(srcs[0]) + T(out) + 2 * T(w)),
         'cat_ln_bwd': lambda g, srcs, resid, w, *_:
@@ -209,15 +213,23 @@ def cpu_baseline(cname, c, batch, max_seconds=20.0):
         torch.set_num_threads(nt)
         one()
         probe[nt] = min(one(), one())
-    best = min(probe, key=probe.get)
+    # the two fastest thread counts of the probe are both timed properly (the probe is 2 steps and
+    # a noisy host can mislead it); the better median is the baseline
+    finalists = sorted(probe, key=probe.get)[:2]
+    runs = {}
+    for nt in finalists:
+        torch.set_num_threads(nt)
+        ts = []
+        t_start = time.time()
+        for i in range(30):
+            ts.append(one())
+            if time.time() - t_start > max_seconds / len(finalists) and len(ts) >= 8:
+                break
+        runs[nt] = ts
+    best = min(runs, key=lambda k: statistics.median(runs[k][3:]))
     torch.set_num_threads(best)
-    times = []
-    t_start = time.time()
-    for i in range(45):
-        times.append(one())
-        if time.time() - t_start > max_seconds and len(times) >= 8:
-            break
-    timed = times[5:] if len(times) > 8 else times[1:]
+    times = runs[best]
+    timed = times[3:]
     med = statistics.median(timed)
     return {'value': round(1.0 / med, 3), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
             'kind': 'port', 'ms_per_step': round(med * 1e3, 3),
@@ -226,7 +238,7 @@ def cpu_baseline(cname, c, batch, max_seconds=20.0):
             'thread_probe_ms': {str(k): round(v * 1e3, 2) for k, v in probe.items()},
             'sample': f'{len(timed)} timed fwd+bwd steps (after {len(times) - len(timed)} warm-up) of the '
                       f'same {cname} batch-{batch} synthetic workload, torch CPU fp32, median; threads = '
-                      f'fastest of a probe over {sorted(probe)} on a {ncpu}-cpu host'}
+                      f'faster of the two best of a probe over {sorted(probe)} on a {ncpu}-cpu host'}
 
 
 def main():

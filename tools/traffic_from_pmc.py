@@ -10,8 +10,11 @@ import json
 import sys
 
 fetch_csv, write_csv, out = sys.argv[1:4]
-STREAMING = ('mixsum', 'cat_ln', 'ln_affine', 'node_mix', 'bn_', 'fold_weight')
-WRAPPER = [('mixsum_fwd_k', 'mixsum_fwd'), ('mixsum_bwd_k', 'mixsum_bwd'), ('cat_ln_fwd_k', 'cat_ln_fwd'),
+STREAMING = ('mixsum', 'cat_ln', 'ln_affine', 'node_mix', 'bn_', 'fold_weight', 'adam')
+WRAPPER = [('mixsum_pair_fwd_k', 'mixsum_pair_fwd'), ('mixsum_pair_bwd_k', 'mixsum_pair_bwd'),
+           ('node_mix_ln_fwd_k', 'node_mix_ln_fwd'), ('conv_fwd_sdpa_k', 'conv1x1_fwd_sdpa'),
+           ('conv_bwd_sdpa_k', 'conv1x1_bwd_data_sdpa'), ('adam_multi_k', 'adam_multi'),
+           ('linear_fwd_k', 'linear_fwd'), ('mixsum_fwd_k', 'mixsum_fwd'), ('mixsum_bwd_k', 'mixsum_bwd'), ('cat_ln_fwd_k', 'cat_ln_fwd'),
            ('cat_ln_bwd_k', 'cat_ln_bwd'), ('ln_affine_bwd_k', 'ln_affine_bwd'), ('sdpa_ln_fwd_k', 'sdpa_ln_fwd'),
            ('sdpa_ln_bwd_k', 'sdpa_ln_bwd'), ('<true', 'conv1x1_fwd'), ('<false', 'conv1x1_bwd_data'),
            ('conv_w_k', 'conv1x1_bwd_weight'), ('node_mix_fwd_k', 'node_mix_fwd'), ('node_mix_bwd_k', 'node_mix_bwd'),
@@ -33,7 +36,9 @@ for k in f:
     if 'bmnas' not in k and not any(p in name for p, _ in WRAPPER):
         continue
     wrap = next((wn for p, wn in WRAPPER if p in name), None)
-    if wrap is None or (wrap.startswith('conv1x1_') and 'conv' not in name):
+    if wrap is None or (wrap.startswith('conv1x1_') and 'conv' not in name) or \
+            (wrap in ('conv1x1_fwd', 'conv1x1_bwd_data') and 'ksplit' not in name and 'conv_nj' not in name
+             and 'conv_lds' not in name):
         continue
     d = per_wrapper[wrap]
     d['launches'] += len(f[k])
