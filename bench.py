@@ -118,6 +118,8 @@ def algo_table(C, L):
             ('mfma', 2.0 * M * len(srcs) * Cs * b * L_ + 4.0 * b * L_ * L_ * Cs),
         'conv1x1_bwd_data_sdpa': lambda dU, W, ldw, ds, Cs, m, b, L_, M, *_:
             ('mfma', 2.0 * M * len(ds) * Cs * b * L_ + 12.0 * b * L_ * L_ * Cs),
+        'conv1x1_bwd_all_sdpa': lambda dU, W, ldw, ds, Cs, m, b, L_, M, *_:
+            ('mfma', 4.0 * M * len(ds) * Cs * b * L_ + 12.0 * b * L_ * L_ * Cs),
         'conv1x1_bwd_weight': lambda dU, srcs, Cs, dW, ldw, db, dup, b, L_, M, *_:
             ('mfma', 2.0 * M * len(srcs) * Cs * b * L_),
         'node_mix_fwd': lambda x, y, p1, U, ch, gm, out, *_: ('hbm', T(U) + 3 * T(out)),

@@ -235,6 +235,13 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
                 seen[id(s)] = q
             slots.append(s)
     bufs, mask = _write_group(slots)
+    if attn is not None and dW is not None and FUSE_BWD_ALL:
+        # data gradient, weight gradient and the attention backward share one grid
+        lib.conv1x1_bwd_all_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, sv.srcs, dW,
+                                 dW.shape[1], dbias, sv.dup, *attn)
+        for s, tmp in extra:
+            s.buf().add_(tmp.buf())
+        return
     if attn is not None:
         lib.conv1x1_bwd_data_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, *attn)
     elif any(x is not None for x in bufs):
@@ -293,6 +300,8 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None):
 
 # search mode: attention branch and conv GEMM share a launch (fwd and bwd); BMNAS_FUSE_ATTN_GEMM=0 for A/B runs
 FUSE_ATTN_GEMM = os.environ.get('BMNAS_FUSE_ATTN_GEMM', '1') != '0'
+# ... and the weight-gradient GEMM joins the backward launch
+FUSE_BWD_ALL = os.environ.get('BMNAS_FUSE_BWD_ALL', '1') != '0'
 
 
 def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None):

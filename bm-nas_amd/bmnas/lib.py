@@ -55,6 +55,8 @@ SIGNATURES = {
                                 _P, _P, _P, _P, _P, _P, _P, _I, Dropout, _P], _I),
     'bmnas_conv1x1_bwd_data_sdpa': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P], _I),
+    'bmnas_conv1x1_bwd_all_sdpa': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _PP, _P, _I, _P, _I,
+                                    _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P], _I),
     'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
@@ -249,6 +251,16 @@ def conv1x1_bwd_data_sdpa(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, g, 
                                               sdpa_acc_mask, Cc, drop, _stream()), 'conv1x1_bwd_data_sdpa')
 
 
+def conv1x1_bwd_all_sdpa(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, wsrcs, dW, ldw_grad, dbias, dup_cols,
+                         g, gscale, x, y, ln_w, xhat, stats, dx, dy, sdpa_acc_mask, Cc, drop):
+    _check(load().bmnas_conv1x1_bwd_all_sdpa(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs),
+                                             C_src, acc_mask, b, L, M, _ptrs(wsrcs), dW.data_ptr(), ldw_grad,
+                                             None if dbias is None else dbias.data_ptr(), dup_cols, _ptr(g),
+                                             None if gscale is None else gscale.data_ptr(), _ptr(x), _ptr(y),
+                                             _ptr(ln_w), _ptr(xhat), _ptr(stats), _ptr(dx), _ptr(dy),
+                                             sdpa_acc_mask, Cc, drop, _stream()), 'conv1x1_bwd_all_sdpa')
+
+
 def conv1x1_bwd_weight(dU, srcs, C_src, dW, ldw, dbias, dup_cols, b, L, M):
     _check(load().bmnas_conv1x1_bwd_weight(_ptr(dU), _ptrs(srcs), len(srcs), C_src, dW.data_ptr(), ldw,
                                            None if dbias is None else dbias.data_ptr(), dup_cols, b, L,
@@ -411,7 +423,7 @@ def profile_end():
 
 _TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
-                'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa',
+                'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',
                 'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy', 'adam_multi')

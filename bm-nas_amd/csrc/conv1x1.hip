@@ -640,16 +640,17 @@ struct ConvWArgs {
 // operands are float4 along l (next group's loads issued before this group's 16 MFMAs), the
 // eight partial tiles meet in LDS and leave with coalesced stores (single split) or
 // well-shaped fp32 atomics (128-B runs along k).
-__global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
-  __shared__ float tile[8][32 * 33];
-  __shared__ float brow[8][32];
+template <int NW>
+__device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, const int by, const int bz) {
+  __shared__ float tile[NW][32 * 33];
+  __shared__ float brow[NW][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
-  const int m0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
-  const int gbeg = blockIdx.z * a.groups_per_split;
+  const int m0 = bx * 32, k0 = by * 32;
+  const int gbeg = bz * a.groups_per_split;
   int gend = gbeg + a.groups_per_split;
   if (gend > a.n_groups) gend = a.n_groups;
-  const bool want_bias = (a.dbias != nullptr) && (blockIdx.y == 0);
+  const bool want_bias = (a.dbias != nullptr) && (by == 0);
 
   // tiles past the edge are clamped (their results are never stored)
   auto a_row = [&](int t) __attribute__((always_inline)) -> int64_t {
@@ -715,10 +716,10 @@ __global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
   // 15.9 us for issuing all of a wave's loads up front.
   int g = gbeg + wave;
   load_ops(a0, b0, g);
-  for (; g + 8 < gend; g += 16) {
-    load_ops(a1, b1, g + 8);
+  for (; g + NW < gend; g += 2 * NW) {
+    load_ops(a1, b1, g + NW);
     mma_ops(a0, b0);
-    load_ops(a0, b0, g + 16);
+    load_ops(a0, b0, g + 2 * NW);
     mma_ops(a1, b1);
   }
   if (g < gend) mma_ops(a0, b0);
@@ -739,13 +740,13 @@ __global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 32 * 32; e += 512) {
+  for (int e = threadIdx.x; e < 32 * 32; e += 64 * NW) {
     const int mm = e >> 5, kk = e & 31;
     const int m = m0 + mm, k = k0 + kk;
     if (m < a.M && k < a.K) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v += tile[w][mm * 33 + kk];
+      for (int w = 0; w < NW; ++w) v += tile[w][mm * 33 + kk];
       float* pp = a.dW + (int64_t)m * a.ldw + k;
       if (a.use_atomic) {
         atomicAdd(pp, v);
@@ -761,10 +762,36 @@ __global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
     if (m < a.M) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v += brow[w][threadIdx.x];
+      for (int w = 0; w < NW; ++w) v += brow[w][threadIdx.x];
       if (a.use_atomic) atomicAdd(a.dbias + m, v);
       else a.dbias[m] += v;
     }
+  }
+}
+
+__global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
+  conv_w_body<8>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The whole backward of a NodeMixedOp's contractions in ONE grid (search mode): attention
+// backward workgroups first (long dependent chains), then the data-gradient GEMM tiles, then the
+// weight-gradient tiles (4-wave variant of conv_w_k).  All three only read dU / z / g and write
+// disjoint outputs.
+template <int TN, int TJ, int KCH>
+__global__ __launch_bounds__(256) void conv_bwd_all_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
+                                                      int n_data, int wx, int wy) {
+  constexpr int KPW = 3 * KCH;
+  const int blk = blockIdx.x;
+  if (blk < s.groups) {
+    sdpa_bwd_body<KCH>(blk, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask, s.G,
+                       s.drop);
+  } else if (blk < s.groups + n_data) {
+    const int t = blk - s.groups;
+    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx);
+  } else {
+    const int t = blk - s.groups - n_data;
+    const int bz = t / (wx * wy), r = t - bz * wx * wy;
+    conv_w_body<4>(w, r % wx, r / wx, bz);
   }
 }
 
@@ -1026,16 +1053,15 @@ extern "C" int bmnas_conv1x1_bwd_data_sdpa(const float* dU, const float* W, int 
   return 0;
 }
 
-extern "C" int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* srcs, int n_src,
-                                        int C_src, float* dW, int ldw, float* dbias, int dup_cols,
-                                        int b, int L, int M, void* stream) {
+namespace {
+// fill the weight-gradient arguments; waves = waves per workgroup of the kernel that will run them
+int fill_w_args(ConvWArgs& a, const float* dU, const float* const* srcs, int n_src, int C_src, float* dW,
+                int ldw, float* dbias, int dup_cols, int b, int L, int M, int waves, dim3* grid) {
   if (!dU || !srcs || !dW || n_src < 1 || C_src < 1 || b < 0 || M < 1 || dup_cols < 0)
     return BMNAS_E_ARG;
   if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
   if (C_src % 16 || M % 16 || ldw < n_src * C_src + dup_cols) return BMNAS_E_SHAPE;
-  ConvWArgs a{};
   if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
-  if (b == 0) return 0;
   for (int q = 0; q < n_src; ++q) {
     if (!srcs[q]) return BMNAS_E_ARG;
     a.src.p[q] = srcs[q];
@@ -1043,17 +1069,102 @@ extern "C" int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* src
   a.dU = dU; a.dW = dW; a.dbias = dbias; a.ldw = ldw; a.C_src = C_src; a.M = M;
   a.K = n_src * C_src; a.dup_cols = dup_cols; a.b = b; a.L = L;
   const int tiles = ((M + 31) / 32) * ((a.K + 31) / 32);
-  // about one 8-wave workgroup per CU (all resident at once), at most 8 n-groups per wave
-  // (64 per split), never fewer than one group per wave
-  int splits = (256 + tiles - 1) / tiles;
+  // splits of the batch: as many as keep the grid at <= ~256 eight-wave workgroups (measured at
+  // 108 tiles: 2 splits 9.1 us, 3: 10.9, 4: 9.8, 1: 16.8 — every extra split is another round of
+  // fp32 atomics on dW), at most 8 n-groups per wave per split, never fewer than one
+  int splits = (256 * 8 / waves) / tiles;
+  {
+    static const int forced = []() { const char* e = getenv("BMNAS_CONVW_SPLITS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) splits = forced;
+  }
   const int max_splits = (a.n_groups + 7) / 8;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   a.groups_per_split = (a.n_groups + splits - 1) / splits;
   splits = (a.n_groups + a.groups_per_split - 1) / a.groups_per_split;
   a.use_atomic = splits > 1;
-  dim3 grid((M + 31) / 32, (a.K + 31) / 32, splits);
+  *grid = dim3((M + 31) / 32, (a.K + 31) / 32, splits);
+  return 0;
+}
+}  // namespace
+
+extern "C" int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* srcs, int n_src,
+                                        int C_src, float* dW, int ldw, float* dbias, int dup_cols,
+                                        int b, int L, int M, void* stream) {
+  ConvWArgs a{};
+  dim3 grid;
+  if (int e = fill_w_args(a, dU, srcs, n_src, C_src, dW, ldw, dbias, dup_cols, b, L, M, 8, &grid)) return e;
+  if (b == 0) return 0;
   hipLaunchKernelGGL(conv_w_k, grid, dim3(512), 0, (hipStream_t)stream, a);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int ldw, int fold_cols,
+                                          float* const* dsrcs, int n_src, int C_src,
+                                          uint32_t accumulate_mask, int b, int L, int M,
+                                          const float* const* wsrcs, float* dW, int ldw_grad,
+                                          float* dbias, int dup_cols, const float* g,
+                                          const float* gscale, const float* x, const float* y,
+                                          const float* ln_w, const float* xhat, const float* stats,
+                                          float* dx, float* dy, uint32_t sdpa_accumulate_mask, int C,
+                                          bmnas_dropout_t drop, void* stream) {
+  if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
+  if (!g || !x || !y || !ln_w || !xhat || !stats || !dx) return BMNAS_E_ARG;
+  if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
+  if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
+  if (C_src % 16 || M % 16 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
+  for (int q = 0; q < n_src; ++q)
+    if (dsrcs[q] == dx || (dy && dsrcs[q] == dy)) return BMNAS_E_ARG;
+  ConvWArgs w{};
+  dim3 wgrid;
+  if (int e = fill_w_args(w, dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, 4, &wgrid))
+    return e;
+  ConvArgs a{};
+  if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
+  SdpaBwdArgs s{};
+  if (int e = geom(b, C, L, &s.G)) return e;
+  if (b == 0) return 0;
+  a.act.p[0] = dU;
+  for (int q = 0; q < n_src; ++q) a.dst.p[q] = dsrcs[q];
+  a.W = W; a.bias = nullptr; a.part = nullptr; a.ldw = ldw;
+  a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
+  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = 0; a.fold = fold_cols;
+  s.g = g; s.gscale = gscale; s.x = x; s.y = y; s.ln_w = ln_w; s.xhat = xhat; s.stats = stats;
+  s.dx = dx; s.dy = dy; s.acc_mask = sdpa_accumulate_mask; s.drop = to_cfg(drop);
+  s.groups = (b + s.G.spw - 1) / s.G.spw;
+  hipStream_t st = (hipStream_t)stream;
+  const int kch = sdpa_kch(C);
+  bool done = false;
+  if (a.I == 3 * C && C % 64 == 0 && kch <= 4) {
+    const long jt = a.J / 16, ng = a.n_groups;
+    const bool big = ((ng + 1) / 2) * ((jt + 1) / 2) >= 1024 && 3 * kch * 16 + 16 <= 232;
+    const int TNv = big ? 2 : 1;
+    if (3 * kch * 4 * (2 * TNv) + 4 * TNv * TNv <= 232) {
+      const int gx = (a.n_groups + TNv - 1) / TNv, gy = (a.J / 16 + TNv - 1) / TNv;
+      const int n_data = gx * gy, n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
+      dim3 grid((unsigned)(s.groups + n_data + n_w));
+      const size_t lds = sdpa_bwd_lds(C);
+#define ALL_CASE(T, K)                                                                                 \
+  if (!done && TNv == T && kch == K) {                                                                 \
+    hipLaunchKernelGGL((conv_bwd_all_k<T, T, K>), grid, dim3(256), lds, st, a, s, w, gx, n_data,       \
+                       (int)wgrid.x, (int)wgrid.y);                                                    \
+    done = true;                                                                                       \
+  }
+      ALL_CASE(1, 1) ALL_CASE(1, 2) ALL_CASE(1, 3) ALL_CASE(1, 4)
+      ALL_CASE(2, 1) ALL_CASE(2, 2) ALL_CASE(2, 3) ALL_CASE(2, 4)
+#undef ALL_CASE
+    }
+  }
+  if (!done) {                                       // shape outside the merged kernels: three launches
+    if (int e = bmnas_conv1x1_bwd_data(dU, W, ldw, fold_cols, dsrcs, n_src, C_src, accumulate_mask, b, L, M,
+                                       stream))
+      return e;
+    if (int e = bmnas_sdpa_ln_bwd(g, gscale, x, y, ln_w, xhat, stats, dx, dy, sdpa_accumulate_mask, b, C, L,
+                                  drop, stream))
+      return e;
+    return bmnas_conv1x1_bwd_weight(dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, stream);
+  }
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
