@@ -269,6 +269,7 @@ def main():
     torch.manual_seed(2)                         # the mains' default --seed 2
     model = HyperNet(c).to(device).train()
     from bmnas import nn as bnn
+    from bmnas.functions import unit_grad
     crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
     xs, y = synth_batch(c, a.batch, device, seed=rank)
     params = [p for p in model.parameters()]
@@ -313,7 +314,7 @@ def main():
             for t, g in zip(xs, grads[len(shared):]):
                 t.grad = g
         else:
-            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+            grads = torch.autograd.grad(loss, leaves, grad_outputs=unit_grad(device), allow_unused=True)
             for t, g in zip(leaves, grads):
                 t.grad = g
         return loss

@@ -262,7 +262,7 @@ class MixedSaved:
     pass
 
 
-def node_mixed_fwd(x, y, gamma_row, P, training, ln=None):
+def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None):
     """NodeMixedOp.forward (node_operations.py:118-120).  P: parameter pack of one NodeMixedOp
     (see models.search.darts.node_operations.NodeMixedOp.pack()).  x may be y (search).
     ln = (resid, ln_w, ln_b, stats): fuse the NodeCell tail `out += x; ln(out)` (node_search.py:67-68)
@@ -282,11 +282,11 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None):
     sv.merged = same and FUSE_ATTN_GEMM
     if sv.merged:
         U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C,
-                                  attn=(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, C, sv.d_attn))
+                                  attn=(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, C, sv.d_attn), Weff=Weff)
     else:
         with _Fork(x.device) as fork:
             fork.side(lambda: lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, b, C, L, sv.d_attn))
-            U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C)
+            U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C, Weff=Weff)
     out = torch.empty_like(x)
     if ln is None:
         lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc)
@@ -302,16 +302,19 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None):
 FUSE_ATTN_GEMM = os.environ.get('BMNAS_FUSE_ATTN_GEMM', '1') != '0'
 # ... and the weight-gradient GEMM joins the backward launch
 FUSE_BWD_ALL = os.environ.get('BMNAS_FUSE_BWD_ALL', '1') != '0'
+# arch softmaxes + folded conv weights of a cell in one launch
+FUSE_PROLOGUE = os.environ.get('BMNAS_FUSE_PROLOGUE', '1') != '0'
 
 
-def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None):
+def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None, Weff=None):
     # stacked [LinearGLU | ConcatFC] conv + BN
     if same:
         # conv(cat[z, z]) = (W[:, :C] + W[:, C:]) z: K is C instead of 2C.  The halves are added once
         # into a folded copy (2.3 us); letting the GEMMs add them while fetching their operand
         # (fold_cols of the C ABI) was measured slower: +4 us per GEMM for the doubled weight loads.
-        Weff = _empty(x, 3 * C, C)
-        lib.fold_weight(P.stack_W, Weff, 3 * C, C)
+        if Weff is None:                     # (the fused cell folds every node's weights up front)
+            Weff = _empty(x, 3 * C, C)
+            lib.fold_weight(P.stack_W, Weff, 3 * C, C)
         U, chan, sv.conv = conv_bn_fwd([x], C, Weff, C, P.stack_bias, P.stack_bn_w, P.stack_bn_b,
                                        P.stack_rm, P.stack_rv, P.stack_nbt, training, dup=C, attn=attn)
     else:
@@ -397,7 +400,7 @@ FUSE_TAIL = True   # node_multiplier == 1: NodeMixedOp + residual + LayerNorm in
 FUSE_PAIR = True   # search mode: cell-level mixed sum + the node's first inner sum in one launch
 
 
-def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None):
+def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=None):
     """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
     device tensors.  NP: parameter pack of the NodeCell.  z0: the first inner mixed sum when the
     caller already formed it (bmnas_mixsum_pair_fwd)."""
@@ -414,7 +417,8 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None):
         z = z0 if (t == 0 and z0 is not None) else mixsum_fwd(states, beta_w[offset:, 1])
         last = sv.fused_tail and t == ns - 1
         s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
-                                (x, NP.ln_w, NP.ln_b, sv.stats) if last else None)
+                                (x, NP.ln_w, NP.ln_b, sv.stats) if last else None,
+                                None if weffs is None else weffs[t])
         sv.zs.append(z)
         sv.mixed.append(msv)
         sv.offsets.append(offset)
@@ -490,7 +494,7 @@ class CellSaved:
     pass
 
 
-def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm):
+def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, weffs=None):
     """FusionCell.forward (model_search.py:50-68) with the step nodes in search mode
     (FusionNode(x, x), model_search.py:59).  alpha_w (k, 2) softmaxed device tensor."""
     N = len(xs)
@@ -506,7 +510,8 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm):
             lib.mixsum_pair_fwd(states, alpha_w[offset:, 1], 2, beta_ws[i][:, 1], 2, sif, z0)
         else:
             sif, z0 = mixsum_fwd(states, alpha_w[offset:, 1]), None
-        out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm, z0)
+        out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm, z0,
+                                 None if weffs is None else weffs[i * ns:(i + 1) * ns])
         nsv.paired = z0 is not None
         sv.sifs.append(sif)
         sv.nodes.append(nsv)

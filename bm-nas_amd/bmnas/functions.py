@@ -244,16 +244,25 @@ class FusedCellFn(Function):
         if alpha_is_logits:
             logits = [_c(alpha)] + logits
         ws = [torch.empty_like(t) for t in logits]
-        lib.arch_softmax_multi(logits, None, ws, False)          # every arch tensor, one launch
+        CP = cell.pack()
+        # every arch softmax and (search mode: conv applied to cat[z, z]) every NodeMixedOp's folded
+        # conv weight in ONE launch
+        mixed = [m for n in CP.nodes for m in n.mixed]
+        C_ = xs[0].shape[1]
+        weffs = None
+        if K.FUSE_PROLOGUE and 0 < len(mixed) <= 8:
+            weffs = [torch.empty((3 * C_, C_), device=dev, dtype=torch.float32) for _ in mixed]
+            lib.cell_prologue(logits, ws, [m.stack_W for m in mixed], weffs, 3 * C_, C_)
+        else:
+            lib.arch_softmax_multi(logits, None, ws, False)      # every arch tensor, one launch
         if alpha_is_logits:
             alpha_w, ws = ws[0], ws[1:]
         else:
             alpha_w = _c(alpha)
         beta_ws, gamma_ws = ws[0::2], ws[1::2]
         ctx.alpha_is_logits = alpha_is_logits
-        CP = cell.pack()
         out, sv = K.fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S,
-                                    cell._multiplier, cell.args.node_steps, cell.args.node_multiplier)
+                                    cell._multiplier, cell.args.node_steps, cell.args.node_multiplier, weffs)
         ctx.cell, ctx.sv, ctx.beta_ws, ctx.gamma_ws, ctx.N, ctx.S = cell, sv, beta_ws, gamma_ws, N, S
         ctx.dev = dev
         return out
@@ -312,6 +321,22 @@ class LinearFn(Function):
         return dfeat, dW, db
 
 
+_UNIT = {}
+
+
+def unit_grad(device):
+    """A cached 0-dim tensor holding 1.0 to pass as `grad_outputs` / `loss.backward(gradient=...)`.
+    autograd otherwise launches a fill kernel for ones_like(loss) and our loss functions a multiply
+    by it; when the incoming gradient IS this constant the criterion hands its stored dloss/dlogits
+    back untouched (two ~4 us launches less per step; same numbers)."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), device=f'{key[0]}:{key[1]}', dtype=torch.float32)
+    return t
+
+
 class _LossFn(Function):
     """mean loss with dloss/dlogits produced in the forward pass."""
 
@@ -323,6 +348,9 @@ class _LossFn(Function):
     @staticmethod
     def backward(ctx, gl):
         (dz,) = ctx.saved_tensors
+        u = _UNIT.get((gl.device.type, gl.device.index))
+        if u is not None and gl.data_ptr() == u.data_ptr():
+            return dz, None                      # gradient of the loss is the constant 1
         return dz * gl, None
 
 

@@ -9,6 +9,7 @@ the kernels add a DEVICE counter to their Philox offsets and the graph advances 
 import torch
 
 from . import cell as K
+from .functions import unit_grad
 
 
 class GraphedStep:
@@ -90,8 +91,11 @@ class GraphedTrainStep:
             if isinstance(logits, tuple):
                 logits = logits[-1]
             loss = criterion(logits, self.labels)
-            grads = torch.autograd.grad(loss * scale if reducer is not None else loss, self.targets,
-                                        allow_unused=True)
+            if reducer is not None:
+                grads = torch.autograd.grad(loss * scale, self.targets, allow_unused=True)
+            else:
+                grads = torch.autograd.grad(loss, self.targets, grad_outputs=unit_grad(loss.device),
+                                            allow_unused=True)
             if reducer is not None:
                 have = [(v, g) for v, g in zip(views, grads) if g is not None]
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])

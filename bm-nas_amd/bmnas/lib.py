@@ -78,6 +78,7 @@ SIGNATURES = {
     'bmnas_adam_multi': ([_P, _P, _I, _P, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
+    'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
                                  _P], _I),
 }
@@ -363,6 +364,19 @@ def adam_multi(table, chunks, n_chunks, hyp):
     hyp: float32 device (rows, 8)."""
     _check(load().bmnas_adam_multi(table.data_ptr(), chunks.data_ptr(), n_chunks, hyp.data_ptr(), _stream()),
            'adam_multi')
+
+
+def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc):
+    """Row softmax of every arch tensor + folded conv weights of every NodeMixedOp, one launch."""
+    n = len(a_list)
+    rows = (C.c_int * max(n, 1))(*[t.shape[0] for t in a_list])
+    cols = (C.c_int * max(n, 1))(*[t.shape[1] for t in a_list])
+    pa = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in a_list])
+    po = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in out_list])
+    nf = len(Ws)
+    pw = (C.c_void_p * max(nf, 1))(*[t.data_ptr() for t in Ws])
+    pe = (C.c_void_p * max(nf, 1))(*[t.data_ptr() for t in Weffs])
+    _check(load().bmnas_cell_prologue(pa, po, rows, cols, n, pw, pe, nf, M, Cc, _stream()), 'cell_prologue')
 
 
 def arch_softmax_multi(a_list, dw_list, out_list, backward, n_shards=1, shard_stride=0):

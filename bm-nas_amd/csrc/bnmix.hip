@@ -576,6 +576,49 @@ inline int pick_chunk(int b, int slots4) {
   return b >= 32 ? 8 : 4;
 }
 
+// ---- cell prologue: everything a FusionCell forward needs before its first data kernel, in
+// ONE launch — the row softmax of every architecture tensor (alpha, betas, gammas) and the folded
+// conv weights Weff = W[:, :C] + W[:, C:] of every NodeMixedOp (search mode feeds cat[z, z]).
+// Three 4-us launches (2 folds + softmax at MM-IMDB) become one.
+constexpr int kMaxFold = 8;
+struct FoldPack {
+  const float* W[kMaxFold];
+  float* Weff[kMaxFold];
+  int n, M, C, blocks_per;
+};
+
+__global__ __launch_bounds__(256) void cell_prologue_k(ArchPack P, FoldPack F) {
+  const int nfb = F.n * F.blocks_per;
+  if ((int)blockIdx.x < nfb) {
+    const int q = blockIdx.x / F.blocks_per, bi = blockIdx.x - q * F.blocks_per;   // workgroup-uniform
+    const float* __restrict__ W = F.W[q];
+    float* __restrict__ We = F.Weff[q];
+    const int c4n = F.C / 4;
+    const int total = F.M * c4n;
+    for (int i = bi * 256 + threadIdx.x; i < total; i += F.blocks_per * 256) {
+      const int m = i / c4n, c4 = i - m * c4n;
+      const float* r = W + (int64_t)m * 2 * F.C + 4 * c4;
+      st4(We + (int64_t)m * F.C + 4 * c4, f4_add(ld4(r), ld4(r + F.C)));
+    }
+    return;
+  }
+  int r = (blockIdx.x - nfb) * 256 + threadIdx.x;
+  for (int t = 0; t < P.n; ++t) {
+    if (r < P.rows[t]) {
+      const int cols = P.cols[t];
+      const float* a = P.a[t] + r * cols;
+      float* o = P.o[t] + r * cols;
+      float mx = a[0];
+      for (int p = 1; p < cols; ++p) mx = fmaxf(mx, a[p]);
+      float den = 0.f;
+      for (int p = 0; p < cols; ++p) den += expf(a[p] - mx);
+      for (int p = 0; p < cols; ++p) o[p] = expf(a[p] - mx) / den;
+      return;
+    }
+    r -= P.rows[t];
+  }
+}
+
 }  // namespace
 
 extern "C" int bmnas_version(void) { return 100; }
@@ -770,6 +813,43 @@ extern "C" int bmnas_arch_softmax_multi(const float* const* a, const float* cons
   }
   hipLaunchKernelGGL(arch_softmax_multi_k, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, P,
                      backward);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, const int* rows,
+                                   const int* cols, int n_arch, const float* const* W,
+                                   float* const* Weff, int n_fold, int M, int C, void* stream) {
+  if (n_arch < 0 || n_fold < 0 || (n_arch > 0 && (!a || !out || !rows || !cols)) ||
+      (n_fold > 0 && (!W || !Weff || M < 1 || C < 1)))
+    return BMNAS_E_ARG;
+  if (n_arch > BMNAS_MAX_PTRS || n_fold > kMaxFold) return BMNAS_E_LIMIT;
+  if (n_fold > 0 && C % 4) return BMNAS_E_SHAPE;
+  ArchPack P{};
+  int total = 0;
+  for (int t = 0; t < n_arch; ++t) {
+    if (!a[t] || !out[t] || rows[t] < 1 || cols[t] < 1 || cols[t] > 4) return BMNAS_E_ARG;
+    P.a[t] = a[t];
+    P.o[t] = out[t];
+    P.rows[t] = rows[t];
+    P.cols[t] = cols[t];
+    total += rows[t];
+  }
+  P.n = n_arch;
+  P.n_shards = 1;
+  FoldPack F{};
+  for (int q = 0; q < n_fold; ++q) {
+    if (!W[q] || !Weff[q]) return BMNAS_E_ARG;
+    F.W[q] = W[q];
+    F.Weff[q] = Weff[q];
+  }
+  F.n = n_fold; F.M = M; F.C = C;
+  int per = n_fold > 0 ? (int)(((int64_t)M * (C / 4) + 255) / 256) : 0;
+  if (per > 128) per = 128;
+  F.blocks_per = per;
+  const int blocks = n_fold * per + (total + 255) / 256;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(cell_prologue_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, F);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

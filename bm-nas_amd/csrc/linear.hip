@@ -90,15 +90,15 @@ __global__ __launch_bounds__(256) void linear_fwd_k(const float* __restrict__ fe
 // along k.  Both kernels are built for ONE memory round trip per wave (the first version
 // walked 8 row blocks x 6 steps + 32 steps serially per wave: 22 us for 100 MFLOP).
 //   dfeat[m][k] = gs * sum_o g[m][o] W[o][k]    one wave per (16 samples, 16 k): D[k][m]
-__global__ __launch_bounds__(256) void linear_dfeat_k(const float* __restrict__ g,
-                                                      const float* __restrict__ gscale,
-                                                      const float* __restrict__ W,
-                                                      float* __restrict__ dfeat, int b, int O, int K) {
+__device__ __forceinline__ void linear_dfeat_body(const int bx, const int by, const float* __restrict__ g,
+                                                  const float* __restrict__ gscale,
+                                                  const float* __restrict__ W,
+                                                  float* __restrict__ dfeat, int b, int O, int K) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
-  const int kt = blockIdx.x * 4 + wave;
+  const int kt = bx * 4 + wave;
   if (kt * 16 >= K) return;
-  const int k0 = kt * 16, m0 = blockIdx.y * 16;
+  const int k0 = kt * 16, m0 = by * 16;
   int mc = m0 + lo;
   mc = mc < b ? mc : b - 1;
   const float gs = (gscale != nullptr) ? gscale[0] : 1.f;
@@ -120,14 +120,14 @@ __global__ __launch_bounds__(256) void linear_dfeat_k(const float* __restrict__ 
 //   dW[o][k] = gs * sum_m g[m][o] feat[m][k]    workgroup = one 16-k block, its 4 waves split
 //   the samples, partial tiles are summed through LDS:  D[k][o]
 template <int TJ>
-__global__ __launch_bounds__(256) void linear_dw_k(const float* __restrict__ g,
-                                                   const float* __restrict__ gscale,
-                                                   const float* __restrict__ feat,
-                                                   float* __restrict__ dW, int b, int O, int K) {
+__device__ __forceinline__ void linear_dw_body(const int bx, const float* __restrict__ g,
+                                               const float* __restrict__ gscale,
+                                               const float* __restrict__ feat,
+                                               float* __restrict__ dW, int b, int O, int K) {
   __shared__ float4 part[4][TJ][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
-  const int k0 = blockIdx.x * 16;
+  const int k0 = bx * 16;
   const float gs = (gscale != nullptr) ? gscale[0] : 1.f;
   const int msteps = (b + 3) / 4;
   const int per = (msteps + 3) / 4;
@@ -166,15 +166,34 @@ __global__ __launch_bounds__(256) void linear_dw_k(const float* __restrict__ g,
 }
 
 // dbias[o] = gs * sum_m g[m][o]
-__global__ __launch_bounds__(256) void linear_dbias_k(const float* __restrict__ g,
-                                                      const float* __restrict__ gscale,
-                                                      float* __restrict__ dbias, int b, int O) {
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per class
+__device__ __forceinline__ void linear_dbias_body(const int bx, const float* __restrict__ g,
+                                                  const float* __restrict__ gscale,
+                                                  float* __restrict__ dbias, int b, int O) {
+  const int o = bx * 4 + (threadIdx.x >> 6);                  // one wave per class
   if (o >= O) return;
   float s = 0.f;
   for (int m = threadIdx.x & 63; m < b; m += 64) s += g[(int64_t)m * O + o];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) dbias[o] = s * ((gscale != nullptr) ? gscale[0] : 1.f);
+}
+
+// the three backward products are independent: one grid carries them all (dfeat tiles first,
+// then the dW blocks, then the bias rows); three launches of 3-4 us each took 12.6 us
+template <int TJ>
+__global__ __launch_bounds__(256) void linear_bwd_k(const float* __restrict__ g,
+                                                    const float* __restrict__ gscale,
+                                                    const float* __restrict__ feat,
+                                                    const float* __restrict__ W, float* __restrict__ dfeat,
+                                                    float* __restrict__ dW, float* __restrict__ dbias, int b,
+                                                    int O, int K, int fx, int n_feat, int n_dw) {
+  const int blk = blockIdx.x;
+  if (blk < n_feat) {
+    linear_dfeat_body(blk % fx, blk / fx, g, gscale, W, dfeat, b, O, K);
+  } else if (blk < n_feat + n_dw) {
+    linear_dw_body<TJ>(blk - n_feat, g, gscale, feat, dW, b, O, K);
+  } else {
+    linear_dbias_body(blk - n_feat - n_dw, g, gscale, dbias, b, O);
+  }
 }
 
 // ---- losses (mean reduction) with the logits gradient produced in the same pass -----------
@@ -277,21 +296,17 @@ extern "C" int bmnas_linear_bwd(const float* g, const float* gscale, const float
   if (tj > kMaxTJ) return BMNAS_E_LIMIT;
   hipStream_t st = (hipStream_t)stream;
   const int kt = K / 16;
-  if (dfeat) {
-    hipLaunchKernelGGL(linear_dfeat_k, dim3((kt + 3) / 4, (b + 15) / 16), dim3(256), 0, st, g, gscale, W,
-                       dfeat, b, O, K);
-    BMNAS_CHECK_LAUNCH();
-  }
-  if (dW) {
-#define CALL(T) hipLaunchKernelGGL(linear_dw_k<T>, dim3(kt), dim3(256), 0, st, g, gscale, feat, dW, b, O, K)
-    LIN_DISPATCH(tj, CALL)
+  const int fx = (kt + 3) / 4;
+  const int n_feat = dfeat ? fx * ((b + 15) / 16) : 0;
+  const int n_dw = dW ? kt : 0;
+  const int n_db = dbias ? (O + 3) / 4 : 0;
+  if (n_feat + n_dw + n_db == 0) return 0;
+#define CALL(T)                                                                                         \
+  hipLaunchKernelGGL(linear_bwd_k<T>, dim3(n_feat + n_dw + n_db), dim3(256), 0, st, g, gscale, feat, W, \
+                     dfeat, dW, dbias, b, O, K, fx, n_feat, n_dw)
+  LIN_DISPATCH(tj, CALL)
 #undef CALL
-    BMNAS_CHECK_LAUNCH();
-  }
-  if (dbias) {
-    hipLaunchKernelGGL(linear_dbias_k, dim3((O + 3) / 4), dim3(256), 0, st, g, gscale, dbias, b, O);
-    BMNAS_CHECK_LAUNCH();
-  }
+  BMNAS_CHECK_LAUNCH();
   return 0;
 }
 

@@ -275,6 +275,12 @@ int bmnas_arch_softmax_bwd(const float* w, const float* dw, float* dlogits, int 
 int bmnas_arch_softmax_multi(const float* const* a, const float* const* dw, float* const* out,
                              const int* rows, const int* cols, int n, int backward, int n_shards,
                              int64_t shard_stride, void* stream);
+/* The forward prologue of a FusionCell in ONE launch: the n_arch row softmaxes of
+ * bmnas_arch_softmax_multi (forward) and, for each of n_fold (<= 8) NodeMixedOps of the cell,
+ * Weff[q] (M, C) = W[q][:, :C] + W[q][:, C:] as bmnas_fold_weight does (W[q] is (M, 2C)). */
+int bmnas_cell_prologue(const float* const* a, float* const* out, const int* rows, const int* cols,
+                        int n_arch, const float* const* W, float* const* Weff, int n_fold, int M,
+                        int C, void* stream);
 
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at
