@@ -110,8 +110,10 @@ class Arena:
         self.total += (n + 3) // 4 * 4
         return len(self.req) - 1
 
-    def alloc(self, device):
-        self.buf = torch.zeros(self.total, device=device, dtype=torch.float32)
+    def alloc(self, device, zero=True):
+        """zero=False: the caller has the first kernel of its backward clear the buffer
+        (the `scrub` side job of bmnas_cat_ln_bwd) instead of paying a memset launch."""
+        self.buf = (torch.zeros if zero else torch.empty)(self.total, device=device, dtype=torch.float32)
         return self
 
     def view(self, idx):
@@ -535,7 +537,7 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
     tail = slots[-M:]
     bufs, mask = _write_group(tail)
     lib.cat_ln_bwd(g, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, bufs, None, mask, None, None,
-                   b, C, L, True)
+                   b, C, L, True, getattr(CG, 'scrub', None))
     deferred = Deferred()
     _ln_affine(deferred, g, None, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, CG.dln_w, CG.dln_b,
                b, C, L, True, False)

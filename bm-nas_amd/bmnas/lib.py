@@ -41,7 +41,7 @@ SIGNATURES = {
     'bmnas_mixsum_pair_bwd': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _U32, _I64, _P],
                               _I),
     'bmnas_cat_ln_fwd': ([_PP, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
-    'bmnas_cat_ln_bwd': ([_P, _PP, _I, _P, _P, _P, _P, _PP, _P, _U32, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_cat_ln_bwd': ([_P, _PP, _I, _P, _P, _P, _P, _PP, _P, _U32, _P, _P, _I, _I, _I, _I, _P, _I64, _P], _I),
     'bmnas_ln_affine_bwd': ([_P, _P, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     'bmnas_ln_affine_bwd_multi': ([_I, _PP, _PP, C.POINTER(_PP), C.POINTER(C.c_int), _PP, _PP, _PP, _PP, _PP,
                                   _PP, _I, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _P],
@@ -177,10 +177,13 @@ def cat_ln_fwd(srcs, resid, ln_w, ln_b, out, stats, b, Cc, L, relu):
                                    _ptr(out), _ptr(stats), b, Cc, L, int(relu), _stream()), 'cat_ln_fwd')
 
 
-def cat_ln_bwd(g, srcs, resid, ln_w, ln_b, stats, dsrcs, dresid, acc_mask, dln_w, dln_b, b, Cc, L, relu):
+def cat_ln_bwd(g, srcs, resid, ln_w, ln_b, stats, dsrcs, dresid, acc_mask, dln_w, dln_b, b, Cc, L, relu,
+               scrub=None):
+    """scrub: a flat fp32 tensor (numel % 4 == 0) that the launch also zero-fills."""
     _check(load().bmnas_cat_ln_bwd(_ptr(g), _ptrs(srcs), len(srcs), _ptr(resid), _ptr(ln_w), _ptr(ln_b),
                                    _ptr(stats), _ptrs(dsrcs), _ptr(dresid), acc_mask, _ptr(dln_w),
-                                   _ptr(dln_b), b, Cc, L, int(relu), _stream()), 'cat_ln_bwd')
+                                   _ptr(dln_b), b, Cc, L, int(relu), _ptr(scrub),
+                                   0 if scrub is None else scrub.numel(), _stream()), 'cat_ln_bwd')
 
 
 def ln_affine_bwd(g, gscale, srcs, resid, ln_w, ln_b, stats, dln_w, dln_b, b, Cc, L, relu, prenorm):

@@ -87,9 +87,13 @@ __global__ __launch_bounds__(256) void cat_ln_bwd_k(const float* __restrict__ g,
                                                     const float* __restrict__ ln_b,
                                                     const float* __restrict__ stats, LnDst dsrcs,
                                                     float* dresid, uint32_t acc_mask, float* dln_w,
-                                                    float* dln_b, int cl4, int d4, int relu) {
+                                                    float* dln_b, int cl4, int d4, int relu,
+                                                    float* __restrict__ scrub, int64_t scrub4) {
   __shared__ float red[4];
   const int s = blockIdx.x;
+  // side job: clear the caller's accumulation arena (saves a memset launch per backward)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < scrub4; i += (int64_t)gridDim.x * 256)
+    st4(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   const float mean = stats[2 * s], rstd = stats[2 * s + 1];
   float4 xh[VPT], dxh[VPT];
   float s1 = 0.f, s2 = 0.f;
@@ -292,9 +296,10 @@ extern "C" int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_
                                 const float* resid, const float* ln_w, const float* ln_b,
                                 const float* stats, float* const* dsrcs, float* dresid,
                                 uint32_t accumulate_mask, float* dln_w, float* dln_b, int b, int C,
-                                int L, int relu, void* stream) {
+                                int L, int relu, float* scrub, int64_t scrub_n, void* stream) {
   if (!g || !srcs || !ln_w || !ln_b || !stats || !dsrcs || n_src < 1 || b < 0 || C < 1 || L < 1)
     return BMNAS_E_ARG;
+  if (scrub_n < 0 || (scrub_n > 0 && !scrub) || scrub_n % 4) return BMNAS_E_ARG;
   if ((dln_w == nullptr) != (dln_b == nullptr)) return BMNAS_E_ARG;
   if (n_src > 4) return BMNAS_E_LIMIT;
   if (resid && n_src != 1) return BMNAS_E_ARG;
@@ -310,7 +315,7 @@ extern "C" int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_
   const int cl4 = C * L / 4, d4 = cl4 * n_src;
   const int vpt = pick_vpt(d4);
   hipStream_t st = (hipStream_t)stream;
-#define CALL(V) hipLaunchKernelGGL(cat_ln_bwd_k<V>, dim3(b), dim3(256), 0, st, g, s, resid, ln_w, ln_b, stats, d, dresid, accumulate_mask, dln_w, dln_b, cl4, d4, relu)
+#define CALL(V) hipLaunchKernelGGL(cat_ln_bwd_k<V>, dim3(b), dim3(256), 0, st, g, s, resid, ln_w, ln_b, stats, d, dresid, accumulate_mask, dln_w, dln_b, cl4, d4, relu, scrub, scrub_n / 4)
   LN_DISPATCH(vpt, CALL)
 #undef CALL
   BMNAS_CHECK_LAUNCH();

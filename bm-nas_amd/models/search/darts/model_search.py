@@ -70,8 +70,8 @@ class FusionCell(nn.Module):
         hg = [arena.ask(*t.shape) for t in gamma_ws]
         stride = arena.total - base
         arena.total += stride * (ARCH_SHARDS - 1)
-        arena.alloc(device)
-        CG = Pack(nodes=[n.node_cell.bind_grads(arena, h) for n, h in zip(self._step_nodes, hn)],
+        arena.alloc(device, zero=False)      # cleared by the first kernel of the backward (K7's)
+        CG = Pack(scrub=arena.buf, nodes=[n.node_cell.bind_grads(arena, h) for n, h in zip(self._step_nodes, hn)],
                   dln_w=arena.view(hl[0]), dln_b=arena.view(hl[1]), shards=ARCH_SHARDS, shard_stride=stride)
         for g in CG.nodes:
             g.shards, g.shard_stride = ARCH_SHARDS, stride

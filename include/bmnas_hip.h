@@ -101,11 +101,14 @@ int bmnas_cat_ln_fwd(const float* const* srcs, int n_src, const float* resid, co
                      void* stream);
 /* g: gradient of `out`.  dsrcs[q] (NULL to skip) / dresid (NULL to skip) receive the input
  * gradient (acc bits: bit q for dsrcs[q], bit 31 for dresid); dln_w / dln_b += (atomic per
- * sample; pass NULL and use bmnas_ln_affine_bwd, which needs 16x fewer atomics). */
+ * sample; pass NULL and use bmnas_ln_affine_bwd, which needs 16x fewer atomics).
+ * scrub (nullable): scrub_n floats (multiple of 4) that the launch also zero-fills — the caller's
+ * gradient-accumulation arena, cleared without a memset launch of its own. */
 int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_src, const float* resid,
                      const float* ln_w, const float* ln_b, const float* stats,
                      float* const* dsrcs, float* dresid, uint32_t accumulate_mask,
-                     float* dln_w, float* dln_b, int b, int C, int L, int relu, void* stream);
+                     float* dln_w, float* dln_b, int b, int C, int L, int relu, float* scrub,
+                     int64_t scrub_n, void* stream);
 
 /* LayerNorm affine gradients (a reduction over samples, kept out of the per-sample kernels):
  * dln_w[e] += sum_s gy*x_hat, dln_b[e] += sum_s gy with gy = g * (*gscale) * relu-mask.
