@@ -102,24 +102,26 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
 // memory on its own — one workgroup per sample forms s, adds the residual X, keeps the sample
 // in registers for the two LayerNorm reductions and writes pre = s + X (saved for backward)
 // and out = LN(pre).  Saves one launch and 3 T of traffic per step node.
-template <int VPT>
-__global__ __launch_bounds__(256) void node_mix_ln_fwd_k(
+template <int VPT, int BS>
+__global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ p1,
     const float* __restrict__ U, const float* __restrict__ chan, const float* __restrict__ gamma,
     const float* __restrict__ resid, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
     float* __restrict__ pre, float* __restrict__ out, float* __restrict__ stats, int C, int L,
     DropCfg dglu, DropCfg dfc) {
-  __shared__ float red[4];
+  __shared__ float red[8];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   const int smp = blockIdx.x;
   const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
-  float4 v[VPT];
+  float4 v[VPT], lw[VPT], lb[VPT];
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int r = threadIdx.x + k * 256;
-    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r = threadIdx.x + k * BS;
+    v[k] = lw[k] = lb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < cl4) {
+      lw[k] = ld4(ln_w + (int64_t)r * 4);            // with the first round of loads, not after
+      lb[k] = ld4(ln_b + (int64_t)r * 4);            // the reductions
       const int c = r / l4n;
       const int64_t e = ((int64_t)smp * cl4 + r) * 4;
       const int64_t ub = ((int64_t)smp * M) * L + (int64_t)r * 4;
@@ -139,17 +141,17 @@ __global__ __launch_bounds__(256) void node_mix_ln_fwd_k(
     }
   }
   const float inv_d = 1.f / (float)(cl4 * 4);
-  const float mean = block_sum256(sum, red) * inv_d;
+  const float mean = block_sum<BS / 64>(sum, red) * inv_d;
   float sq = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int r = threadIdx.x + k * 256;
+    const int r = threadIdx.x + k * BS;
     if (r < cl4) {
       const float4 cdev = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
       sq += f4_dot(cdev, cdev);
     }
   }
-  const float var = block_sum256(sq, red) * inv_d;
+  const float var = block_sum<BS / 64>(sq, red) * inv_d;
   const float rstd = 1.f / sqrtf(var + kEps);
   if (threadIdx.x == 0) {
     stats[2 * smp] = mean;
@@ -157,9 +159,9 @@ __global__ __launch_bounds__(256) void node_mix_ln_fwd_k(
   }
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int r = threadIdx.x + k * 256;
+    const int r = threadIdx.x + k * BS;
     if (r < cl4) {
-      const float4 w = ld4(ln_w + (int64_t)r * 4), bb = ld4(ln_b + (int64_t)r * 4);
+      const float4 w = lw[k], bb = lb[k];
       st4(out + ((int64_t)smp * cl4 + r) * 4,
           make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
                       (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w));
@@ -662,13 +664,24 @@ extern "C" int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float
     return BMNAS_E_ARG;
   if (L % 4 || L > 16) return BMNAS_E_SHAPE;
   if (b == 0) return 0;
-  const int need = (C * L / 4 + 255) / 256;
+  const bool wide = b <= 256 && C * L / 4 >= 512;   // fewer samples than CUs: 8 waves per sample
+  const int bs = wide ? 512 : 256;
+  const int need = (C * L / 4 + bs - 1) / bs;
   hipStream_t st = (hipStream_t)stream;
 #define NML(V)                                                                                         \
-  hipLaunchKernelGGL(node_mix_ln_fwd_k<V>, dim3(b), dim3(256), 0, st, x, y, p1, U, chan, gamma, resid, \
-                     ln_w, ln_b, pre, out, stats, C, L, to_cfg(drop_glu), to_cfg(drop_fc))
+  do {                                                                                                 \
+    if (wide)                                                                                          \
+      hipLaunchKernelGGL((node_mix_ln_fwd_k<V, 512>), dim3(b), dim3(512), 0, st, x, y, p1, U, chan,    \
+                         gamma, resid, ln_w, ln_b, pre, out, stats, C, L, to_cfg(drop_glu),            \
+                         to_cfg(drop_fc));                                                             \
+    else                                                                                               \
+      hipLaunchKernelGGL((node_mix_ln_fwd_k<V, 256>), dim3(b), dim3(256), 0, st, x, y, p1, U, chan,    \
+                         gamma, resid, ln_w, ln_b, pre, out, stats, C, L, to_cfg(drop_glu),            \
+                         to_cfg(drop_fc));                                                             \
+  } while (0)
   if (need <= 1) NML(1);
   else if (need <= 2) NML(2);
+  else if (need <= 3) NML(3);
   else if (need <= 4) NML(4);
   else if (need <= 8) NML(8);
   else return BMNAS_E_LIMIT;

@@ -23,40 +23,44 @@ __device__ __forceinline__ const float* src_ptr(const LnSrc& s, int i4, int cl4,
   return s.p[q] + ((int64_t)sample * cl4 + off) * 4;
 }
 
-template <int VPT>
-__global__ __launch_bounds__(256) void cat_ln_fwd_k(LnSrc srcs, const float* __restrict__ resid,
+// BS = threads per workgroup: 512 when the batch leaves CUs idle (one workgroup per sample), so
+// that a sample is spread over twice the waves and each thread's dependent chain is half as long.
+template <int VPT, int BS>
+__global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __restrict__ resid,
                                                     const float* __restrict__ ln_w,
                                                     const float* __restrict__ ln_b,
                                                     float* __restrict__ out,
                                                     float* __restrict__ stats, int cl4, int d4,
                                                     int relu) {
-  __shared__ float red[4];
+  __shared__ float red[8];
   const int s = blockIdx.x;
-  float4 v[VPT];
+  float4 v[VPT], lw[VPT], lb[VPT];
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int i = threadIdx.x + k * 256;
+    const int i = threadIdx.x + k * BS;
     if (i < d4) {
       v[k] = ld4(src_ptr(srcs, i, cl4, s));
       if (resid != nullptr) v[k] = f4_add(v[k], ld4(resid + ((int64_t)s * d4 + i) * 4));
+      lw[k] = ld4(ln_w + (int64_t)i * 4);          // requested with the sample: no second round
+      lb[k] = ld4(ln_b + (int64_t)i * 4);          // trip after the two reductions
       sum += f4_hsum(v[k]);
     } else {
-      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[k] = lw[k] = lb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   const float inv_d = 1.f / (float)(d4 * 4);
-  const float mean = block_sum256(sum, red) * inv_d;
+  const float mean = block_sum<BS / 64>(sum, red) * inv_d;
   float sq = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int i = threadIdx.x + k * 256;
+    const int i = threadIdx.x + k * BS;
     if (i < d4) {
       const float4 c = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
       sq += f4_dot(c, c);
     }
   }
-  const float var = block_sum256(sq, red) * inv_d;
+  const float var = block_sum<BS / 64>(sq, red) * inv_d;
   const float rstd = 1.f / sqrtf(var + kEps);
   if (threadIdx.x == 0) {
     stats[2 * s] = mean;
@@ -64,9 +68,9 @@ __global__ __launch_bounds__(256) void cat_ln_fwd_k(LnSrc srcs, const float* __r
   }
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int i = threadIdx.x + k * 256;
+    const int i = threadIdx.x + k * BS;
     if (i < d4) {
-      const float4 w = ld4(ln_w + (int64_t)i * 4), bb = ld4(ln_b + (int64_t)i * 4);
+      const float4 w = lw[k], bb = lb[k];
       float4 o;
       o.x = (v[k].x - mean) * rstd * w.x + bb.x;
       o.y = (v[k].y - mean) * rstd * w.y + bb.y;
@@ -80,8 +84,8 @@ __global__ __launch_bounds__(256) void cat_ln_fwd_k(LnSrc srcs, const float* __r
   }
 }
 
-template <int VPT>
-__global__ __launch_bounds__(256) void cat_ln_bwd_k(const float* __restrict__ g, LnSrc srcs,
+template <int VPT, int BS>
+__global__ __launch_bounds__(BS) void cat_ln_bwd_k(const float* __restrict__ g, LnSrc srcs,
                                                     const float* __restrict__ resid,
                                                     const float* __restrict__ ln_w,
                                                     const float* __restrict__ ln_b,
@@ -89,17 +93,17 @@ __global__ __launch_bounds__(256) void cat_ln_bwd_k(const float* __restrict__ g,
                                                     float* dresid, uint32_t acc_mask, float* dln_w,
                                                     float* dln_b, int cl4, int d4, int relu,
                                                     float* __restrict__ scrub, int64_t scrub4) {
-  __shared__ float red[4];
+  __shared__ float red[8];
   const int s = blockIdx.x;
   // side job: clear the caller's accumulation arena (saves a memset launch per backward)
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < scrub4; i += (int64_t)gridDim.x * 256)
+  for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < scrub4; i += (int64_t)gridDim.x * BS)
     st4(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   const float mean = stats[2 * s], rstd = stats[2 * s + 1];
   float4 xh[VPT], dxh[VPT];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int i = threadIdx.x + k * 256;
+    const int i = threadIdx.x + k * BS;
     if (i < d4) {
       float4 x = ld4(src_ptr(srcs, i, cl4, s));
       if (resid != nullptr) x = f4_add(x, ld4(resid + ((int64_t)s * d4 + i) * 4));
@@ -134,11 +138,11 @@ __global__ __launch_bounds__(256) void cat_ln_bwd_k(const float* __restrict__ g,
     }
   }
   const float inv_d = 1.f / (float)(d4 * 4);
-  const float m1 = block_sum256(s1, red) * inv_d;
-  const float m2 = block_sum256(s2, red) * inv_d;
+  const float m1 = block_sum<BS / 64>(s1, red) * inv_d;
+  const float m2 = block_sum<BS / 64>(s2, red) * inv_d;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int i = threadIdx.x + k * 256;
+    const int i = threadIdx.x + k * BS;
     if (i < d4) {
       float4 dx;
       dx.x = rstd * (dxh[k].x - m1 - xh[k].x * m2);
@@ -246,10 +250,11 @@ __global__ __launch_bounds__(256) void ln_affine_bwd_k(LnAffineBatch B) {
   ln_affine_body(P, B.b, B.chunk, red);
 }
 
-inline int pick_vpt(int d4) {
-  const int need = (d4 + 255) / 256;
+inline int pick_vpt(int d4, int bs) {
+  const int need = (d4 + bs - 1) / bs;
   if (need <= 1) return 1;
   if (need <= 2) return 2;
+  if (need <= 3) return 3;
   if (need <= 4) return 4;
   if (need <= 8) return 8;
   if (need <= 16) return 16;
@@ -262,6 +267,7 @@ inline int pick_vpt(int d4) {
   switch (V) {                    \
     case 1: CALL(1); break;       \
     case 2: CALL(2); break;       \
+    case 3: CALL(3); break;       \
     case 4: CALL(4); break;       \
     case 8: CALL(8); break;       \
     case 16: CALL(16); break;     \
@@ -283,9 +289,14 @@ extern "C" int bmnas_cat_ln_fwd(const float* const* srcs, int n_src, const float
     s.p[q] = srcs[q];
   }
   const int cl4 = C * L / 4, d4 = cl4 * n_src;
-  const int vpt = pick_vpt(d4);
+  const bool wide = b <= 256 && d4 >= 512;          // fewer samples than CUs: 8 waves per sample
+  const int vpt = pick_vpt(d4, wide ? 512 : 256);
   hipStream_t st = (hipStream_t)stream;
-#define CALL(V) hipLaunchKernelGGL(cat_ln_fwd_k<V>, dim3(b), dim3(256), 0, st, s, resid, ln_w, ln_b, out, stats, cl4, d4, relu)
+#define CALL(V)                                                                                         \
+  do {                                                                                                  \
+    if (wide) hipLaunchKernelGGL((cat_ln_fwd_k<V, 512>), dim3(b), dim3(512), 0, st, s, resid, ln_w, ln_b, out, stats, cl4, d4, relu); \
+    else hipLaunchKernelGGL((cat_ln_fwd_k<V, 256>), dim3(b), dim3(256), 0, st, s, resid, ln_w, ln_b, out, stats, cl4, d4, relu);      \
+  } while (0)
   LN_DISPATCH(vpt, CALL)
 #undef CALL
   BMNAS_CHECK_LAUNCH();
@@ -313,9 +324,14 @@ extern "C" int bmnas_cat_ln_bwd(const float* g, const float* const* srcs, int n_
     d.p[q] = dsrcs[q];
   }
   const int cl4 = C * L / 4, d4 = cl4 * n_src;
-  const int vpt = pick_vpt(d4);
+  const bool wide = b <= 256 && d4 >= 512;
+  const int vpt = pick_vpt(d4, wide ? 512 : 256);
   hipStream_t st = (hipStream_t)stream;
-#define CALL(V) hipLaunchKernelGGL(cat_ln_bwd_k<V>, dim3(b), dim3(256), 0, st, g, s, resid, ln_w, ln_b, stats, d, dresid, accumulate_mask, dln_w, dln_b, cl4, d4, relu, scrub, scrub_n / 4)
+#define CALL(V)                                                                                         \
+  do {                                                                                                  \
+    if (wide) hipLaunchKernelGGL((cat_ln_bwd_k<V, 512>), dim3(b), dim3(512), 0, st, g, s, resid, ln_w, ln_b, stats, d, dresid, accumulate_mask, dln_w, dln_b, cl4, d4, relu, scrub, scrub_n / 4); \
+    else hipLaunchKernelGGL((cat_ln_bwd_k<V, 256>), dim3(b), dim3(256), 0, st, g, s, resid, ln_w, ln_b, stats, d, dresid, accumulate_mask, dln_w, dln_b, cl4, d4, relu, scrub, scrub_n / 4);      \
+  } while (0)
   LN_DISPATCH(vpt, CALL)
 #undef CALL
   BMNAS_CHECK_LAUNCH();
