@@ -11,7 +11,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libbmnas_hip.so')
+LIB_PATH = os.environ.get('BMNAS_LIB') or os.path.join(HERE, 'libbmnas_hip.so')   # BMNAS_LIB: A/B runs of two builds
 MAX_PTRS = 16
 
 
