@@ -28,17 +28,38 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
   float mean, rstd;
   if (training) {
     const int N = b * L;
-    const float* pm = part + (int64_t)m * n_part * 2;
+    const float2* pm = reinterpret_cast<const float2*>(part) + (int64_t)m * n_part;
+    // the first kKeep partials of a lane stay in registers for the second pass (batch <= 4096
+    // columns per lane-stride: one memory round trip instead of two); the rest are re-read
+    constexpr int kKeep = 4;
+    float2 keep[kKeep];
     float tot = 0.f;
-    for (int p = lane; p < n_part; p += 64) tot += pm[2 * p];
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+      const int p = lane + 64 * k;
+      keep[k] = (p < n_part) ? pm[p] : make_float2(0.f, 0.f);
+      tot += keep[k].x;
+    }
+    for (int p = lane + 64 * kKeep; p < n_part; p += 64) tot += pm[p].x;
     tot = wave_sum(tot);
     mean = tot / (float)N;
     float m2 = 0.f;
-    for (int p = lane; p < n_part; p += 64) {
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+      const int p = lane + 64 * k;
+      if (p < n_part) {
+        int cnt = N - 16 * p;
+        cnt = cnt > 16 ? 16 : cnt;
+        const float d = keep[k].x / (float)cnt - mean;
+        m2 += keep[k].y + (float)cnt * d * d;
+      }
+    }
+    for (int p = lane + 64 * kKeep; p < n_part; p += 64) {
       int cnt = N - 16 * p;
       cnt = cnt > 16 ? 16 : cnt;
-      const float d = pm[2 * p] / (float)cnt - mean;
-      m2 += pm[2 * p + 1] + (float)cnt * d * d;
+      const float2 v = pm[p];
+      const float d = v.x / (float)cnt - mean;
+      m2 += v.y + (float)cnt * d * d;
     }
     m2 = wave_sum(m2);
     const float var = m2 / (float)N;
