@@ -395,77 +395,90 @@ def main():
 
     log(f'timed region done: {dt / a.steps * 1e3:.4f} ms/step')
     if not a.no_full_step:
-        result['full_search_step'] = full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log)
+        # secondary figure: never allowed to take the headline line down with it
+        try:
+            result['full_search_step'] = full_search_step(model, crit, params, arch, xs, y, c, a, world, device,
+                                                          log)
+        except Exception as e:                       # noqa: BLE001
+            result['full_search_step'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+            log(f'full search step failed: {e}')
     if rank == 0 and not a.no_roofline:
-        # instrumented eager pass: HIP events on the launch stream around every kernel call
-        n_prof = min(a.steps, 10)
-        for _ in range(2):
-            step()
-        # Eager Python issues kernels slower than the GPU retires them, so an event pair around a
-        # launch would also time the host gap.  Park the GPU behind ~50 ms of GEMMs first: the
-        # instrumented steps are then all queued before the GPU reaches them and run back to
-        # back, and start->end event deltas are kernel durations (+ the event records).
-        torch.cuda.synchronize()
-        # the blocker: a one-thread spin kernel (torch.cuda._sleep) on the launch stream, calibrated
-        # in wall time first.  (A stack of big GEMMs was used before; on some boxes the instrumented
-        # kernels then ran 1.5-2x slow, as if next to it.)  The pass is only accepted if the blocker
-        # was still running when the host finished queueing: otherwise brackets contain host gaps.
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        torch.cuda._sleep(20_000_000)
-        e1.record()
-        torch.cuda.synchronize()
-        cycles_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
-        recs, ev_ms, park_ms = {}, 0.0, 0
-        for park_ms in (80, 200, 500):
-            torch.cuda._sleep(int(cycles_per_ms * park_ms))
-            guard = torch.cuda.Event()
-            guard.record()
-            lib.profile_begin(algo_table(c['C'], c['L']))
-            for _ in range(n_prof):
+        try:
+            # instrumented eager pass: HIP events on the launch stream around every kernel call
+            n_prof = min(a.steps, 10)
+            for _ in range(2):
                 step()
-            queued_in_time = not guard.query()
-            recs, ev_ms = lib.profile_end()
-            if queued_in_time:
-                break
-            log(f'roofline pass: host needed more than the {park_ms} ms blocker to queue {n_prof} steps; retrying')
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE with
-        # the gfx950 read-side correction; tools/traffic_from_pmc.py); null if not collected
-        traffic = {}
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if a.config == 'mmimdb' and a.batch == 128 and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = {k: v['traffic_bytes'] for k, v in json.load(f).items()}
-        rows = []
-        for name, rr in recs.items():
-            tot_ms = sum(max(r[0] - ev_ms, 1e-4) for r in rr)      # minus the empty-bracket time
-            units = sum(r[2] for r in rr)
-            bound = rr[0][1]
-            per_launch_us = tot_ms / len(rr) * 1e3
-            if bound == 'hbm':
-                achieved = units / (tot_ms * 1e-3) / 1e9
-                peak, unit = HBM_PEAK_GBS, 'GB/s'
-            else:
-                achieved = units / (tot_ms * 1e-3) / 1e12
-                peak, unit = MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
-            rows.append({'kernel': name, 'bound': bound, 'achieved': round(achieved, 2), 'peak': peak,
-                         'unit': unit, 'frac': round(achieved / peak, 4), 'traffic': traffic.get(name),
-                         'algorithmic_units_per_launch': round(units / len(rr)),
-                         'launches_per_step': len(rr) / n_prof, 'avg_us': round(per_launch_us, 2),
-                         'us_per_step': round(tot_ms / n_prof * 1e3, 2)})
-        rows.sort(key=lambda r: -r['us_per_step'])
-        if rows:
-            top = dict(rows[0])
-            top['measured'] = (f'HIP events on the launch stream around every launch, instrumented pass of '
-                               f'{n_prof} steps queued behind a {park_ms} ms GPU-side spin blocker (back-to-back execution), '
-                               'after the timed region; avg per launch minus the elapsed time of an empty '
-                               f'event bracket ({ev_ms * 1e3:.2f} us); cross-check: profiles/ rocprofv3 stats')
-            result['roofline'] = top
-            result['roofline_kernels'] = rows
+            # Eager Python issues kernels slower than the GPU retires them, so an event pair around a
+            # launch would also time the host gap.  Park the GPU behind ~50 ms of GEMMs first: the
+            # instrumented steps are then all queued before the GPU reaches them and run back to
+            # back, and start->end event deltas are kernel durations (+ the event records).
+            torch.cuda.synchronize()
+            # the blocker: a one-thread spin kernel (torch.cuda._sleep) on the launch stream, calibrated
+            # in wall time first.  (A stack of big GEMMs was used before; on some boxes the instrumented
+            # kernels then ran 1.5-2x slow, as if next to it.)  The pass is only accepted if the blocker
+            # was still running when the host finished queueing: otherwise brackets contain host gaps.
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.cuda._sleep(20_000_000)
+            e1.record()
+            torch.cuda.synchronize()
+            cycles_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+            recs, ev_ms, park_ms = {}, 0.0, 0
+            for park_ms in (80, 200, 500):
+                torch.cuda._sleep(int(cycles_per_ms * park_ms))
+                guard = torch.cuda.Event()
+                guard.record()
+                lib.profile_begin(algo_table(c['C'], c['L']))
+                for _ in range(n_prof):
+                    step()
+                queued_in_time = not guard.query()
+                recs, ev_ms = lib.profile_end()
+                if queued_in_time:
+                    break
+                log(f'roofline pass: host needed more than the {park_ms} ms blocker to queue {n_prof} steps; retrying')
+            # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE with
+            # the gfx950 read-side correction; tools/traffic_from_pmc.py); null if not collected
+            traffic = {}
+            tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+            if a.config == 'mmimdb' and a.batch == 128 and os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = {k: v['traffic_bytes'] for k, v in json.load(f).items()}
+            rows = []
+            for name, rr in recs.items():
+                tot_ms = sum(max(r[0] - ev_ms, 1e-4) for r in rr)      # minus the empty-bracket time
+                units = sum(r[2] for r in rr)
+                bound = rr[0][1]
+                per_launch_us = tot_ms / len(rr) * 1e3
+                if bound == 'hbm':
+                    achieved = units / (tot_ms * 1e-3) / 1e9
+                    peak, unit = HBM_PEAK_GBS, 'GB/s'
+                else:
+                    achieved = units / (tot_ms * 1e-3) / 1e12
+                    peak, unit = MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
+                rows.append({'kernel': name, 'bound': bound, 'achieved': round(achieved, 2), 'peak': peak,
+                             'unit': unit, 'frac': round(achieved / peak, 4), 'traffic': traffic.get(name),
+                             'algorithmic_units_per_launch': round(units / len(rr)),
+                             'launches_per_step': len(rr) / n_prof, 'avg_us': round(per_launch_us, 2),
+                             'us_per_step': round(tot_ms / n_prof * 1e3, 2)})
+            rows.sort(key=lambda r: -r['us_per_step'])
+            if rows:
+                top = dict(rows[0])
+                top['measured'] = (f'HIP events on the launch stream around every launch, instrumented pass of '
+                                   f'{n_prof} steps queued behind a {park_ms} ms GPU-side spin blocker (back-to-back execution), '
+                                   'after the timed region; avg per launch minus the elapsed time of an empty '
+                                   f'event bracket ({ev_ms * 1e3:.2f} us); cross-check: profiles/ rocprofv3 stats')
+                result['roofline'] = top
+                result['roofline_kernels'] = rows
+        except Exception as e:                       # noqa: BLE001 — diagnostics must not cost the headline
+            result['roofline_error'] = f'{type(e).__name__}: {e}'[:300]
+            log(f'roofline pass failed: {e}')
     log('roofline pass done')
     if rank == 0 and not a.no_cpu_baseline and world == 1:
-        result['cpu_baseline'] = cpu_baseline(a.config, c, a.batch)
-        result['speedup_vs_cpu_baseline'] = round(result['value'] / result['cpu_baseline']['value'], 1)
+        try:
+            result['cpu_baseline'] = cpu_baseline(a.config, c, a.batch)
+            result['speedup_vs_cpu_baseline'] = round(result['value'] / result['cpu_baseline']['value'], 1)
+        except Exception as e:                       # noqa: BLE001
+            result['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -779,19 +779,21 @@ __global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
 // disjoint outputs.
 template <int TN, int TJ, int KCH>
 __global__ __launch_bounds__(256) void conv_bwd_all_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
-                                                      int n_data, int wx, int wy) {
+                                                      int n_w, int wx, int wy) {
   constexpr int KPW = 3 * KCH;
   const int blk = blockIdx.x;
   if (blk < s.groups) {
     sdpa_bwd_body<KCH>(blk, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask, s.G,
                        s.drop);
-  } else if (blk < s.groups + n_data) {
+  } else if (blk < s.groups + n_w) {
+    // the weight-gradient tiles walk many n-groups each (long-running): dispatched before the
+    // short data-gradient tiles, which then fill the gaps
     const int t = blk - s.groups;
-    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx);
-  } else {
-    const int t = blk - s.groups - n_data;
     const int bz = t / (wx * wy), r = t - bz * wx * wy;
     conv_w_body<4>(w, r % wx, r / wx, bz);
+  } else {
+    const int t = blk - s.groups - n_w;
+    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx);
   }
 }
 
@@ -1147,7 +1149,7 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
       const size_t lds = sdpa_bwd_lds(C);
 #define ALL_CASE(T, K)                                                                                 \
   if (!done && TNv == T && kch == K) {                                                                 \
-    hipLaunchKernelGGL((conv_bwd_all_k<T, T, K>), grid, dim3(256), lds, st, a, s, w, gx, n_data,       \
+    hipLaunchKernelGGL((conv_bwd_all_k<T, T, K>), grid, dim3(256), lds, st, a, s, w, gx, n_w,          \
                        (int)wgrid.x, (int)wgrid.y);                                                    \
     done = true;                                                                                       \
   }
