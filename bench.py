@@ -299,7 +299,10 @@ def main():
         for t in shared:
             flat_views.append(flat[off:off + t.numel()].view(t.shape))
             off += t.numel()
-    loss_scale = 1.0 / world
+    # RCCL can average in the collective (ReduceOp.AVG): the captured step is then exactly the
+    # single-GPU one; without it (gloo test harness) the loss is pre-scaled and the bucket summed
+    use_avg = world > 1 and bdist.avg_supported(device)
+    loss_scale = 1.0 if (world == 1 or use_avg) else 1.0 / world
 
     def step_for_capture():
         # same work as step(); gradients are taken with autograd.grad (no AccumulateGrad nodes,
@@ -307,7 +310,10 @@ def main():
         # attached as .grad — the tensors are static, replays refresh them in place
         loss = crit(model(xs), y)
         if world > 1:
-            grads = torch.autograd.grad(loss * loss_scale, leaves, allow_unused=True)
+            if loss_scale != 1.0:
+                grads = torch.autograd.grad(loss * loss_scale, leaves, allow_unused=True)
+            else:
+                grads = torch.autograd.grad(loss, leaves, grad_outputs=unit_grad(device), allow_unused=True)
             torch._foreach_copy_(flat_views, list(grads[:len(shared)]))
             for t, v in zip(shared, flat_views):
                 t.grad = v
@@ -346,7 +352,8 @@ def main():
         run_local()
         if world > 1:
             if a.mode == 'graph':
-                torch.distributed.all_reduce(flat)           # grads already carry the 1/world factor
+                torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.AVG if use_avg
+                                             else torch.distributed.ReduceOp.SUM)
             else:
                 red_all()
 

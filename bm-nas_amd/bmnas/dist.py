@@ -47,6 +47,27 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+_AVG = {}
+
+
+def avg_supported(device, group=None):
+    """True when the backend can all-reduce with ReduceOp.AVG (RCCL / NCCL >= 2.10 can, gloo
+    cannot): the mean over ranks then needs neither a pre-scaled loss nor a scale kernel.
+    Probed once per process with a 1-element collective — every rank must call this."""
+    key = (str(device), id(group))
+    if key not in _AVG:
+        ok = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        if ok:
+            try:
+                t = torch.ones(1, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+                ok = abs(float(t) - 1.0) < 1e-6
+            except Exception:                    # noqa: BLE001 — any refusal means "not supported"
+                ok = False
+        _AVG[key] = ok
+    return _AVG[key]
+
+
 def shard(t, rank, world, dim=0):
     """rank's contiguous shard of the global batch (equal shards: mean of means == global mean)."""
     n = t.shape[dim]
@@ -78,9 +99,11 @@ class FlatGradAllReducer:
                 off += t.numel()
         return self.views
 
-    def all_reduce_bucket(self):
+    def all_reduce_bucket(self, average=False):
+        """average=False: the bucket holds gradients pre-scaled by 1/world (sum them);
+        average=True: unscaled gradients, reduced with ReduceOp.AVG (see avg_supported)."""
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if average else dist.ReduceOp.SUM, group=self.group)
         self.reduced = True                      # the optimizer pre-hook must not average again
 
     def __call__(self):

@@ -9,6 +9,7 @@ the kernels add a DEVICE counter to their Philox offsets and the graph advances 
 import torch
 
 from . import cell as K
+from .dist import avg_supported
 from .functions import unit_grad
 
 
@@ -82,8 +83,11 @@ class GraphedTrainStep:
         self.inputs = [x.detach().clone().requires_grad_(x.requires_grad) for x in inputs]
         self.labels = labels.detach().clone()
         self.in_graph_step = reducer is None
-        scale = 1.0 / reducer.world if reducer is not None else 1.0
         views = reducer.ensure_bucket() if reducer is not None else None
+        # with ReduceOp.AVG (RCCL) the captured step is the single-GPU one: unscaled loss, constant
+        # unit gradient; otherwise the loss is pre-scaled by 1/world and the bucket is summed
+        self.average = reducer is not None and avg_supported(self.labels.device, reducer.group)
+        scale = 1.0 / reducer.world if (reducer is not None and not self.average) else 1.0
         armed = [False]
 
         def fn():
@@ -91,7 +95,7 @@ class GraphedTrainStep:
             if isinstance(logits, tuple):
                 logits = logits[-1]
             loss = criterion(logits, self.labels)
-            if reducer is not None:
+            if scale != 1.0:
                 grads = torch.autograd.grad(loss * scale, self.targets, allow_unused=True)
             else:
                 grads = torch.autograd.grad(loss, self.targets, grad_outputs=unit_grad(loss.device),
@@ -159,6 +163,6 @@ class GraphedTrainStep:
             opt.mark_launched()
         else:
             loss, logits = self._g.replay()
-            self.reducer.all_reduce_bucket()
+            self.reducer.all_reduce_bucket(self.average)
             opt.step()
         return loss, logits

@@ -87,6 +87,26 @@ def _worker(rank, world, port, tmp):
     assert torch.equal(flat, other)
     with pytest.raises(ValueError):
         bdist.shard(torch.zeros(7, 2), rank, world)
+    # persistent-bucket mode (what the captured hipGraph step uses): gradients are written into the
+    # reducer's flat buffer pre-scaled by 1/world, one all-reduce(sum), and the optimizer pre-hook
+    # must NOT average a second time.  gloo has no ReduceOp.AVG: avg_supported() must say so.
+    assert bdist.avg_supported(torch.device('cpu')) is False
+    red = opt._bmnas_reducer
+    views = red.ensure_bucket()
+    xs, ys = bdist.shard(X, rank, world), bdist.shard(Y, rank, world)
+    grads = torch.autograd.grad(crit(model(xs), ys) / world, list(model.parameters()))
+    for p, v, g in zip(model.parameters(), views, grads):
+        v.copy_(g)
+        p.grad = v
+    red.all_reduce_bucket()
+    want = torch.autograd.grad(crit(ref(X), Y), list(ref.parameters()))
+    for v, w_ in zip(views, want):
+        assert torch.allclose(v, w_, rtol=1e-5, atol=1e-6)
+    before = [v.clone() for v in views]
+    opt.step()                         # hook sees `reduced` and leaves the bucket alone
+    assert red.reduced is False
+    for v, b_ in zip(views, before):
+        assert torch.equal(v, b_)
     dist.destroy_process_group()
     open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
 
