@@ -36,10 +36,15 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):
-                self.outputs = fn()
+                out = fn()
                 self.span = K.DROP.offset
                 if self.span > 0:
                     self.counter.add_(self.span)      # next replay draws new dropout masks
+            # keep the static storage, not the Python autograd graph that produced it (a retained
+            # graph would get in the way of later captures: GraphedTrainStep._live_graph_tensors)
+            det = lambda o: o.detach() if torch.is_tensor(o) else o
+            self.outputs = type(out)(det(o) for o in out) if isinstance(out, (tuple, list)) else det(out)
+            del out
         finally:
             K.DROP.offset, K.DROP.device_counter = saved
         # keep later eager calls clear of the offsets the graph will use
@@ -73,7 +78,31 @@ class GraphedTrainStep:
       batch through the eager path.
     Returned `loss` / `logits` are static tensors that the next call overwrites."""
 
+    @staticmethod
+    def _live_graph_tensors(device):
+        """Non-leaf tensors on `device` that are still referenced somewhere: evidence of an autograd
+        graph from an earlier eager step being kept alive (a held `loss` / `logits`).  Such a graph
+        pins the AccumulateGrad nodes of the parameters to the stream they were created on; the
+        engine then makes that stream wait on the capture stream, the capture never joins, and
+        HIP's capture_end segfaults instead of reporting it."""
+        import gc
+        n = 0
+        for o in gc.get_objects():
+            try:
+                if isinstance(o, torch.Tensor) and o.grad_fn is not None and o.device == device:
+                    n += 1
+            except Exception:                    # noqa: BLE001 — objects in odd states during gc walk
+                pass
+        return n
+
     def __init__(self, model, criterion, optimizer, inputs, labels, warmup=2):
+        import gc
+        gc.collect()
+        live = self._live_graph_tensors(labels.device)
+        if live:
+            raise RuntimeError(f'{live} tensor(s) of an earlier autograd graph are still referenced (a held '
+                               'loss / output?): capturing now would tie the capture to their streams; '
+                               'drop them (or call this before the first eager backward)')
         self.optimizer = optimizer
         self.targets = [p for g in optimizer.param_groups for p in g['params']]
         reducer = getattr(optimizer, '_bmnas_reducer', None)
@@ -118,16 +147,33 @@ class GraphedTrainStep:
         state = {k: v.clone() for k, v in model.state_dict().items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                fn()
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    fn()
+                # dress rehearsal: anything that synchronises with the host (.item(), .cpu(), nonzero,
+                # ...) cannot be captured.  Find out HERE, with torch's sync detector, not by letting
+                # a real capture fail: a capture that dies half-way was seen to leave the HIP runtime
+                # in a state where a later, unrelated capture segfaults.
+                mode = torch.cuda.get_sync_debug_mode()
+                torch.cuda.set_sync_debug_mode('error')
+                try:
+                    fn()
+                finally:
+                    torch.cuda.set_sync_debug_mode(mode)
+        except BaseException:
+            torch.cuda.synchronize()
+            model.load_state_dict(state)
+            raise
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.in_graph_step:
-            optimizer.capture_safe()
-        armed[0] = True
-        self._g = GraphedStep(fn, warmup=0)
-        model.load_state_dict(state)
+        try:
+            if self.in_graph_step:
+                optimizer.capture_safe()
+            armed[0] = True
+            self._g = GraphedStep(fn, warmup=0)
+        finally:
+            model.load_state_dict(state)        # also when the capture fails and the caller stays eager
 
     @staticmethod
     def try_build(model, criterion, optimizer, inputs, labels, logger=None):
@@ -145,6 +191,21 @@ class GraphedTrainStep:
                 logger.info('hipGraph capture of the step failed ({}: {}); staying eager'.format(
                     type(e).__name__, e))
             return False
+
+    @staticmethod
+    def enabled(args):
+        """Whether the trainer loops replay their steps as hipGraphs: `args.hip_graph` if the caller
+        set it, else the BMNAS_HIP_GRAPH environment variable, else ON for single-process runs
+        (a step that cannot be captured falls back to eager by itself) and OFF under data
+        parallelism, where it stays opt-in."""
+        import os
+        import torch.distributed as dist
+        v = getattr(args, 'hip_graph', None)
+        if v is None and os.environ.get('BMNAS_HIP_GRAPH') is not None:
+            v = os.environ['BMNAS_HIP_GRAPH'] not in ('0', '', 'false', 'False')
+        if v is None:
+            v = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        return bool(v) and torch.cuda.is_available()
 
     def matches(self, inputs, labels):
         return (len(inputs) == len(self.inputs) and labels.shape == self.labels.shape and

@@ -7,9 +7,11 @@ class Architect(object):
         self.criterion = criterion
         self.model = model
         self.optimizer = optimizer
-        # opt-in (args.hip_graph): forward + criterion + backward + Adam(alpha) as one hipGraph replay
-        self.use_graph = bool(getattr(args, 'hip_graph', False))
+        # forward + criterion + backward + Adam(alpha) as one hipGraph replay (GraphedTrainStep.enabled)
+        from bmnas.graph import GraphedTrainStep
+        self.use_graph = GraphedTrainStep.enabled(args)
         self._graph = None
+        self._attempts = 0
         self.graph_replays = 0
 
     def log_learning_rate(self, logger):
@@ -19,10 +21,11 @@ class Architect(object):
 
     def step(self, input_valid, target_valid, logger):
         if self.use_graph:
-            if self._graph is None:
+            if self._graph is None and self._attempts < 3:
                 from bmnas.graph import GraphedTrainStep
+                self._attempts += 1
                 self._graph = GraphedTrainStep.try_build(self.model, self.criterion, self.optimizer,
-                                                         input_valid, target_valid, logger)
+                                                         input_valid, target_valid, logger) or None
             if self._graph and self._graph.matches(input_valid, target_valid):
                 self._graph(input_valid, target_valid)
                 self.graph_replays += 1

@@ -8,10 +8,10 @@ Differences, all on the host side of the hot path:
     device and are read once per phase (same numbers, no stall per batch);
   * `parallel` means one process per GPU (bmnas.dist); statistics are summed over ranks and only
     rank 0 writes checkpoints — there is no `.module` indirection;
-  * opt-in `args.hip_graph`: the weight step (forward + criterion + backward + Adam) and the
-    Architect step are captured once and replayed as one hipGraph launch per batch
-    (bmnas.graph.GraphedTrainStep); a ragged last batch, or a model that cannot be captured,
-    runs the eager path.
+  * the weight step (forward + criterion + backward + Adam) and the Architect step are captured
+    once and replayed as one hipGraph launch per batch (bmnas.graph.GraphedTrainStep); a ragged
+    last batch, or a model that cannot be captured, runs the eager path.  On by default for
+    single-process runs; `args.hip_graph` / BMNAS_HIP_GRAPH switch it (GraphedTrainStep.enabled).
 """
 import copy
 import os
@@ -87,8 +87,9 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
         nan_escape=False):
     """-> dict(best_dev, best_dev_genotype, best_test, best_test_genotype, last_genotype, nan_abort)."""
     cosine = isinstance(scheduler, sc.LRCosineAnnealingScheduler)
-    use_graph = bool(getattr(args, 'hip_graph', False))
-    w_graph = None
+    from bmnas.graph import GraphedTrainStep
+    use_graph = GraphedTrainStep.enabled(args)
+    w_graph, w_attempts = None, 0
     stats = run.stats = dict(graph_replays=0, eager_steps=0)
     best = dict(best_dev=None, best_dev_genotype=None, best_dev_epoch=0, best_test=None,
                 best_test_genotype=None, best_test_epoch=0, last_genotype=None, nan_abort=False)
@@ -114,12 +115,16 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
             learn = phase == 'train' or (phase == 'dev' and status == 'eval')
             for data in dataloaders[phase]:
                 inputs, labels = unpack(data, device)
+                # nothing of the previous batch's autograd graph may stay referenced while a step is
+                # being captured (see GraphedTrainStep._live_graph_tensors)
+                output = loss = None
                 if status == 'search' and phase in ('dev', 'test') and architect is not None:
                     architect.step(inputs, labels, logger)
                 if learn and use_graph:
-                    if w_graph is None:
-                        from bmnas.graph import GraphedTrainStep
-                        w_graph = GraphedTrainStep.try_build(model, criterion, optimizer, inputs, labels, logger)
+                    if w_graph is None and w_attempts < 3:
+                        w_attempts += 1
+                        w_graph = GraphedTrainStep.try_build(model, criterion, optimizer, inputs, labels,
+                                                             logger) or None
                     if w_graph and w_graph.matches(inputs, labels):
                         if cosine:
                             scheduler.step()

@@ -138,3 +138,42 @@ def test_mmimdb_search_driver_with_hip_graph_steps(tmp_path, monkeypatch):
     assert loop.run.stats['graph_replays'] == 4, loop.run.stats
     sd = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
+
+
+def test_hip_graph_falls_back_when_the_model_cannot_be_captured(tmp_path, monkeypatch):
+    """A backbone that synchronises with the host (here: .item()) cannot be captured: the
+    trainer must notice, stay on the eager path and still finish the search."""
+    central = types.ModuleType('models.central')
+    fake = types.ModuleType('models.central.mmimdb')
+    fake.GP_VGG, fake.MaxOut_MLP = _FakeVGG, _FakeMLP
+    central.mmimdb = fake
+    monkeypatch.setitem(sys.modules, 'models.central', central)
+    monkeypatch.setitem(sys.modules, 'models.central.mmimdb', fake)
+    import models.search.mmimdb_darts_searchable as drv
+    import models.search.train_searchable._loop as loop
+    from models.search.darts.utils import create_exp_dir
+
+    class Args:
+        pass
+
+    a = Args()
+    a.C, a.L, a.drpt = 32, 16, 0.1
+    a.num_input_nodes, a.num_keep_edges, a.steps, a.multiplier = 6, 2, 2, 2
+    a.node_steps, a.node_multiplier, a.num_outputs = 1, 1, 23
+    a.batchsize, a.epochs = 8, 1
+    a.eta_max, a.eta_min, a.Ti, a.Tm = 1e-3, 1e-6, 1, 2
+    a.arch_learning_rate, a.arch_weight_decay, a.weight_decay = 3e-4, 1e-3, 1e-4
+    a.f1_type = 'weighted'
+    a.use_dataparallel = False
+    a.hip_graph = True
+    a.save = str(tmp_path / 'exp')
+    create_exp_dir(a.save)
+    loaders = {k: DataLoader(_DS(n, s), batch_size=a.batchsize, shuffle=True, drop_last=False)
+               for k, n, s in (('train', 16, 1), ('dev', 8, 2), ('test', 8, 3))}
+    logger = logging.getLogger('bmnas-test')
+    best_f1, genotype = drv.train_darts_model(loaders, a, torch.device('cuda:0'), logger)
+    assert 0.0 <= best_f1 <= 1.0
+    assert loop.run.stats['graph_replays'] == 0 and loop.run.stats['eager_steps'] > 0
+    # the GPU is still usable afterwards
+    x = torch.ones(4, device='cuda')
+    assert float((x * 2).sum()) == 8.0
