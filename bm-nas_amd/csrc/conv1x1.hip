@@ -10,6 +10,7 @@
 // The k-permutation is legal because A and B use the same one.
 // FLOPs: 2*M*K*b*L each; bound: fp32 MFMA (157 TFLOP/s dense).
 #include "sdpa_body.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -217,8 +218,9 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
 // LDS.  Splitting K four ways also quadruples the number of waves, which is what hides the
 // latency at batch 128.
 template <bool TRANS, int TN, int TJ, int KPW>
-__device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx, const int by) {
-  __shared__ float4 part[4][TN * TJ][64];
+__device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx, const int by, char* lds) {
+  // caller-provided LDS (conv_ksplit_lds<TN, TJ>() bytes): merged launches pay max(), not sum()
+  float4 (*part)[TN * TJ][64] = reinterpret_cast<float4 (*)[TN * TJ][64]>(lds);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int g0 = bx * TN;
@@ -361,10 +363,301 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
   }
 }
 
+template <int TN, int TJ>
+constexpr size_t conv_ksplit_lds() { return (size_t)4 * TN * TJ * 64 * sizeof(float4); }
+
 template <bool TRANS, int TN, int TJ, int KPW>
 __global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
-  conv_ksplit_body<TRANS, TN, TJ, KPW>(a, blockIdx.x, blockIdx.y);
+  __shared__ __attribute__((aligned(16))) char lds[conv_ksplit_lds<TN, TJ>()];
+  conv_ksplit_body<TRANS, TN, TJ, KPW>(a, blockIdx.x, blockIdx.y, lds);
 }
+
+// ---- pipelined LDS tile kernel (forward) -----------------------------------------------------------
+// Counters (profiles/r01_pmc_gemm.txt) show the split-K kernel spending 45 % of a wave's life in one
+// burst of operand fetches (83 MB through L2 for 6 MB of unique data: every 16x16 / 32x32 tile
+// re-reads its operands) and 42 % queued on the MFMA pipe, the two phases in lockstep.  Here a
+// workgroup owns a 64 (n) x 96 (j) tile, walks K in chunks of KC channels, and keeps two LDS
+// buffers: while the four waves run the MFMAs of chunk c out of one buffer, the 16-byte global
+// loads of chunk c+1 are in flight and land in the other.  Operand bytes through L2: 23 MB.
+// LDS 2 x (64*KC + 96*(KC+4)) floats = 63 KB at KC = 48: two workgroups per CU, and the
+// attention workgroups of the merged launch still fit next to them.
+constexpr int kPipeJ = 96;
+
+template <int KC>
+__device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int bx, const int by,
+                                                   float* __restrict__ smem) {
+  constexpr int KP = KC + 4;
+  constexpr int A4 = 64 * KC / 4, B4 = kPipeJ * KC / 4;       // float4 per chunk
+  constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
+  constexpr int BUF = 64 * KC + kPipeJ * KP;                   // floats per buffer
+  const int t = threadIdx.x;
+  const int wave = t >> 6, lane = t & 63, lo = lane & 15, h = lane >> 4;
+  const int spt = 64 >> a.Lb;                                  // samples per tile
+  const int s0 = bx * spt, j0 = by * kPipeJ;
+  const int K = a.I;
+  const int cl4 = (KC << a.Lb) >> 2;                           // float4 per sample per chunk
+  const float* __restrict__ act = a.act.p[0];
+  const int nchunk = K / KC;
+
+  // global addresses of this thread's pieces of a chunk (chunk c adds c*KC channels)
+  int64_t aoffg[NA];
+  int asl[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = t + 256 * i;
+    const int qq = q < A4 ? q : A4 - 1;
+    const int sl = qq / cl4;                                   // sample inside the tile
+    int s = s0 + sl;
+    s = s < a.b ? s : a.b - 1;                                 // clamped: padded samples are never stored
+    aoffg[i] = ((int64_t)s * K << a.Lb) + (int64_t)(qq - sl * cl4) * 4;
+    asl[i] = qq * 4;                                           // LDS float offset (verbatim copy)
+  }
+  int64_t boffg[NB];
+  int bsl[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int q = t + 256 * i;
+    const int qq = q < B4 ? q : B4 - 1;
+    const int jr = qq / (KC / 4), c4 = qq - jr * (KC / 4);
+    int j = j0 + jr;
+    j = j < a.J ? j : a.J - 1;
+    boffg[i] = (int64_t)j * a.ldw + 4 * c4;
+    bsl[i] = 64 * KC + jr * KP + 4 * c4;
+  }
+  float4 ra[NA], rb[NB];
+  auto fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = ld4(a.W + boffg[i] + c * KC);
+  };
+  auto stash = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (t + 256 * i < A4) st4(buf + asl[i], ra[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (t + 256 * i < B4) st4(buf + bsl[i], rb[i]);
+  };
+
+  const int gl0 = 2 * (wave & 1), jl0 = 3 * (wave >> 1);
+  int aoff[2], boff[3];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+    aoff[tn] = (((gl0 + tn) * a.spw + (lo >> a.Lb)) * KC << a.Lb) + (lo & (a.L - 1));
+#pragma unroll
+  for (int tj = 0; tj < 3; ++tj) boff[tj] = 64 * KC + ((jl0 + tj) * 16 + lo) * KP + 4 * h;
+  f32x4 acc[2][3];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int tj = 0; tj < 3; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  fetch(0);
+  stash(smem);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const float* cur = smem + (c & 1) * BUF;
+    if (c + 1 < nchunk) fetch(c + 1);                          // in flight during this chunk's MFMAs
+#pragma unroll
+    for (int kb = 0; kb < KC / 16; ++kb) {
+      const int c0 = 16 * kb + 4 * h;
+      float av[2][4];
+      float4 bv[3];
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[tn][r] = cur[aoff[tn] + ((c0 + r) << a.Lb)];
+#pragma unroll
+      for (int tj = 0; tj < 3; ++tj) bv[tj] = ld4(cur + boff[tj] + 16 * kb);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj) {
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][0], bv[tj].x, acc[tn][tj], 0, 0, 0);
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][1], bv[tj].y, acc[tn][tj], 0, 0, 0);
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][2], bv[tj].z, acc[tn][tj], 0, 0, 0);
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][3], bv[tj].w, acc[tn][tj], 0, 0, 0);
+        }
+    }
+    if (c + 1 < nchunk) {
+      stash(smem + ((c + 1) & 1) * BUF);                       // the other buffer: nobody reads it now
+      __syncthreads();
+    }
+  }
+
+  // epilogue: acc[tn][tj][r] = OUT[n = 16*g + 4h + r][j = jt + lo]
+  const int l0 = (4 * h) & (a.L - 1);
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int tj = 0; tj < 3; ++tj) {
+      const int g = bx * 4 + gl0 + tn, jt = j0 + 16 * (jl0 + tj);
+      if (g >= a.n_groups || jt >= a.J) continue;              // wave-uniform
+      const int jj = jt + lo;
+      const float bj = (a.bias != nullptr) ? a.bias[jj] : 0.f;
+      const float4 o = make_float4(acc[tn][tj][0] + bj, acc[tn][tj][1] + bj, acc[tn][tj][2] + bj,
+                                   acc[tn][tj][3] + bj);
+      const int so = g * a.spw + ((4 * h) >> a.Lb);
+      const bool vo = so < a.b;
+      if (vo) st4(a.dst.p[0] + ((int64_t)so * a.Cj + jj) * a.L + l0, o);
+      if (a.part != nullptr) {
+        float sum = vo ? f4_hsum(o) : 0.f;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        int cnt = a.b * a.L - 16 * g;
+        cnt = cnt > 16 ? 16 : cnt;
+        const float mean = sum / (float)cnt;
+        float m2 = 0.f;
+        if (vo) {
+          const float4 cc = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
+          m2 = f4_dot(cc, cc);
+        }
+        m2 += __shfl_xor(m2, 16, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        if (h == 0) {
+          float* pp = a.part + ((int64_t)jj * a.n_part + g) * 2;
+          pp[0] = sum;
+          pp[1] = m2;
+        }
+      }
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void conv_pipe_fwd_k(ConvArgs a, int gx) {
+  extern __shared__ __attribute__((aligned(16))) float pipe_smem[];
+  conv_pipe_fwd_body<KC>(a, blockIdx.x % gx, blockIdx.x / gx, pipe_smem);
+}
+
+// Data-gradient twin: OUT[n][j] = sum_i ACT[i][n] W[i][j], long contraction (I = 3C), narrow output.
+// Tile 32 (n) x 64 (j): 192 workgroups at batch 128, each wave owns 1 n-group x 2 j-tiles... (wave w:
+// n-group w & 1, j-tiles 2*(w >> 1), +1).  W chunk is k-major in LDS, rows of 64 + 4 floats.
+constexpr int kPipeBN = 32, kPipeBJ = 64;
+
+template <int KC>
+__device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int bx, const int by,
+                                                   float* __restrict__ smem) {
+  constexpr int JP = kPipeBJ + 4;
+  constexpr int A4 = kPipeBN * KC / 4, B4 = KC * kPipeBJ / 4;
+  constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
+  constexpr int BUF = kPipeBN * KC + KC * JP;
+  const int t = threadIdx.x;
+  const int wave = t >> 6, lane = t & 63, lo = lane & 15, h = lane >> 4;
+  const int spt = kPipeBN >> a.Lb;
+  const int s0 = bx * spt, j0 = by * kPipeBJ;
+  const int K = a.I;
+  const int cl4 = (KC << a.Lb) >> 2;
+  const float* __restrict__ act = a.act.p[0];
+  const int nchunk = K / KC;
+  int64_t aoffg[NA];
+  int asl[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = t + 256 * i;
+    const int qq = q < A4 ? q : A4 - 1;
+    const int sl = qq / cl4;
+    int s = s0 + sl;
+    s = s < a.b ? s : a.b - 1;
+    aoffg[i] = ((int64_t)s * K << a.Lb) + (int64_t)(qq - sl * cl4) * 4;
+    asl[i] = qq * 4;
+  }
+  int64_t boffg[NB];
+  int bsl[NB];
+  const int jmax4 = a.J / 4 - 1;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int q = t + 256 * i;
+    const int qq = q < B4 ? q : B4 - 1;
+    const int kr = qq / (kPipeBJ / 4), c4 = qq - kr * (kPipeBJ / 4);
+    int j4 = j0 / 4 + c4;
+    j4 = j4 < jmax4 ? j4 : jmax4;
+    boffg[i] = (int64_t)kr * a.ldw + 4 * j4;
+    bsl[i] = kPipeBN * KC + kr * JP + 4 * c4;
+  }
+  float4 ra[NA], rb[NB];
+  auto fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = ld4(a.W + boffg[i] + (int64_t)(c * KC) * a.ldw);
+  };
+  auto stash = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (t + 256 * i < A4) st4(buf + asl[i], ra[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (t + 256 * i < B4) st4(buf + bsl[i], rb[i]);
+  };
+  const int gl = wave & 1, jl0 = 2 * (wave >> 1);
+  const int aoff = ((gl * a.spw + (lo >> a.Lb)) * KC << a.Lb) + (lo & (a.L - 1));
+  int boff[2];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) boff[tj] = kPipeBN * KC + 4 * h * JP + (jl0 + tj) * 16 + lo;
+  f32x4 acc[2];
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  stash(smem);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const float* cur = smem + (c & 1) * BUF;
+    if (c + 1 < nchunk) fetch(c + 1);
+#pragma unroll
+    for (int kb = 0; kb < KC / 16; ++kb) {
+      const int c0 = 16 * kb + 4 * h;
+      float av[4], bv[2][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) av[r] = cur[aoff + ((c0 + r) << a.Lb)];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[tj][r] = cur[boff[tj] + (16 * kb + r) * JP];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[tj][r], acc[tj], 0, 0, 0);
+    }
+    if (c + 1 < nchunk) {
+      stash(smem + ((c + 1) & 1) * BUF);
+      __syncthreads();
+    }
+  }
+  const int l0 = (4 * h) & (a.L - 1);
+  const int g = bx * (kPipeBN / 16) + gl;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int jt = j0 + 16 * (jl0 + tj);
+    if (g >= a.n_groups || jt >= a.J) continue;                // wave-uniform
+    const int jj = jt + lo;
+    const int q = jj / a.Cj;
+    const int cj = jj - q * a.Cj;
+    float* d = a.dst.p[0];
+#pragma unroll
+    for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
+    const int so = g * a.spw + ((4 * h) >> a.Lb);
+    if (so >= a.b || d == nullptr) continue;
+    float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
+    const float4 o = make_float4(acc[tj][0], acc[tj][1], acc[tj][2], acc[tj][3]);
+    st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
+  }
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void conv_pipe_bwd_k(ConvArgs a, int gx) {
+  extern __shared__ __attribute__((aligned(16))) float pipe_smem[];
+  conv_pipe_bwd_body<KC>(a, blockIdx.x % gx, blockIdx.x / gx, pipe_smem);
+}
+
+template <int KC>
+constexpr size_t conv_pipe_bwd_lds() {
+  return (size_t)2 * (kPipeBN * KC + KC * (kPipeBJ + 4)) * sizeof(float);
+}
+
+template <int KC>
+constexpr size_t conv_pipe_lds() { return (size_t)2 * (64 * KC + kPipeJ * (KC + 4)) * sizeof(float); }
 
 // ---- GEMM + attention in one launch ---------------------------------------------------------
 // In a NodeMixedOp the attention branch and the stacked LinearGLU/ConcatFC conv read the same
@@ -395,23 +688,37 @@ struct SdpaBwdArgs {
 template <int TN, int TJ, int KCH>
 __global__ __launch_bounds__(256) void conv_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s, int gx) {
   constexpr int KPW = KCH;
+  extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   if ((int)blockIdx.x < s.groups) {
-    sdpa_fwd_body<KCH>(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop);
+    sdpa_fwd_body<KCH>(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop, merged_smem);
   } else {
     const int t = blockIdx.x - s.groups;
-    conv_ksplit_body<true, TN, TJ, KPW>(a, t % gx, t / gx);
+    conv_ksplit_body<true, TN, TJ, KPW>(a, t % gx, t / gx, merged_smem);
   }
 }
 
 template <int TN, int TJ, int KCH>
 __global__ __launch_bounds__(256) void conv_bwd_sdpa_k(ConvArgs a, SdpaBwdArgs s, int gx) {
   constexpr int KPW = 3 * KCH;
+  extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   if ((int)blockIdx.x < s.groups) {
     sdpa_bwd_body<KCH>(blockIdx.x, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask,
-                  s.G, s.drop);
+                       s.G, s.drop, merged_smem);
   } else {
     const int t = blockIdx.x - s.groups;
-    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx);
+    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx, merged_smem);
+  }
+}
+
+// the same merged forward launch with the pipelined tile kernel as the GEMM half
+template <int KC, int KCH>
+__global__ __launch_bounds__(256) void conv_pipe_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s, int gx) {
+  extern __shared__ __attribute__((aligned(16))) char merged_smem[];
+  if ((int)blockIdx.x < s.groups) {
+    sdpa_fwd_body<KCH>(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop, merged_smem);
+  } else {
+    const int t = blockIdx.x - s.groups;
+    conv_pipe_fwd_body<KC>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
   }
 }
 
@@ -641,9 +948,10 @@ struct ConvWArgs {
 // eight partial tiles meet in LDS and leave with coalesced stores (single split) or
 // well-shaped fp32 atomics (128-B runs along k).
 template <int NW>
-__device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, const int by, const int bz) {
-  __shared__ float tile[NW][32 * 33];
-  __shared__ float brow[NW][32];
+__device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, const int by, const int bz,
+                                            char* lds) {
+  float (*tile)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(lds);                          // [NW][1056]
+  float (*brow)[32] = reinterpret_cast<float (*)[32]>(lds + (size_t)NW * 32 * 33 * sizeof(float));   // [NW][32]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int m0 = bx * 32, k0 = by * 32;
@@ -769,8 +1077,12 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
   }
 }
 
+template <int NW>
+constexpr size_t conv_w_lds() { return (size_t)NW * (32 * 33 + 32) * sizeof(float); }
+
 __global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
-  conv_w_body<8>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+  __shared__ __attribute__((aligned(16))) char lds[conv_w_lds<8>()];
+  conv_w_body<8>(a, blockIdx.x, blockIdx.y, blockIdx.z, lds);
 }
 
 // The whole backward of a NodeMixedOp's contractions in ONE grid (search mode): attention
@@ -781,19 +1093,38 @@ template <int TN, int TJ, int KCH>
 __global__ __launch_bounds__(256) void conv_bwd_all_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
                                                       int n_w, int wx, int wy) {
   constexpr int KPW = 3 * KCH;
+  extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   const int blk = blockIdx.x;
   if (blk < s.groups) {
     sdpa_bwd_body<KCH>(blk, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask, s.G,
-                       s.drop);
+                       s.drop, merged_smem);
   } else if (blk < s.groups + n_w) {
     // the weight-gradient tiles walk many n-groups each (long-running): dispatched before the
     // short data-gradient tiles, which then fill the gaps
     const int t = blk - s.groups;
     const int bz = t / (wx * wy), r = t - bz * wx * wy;
-    conv_w_body<4>(w, r % wx, r / wx, bz);
+    conv_w_body<4>(w, r % wx, r / wx, bz, merged_smem);
   } else {
     const int t = blk - s.groups - n_w;
-    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx);
+    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx, merged_smem);
+  }
+}
+
+template <int KC, int KCH>
+__global__ __launch_bounds__(256) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
+                                                           int n_w, int wx, int wy) {
+  extern __shared__ __attribute__((aligned(16))) char merged_smem[];
+  const int blk = blockIdx.x;
+  if (blk < s.groups) {
+    sdpa_bwd_body<KCH>(blk, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask, s.G,
+                       s.drop, merged_smem);
+  } else if (blk < s.groups + n_w) {
+    const int t = blk - s.groups;
+    const int bz = t / (wx * wy), r = t - bz * wx * wy;
+    conv_w_body<4>(w, r % wx, r / wx, bz, merged_smem);
+  } else {
+    const int t = blk - s.groups - n_w;
+    conv_pipe_bwd_body<KC>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
   }
 }
 
@@ -858,7 +1189,8 @@ bool launch_ksplit_sdpa_fwd(const ConvArgs& a, const SdpaFwdArgs& s, hipStream_t
   dim3 grid((unsigned)(s.groups + gx * gy));
 #define KS_CASE(K)                                                                                   \
   if (kch == K) {                                                                                    \
-    hipLaunchKernelGGL((conv_fwd_sdpa_k<TN, TJ, K>), grid, dim3(256), 0, st, a, s, gx);              \
+    hipLaunchKernelGGL((conv_fwd_sdpa_k<TN, TJ, K>), grid, dim3(256),                                 \
+                       std::max((size_t)kSdpaFwdLds, conv_ksplit_lds<TN, TJ>()), st, a, s, gx);       \
     return true;                                                                                     \
   }
   KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4)
@@ -873,7 +1205,7 @@ bool launch_ksplit_sdpa_bwd(const ConvArgs& a, const SdpaBwdArgs& s, hipStream_t
   if (3 * kch * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;
   const int gx = (a.n_groups + TN - 1) / TN, gy = (a.J / 16 + TJ - 1) / TJ;
   dim3 grid((unsigned)(s.groups + gx * gy));
-  const size_t lds = sdpa_bwd_lds(s.G.C);
+  const size_t lds = std::max(sdpa_bwd_lds(s.G.C), conv_ksplit_lds<TN, TJ>());
 #define KS_CASE(K)                                                                                   \
   if (kch == K) {                                                                                    \
     hipLaunchKernelGGL((conv_bwd_sdpa_k<TN, TJ, K>), grid, dim3(256), lds, st, a, s, gx);            \
@@ -884,9 +1216,58 @@ bool launch_ksplit_sdpa_bwd(const ConvArgs& a, const SdpaBwdArgs& s, hipStream_t
   return false;
 }
 
+inline int conv_pipe_mode() {        // BMNAS_CONV_PIPE=0 falls back to the split-K kernels (A/B runs)
+  static const int v = []() { const char* e = getenv("BMNAS_CONV_PIPE"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+// pipelined tile kernel (forward); false when the shape is not covered
+inline bool launch_pipe_fwd(const ConvArgs& a, hipStream_t st) {
+  if (!conv_pipe_mode() || a.I != a.Ci || a.fold != 0 || a.acc_mask != 0 || a.ldw % 4) return false;
+  const int gx = (a.n_groups + 3) / 4, gy = (a.J + kPipeJ - 1) / kPipeJ;
+  if (gx * gy < 96) return false;
+  static const int kc = []() { const char* e = getenv("BMNAS_PIPE_KC"); return e ? atoi(e) : 48; }();
+  if (kc == 96 && a.I % 96 == 0) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_pipe_fwd_k<96>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)conv_pipe_lds<96>());
+    (void)attr;
+    hipLaunchKernelGGL((conv_pipe_fwd_k<96>), dim3((unsigned)(gx * gy)), dim3(256), conv_pipe_lds<96>(), st, a, gx);
+    return true;
+  }
+  if (a.I % 48 == 0) {
+    hipLaunchKernelGGL((conv_pipe_fwd_k<48>), dim3((unsigned)(gx * gy)), dim3(256), conv_pipe_lds<48>(), st, a, gx);
+    return true;
+  }
+  if (a.I % 32 == 0) {
+    hipLaunchKernelGGL((conv_pipe_fwd_k<32>), dim3((unsigned)(gx * gy)), dim3(256), conv_pipe_lds<32>(), st, a, gx);
+    return true;
+  }
+  return false;
+}
+
 template <bool TRANS>
 void launch_nj(const ConvArgs& a, hipStream_t st) {
   const long jt = a.J / 16, ng = a.n_groups;
+  if (TRANS && launch_pipe_fwd(a, st)) return;
+  if (!TRANS && conv_pipe_mode() && a.I == a.Ci && a.fold == 0 && a.I % 48 == 0 && a.J % 16 == 0 && a.ldw % 4 == 0) {
+    const int gx = (a.n_groups + 1) / 2, gy = (a.J + kPipeBJ - 1) / kPipeBJ;
+    if (gx * gy >= 96) {
+      static const int kc = []() { const char* e = getenv("BMNAS_PIPE_KC"); return e ? atoi(e) : 48; }();
+      if (kc == 96 && a.I % 96 == 0) {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)conv_pipe_bwd_k<96>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           (int)conv_pipe_bwd_lds<96>());
+        (void)attr;
+        hipLaunchKernelGGL((conv_pipe_bwd_k<96>), dim3((unsigned)(gx * gy)), dim3(256), conv_pipe_bwd_lds<96>(),
+                           st, a, gx);
+      } else {
+        hipLaunchKernelGGL((conv_pipe_bwd_k<48>), dim3((unsigned)(gx * gy)), dim3(256), conv_pipe_bwd_lds<48>(),
+                           st, a, gx);
+      }
+      return;
+    }
+  }
   {
     // split-K kernel.  Measured on MI355X: what costs time at batch 128 is the number of
     // ROUNDS of workgroups a CU has to run (each round pays launch + one memory round trip +
@@ -1001,7 +1382,23 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
   hipStream_t st = (hipStream_t)stream;
   const long jt = a.J / 16, ng = a.n_groups;
   bool done = false;
-  if (((ng + 1) / 2) * ((jt + 1) / 2) >= 1024) done = launch_ksplit_sdpa_fwd<2, 2>(a, s, st);
+  {
+    const int kch = sdpa_kch(C);
+    const int gx = (a.n_groups + 3) / 4, gy = (a.J + kPipeJ - 1) / kPipeJ;
+    if (conv_pipe_mode() && a.I == C && a.fold == 0 && a.ldw % 4 == 0 && gx * gy >= 96 && kch <= 4) {
+      dim3 grid((unsigned)(s.groups + gx * gy));
+#define PF_CASE(KCv, K)                                                                                \
+  if (!done && a.I % KCv == 0 && kch == K) {                                                           \
+    hipLaunchKernelGGL((conv_pipe_fwd_sdpa_k<KCv, K>), grid, dim3(256),                                \
+                       std::max((size_t)kSdpaFwdLds, conv_pipe_lds<KCv>()), st, a, s, gx);             \
+    done = true;                                                                                       \
+  }
+      PF_CASE(48, 1) PF_CASE(48, 2) PF_CASE(48, 3) PF_CASE(48, 4)
+      PF_CASE(32, 1) PF_CASE(32, 2) PF_CASE(32, 3) PF_CASE(32, 4)
+#undef PF_CASE
+    }
+  }
+  if (!done && ((ng + 1) / 2) * ((jt + 1) / 2) >= 1024) done = launch_ksplit_sdpa_fwd<2, 2>(a, s, st);
   if (!done) done = launch_ksplit_sdpa_fwd<1, 1>(a, s, st);
   if (!done) {
     launch_nj<true>(a, st);
@@ -1138,7 +1535,23 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   hipStream_t st = (hipStream_t)stream;
   const int kch = sdpa_kch(C);
   bool done = false;
-  if (a.I == 3 * C && C % 64 == 0 && kch <= 4) {
+  if (conv_pipe_mode() && a.I % 48 == 0 && a.fold == 0 && a.ldw % 4 == 0 && a.J % 16 == 0 && kch <= 4) {
+    const int gx = (a.n_groups + 1) / 2, gy = (a.J + kPipeBJ - 1) / kPipeBJ;
+    if (gx * gy >= 96) {
+      const int n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
+      dim3 grid((unsigned)(s.groups + n_w + gx * gy));
+      const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), conv_pipe_bwd_lds<48>());
+#define PB_CASE(K)                                                                                     \
+  if (!done && kch == K) {                                                                             \
+    hipLaunchKernelGGL((conv_bwd_all_pipe_k<48, K>), grid, dim3(256), lds, st, a, s, w, gx, n_w,       \
+                       (int)wgrid.x, (int)wgrid.y);                                                    \
+    done = true;                                                                                       \
+  }
+      PB_CASE(1) PB_CASE(2) PB_CASE(3) PB_CASE(4)
+#undef PB_CASE
+    }
+  }
+  if (!done && a.I == 3 * C && C % 64 == 0 && kch <= 4) {
     const long jt = a.J / 16, ng = a.n_groups;
     const bool big = ((ng + 1) / 2) * ((jt + 1) / 2) >= 1024 && 3 * kch * 16 + 16 <= 232;
     const int TNv = big ? 2 : 1;
@@ -1146,7 +1559,7 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
       const int gx = (a.n_groups + TNv - 1) / TNv, gy = (a.J / 16 + TNv - 1) / TNv;
       const int n_data = gx * gy, n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
       dim3 grid((unsigned)(s.groups + n_data + n_w));
-      const size_t lds = sdpa_bwd_lds(C);
+      const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), conv_ksplit_lds<2, 2>());
 #define ALL_CASE(T, K)                                                                                 \
   if (!done && TNv == T && kch == K) {                                                                 \
     hipLaunchKernelGGL((conv_bwd_all_k<T, T, K>), grid, dim3(256), lds, st, a, s, w, gx, n_w,          \

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void sdpa_ln_fwd_k(const float* __restrict__ x
                                                      float* __restrict__ xhat,
                                                      float* __restrict__ stats, SdpaGeom G,
                                                      DropCfg drop) {
-  sdpa_fwd_body<KCH>(blockIdx.x, x, y, ln_w, ln_b, out, xhat, stats, G, drop);
+  extern __shared__ __attribute__((aligned(16))) char sdpa_smem[];
+  sdpa_fwd_body<KCH>(blockIdx.x, x, y, ln_w, ln_b, out, xhat, stats, G, drop, sdpa_smem);
 }
 
 template <int KCH>
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(256) void sdpa_ln_bwd_k(
     const float* __restrict__ gout, const float* __restrict__ gscale, const float* __restrict__ x,
     const float* __restrict__ y, const float* __restrict__ ln_w, const float* __restrict__ xhat,
     const float* __restrict__ stats, float* dx, float* dy, uint32_t acc_mask, SdpaGeom G, DropCfg drop) {
-  sdpa_bwd_body<KCH>(blockIdx.x, gout, gscale, x, y, ln_w, xhat, stats, dx, dy, acc_mask, G, drop);
+  extern __shared__ __attribute__((aligned(16))) char sdpa_smem[];
+  sdpa_bwd_body<KCH>(blockIdx.x, gout, gscale, x, y, ln_w, xhat, stats, dx, dy, acc_mask, G, drop, sdpa_smem);
 }
 
 }  // namespace
@@ -59,7 +61,7 @@ extern "C" int bmnas_sdpa_ln_fwd(const float* x, const float* y, const float* ln
   if (b == 0) return 0;
   const int groups = (b + G.spw - 1) / G.spw;
 #define SDPA_F(K)                                                                                     \
-  hipLaunchKernelGGL(sdpa_ln_fwd_k<K>, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, y, ln_w, ln_b, \
+  hipLaunchKernelGGL(sdpa_ln_fwd_k<K>, dim3(groups), dim3(256), kSdpaFwdLds, (hipStream_t)stream, x, y, ln_w, ln_b, \
                      out, xhat, stats, G, to_cfg(drop))
   SDPA_KCH_DISPATCH(sdpa_kch(C), SDPA_F);
 #undef SDPA_F

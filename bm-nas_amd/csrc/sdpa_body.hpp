@@ -9,6 +9,8 @@
 namespace {
 
 constexpr float kEps = 1e-5f;
+constexpr int kSdpaFwdLds = 4096 + 64;                 // bytes of LDS sdpa_fwd_body needs
+constexpr int kSdpaBwdFixedLds = 4096 + 2 * 4352 + 64;  // ... sdpa_bwd_body, before its [C][17] transpose buffer
 constexpr int kMaxCh = 8;          // 16-channel chunks per wave: C <= 4 * 8 * 16 = 512
 // The bodies are templated on KCH = chunks per wave actually needed (ceil(C / 64)): the operand
 // prefetch arrays are sized by it, and a fixed size of 8 cost 212 VGPRs and 5 redundant (clamped)
@@ -115,9 +117,11 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
                                               const float* __restrict__ ln_w,
                                               const float* __restrict__ ln_b, float* __restrict__ out,
                                               float* __restrict__ xhat, float* __restrict__ stats,
-                                              const SdpaGeom& G, const DropCfg& drop) {
-  __shared__ float4 ldsS[4 * 64];
-  __shared__ float red[4][4];
+                                              const SdpaGeom& G, const DropCfg& drop, char* lds) {
+  // LDS comes from the caller (kSdpaFwdLds bytes, 16-byte aligned) so that a launch that merges
+  // this body with others pays max(), not sum(), of their footprints
+  float4* ldsS = reinterpret_cast<float4*>(lds);                 // [4 * 64]
+  float (*red)[4] = reinterpret_cast<float (*)[4]>(lds + 4096);  // [4][4]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int sh = g * G.spw + ((4 * h) >> G.Lb);
@@ -194,13 +198,13 @@ __device__ __forceinline__ void sdpa_bwd_body(
     const int g, const float* __restrict__ gout, const float* __restrict__ gscale,
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ ln_w,
     const float* __restrict__ xhat, const float* __restrict__ stats, float* dx, float* dy,
-    uint32_t acc_mask, const SdpaGeom& G, const DropCfg& drop) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* dOt = reinterpret_cast<float*>(smem);                   // [C][17]: dO as [c][i]
-  __shared__ float4 ldsS[4 * 64];
-  __shared__ float tP[4][16 * 17];
-  __shared__ float tS[4][16 * 17];
-  __shared__ float red[4][4];
+    uint32_t acc_mask, const SdpaGeom& G, const DropCfg& drop, char* lds) {
+  // LDS from the caller: sdpa_bwd_lds(C) bytes, 16-byte aligned (see sdpa_fwd_body)
+  float4* ldsS = reinterpret_cast<float4*>(lds);                                  // [4 * 64]
+  float (*tP)[16 * 17] = reinterpret_cast<float (*)[16 * 17]>(lds + 4096);        // [4][272]
+  float (*tS)[16 * 17] = reinterpret_cast<float (*)[16 * 17]>(lds + 4096 + 4352); // [4][272]
+  float (*red)[4] = reinterpret_cast<float (*)[4]>(lds + 4096 + 2 * 4352);        // [4][4]
+  float* dOt = reinterpret_cast<float*>(lds + kSdpaBwdFixedLds);                  // [C][17]: dO as [c][i]
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
@@ -367,6 +371,6 @@ inline DropCfg to_cfg(const bmnas_dropout_t& d) {
 }
 
 
-inline size_t sdpa_bwd_lds(int C) { return (size_t)C * 17 * 4; }
+inline size_t sdpa_bwd_lds(int C) { return kSdpaBwdFixedLds + (size_t)C * 17 * 4; }
 
 }  // namespace
