@@ -1119,6 +1119,11 @@ __global__ __launch_bounds__(256) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdAr
                                                            int n_w, int wx, int wy) {
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   const int blk = blockIdx.x;
+  // BMNAS_CONV_PROBE bits 16 / 32 / 64 drop the attention / weight-gradient / data-gradient blocks:
+  // timing diagnostics only (tools/ktable.py), the results are then incomplete
+  if ((a.probe & 16) && blk < s.groups) return;
+  if ((a.probe & 32) && blk >= s.groups && blk < s.groups + n_w) return;
+  if ((a.probe & 64) && blk >= s.groups + n_w) return;
   if (blk < s.groups) {
     sdpa_bwd_body<KCH>(blk, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask, s.G,
                        s.drop, merged_smem);
@@ -1522,7 +1527,7 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   for (int q = 0; q < n_src; ++q) a.dst.p[q] = dsrcs[q];
   a.W = W; a.bias = nullptr; a.part = nullptr; a.ldw = ldw;
   a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
-  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = 0; a.fold = fold_cols;
+  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = conv_probe(); a.fold = fold_cols;
   s.g = g; s.gscale = gscale; s.x = x; s.y = y; s.ln_w = ln_w; s.xhat = xhat; s.stats = stats;
   s.dx = dx; s.dy = dy; s.acc_mask = sdpa_accumulate_mask; s.drop = to_cfg(drop);
   s.groups = (b + s.G.spw - 1) / s.G.spw;
