@@ -1225,6 +1225,11 @@ bool launch_ksplit_sdpa_bwd(const ConvArgs& a, const SdpaBwdArgs& s, hipStream_t
   return false;
 }
 
+inline int conv_pipe_min() {         // fewest GEMM workgroups for which the tile kernels are used
+  static const int v = []() { const char* e = getenv("BMNAS_PIPE_MIN"); return e ? atoi(e) : 96; }();
+  return v;
+}
+
 inline int conv_pipe_mode() {        // BMNAS_CONV_PIPE=0 falls back to the split-K kernels (A/B runs)
   static const int v = []() { const char* e = getenv("BMNAS_CONV_PIPE"); return e ? atoi(e) : 1; }();
   return v;
@@ -1380,7 +1385,7 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
     const int gy = (a.J + kPipeJ - 1) / kPipeJ;
     const int ngv = ng_forced ? ng_forced : ((a.n_groups + 3) / 4 * gy >= 512 ? 4 : 2);
     const int gx = (a.n_groups + ngv - 1) / ngv;
-    if (conv_pipe_mode() && a.I == C && a.fold == 0 && a.ldw % 4 == 0 && gx * gy >= 96 && kch <= 4) {
+    if (conv_pipe_mode() && a.I == C && a.fold == 0 && a.ldw % 4 == 0 && gx * gy >= conv_pipe_min() && kch <= 4) {
       dim3 grid((unsigned)(s.groups + gx * gy));
 #define PF_CASE(KCv, K)                                                                                \
   if (!done && a.I % KCv == 0 && kch == K) {                                                           \
@@ -1539,7 +1544,7 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
     const int gy = (a.J + kPipeBJ - 1) / kPipeBJ;
     const int ngv = ng_forced ? ng_forced : 2;
     const int gx = (a.n_groups + ngv - 1) / ngv;
-    if (gx * gy >= 96) {
+    if (gx * gy >= conv_pipe_min() / 2) {         // measured: pays from ~48 data-gradient tiles up
       const int n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
       dim3 grid((unsigned)(s.groups + n_w + gx * gy));
       const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), (conv_pipe_bwd_lds<48, 2>()));
