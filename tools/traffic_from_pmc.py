@@ -12,7 +12,9 @@ import sys
 fetch_csv, write_csv, out = sys.argv[1:4]
 STREAMING = ('mixsum', 'cat_ln', 'ln_affine', 'node_mix', 'bn_', 'fold_weight', 'adam')
 WRAPPER = [('mixsum_pair_fwd_k', 'mixsum_pair_fwd'), ('mixsum_pair_bwd_k', 'mixsum_pair_bwd'),
-           ('node_mix_ln_fwd_k', 'node_mix_ln_fwd'), ('conv_fwd_sdpa_k', 'conv1x1_fwd_sdpa'),
+           ('node_mix_ln_fwd_k', 'node_mix_ln_fwd'), ('conv_fwd_sdpa_k', 'conv1x1_fwd_sdpa'), ('conv_pipe_fwd_sdpa_k', 'conv1x1_fwd_sdpa'),
+           ('conv_bwd_all_pipe_k', 'conv1x1_bwd_all_sdpa'), ('conv_pipe_fwd_k', 'conv1x1_fwd'),
+           ('conv_pipe_bwd_k', 'conv1x1_bwd_data'),
            ('conv_bwd_sdpa_k', 'conv1x1_bwd_data_sdpa'), ('conv_bwd_all_k', 'conv1x1_bwd_all_sdpa'),
            ('linear_bwd_k', 'linear_bwd'), ('cell_prologue_k', 'cell_prologue'), ('adam_multi_k', 'adam_multi'),
            ('linear_fwd_k', 'linear_fwd'), ('mixsum_fwd_k', 'mixsum_fwd'), ('mixsum_bwd_k', 'mixsum_bwd'), ('cat_ln_fwd_k', 'cat_ln_fwd'),
@@ -39,7 +41,7 @@ for k in f:
     wrap = next((wn for p, wn in WRAPPER if p in name), None)
     if wrap is None or (wrap.startswith('conv1x1_') and 'conv' not in name) or \
             (wrap in ('conv1x1_fwd', 'conv1x1_bwd_data') and 'ksplit' not in name and 'conv_nj' not in name
-             and 'conv_lds' not in name):
+             and 'conv_lds' not in name and 'conv_pipe' not in name):
         continue
     d = per_wrapper[wrap]
     d['launches'] += len(f[k])
