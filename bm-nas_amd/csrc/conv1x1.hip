@@ -391,7 +391,10 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
   constexpr int TNC = 16 * NG, WN = NG / 2;                    // tile columns, n-groups per wave
   constexpr int A4 = TNC * KC / 4, B4 = kPipeJ * KC / 4;       // float4 per chunk
   constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
-  constexpr int BUF = TNC * KC + kPipeJ * KP;                   // floats per buffer
+  // activation rows (one channel of one sample: L floats) are padded to L + 4 in LDS: the four
+  // k-slots of a wave then read rows 4 apart on different banks (unpadded: 2-way conflict)
+  const int ABUF = ((TNC * KC) >> a.Lb) * (a.L + 4);
+  const int BUF = ABUF + kPipeJ * KP;                   // floats per buffer
   const int t = threadIdx.x;
   const int wave = t >> 6, lane = t & 63, lo = lane & 15, h = lane >> 4;
   const int spt = TNC >> a.Lb;                                  // samples per tile
@@ -412,7 +415,8 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     int s = s0 + sl;
     s = s < a.b ? s : a.b - 1;                                 // clamped: padded samples are never stored
     aoffg[i] = ((int64_t)s * K << a.Lb) + (int64_t)(qq - sl * cl4) * 4;
-    asl[i] = qq * 4;                                           // LDS float offset (verbatim copy)
+    const int row = (qq * 4) >> a.Lb, col = (qq * 4) & (a.L - 1);   // row = sample_local * KC + channel
+    asl[i] = row * (a.L + 4) + col;
   }
   int64_t boffg[NB];
   int bsl[NB];
@@ -424,7 +428,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     int j = j0 + jr;
     j = j < a.J ? j : a.J - 1;
     boffg[i] = (int64_t)j * a.ldw + 4 * c4;
-    bsl[i] = TNC * KC + jr * KP + 4 * c4;
+    bsl[i] = ABUF + jr * KP + 4 * c4;
   }
   float4 ra[NA], rb[NB];
   auto fetch = [&](int c) __attribute__((always_inline)) {
@@ -446,9 +450,9 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
   int aoff[WN], boff[3];
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn)
-    aoff[tn] = (((gl0 + tn) * a.spw + (lo >> a.Lb)) * KC << a.Lb) + (lo & (a.L - 1));
+    aoff[tn] = ((gl0 + tn) * a.spw + (lo >> a.Lb)) * KC * (a.L + 4) + (lo & (a.L - 1));
 #pragma unroll
-  for (int tj = 0; tj < 3; ++tj) boff[tj] = TNC * KC + ((jl0 + tj) * 16 + lo) * KP + 4 * h;
+  for (int tj = 0; tj < 3; ++tj) boff[tj] = ABUF + ((jl0 + tj) * 16 + lo) * KP + 4 * h;
   f32x4 acc[WN][3];
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn)
@@ -469,7 +473,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) av[tn][r] = cur[aoff[tn] + ((c0 + r) << a.Lb)];
+        for (int r = 0; r < 4; ++r) av[tn][r] = cur[aoff[tn] + (c0 + r) * (a.L + 4)];
 #pragma unroll
       for (int tj = 0; tj < 3; ++tj) bv[tj] = ld4(cur + boff[tj] + 16 * kb);
 #pragma unroll
@@ -545,7 +549,8 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
   constexpr int TNC = 16 * NG, WJ = NG;                       // tile columns, j-tiles per wave
   constexpr int A4 = TNC * KC / 4, B4 = KC * kPipeBJ / 4;
   constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
-  constexpr int BUF = TNC * KC + KC * JP;
+  const int ABUF = ((TNC * KC) >> a.Lb) * (a.L + 4);           // rows padded to L + 4 (see forward body)
+  const int BUF = ABUF + KC * JP;
   const int t = threadIdx.x;
   const int wave = t >> 6, lane = t & 63, lo = lane & 15, h = lane >> 4;
   const int spt = TNC >> a.Lb;
@@ -564,7 +569,8 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     int s = s0 + sl;
     s = s < a.b ? s : a.b - 1;
     aoffg[i] = ((int64_t)s * K << a.Lb) + (int64_t)(qq - sl * cl4) * 4;
-    asl[i] = qq * 4;
+    const int row = (qq * 4) >> a.Lb, col = (qq * 4) & (a.L - 1);
+    asl[i] = row * (a.L + 4) + col;
   }
   int64_t boffg[NB];
   int bsl[NB];
@@ -577,7 +583,7 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     int j4 = j0 / 4 + c4;
     j4 = j4 < jmax4 ? j4 : jmax4;
     boffg[i] = (int64_t)kr * a.ldw + 4 * j4;
-    bsl[i] = TNC * KC + kr * JP + 4 * c4;
+    bsl[i] = ABUF + kr * JP + 4 * c4;
   }
   float4 ra[NA], rb[NB];
   auto fetch = [&](int c) __attribute__((always_inline)) {
@@ -595,10 +601,10 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
       if (t + 256 * i < B4) st4(buf + bsl[i], rb[i]);
   };
   const int gl = (NG == 2) ? (wave & 1) : 0, jl0 = (NG == 2) ? 2 * (wave >> 1) : wave;
-  const int aoff = ((gl * a.spw + (lo >> a.Lb)) * KC << a.Lb) + (lo & (a.L - 1));
+  const int aoff = (gl * a.spw + (lo >> a.Lb)) * KC * (a.L + 4) + (lo & (a.L - 1));
   int boff[WJ];
 #pragma unroll
-  for (int tj = 0; tj < WJ; ++tj) boff[tj] = TNC * KC + 4 * h * JP + (jl0 + tj) * 16 + lo;
+  for (int tj = 0; tj < WJ; ++tj) boff[tj] = ABUF + 4 * h * JP + (jl0 + tj) * 16 + lo;
   f32x4 acc[WJ];
 #pragma unroll
   for (int tj = 0; tj < WJ; ++tj) acc[tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -613,7 +619,7 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
       const int c0 = 16 * kb + 4 * h;
       float av[4], bv[WJ][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) av[r] = cur[aoff + ((c0 + r) << a.Lb)];
+      for (int r = 0; r < 4; ++r) av[r] = cur[aoff + (c0 + r) * (a.L + 4)];
 #pragma unroll
       for (int tj = 0; tj < WJ; ++tj)
 #pragma unroll
@@ -656,12 +662,14 @@ __global__ __launch_bounds__(256) void conv_pipe_bwd_k(ConvArgs a, int gx) {
 }
 
 template <int KC, int NG>
-constexpr size_t conv_pipe_bwd_lds() {
-  return (size_t)2 * (16 * NG * KC + KC * (kPipeBJ + 4)) * sizeof(float);
+inline size_t conv_pipe_bwd_lds(int L) {
+  return (size_t)2 * (16 * NG * KC / L * (L + 4) + KC * (kPipeBJ + 4)) * sizeof(float);
 }
 
 template <int KC, int NG>
-constexpr size_t conv_pipe_lds() { return (size_t)2 * (16 * NG * KC + kPipeJ * (KC + 4)) * sizeof(float); }
+inline size_t conv_pipe_lds(int L) {
+  return (size_t)2 * (16 * NG * KC / L * (L + 4) + kPipeJ * (KC + 4)) * sizeof(float);
+}
 
 // ---- GEMM + attention in one launch ---------------------------------------------------------
 // In a NodeMixedOp the attention branch and the stacked LinearGLU/ConcatFC conv read the same
@@ -1240,12 +1248,12 @@ inline bool launch_pipe_fwd(const ConvArgs& a, hipStream_t st) {
   if (!conv_pipe_mode() || a.I != a.Ci || a.fold != 0 || a.acc_mask != 0 || a.ldw % 4) return false;
   const int gx = (a.n_groups + 3) / 4, gy = (a.J + kPipeJ - 1) / kPipeJ;
   if (gx * gy < 96) return false;
-  if (a.I % 48 == 0) {
-    hipLaunchKernelGGL((conv_pipe_fwd_k<48, 4>), dim3((unsigned)(gx * gy)), dim3(256), (conv_pipe_lds<48, 4>()), st, a, gx);
+  if (a.I % 48 == 0 && conv_pipe_lds<48, 4>(a.L) <= 65536) {     // (L = 4 pads rows to twice their size)
+    hipLaunchKernelGGL((conv_pipe_fwd_k<48, 4>), dim3((unsigned)(gx * gy)), dim3(256), (conv_pipe_lds<48, 4>(a.L)), st, a, gx);
     return true;
   }
   if (a.I % 32 == 0) {
-    hipLaunchKernelGGL((conv_pipe_fwd_k<32, 4>), dim3((unsigned)(gx * gy)), dim3(256), (conv_pipe_lds<32, 4>()), st, a, gx);
+    hipLaunchKernelGGL((conv_pipe_fwd_k<32, 4>), dim3((unsigned)(gx * gy)), dim3(256), (conv_pipe_lds<32, 4>(a.L)), st, a, gx);
     return true;
   }
   return false;
@@ -1259,7 +1267,7 @@ void launch_nj(const ConvArgs& a, hipStream_t st) {
     const int gx = (a.n_groups + 1) / 2, gy = (a.J + kPipeBJ - 1) / kPipeBJ;
     if (gx * gy >= 96) {
       hipLaunchKernelGGL((conv_pipe_bwd_k<48, 2>), dim3((unsigned)(gx * gy)), dim3(256),
-                         (conv_pipe_bwd_lds<48, 2>()), st, a, gx);
+                         (conv_pipe_bwd_lds<48, 2>(a.L)), st, a, gx);
       return;
     }
   }
@@ -1388,13 +1396,13 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
     if (conv_pipe_mode() && a.I == C && a.fold == 0 && a.ldw % 4 == 0 && gx * gy >= conv_pipe_min() && kch <= 4) {
       dim3 grid((unsigned)(s.groups + gx * gy));
 #define PF_CASE(KCv, K)                                                                                \
-  if (!done && a.I % KCv == 0 && kch == K) {                                                           \
+  if (!done && a.I % KCv == 0 && kch == K && conv_pipe_lds<KCv, 4>(a.L) <= 65536) {                    \
     if (ngv == 2)                                                                                      \
       hipLaunchKernelGGL((conv_pipe_fwd_sdpa_k<KCv, K, 2>), grid, dim3(256),                           \
-                         std::max((size_t)kSdpaFwdLds, (conv_pipe_lds<KCv, 2>())), st, a, s, gx);        \
+                         std::max((size_t)kSdpaFwdLds, (conv_pipe_lds<KCv, 2>(a.L))), st, a, s, gx);        \
     else                                                                                               \
       hipLaunchKernelGGL((conv_pipe_fwd_sdpa_k<KCv, K, 4>), grid, dim3(256),                           \
-                         std::max((size_t)kSdpaFwdLds, (conv_pipe_lds<KCv, 4>())), st, a, s, gx);        \
+                         std::max((size_t)kSdpaFwdLds, (conv_pipe_lds<KCv, 4>(a.L))), st, a, s, gx);        \
     done = true;                                                                                       \
   }
       PF_CASE(48, 1) PF_CASE(48, 2) PF_CASE(48, 3) PF_CASE(48, 4)
@@ -1547,7 +1555,7 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
     if (gx * gy >= conv_pipe_min() / 2) {         // measured: pays from ~48 data-gradient tiles up
       const int n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
       dim3 grid((unsigned)(s.groups + n_w + gx * gy));
-      const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), (conv_pipe_bwd_lds<48, 2>()));
+      const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), (conv_pipe_bwd_lds<48, 2>(a.L)));
 #define PB_CASE(K)                                                                                     \
   if (!done && kch == K) {                                                                             \
     if (ngv == 1)                                                                                      \

@@ -295,7 +295,7 @@ def test_cross_entropy_loss(b, O):
 
 @pytest.mark.parametrize('b,C,L,M,bias,stats', [(128, 192, 16, 576, True, True), (100, 192, 16, 576, False, True),
                                               (250, 128, 8, 384, True, True), (509, 64, 4, 208, True, False),
-                                              (128, 192, 16, 80, True, True)])
+                                              (128, 192, 16, 80, True, True), (400, 96, 4, 288, True, True)])
 def test_conv1x1_fwd_large_single_source(b, C, L, M, bias, stats):
     """The production-size forward GEMM through the C ABI: U = W x + bias and the per-16-column
     BatchNorm partials (sum, centred second moment), against float64 on the CPU.  Ragged batches
