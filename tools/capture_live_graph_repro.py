@@ -1,3 +1,7 @@
+"""Reproduces the condition GraphedTrainStep guards against: capturing a step while tensors of an
+earlier eager autograd graph are still referenced (flag `del` drops them -> capture succeeds).  Without
+the guard HIP's capture_end segfaults (the stale AccumulateGrad nodes pull the default stream into the
+capture).  Flags: nostep noopt torchw bnnlin bnnloss bigC bigB drop sync mm L16 N6 late del."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'bm-nas_amd'), os.path.join(ROOT, 'tests')):
