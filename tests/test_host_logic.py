@@ -152,3 +152,41 @@ def test_found_network_state_dict_keys():
     og = fo.genotype_from_jsonable(fo.genotype_to_jsonable(g))
     assert set(f.state_dict()) == set(fo.found_param_shapes(cfg, og))
     assert f.get_genotype() is g
+
+
+def test_graph_step_switch_precedence(monkeypatch):
+    """GraphedTrainStep.enabled: args.hip_graph beats BMNAS_HIP_GRAPH beats the default (on for a
+    single process); never on without a GPU."""
+    import torch
+    from bmnas.graph import GraphedTrainStep
+
+    class A:
+        pass
+
+    monkeypatch.delenv('BMNAS_HIP_GRAPH', raising=False)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    a = A()
+    assert GraphedTrainStep.enabled(a) is True                 # default: single process -> on
+    monkeypatch.setenv('BMNAS_HIP_GRAPH', '0')
+    assert GraphedTrainStep.enabled(a) is False
+    a.hip_graph = True
+    assert GraphedTrainStep.enabled(a) is True                 # explicit argument wins over the environment
+    a.hip_graph = False
+    monkeypatch.setenv('BMNAS_HIP_GRAPH', '1')
+    assert GraphedTrainStep.enabled(a) is False
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
+    a.hip_graph = True
+    assert GraphedTrainStep.enabled(a) is False                # no GPU, no graphs
+
+
+def test_live_autograd_graph_detector():
+    """The guard in front of every capture: non-leaf tensors that are still referenced count."""
+    import torch
+    from bmnas.graph import GraphedTrainStep
+    dev = torch.device('cpu')
+    base = GraphedTrainStep._live_graph_tensors(dev)
+    w = torch.ones(3, requires_grad=True)
+    held = (w * 2).sum()                                       # a loss someone keeps
+    assert GraphedTrainStep._live_graph_tensors(dev) == base + 1
+    held = held.detach()
+    assert GraphedTrainStep._live_graph_tensors(dev) == base
