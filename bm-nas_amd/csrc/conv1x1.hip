@@ -465,27 +465,34 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
   for (int c = 0; c < nchunk; ++c) {
     const float* cur = smem + (c & 1) * BUF;
     if (c + 1 < nchunk) fetch(c + 1);                          // in flight during this chunk's MFMAs
+    // LDS operand reads of the whole chunk first, then its MFMAs back to back (see the
+    // data-gradient body)
+    constexpr int NKB = KC / 16;
+    float av[NKB][WN][4];
+    float4 bv[NKB][3];
 #pragma unroll
-    for (int kb = 0; kb < KC / 16; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       const int c0 = 16 * kb + 4 * h;
-      float av[WN][4];
-      float4 bv[3];
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) av[tn][r] = cur[aoff[tn] + (c0 + r) * (a.L + 4)];
+        for (int r = 0; r < 4; ++r) av[kb][tn][r] = cur[aoff[tn] + (c0 + r) * (a.L + 4)];
 #pragma unroll
-      for (int tj = 0; tj < 3; ++tj) bv[tj] = ld4(cur + boff[tj] + 16 * kb);
+      for (int tj = 0; tj < 3; ++tj) bv[kb][tj] = ld4(cur + boff[tj] + 16 * kb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
         for (int tj = 0; tj < 3; ++tj) {
-          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][0], bv[tj].x, acc[tn][tj], 0, 0, 0);
-          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][1], bv[tj].y, acc[tn][tj], 0, 0, 0);
-          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][2], bv[tj].z, acc[tn][tj], 0, 0, 0);
-          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tn][3], bv[tj].w, acc[tn][tj], 0, 0, 0);
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][0], bv[kb][tj].x, acc[tn][tj], 0, 0, 0);
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][1], bv[kb][tj].y, acc[tn][tj], 0, 0, 0);
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][2], bv[kb][tj].z, acc[tn][tj], 0, 0, 0);
+          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][3], bv[kb][tj].w, acc[tn][tj], 0, 0, 0);
         }
-    }
+    __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < nchunk) {
       stash(smem + ((c + 1) & 1) * BUF);                       // the other buffer: nobody reads it now
       __syncthreads();
@@ -614,22 +621,30 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
   for (int c = 0; c < nchunk; ++c) {
     const float* cur = smem + (c & 1) * BUF;
     if (c + 1 < nchunk) fetch(c + 1);
+    // all LDS operand reads of the chunk first, then its MFMAs back to back: with one wave per
+    // SIMD nothing else hides the LDS latency, so it is paid once per chunk instead of per k-block
+    // (the fences keep hipcc from re-interleaving them and from hoisting the barrier above the MFMAs)
+    constexpr int NKB = KC / 16;
+    float av[NKB][4], bv[NKB][WJ][4];
 #pragma unroll
-    for (int kb = 0; kb < KC / 16; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       const int c0 = 16 * kb + 4 * h;
-      float av[4], bv[WJ][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) av[r] = cur[aoff + (c0 + r) * (a.L + 4)];
+      for (int r = 0; r < 4; ++r) av[kb][r] = cur[aoff + (c0 + r) * (a.L + 4)];
 #pragma unroll
       for (int tj = 0; tj < WJ; ++tj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[tj][r] = cur[boff[tj] + (16 * kb + r) * JP];
+        for (int r = 0; r < 4; ++r) bv[kb][tj][r] = cur[boff[tj] + (16 * kb + r) * JP];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int tj = 0; tj < WJ; ++tj)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[tj][r], acc[tj], 0, 0, 0);
-    }
+          acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][r], bv[kb][tj][r], acc[tj], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < nchunk) {
       stash(smem + ((c + 1) & 1) * BUF);
       __syncthreads();
