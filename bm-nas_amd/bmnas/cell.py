@@ -71,6 +71,7 @@ class _DropState:
     def __init__(self):
         self.offset = 0
         self.device_counter = None       # int64 cuda tensor while capturing / replaying
+        self.pending_advance = None      # (counter, span) to hand to the first cell prologue of a capture
 
     def make(self, p, numel, training):
         if not training or p <= 0.0:

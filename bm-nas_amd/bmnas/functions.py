@@ -252,7 +252,10 @@ class FusedCellFn(Function):
         weffs = None
         if K.FUSE_PROLOGUE and 0 < len(mixed) <= 8:
             weffs = [torch.empty((3 * C_, C_), device=dev, dtype=torch.float32) for _ in mixed]
-            lib.cell_prologue(logits, ws, [m.stack_W for m in mixed], weffs, 3 * C_, C_)
+            # under capture the first prologue of the step also advances the dropout step counter
+            # (bmnas.graph.GraphedStep), saving the separate add launch at the end of every replay
+            adv, K.DROP.pending_advance = K.DROP.pending_advance, None
+            lib.cell_prologue(logits, ws, [m.stack_W for m in mixed], weffs, 3 * C_, C_, adv)
         else:
             lib.arch_softmax_multi(logits, None, ws, False)      # every arch tensor, one launch
         if alpha_is_logits:

@@ -31,15 +31,21 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.counter = torch.zeros(1, dtype=torch.int64, device=f'cuda:{dev}')
+        self.span_dev = torch.zeros(1, dtype=torch.int64, device=f'cuda:{dev}')
         saved = (K.DROP.offset, K.DROP.device_counter)
         K.DROP.offset, K.DROP.device_counter = 0, self.counter
+        # the first fused-cell prologue of the step advances the counter (no launch of its own);
+        # if the step has none, an add at the end of the graph does
+        K.DROP.pending_advance = (self.counter, self.span_dev)
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):
                 out = fn()
                 self.span = K.DROP.offset
-                if self.span > 0:
+                consumed = K.DROP.pending_advance is None
+                if self.span > 0 and not consumed:
                     self.counter.add_(self.span)      # next replay draws new dropout masks
+            self.span_dev.fill_(self.span)
             # keep the static storage, not the Python autograd graph that produced it (a retained
             # graph would get in the way of later captures: GraphedTrainStep._live_graph_tensors)
             det = lambda o: o.detach() if torch.is_tensor(o) else o
@@ -47,6 +53,7 @@ class GraphedStep:
             del out
         finally:
             K.DROP.offset, K.DROP.device_counter = saved
+            K.DROP.pending_advance = None
         # keep later eager calls clear of the offsets the graph will use
         K.DROP.offset += 1 << 40
 

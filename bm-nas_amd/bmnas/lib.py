@@ -78,7 +78,8 @@ SIGNATURES = {
     'bmnas_adam_multi': ([_P, _P, _I, _P, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
-    'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P], _I),
+    'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P, _P,
+                             _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
                                  _P], _I),
 }
@@ -369,8 +370,9 @@ def adam_multi(table, chunks, n_chunks, hyp):
            'adam_multi')
 
 
-def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc):
-    """Row softmax of every arch tensor + folded conv weights of every NodeMixedOp, one launch."""
+def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc, step=None):
+    """Row softmax of every arch tensor + folded conv weights of every NodeMixedOp, one launch.
+    step = (counter, span): int64 device tensors; the launch also does counter += span."""
     n = len(a_list)
     rows = (C.c_int * max(n, 1))(*[t.shape[0] for t in a_list])
     cols = (C.c_int * max(n, 1))(*[t.shape[1] for t in a_list])
@@ -379,7 +381,8 @@ def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc):
     nf = len(Ws)
     pw = (C.c_void_p * max(nf, 1))(*[t.data_ptr() for t in Ws])
     pe = (C.c_void_p * max(nf, 1))(*[t.data_ptr() for t in Weffs])
-    _check(load().bmnas_cell_prologue(pa, po, rows, cols, n, pw, pe, nf, M, Cc, _stream()), 'cell_prologue')
+    sc, sp = (None, None) if step is None else (step[0].data_ptr(), step[1].data_ptr())
+    _check(load().bmnas_cell_prologue(pa, po, rows, cols, n, pw, pe, nf, M, Cc, sc, sp, _stream()), 'cell_prologue')
 
 
 def arch_softmax_multi(a_list, dw_list, out_list, backward, n_shards=1, shard_stride=0):

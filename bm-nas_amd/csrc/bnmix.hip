@@ -610,8 +610,13 @@ struct FoldPack {
   int n, M, C, blocks_per;
 };
 
-__global__ __launch_bounds__(256) void cell_prologue_k(ArchPack P, FoldPack F) {
+__global__ __launch_bounds__(256) void cell_prologue_k(ArchPack P, FoldPack F, unsigned long long* step_counter,
+                                                       const unsigned long long* step_span) {
   const int nfb = F.n * F.blocks_per;
+  // hipGraph replays: advance the dropout step counter once, here, before any kernel of this replay
+  // reads it (one thread of the last workgroup; every later kernel is ordered after this launch)
+  if (step_counter != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    step_counter[0] += step_span[0];
   if ((int)blockIdx.x < nfb) {
     const int q = blockIdx.x / F.blocks_per, bi = blockIdx.x - q * F.blocks_per;   // workgroup-uniform
     const float* __restrict__ W = F.W[q];
@@ -853,7 +858,9 @@ extern "C" int bmnas_arch_softmax_multi(const float* const* a, const float* cons
 
 extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, const int* rows,
                                    const int* cols, int n_arch, const float* const* W,
-                                   float* const* Weff, int n_fold, int M, int C, void* stream) {
+                                   float* const* Weff, int n_fold, int M, int C,
+                                   uint64_t* step_counter, const uint64_t* step_span, void* stream) {
+  if ((step_counter == nullptr) != (step_span == nullptr)) return BMNAS_E_ARG;
   if (n_arch < 0 || n_fold < 0 || (n_arch > 0 && (!a || !out || !rows || !cols)) ||
       (n_fold > 0 && (!W || !Weff || M < 1 || C < 1)))
     return BMNAS_E_ARG;
@@ -881,9 +888,11 @@ extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, con
   int per = n_fold > 0 ? (int)(((int64_t)M * (C / 4) + 255) / 256) : 0;
   if (per > 128) per = 128;
   F.blocks_per = per;
-  const int blocks = n_fold * per + (total + 255) / 256;
+  int blocks = n_fold * per + (total + 255) / 256;
+  if (blocks == 0 && step_counter != nullptr) blocks = 1;
   if (blocks == 0) return 0;
-  hipLaunchKernelGGL(cell_prologue_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, F);
+  hipLaunchKernelGGL(cell_prologue_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, F,
+                     (unsigned long long*)step_counter, (const unsigned long long*)step_span);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

@@ -280,10 +280,13 @@ int bmnas_arch_softmax_multi(const float* const* a, const float* const* dw, floa
                              int64_t shard_stride, void* stream);
 /* The forward prologue of a FusionCell in ONE launch: the n_arch row softmaxes of
  * bmnas_arch_softmax_multi (forward) and, for each of n_fold (<= 8) NodeMixedOps of the cell,
- * Weff[q] (M, C) = W[q][:, :C] + W[q][:, C:] as bmnas_fold_weight does (W[q] is (M, 2C)). */
+ * Weff[q] (M, C) = W[q][:, :C] + W[q][:, C:] as bmnas_fold_weight does (W[q] is (M, 2C)).
+ * step_counter / step_span (both or neither): *step_counter += *step_span, once, before anything
+ * else of the step reads the dropout step counter (bmnas_dropout_t.step) — how a hipGraph replay
+ * moves on to fresh dropout masks without a launch of its own. */
 int bmnas_cell_prologue(const float* const* a, float* const* out, const int* rows, const int* cols,
                         int n_arch, const float* const* W, float* const* Weff, int n_fold, int M,
-                        int C, void* stream);
+                        int C, uint64_t* step_counter, const uint64_t* step_span, void* stream);
 
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at

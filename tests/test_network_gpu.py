@@ -286,3 +286,37 @@ def test_full_size_batch_properties(name, batch):
         # different summation orders over 16 k (sample, l) terms that largely cancel: fp32 noise
         # relative to the tensor's scale, not to the element
         assert_close_scaled('mean of shard gradients', a / shards, f.cpu(), rel=5e-3)
+
+
+def test_graph_replays_draw_fresh_consistent_dropout_masks():
+    """Train mode with dropout under hipGraph replay: every replay must use new masks — the device
+    step counter advances by the step's span once per replay, inside the cell prologue launch (no
+    add kernel of its own) — and the replayed autograd step stays well-formed (the gradient of
+    sum(feat * s) with respect to the scalar s is sum(feat), exactly)."""
+    from bmnas.graph import GraphedStep
+    cfg = fo.Cfg({**fo.CONFIGS['mmimdb'], 'drpt': 0.3})
+    net = build_search_net(cfg, 11, 'train')
+    xs = [x.to(dev()) for x in synth.make_inputs(cfg, 8, 4)]
+    scale = torch.ones((), device=dev(), requires_grad=True)
+    params = [p for p in net.parameters()]
+
+    def fn():
+        feat = net(xs)
+        loss = (feat * scale).sum()
+        grads = torch.autograd.grad(loss, [scale] + params)
+        return feat, loss, grads[0], grads[1]
+
+    g = GraphedStep(fn, warmup=2)
+    feats, dscale = [], []
+    for _ in range(3):
+        feat, loss, ds, _ = g.replay()
+        torch.cuda.synchronize()
+        feats.append(feat.clone())
+        # d/dscale sum(feat * scale) = sum(feat): exact
+        assert_close_scaled('dscale == sum(feat)', ds, feat.sum().cpu(), rel=1e-5)
+        dscale.append(float(ds))
+    # fresh masks per replay: the outputs differ (same inputs, same weights, BN statistics aside the
+    # dropout pattern is the only thing that changes this much)
+    assert float((feats[0] - feats[1]).abs().max()) > 1e-3
+    assert float((feats[1] - feats[2]).abs().max()) > 1e-3
+    assert int(g.counter) == 3 * g.span and g.span > 0
