@@ -106,6 +106,8 @@ def algo_table(C, L):
             ('hbm', T(g) + (len(srcs) + (1 if resid is not None else 0)) * T(srcs[0])),
         'ln_affine_bwd_multi': lambda probs, b, L_: ('hbm', sum(
             T(p['g']) + (len(p['srcs']) + (1 if p['resid'] is not None else 0)) * T(p['srcs'][0]) for p in probs)),
+        'backward_epilogue': lambda probs, b, L_, *_: ('hbm', sum(
+            T(p['g']) + (len(p['srcs']) + (1 if p['resid'] is not None else 0)) * T(p['srcs'][0]) for p in probs)),
         'sdpa_ln_fwd': lambda x, y, w, b_, out, *_:
             ('hbm', (3 if x.data_ptr() == y.data_ptr() else 4) * T(x) + 2 * T(w)),
         'sdpa_ln_bwd': lambda g, gs, x, y, w, xhat, st, dx, dy, *_:

@@ -307,6 +307,8 @@ FUSE_ATTN_GEMM = os.environ.get('BMNAS_FUSE_ATTN_GEMM', '1') != '0'
 FUSE_BWD_ALL = os.environ.get('BMNAS_FUSE_BWD_ALL', '1') != '0'
 # arch softmaxes + folded conv weights of a cell in one launch
 FUSE_PROLOGUE = os.environ.get('BMNAS_FUSE_PROLOGUE', '1') != '0'
+# LayerNorm affine gradients + arch-softmax backward in one launch at the end of a cell's backward
+FUSE_EPILOGUE = os.environ.get('BMNAS_FUSE_EPILOGUE', '1') != '0'
 
 
 def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None, Weff=None):
@@ -528,7 +530,7 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
     return out, sv
 
 
-def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
+def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, epilogue=None):
     """Returns the list of input gradients (None where not needed).  d*_w: zero-initialised
     buffers for the gradients w.r.t. the softmaxed arch weights.  CG: gradient pack."""
     N, S, M, CP = sv.N, sv.S, sv.M, sv.CP
@@ -561,5 +563,13 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG):
         else:
             mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
                        dalpha_w[off:, 1], 2, CG.shards, CG.shard_stride)
-    deferred.flush(b, L)
+    if epilogue is not None and FUSE_EPILOGUE and 0 < len(deferred.probs) <= 8:
+        # the LayerNorm affine reductions and the arch-softmax backward end the pass in ONE launch
+        ws, dws, outs = epilogue
+        lib.backward_epilogue(deferred.probs, b, L, ws, dws, outs, CG.shards, CG.shard_stride)
+        deferred.probs = []
+        sv.epilogue_done = True
+    else:
+        deferred.flush(b, L)
+        sv.epilogue_done = False
     return [s.get() if s is not None else None for s in slots[:N]]

@@ -277,7 +277,6 @@ class FusedCellFn(Function):
         need_in = [ctx.needs_input_grad[4 + j] for j in range(N)]
         # one zero-filled arena for every gradient that is accumulated with atomics
         CG, dalpha_w, dbeta_ws, dgamma_ws = cell.grad_pack(dev, sv.alpha_w, ctx.beta_ws, ctx.gamma_ws)
-        dxs = K.fusion_cell_bwd(sv, _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws, CG)
         ws, dws = [], []
         for i in range(S):
             ws += [ctx.beta_ws[i], ctx.gamma_ws[i]]
@@ -285,7 +284,9 @@ class FusedCellFn(Function):
         if ctx.alpha_is_logits:
             ws, dws = [sv.alpha_w] + ws, [dalpha_w] + dws
         darch = [torch.empty_like(w) for w in ws]
-        lib.arch_softmax_multi(ws, dws, darch, True, CG.shards, CG.shard_stride)
+        dxs = K.fusion_cell_bwd(sv, _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws, CG, (ws, dws, darch))
+        if not sv.epilogue_done:
+            lib.arch_softmax_multi(ws, dws, darch, True, CG.shards, CG.shard_stride)
         if ctx.alpha_is_logits:
             dalpha, darch = darch[0], darch[1:]
         else:

@@ -78,6 +78,9 @@ SIGNATURES = {
     'bmnas_adam_multi': ([_P, _P, _I, _P, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
+    'bmnas_backward_epilogue': ([_I, _PP, _PP, C.POINTER(_PP), C.POINTER(C.c_int), _PP, _PP, _PP, _PP, _PP,
+                                 _PP, _I, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 _PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I64, _P], _I),
     'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P, _P,
                              _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
@@ -209,6 +212,30 @@ def ln_affine_bwd_multi(probs, b, L):
                                             parr('ln_w'), parr('ln_b'), parr('stats'), parr('dln_w'),
                                             parr('dln_b'), b, ints('C'), L, ints('relu'), ints('prenorm'),
                                             _stream()), 'ln_affine_bwd_multi')
+
+
+def backward_epilogue(probs, b, L, ws, dws, outs, n_shards, shard_stride):
+    """ln_affine_bwd_multi(probs) + arch_softmax_multi(ws, dws, outs, backward) in one launch."""
+    n = len(probs)
+
+    def parr(key):
+        return (C.c_void_p * n)(*[None if p[key] is None else p[key].data_ptr() for p in probs])
+
+    src_arrays = [_ptrs(p['srcs']) for p in probs]
+    srcs = (_PP * n)(*[C.cast(a, _PP) for a in src_arrays])
+    ints = lambda key: (C.c_int * n)(*[int(p[key]) for p in probs])
+    n_src = (C.c_int * n)(*[len(p['srcs']) for p in probs])
+    na = len(ws)
+    rows = (C.c_int * na)(*[t.shape[0] for t in ws])
+    cols = (C.c_int * na)(*[t.shape[1] for t in ws])
+    pw = (C.c_void_p * na)(*[t.data_ptr() for t in ws])
+    pd = (C.c_void_p * na)(*[t.data_ptr() for t in dws])
+    po = (C.c_void_p * na)(*[t.data_ptr() for t in outs])
+    _check(load().bmnas_backward_epilogue(n, parr('g'), parr('gscale'), srcs, n_src, parr('resid'),
+                                          parr('ln_w'), parr('ln_b'), parr('stats'), parr('dln_w'),
+                                          parr('dln_b'), b, ints('C'), L, ints('relu'), ints('prenorm'),
+                                          pw, pd, po, rows, cols, na, n_shards, shard_stride, _stream()),
+           'backward_epilogue')
 
 
 def sdpa_ln_fwd(x, y, ln_w, ln_b, out, xhat, stats, b, Cc, L, drop):
@@ -441,7 +468,7 @@ def profile_end():
     return out, overhead
 
 
-_TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi',
+_TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',

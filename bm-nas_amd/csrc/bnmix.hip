@@ -6,6 +6,7 @@
 // atomic per channel per workgroup.
 #include "common.hpp"
 #include "../../include/bmnas_hip.h"
+#include "arch_body.hpp"
 #include <cstdlib>
 
 namespace {
@@ -507,41 +508,9 @@ __global__ void arch_softmax_bwd_k(const float* __restrict__ w, const float* __r
   for (int p = 0; p < cols; ++p) da[r * cols + p] = w[r * cols + p] * (dw[r * cols + p] - dot);
 }
 
-struct ArchPack {
-  const float* a[BMNAS_MAX_PTRS];     // fwd: logits      bwd: softmax weights
-  const float* b[BMNAS_MAX_PTRS];     //                  bwd: dweights
-  float* o[BMNAS_MAX_PTRS];           // fwd: weights     bwd: dlogits
-  int rows[BMNAS_MAX_PTRS], cols[BMNAS_MAX_PTRS];
-  int n, n_shards;
-  int64_t shard_stride;               // bwd: dweights are summed over n_shards copies
-};
-
-// backward of the above with the shard sum spread over a wavefront: block = one row, lane =
-// (shard group, column); shards beyond 16 are walked by the same lane
+// backward of the row softmaxes with the shard sum spread over a wavefront: block = one row
 __global__ __launch_bounds__(64) void arch_softmax_multi_bwd_k(ArchPack P) {
-  int r = blockIdx.x;
-  const int lane = threadIdx.x, col = lane & 3, sg = lane >> 2;
-  for (int t = 0; t < P.n; ++t) {
-    if (r < P.rows[t]) {
-      const int cols = P.cols[t];
-      float dw = 0.f, w = 0.f;
-      if (col < cols) {
-        const float* dwp = P.b[t] + r * cols + col;
-        for (int sh = sg; sh < P.n_shards; sh += 16) dw += dwp[(int64_t)sh * P.shard_stride];
-        w = P.a[t][r * cols + col];
-      }
-      dw += __shfl_xor(dw, 4, 64);
-      dw += __shfl_xor(dw, 8, 64);
-      dw += __shfl_xor(dw, 16, 64);
-      dw += __shfl_xor(dw, 32, 64);                      // every lane: total of its column
-      float dot = w * dw;
-      dot += __shfl_xor(dot, 1, 64);
-      dot += __shfl_xor(dot, 2, 64);                     // sum over the 4 columns
-      if (sg == 0 && col < cols) P.o[t][r * cols + col] = w * (dw - dot);
-      return;
-    }
-    r -= P.rows[t];
-  }
+  arch_softmax_bwd_row(P, blockIdx.x, threadIdx.x);
 }
 
 // every row of every architecture tensor in ONE launch (<= 94 rows in total)
@@ -828,23 +797,9 @@ extern "C" int bmnas_arch_softmax_multi(const float* const* a, const float* cons
                                         float* const* out, const int* rows, const int* cols, int n,
                                         int backward, int n_shards, int64_t shard_stride,
                                         void* stream) {
-  if (!a || !out || !rows || !cols || n < 1 || (backward && !dw) || n_shards < 1) return BMNAS_E_ARG;
-  if (n > BMNAS_MAX_PTRS) return BMNAS_E_LIMIT;
   ArchPack P{};
-  int total = 0;
-  for (int t = 0; t < n; ++t) {
-    if (!a[t] || !out[t] || rows[t] < 1 || cols[t] < 1 || cols[t] > 4 || (backward && !dw[t]))
-      return BMNAS_E_ARG;
-    P.a[t] = a[t];
-    P.b[t] = backward ? dw[t] : nullptr;
-    P.o[t] = out[t];
-    P.rows[t] = rows[t];
-    P.cols[t] = cols[t];
-    total += rows[t];
-  }
-  P.n = n;
-  P.n_shards = n_shards;
-  P.shard_stride = shard_stride;
+  const int total = fill_arch_pack(P, a, dw, out, rows, cols, n, backward, n_shards, shard_stride);
+  if (total < 0) return total;
   if (backward) {
     hipLaunchKernelGGL(arch_softmax_multi_bwd_k, dim3(total), dim3(64), 0, (hipStream_t)stream, P);
     BMNAS_CHECK_LAUNCH();

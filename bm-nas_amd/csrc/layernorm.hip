@@ -4,6 +4,7 @@
 // Algorithmic bytes fwd: (n_src [+1 resid] + n_src) * T (+ 2*D*4 params), T = b*C*L*4.
 #include "common.hpp"
 #include "../../include/bmnas_hip.h"
+#include "arch_body.hpp"
 
 namespace {
 
@@ -250,6 +251,21 @@ __global__ __launch_bounds__(256) void ln_affine_bwd_k(LnAffineBatch B) {
   ln_affine_body(P, B.b, B.chunk, red);
 }
 
+// The two launches that end a fused cell's backward, as one: blockIdx.z < B.n are the LayerNorm
+// affine problems above, the z = B.n slice walks the rows of the architecture tensors (four rows
+// per workgroup, one wavefront each) for the row-softmax backward.  Independent work.
+__global__ __launch_bounds__(256) void backward_epilogue_k(LnAffineBatch B, ArchPack A, int arch_rows) {
+  __shared__ float4 red[2][3][64];
+  if ((int)blockIdx.z == B.n) {
+    const int r = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + (int)(threadIdx.x >> 6);
+    if (r < arch_rows) arch_softmax_bwd_row(A, r, threadIdx.x & 63);
+    return;
+  }
+  const LnAffineProb& P = B.p[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= P.d4) return;
+  ln_affine_body(P, B.b, B.chunk, red);
+}
+
 inline int pick_vpt(int d4, int bs) {
   const int need = (d4 + bs - 1) / bs;
   if (need <= 1) return 1;
@@ -404,4 +420,41 @@ extern "C" int bmnas_ln_affine_bwd_multi(int n_prob, const float* const* g, cons
   B.n = n_prob;
   B.b = b;
   return launch_ln_affine(B, (hipStream_t)stream);
+}
+
+extern "C" int bmnas_backward_epilogue(int n_prob, const float* const* g, const float* const* gscale,
+                                       const float* const* const* srcs, const int* n_src,
+                                       const float* const* resid, const float* const* ln_w,
+                                       const float* const* ln_b, const float* const* stats,
+                                       float* const* dln_w, float* const* dln_b, int b, const int* C,
+                                       int L, const int* relu, const int* prenorm,
+                                       const float* const* arch_w, const float* const* arch_dw,
+                                       float* const* arch_out, const int* arch_rows, const int* arch_cols,
+                                       int n_arch, int n_shards, int64_t shard_stride, void* stream) {
+  if (n_prob < 1 || b < 1 || !g || !srcs || !n_src || !dln_w || !dln_b || !C || !relu || !prenorm)
+    return BMNAS_E_ARG;
+  if (n_prob > kMaxLnProbs) return BMNAS_E_LIMIT;
+  LnAffineBatch B{};
+  for (int i = 0; i < n_prob; ++i)
+    if (int e = fill_prob(B.p[i], g[i], gscale ? gscale[i] : nullptr, srcs[i], n_src[i],
+                          resid ? resid[i] : nullptr, ln_w ? ln_w[i] : nullptr, ln_b ? ln_b[i] : nullptr,
+                          stats ? stats[i] : nullptr, dln_w[i], dln_b[i], C[i], L, relu[i], prenorm[i]))
+      return e;
+  ArchPack A{};
+  const int total = fill_arch_pack(A, arch_w, arch_dw, arch_out, arch_rows, arch_cols, n_arch, 1, n_shards,
+                                   shard_stride);
+  if (total < 0) return total;
+  B.n = n_prob;
+  B.b = b;
+  B.chunk = 16;
+  int maxd4 = 0;
+  for (int i = 0; i < B.n; ++i) maxd4 = B.p[i].d4 > maxd4 ? B.p[i].d4 : maxd4;
+  dim3 grid((maxd4 + 63) / 64, (B.b + B.chunk - 1) / B.chunk, B.n + 1);
+  // the arch slice needs one wavefront per row, four per workgroup (LayerNorm workgroups past a
+  // problem's width return at once, so widening the grid for tiny shapes costs nothing)
+  const unsigned need_x = (unsigned)((total + 4 * (int)grid.y - 1) / (4 * (int)grid.y));
+  if (grid.x < need_x) grid.x = need_x;
+  hipLaunchKernelGGL(backward_epilogue_k, grid, dim3(256), 0, (hipStream_t)stream, B, A, total);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
 }

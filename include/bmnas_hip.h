@@ -278,6 +278,18 @@ int bmnas_arch_softmax_bwd(const float* w, const float* dw, float* dlogits, int 
 int bmnas_arch_softmax_multi(const float* const* a, const float* const* dw, float* const* out,
                              const int* rows, const int* cols, int n, int backward, int n_shards,
                              int64_t shard_stride, void* stream);
+/* The two launches that end a FusionCell's backward, as one: bmnas_ln_affine_bwd_multi (first 16
+ * arguments) and bmnas_arch_softmax_multi with backward = 1 (arch_w = the softmaxed weights, arch_dw
+ * their gradient shards, arch_out = the gradients of the logits).  Independent work sharing a grid. */
+int bmnas_backward_epilogue(int n_prob, const float* const* g, const float* const* gscale,
+                            const float* const* const* srcs, const int* n_src,
+                            const float* const* resid, const float* const* ln_w,
+                            const float* const* ln_b, const float* const* stats,
+                            float* const* dln_w, float* const* dln_b, int b, const int* C, int L,
+                            const int* relu, const int* prenorm, const float* const* arch_w,
+                            const float* const* arch_dw, float* const* arch_out, const int* arch_rows,
+                            const int* arch_cols, int n_arch, int n_shards, int64_t shard_stride,
+                            void* stream);
 /* The forward prologue of a FusionCell in ONE launch: the n_arch row softmaxes of
  * bmnas_arch_softmax_multi (forward) and, for each of n_fold (<= 8) NodeMixedOps of the cell,
  * Weff[q] (M, C) = W[q][:, :C] + W[q][:, C:] as bmnas_fold_weight does (W[q] is (M, 2C)).
