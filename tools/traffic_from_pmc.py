@@ -10,13 +10,13 @@ import json
 import sys
 
 fetch_csv, write_csv, out = sys.argv[1:4]
-STREAMING = ('mixsum', 'cat_ln', 'ln_affine', 'node_mix', 'bn_', 'fold_weight', 'adam')
+STREAMING = ('mixsum', 'cat_ln', 'ln_affine', 'node_mix', 'bn_', 'fold_weight', 'adam', 'backward_epilogue')
 WRAPPER = [('mixsum_pair_fwd_k', 'mixsum_pair_fwd'), ('mixsum_pair_bwd_k', 'mixsum_pair_bwd'),
            ('node_mix_ln_fwd_k', 'node_mix_ln_fwd'), ('conv_fwd_sdpa_k', 'conv1x1_fwd_sdpa'), ('conv_pipe_fwd_sdpa_k', 'conv1x1_fwd_sdpa'),
            ('conv_bwd_all_pipe_k', 'conv1x1_bwd_all_sdpa'), ('conv_pipe_fwd_k', 'conv1x1_fwd'),
            ('conv_pipe_bwd_k', 'conv1x1_bwd_data'),
            ('conv_bwd_sdpa_k', 'conv1x1_bwd_data_sdpa'), ('conv_bwd_all_k', 'conv1x1_bwd_all_sdpa'),
-           ('linear_bwd_k', 'linear_bwd'), ('cell_prologue_k', 'cell_prologue'), ('adam_multi_k', 'adam_multi'),
+           ('linear_bwd_k', 'linear_bwd'), ('backward_epilogue_k', 'backward_epilogue'), ('cell_prologue_k', 'cell_prologue'), ('adam_multi_k', 'adam_multi'),
            ('linear_fwd_k', 'linear_fwd'), ('mixsum_fwd_k', 'mixsum_fwd'), ('mixsum_bwd_k', 'mixsum_bwd'), ('cat_ln_fwd_k', 'cat_ln_fwd'),
            ('cat_ln_bwd_k', 'cat_ln_bwd'), ('ln_affine_bwd_k', 'ln_affine_bwd'), ('sdpa_ln_fwd_k', 'sdpa_ln_fwd'),
            ('sdpa_ln_bwd_k', 'sdpa_ln_bwd'), ('<true', 'conv1x1_fwd'), ('<false', 'conv1x1_bwd_data'),
