@@ -326,7 +326,8 @@ def test_conv1x1_fwd_large_single_source(b, C, L, M, bias, stats):
 
 @pytest.mark.parametrize('b,C,L,M,n_dst,acc', [(128, 192, 16, 576, 1, 1), (100, 192, 16, 576, 1, 1),
                                               (128, 192, 16, 576, 1, 0), (250, 128, 8, 384, 2, 3),
-                                              (509, 64, 4, 192, 1, 1), (128, 128, 16, 128, 2, 0)])
+                                              (509, 64, 4, 192, 1, 1), (128, 128, 16, 128, 2, 0),
+                                              (100, 80, 16, 240, 1, 1), (77, 48, 8, 144, 3, 5)])
 def test_conv1x1_bwd_data_large(b, C, L, M, n_dst, acc):
     """The production-size data-gradient GEMM through the C ABI, overwrite and accumulate,
     one and two destinations: d src_q (=|+=) W[:, qC:(q+1)C]^T dU."""
