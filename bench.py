@@ -245,6 +245,224 @@ def cpu_baseline(cname, c, batch, max_seconds=20.0):
                       f'faster of the two best of a probe over {sorted(probe)} on a {ncpu}-cpu host'}
 
 
+
+# wrapper (bmnas.lib) -> substrings of the kernel symbols it may launch; used to attach the
+# algorithmic units of an instrumented eager step to the kernels of a profiled graph replay
+KERNELS_OF = {
+    'mixsum_fwd': ('mixsum_fwd_k',), 'mixsum_bwd': ('mixsum_bwd_k',),
+    'mixsum_pair_fwd': ('mixsum_pair_fwd_k',), 'mixsum_pair_bwd': ('mixsum_pair_bwd_k',),
+    'cat_ln_fwd': ('cat_ln_fwd_k',), 'cat_ln_bwd': ('cat_ln_bwd_k',),
+    'ln_affine_bwd': ('ln_affine_bwd_k',), 'ln_affine_bwd_multi': ('ln_affine_bwd_multi_k', 'ln_affine_bwd_k'),
+    'backward_epilogue': ('backward_epilogue_k',),
+    'sdpa_ln_fwd': ('sdpa_ln_fwd_k',), 'sdpa_ln_bwd': ('sdpa_ln_bwd_k',),
+    'conv1x1_fwd': ('conv_pipe_fwd_k', 'conv_ksplit_k', 'conv_fwd_k'),
+    'conv1x1_bwd_data': ('conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_bwd_k'),
+    'conv1x1_bwd_weight': ('conv_w_k',),
+    'conv1x1_fwd_sdpa': ('conv_pipe_fwd_sdpa_k', 'conv_fwd_sdpa_k'),
+    'conv1x1_bwd_data_sdpa': ('conv_pipe_bwd_sdpa_k', 'conv_bwd_sdpa_k'),
+    'conv1x1_bwd_all_sdpa': ('conv_bwd_all_pipe_k', 'conv_bwd_all_k'),
+    'node_mix_fwd': ('node_mix_fwd_k',), 'node_mix_ln_fwd': ('node_mix_ln_fwd_k',),
+    'node_mix_bwd': ('node_mix_bwd_k',), 'node_mix_ln_bwd': ('node_mix_ln_bwd_k',),
+    'bn_relu_fwd': ('bn_relu_fwd_k',), 'bn_relu_bwd': ('bn_relu_bwd_k',),
+    'bn_glu_fwd': ('bn_glu_fwd_k',), 'bn_glu_bwd': ('bn_glu_bwd_k',),
+    'bn_bwd_apply': ('bn_bwd_apply_k',), 'bn_finalize': ('bn_finalize_k',), 'fold_weight': ('fold_weight_k',),
+    'linear_fwd': ('linear_fwd_k',), 'linear_bwd': ('linear_bwd_k',),
+    'bce_logits': ('bce_logits_k',), 'cross_entropy': ('ce_rows_k',),
+    'head_fwd': ('head_fwd_k',), 'head_bwd': ('head_bwd_k',), 'head_loss_bwd': ('head_loss_bwd_k',),
+    'cell_prologue': ('cell_prologue_k',), 'adam_multi': ('adam_multi_k',),
+}
+
+
+def short_kernel_name(n):
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    i = n.find('(')
+    return n if i < 0 else n[:i]
+
+
+def profile_graph_replay(a, log, steps=60):
+    """Run THIS bench command (same config / batch, headline loop only) as a child process under
+    `rocprofv3 --kernel-trace` and return the kernels of its hipGraph replays:
+    [[(name, start_ns, end_ns), ... one replay], ...].  Launch-inclusive device durations — the
+    figures a committed profiles/*_kernel_stats.csv of the same command shows."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rp):
+        raise RuntimeError('rocprofv3 not found')
+    out = tempfile.mkdtemp(prefix='bmnas_prof_', dir='/tmp')
+    cmd = [rp, '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable,
+           os.path.abspath(__file__), '--config', a.config, '--batch', str(a.batch), '--tier', a.tier,
+           '--steps', str(steps), '--warmup', '5', '--no-cpu-baseline', '--no-roofline', '--no-full-step']
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600)
+        files = glob.glob(os.path.join(out, '**', '*kernel_trace.csv'), recursive=True)
+        if r.returncode != 0 or not files:
+            raise RuntimeError(f'rocprofv3 child failed (rc {r.returncode}): {r.stdout[-400:]}')
+        child_ms = None
+        for line in r.stdout.splitlines():
+            if line.startswith('{') and '"ms_per_step"' in line:
+                child_ms = json.loads(line)['ms_per_step']
+        rows = []
+        for f in files:
+            with open(f) as fh:
+                rows += [(x['Kernel_Name'], int(x['Start_Timestamp']), int(x['End_Timestamp']))
+                         for x in csv.DictReader(fh)]
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    rows.sort(key=lambda x: x[1])
+    names = [x[0] for x in rows]
+    # the replays are the periodic tail of the trace: find the period from the last kernels
+    period = None
+    for per in range(4, 400):
+        if len(names) > 3 * per + 3 and names[-per:] == names[-2 * per:-per] == names[-3 * per:-2 * per]:
+            period = per
+            break
+    if period is None:
+        raise RuntimeError('no periodic replay pattern in the kernel trace')
+    n_rep = 0
+    while (n_rep + 2) * period <= len(names) and names[-(n_rep + 1) * period - period:-(n_rep + 1) * period] == names[-period:]:
+        n_rep += 1
+    n_rep = min(n_rep, steps)
+    tail = rows[-n_rep * period:]
+    # rotate so that a replay starts at its first kernel (the trace tail may be cut anywhere: it is not)
+    replays = [tail[i * period:(i + 1) * period] for i in range(n_rep)]
+    log(f'rocprofv3 child: {len(rows)} dispatches, {period} kernels per replay, {n_rep} replays used')
+    return replays, child_ms
+
+
+def roofline_report(a, c, step, ms_per_step, log):
+    """roofline / roofline_kernels: every kernel of the step with its launch-inclusive device
+    duration from a rocprofv3 kernel trace of the hipGraph replay (child process, same command) and
+    the algorithmic bytes / FLOPs of that launch (units from the arguments
+    of an instrumented eager step).  achieved = units / duration; frac = achieved / peak."""
+    from bmnas import lib
+    algo = algo_table(c['C'], c['L'])
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    lib.profile_begin(algo, events=False)
+    step()
+    calls = lib.profile_end_calls()              # [(wrapper, bound, units)] of ONE step, in launch order
+    source = 'rocprofv3 --kernel-trace of this command (child process), hipGraph replays'
+    try:
+        replays, child_ms = profile_graph_replay(a, log)
+    except Exception as e:                           # noqa: BLE001
+        log(f'rocprofv3 child unavailable ({e}); falling back to HIP-event brackets')
+        return roofline_from_events(a, c, step, ms_per_step, log, algo)
+    period = len(replays[0])
+    # mean duration per position of the replay, and the launch spacing (start to next start)
+    dur = [sum(r[i][2] - r[i][1] for r in replays) / len(replays) / 1e3 for i in range(period)]
+    span = sum(r[-1][2] - r[0][1] for r in replays) / len(replays) / 1e3
+    names = [short_kernel_name(replays[0][i][0]) for i in range(period)]
+    # attach the wrappers' units to the kernels, in order
+    units = [None] * period
+    ptr = 0
+    for i, n in enumerate(names):
+        if ptr < len(calls) and any(k in n for k in KERNELS_OF.get(calls[ptr][0], ())):
+            units[i] = calls[ptr]
+            ptr += 1
+    unmatched = [cname for cname, _, _ in calls[ptr:]]
+    tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    traffic = {}
+    if a.config == 'mmimdb' and a.batch == 128 and a.tier == 'F' and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = {k: v.get('traffic_bytes') for k, v in json.load(f).items()}
+    agg = {}
+    for i, n in enumerate(names):
+        g = agg.setdefault(n, {'us': 0.0, 'n': 0, 'units': 0.0, 'bound': None, 'wrapper': None})
+        g['us'] += dur[i]
+        g['n'] += 1
+        if units[i] is not None:
+            g['wrapper'], g['bound'] = units[i][0], units[i][1]
+            g['units'] += units[i][2]
+    rows = []
+    for n, g in agg.items():
+        row = {'kernel': n, 'wrapper': g['wrapper'], 'launches_per_step': g['n'],
+               'avg_us': round(g['us'] / g['n'], 2), 'us_per_step': round(g['us'], 2)}
+        if g['bound'] is not None:
+            per = g['units'] / g['n']
+            sec = g['us'] / g['n'] * 1e-6
+            if g['bound'] == 'hbm':
+                ach, peak, unit = per / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
+            else:
+                ach, peak, unit = per / sec / 1e12, MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
+            row.update({'bound': g['bound'], 'achieved': round(ach, 2), 'peak': peak, 'unit': unit,
+                        'frac': round(ach / peak, 4), 'algorithmic_units_per_launch': round(per),
+                        'traffic': traffic.get(n)})
+        else:
+            row.update({'bound': 'latency', 'achieved': None, 'peak': None, 'unit': None, 'frac': None,
+                        'algorithmic_units_per_launch': None, 'traffic': traffic.get(n)})
+        rows.append(row)
+    rows.sort(key=lambda r: -r['us_per_step'])
+    out = {'roofline_kernels': rows,
+           'roofline_check': {'kernels_per_step': period, 'sum_kernel_us_per_step': round(sum(dur), 2),
+                              'replay_span_us': round(span, 2), 'headline_us_per_step': round(ms_per_step * 1e3, 2),
+                              'profiled_child_us_per_step': None if child_ms is None else round(child_ms * 1e3, 2),
+                              'wrappers_without_kernel': unmatched}}
+    top = next((r for r in rows if r['frac'] is not None), None)
+    if top is not None:
+        top = dict(top)
+        top['measured'] = (source + f'; mean over {len(replays)} replays of End - Start per dispatch; '
+                           'the same figures as profiles/r02_kernel_stats_graph.csv')
+        out['roofline'] = top
+    return out
+
+
+def roofline_from_events(a, c, step, ms_per_step, log, algo):
+    """Fallback when rocprofv3 cannot run: HIP-event brackets around every launch of instrumented
+    eager steps queued behind a GPU-side spin blocker.  The bracket INCLUDES the two event records
+    (~4-5 us on MI355X); nothing is subtracted, so these durations are upper bounds."""
+    from bmnas import lib
+    n_prof = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(20_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    cycles_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    recs = {}
+    for park_ms in (80, 200, 500):
+        torch.cuda._sleep(int(cycles_per_ms * park_ms))
+        guard = torch.cuda.Event()
+        guard.record()
+        lib.profile_begin(algo)
+        for _ in range(n_prof):
+            step()
+        queued_in_time = not guard.query()
+        recs, ev_ms = lib.profile_end()
+        if queued_in_time:
+            break
+    rows = []
+    for name, rr in recs.items():
+        tot_ms = sum(r[0] for r in rr)
+        units = sum(r[2] for r in rr)
+        bound = rr[0][1]
+        if bound == 'hbm':
+            ach, peak, unit = units / (tot_ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
+        else:
+            ach, peak, unit = units / (tot_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
+        rows.append({'kernel': name, 'wrapper': name, 'bound': bound, 'achieved': round(ach, 2), 'peak': peak,
+                     'unit': unit, 'frac': round(ach / peak, 4), 'traffic': None,
+                     'algorithmic_units_per_launch': round(units / len(rr)),
+                     'launches_per_step': len(rr) / n_prof, 'avg_us': round(tot_ms / len(rr) * 1e3, 2),
+                     'us_per_step': round(tot_ms / n_prof * 1e3, 2)})
+    rows.sort(key=lambda r: -r['us_per_step'])
+    out = {'roofline_kernels': rows}
+    if rows:
+        top = dict(rows[0])
+        top['measured'] = ('HIP events on the launch stream around every launch (rocprofv3 was unavailable); the '
+                           f'bracket includes the event records (empty bracket {ev_ms * 1e3:.2f} us), nothing subtracted')
+        out['roofline'] = top
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -253,6 +471,9 @@ def main():
     ap.add_argument('--config', default='mmimdb', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
     ap.add_argument('--mode', default='graph', choices=['graph', 'eager'])
+    ap.add_argument('--tier', default='F', choices=['F', 'R'],
+                    help='F: (b, C, L) features straight into the fusion cell (headline); R: pooled raw '
+                         'features (b, C_in_i, L) through the reshape layers first (SURVEY.md 8(d))')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-full-step', action='store_true')
@@ -411,73 +632,9 @@ def main():
         except Exception as e:                       # noqa: BLE001
             result['full_search_step'] = {'error': f'{type(e).__name__}: {e}'[:300]}
             log(f'full search step failed: {e}')
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and not a.no_roofline and world == 1:
         try:
-            # instrumented eager pass: HIP events on the launch stream around every kernel call
-            n_prof = min(a.steps, 10)
-            for _ in range(2):
-                step()
-            # Eager Python issues kernels slower than the GPU retires them, so an event pair around a
-            # launch would also time the host gap.  Park the GPU behind ~50 ms of GEMMs first: the
-            # instrumented steps are then all queued before the GPU reaches them and run back to
-            # back, and start->end event deltas are kernel durations (+ the event records).
-            torch.cuda.synchronize()
-            # the blocker: a one-thread spin kernel (torch.cuda._sleep) on the launch stream, calibrated
-            # in wall time first.  (A stack of big GEMMs was used before; on some boxes the instrumented
-            # kernels then ran 1.5-2x slow, as if next to it.)  The pass is only accepted if the blocker
-            # was still running when the host finished queueing: otherwise brackets contain host gaps.
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            torch.cuda._sleep(20_000_000)
-            e1.record()
-            torch.cuda.synchronize()
-            cycles_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
-            recs, ev_ms, park_ms = {}, 0.0, 0
-            for park_ms in (80, 200, 500):
-                torch.cuda._sleep(int(cycles_per_ms * park_ms))
-                guard = torch.cuda.Event()
-                guard.record()
-                lib.profile_begin(algo_table(c['C'], c['L']))
-                for _ in range(n_prof):
-                    step()
-                queued_in_time = not guard.query()
-                recs, ev_ms = lib.profile_end()
-                if queued_in_time:
-                    break
-                log(f'roofline pass: host needed more than the {park_ms} ms blocker to queue {n_prof} steps; retrying')
-            # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE with
-            # the gfx950 read-side correction; tools/traffic_from_pmc.py); null if not collected
-            traffic = {}
-            tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-            if a.config == 'mmimdb' and a.batch == 128 and os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = {k: v['traffic_bytes'] for k, v in json.load(f).items()}
-            rows = []
-            for name, rr in recs.items():
-                tot_ms = sum(max(r[0] - ev_ms, 1e-4) for r in rr)      # minus the empty-bracket time
-                units = sum(r[2] for r in rr)
-                bound = rr[0][1]
-                per_launch_us = tot_ms / len(rr) * 1e3
-                if bound == 'hbm':
-                    achieved = units / (tot_ms * 1e-3) / 1e9
-                    peak, unit = HBM_PEAK_GBS, 'GB/s'
-                else:
-                    achieved = units / (tot_ms * 1e-3) / 1e12
-                    peak, unit = MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
-                rows.append({'kernel': name, 'bound': bound, 'achieved': round(achieved, 2), 'peak': peak,
-                             'unit': unit, 'frac': round(achieved / peak, 4), 'traffic': traffic.get(name),
-                             'algorithmic_units_per_launch': round(units / len(rr)),
-                             'launches_per_step': len(rr) / n_prof, 'avg_us': round(per_launch_us, 2),
-                             'us_per_step': round(tot_ms / n_prof * 1e3, 2)})
-            rows.sort(key=lambda r: -r['us_per_step'])
-            if rows:
-                top = dict(rows[0])
-                top['measured'] = (f'HIP events on the launch stream around every launch, instrumented pass of '
-                                   f'{n_prof} steps queued behind a {park_ms} ms GPU-side spin blocker (back-to-back execution), '
-                                   'after the timed region; avg per launch minus the elapsed time of an empty '
-                                   f'event bracket ({ev_ms * 1e3:.2f} us); cross-check: profiles/ rocprofv3 stats')
-                result['roofline'] = top
-                result['roofline_kernels'] = rows
+            result.update(roofline_report(a, c, step, result['ms_per_step'], log))
         except Exception as e:                       # noqa: BLE001 — diagnostics must not cost the headline
             result['roofline_error'] = f'{type(e).__name__}: {e}'[:300]
             log(f'roofline pass failed: {e}')

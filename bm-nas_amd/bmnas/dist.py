@@ -16,7 +16,6 @@ import os
 
 import torch
 import torch.distributed as dist
-from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 
 def env_world():
@@ -45,6 +44,32 @@ def init_from_env(backend=None):
             kw['device_id'] = torch.device('cuda', local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
+
+
+def _staged(t, group=None):
+    """gloo (the CPU test backend, also used to put two ranks on ONE GPU in the -m gpu tests) is
+    given host copies of device tensors; RCCL works on the device buffers in place."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+    if _staged(t, group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.detach().copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def broadcast(t, src=0, group=None):
+    if _staged(t, group):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.detach().copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
 
 
 _AVG = {}
@@ -103,23 +128,28 @@ class FlatGradAllReducer:
         """average=False: the bucket holds gradients pre-scaled by 1/world (sum them);
         average=True: unscaled gradients, reduced with ReduceOp.AVG (see avg_supported)."""
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if average else dist.ReduceOp.SUM, group=self.group)
+            all_reduce(self.flat, dist.ReduceOp.AVG if average else dist.ReduceOp.SUM, self.group)
         self.reduced = True                      # the optimizer pre-hook must not average again
 
     def __call__(self):
+        """Eager path (optimizer.step pre-hook): average .grad across ranks.  The collective always
+        spans the WHOLE tensor list (missing gradients travel as zeros) so that a rank on the eager
+        path and a rank replaying its captured step issue the same all-reduce."""
         if getattr(self, 'reduced', False):
             self.reduced = False
             return
         if self.world <= 1:
             return
-        grads = [t.grad for t in self.tensors if t.grad is not None]
-        if not grads:
-            return
-        flat = _flatten_dense_tensors(grads)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / self.world)
-        for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
-            g.copy_(f)
+        views = self.ensure_bucket()
+        have = [(v, t.grad) for v, t in zip(views, self.tensors) if t.grad is not None]
+        if len(have) < len(views):
+            self.flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        all_reduce(self.flat, dist.ReduceOp.SUM, self.group)
+        self.flat.mul_(1.0 / self.world)
+        if have:
+            torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
 
 
 def attach(optimizer, tensors=None, group=None):
@@ -138,4 +168,4 @@ def broadcast_state(module, arch_tensors=(), src=0, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) <= 1:
         return
     for t in list(module.state_dict().values()) + list(arch_tensors):
-        dist.broadcast(t.data if hasattr(t, 'data') else t, src=src, group=group)
+        broadcast(t.data if hasattr(t, 'data') else t, src=src, group=group)

@@ -16,7 +16,15 @@ from .functions import unit_grad
 class GraphedStep:
     """fn() must read its inputs from static tensors, set ``.grad = None`` on everything it
     differentiates (so the backward writes instead of accumulating) and return tensors that
-    stay referenced (they become static graph outputs)."""
+    stay referenced (they become static graph outputs).
+
+    Dropout under replay: the Philox offsets of the captured sites restart at 0 and the kernels add
+    a device counter that the graph advances by the step's span on every replay.  Each instance
+    starts its counter at `2^60 + (instance << 40)` (eager offsets count up from 0), so two graphs over the same sites (the weight step
+    and the Architect step) never draw the same masks.  The seed is torch.initial_seed() AT
+    CAPTURE: a later torch.manual_seed() does not reach replays (re-capture to reseed)."""
+
+    _instances = 0
 
     def __init__(self, fn, warmup=3):
         quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
@@ -30,7 +38,9 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.counter = torch.zeros(1, dtype=torch.int64, device=f'cuda:{dev}')
+        GraphedStep._instances += 1
+        self.counter_base = (1 << 60) + (GraphedStep._instances << 40)
+        self.counter = torch.full((1,), self.counter_base, dtype=torch.int64, device=f'cuda:{dev}')
         self.span_dev = torch.zeros(1, dtype=torch.int64, device=f'cuda:{dev}')
         saved = (K.DROP.offset, K.DROP.device_counter)
         K.DROP.offset, K.DROP.device_counter = 0, self.counter
@@ -54,8 +64,6 @@ class GraphedStep:
         finally:
             K.DROP.offset, K.DROP.device_counter = saved
             K.DROP.pending_advance = None
-        # keep later eager calls clear of the offsets the graph will use
-        K.DROP.offset += 1 << 40
 
     def replay(self):
         self.graph.replay()
@@ -179,6 +187,9 @@ class GraphedTrainStep:
                 optimizer.capture_safe()
             armed[0] = True
             self._g = GraphedStep(fn, warmup=0)
+            # the graph reads THIS plan's staging buffers and writes THESE gradient tensors for good
+            self.plan = optimizer.captured_plan() if self.in_graph_step else None
+            self.static_grads = [t.grad for t in self.targets]
         finally:
             model.load_state_dict(state)        # also when the capture fails and the caller stays eager
 
@@ -202,16 +213,16 @@ class GraphedTrainStep:
     @staticmethod
     def enabled(args):
         """Whether the trainer loops replay their steps as hipGraphs: `args.hip_graph` if the caller
-        set it, else the BMNAS_HIP_GRAPH environment variable, else ON for single-process runs
-        (a step that cannot be captured falls back to eager by itself) and OFF under data
-        parallelism, where it stays opt-in."""
+        set it, else the BMNAS_HIP_GRAPH environment variable, else ON (a step that cannot be
+        captured falls back to eager by itself).  Under data parallelism the captured step writes
+        its gradients into the reducer's flat bucket; the replay is followed by one all-reduce and
+        the one-launch Adam step."""
         import os
-        import torch.distributed as dist
         v = getattr(args, 'hip_graph', None)
         if v is None and os.environ.get('BMNAS_HIP_GRAPH') is not None:
             v = os.environ['BMNAS_HIP_GRAPH'] not in ('0', '', 'false', 'False')
         if v is None:
-            v = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+            v = True
         return bool(v) and torch.cuda.is_available()
 
     def matches(self, inputs, labels):
@@ -225,12 +236,16 @@ class GraphedTrainStep:
             self.labels.copy_(labels, non_blocking=True)
         opt = self.optimizer
         if self.in_graph_step:
-            opt.wait_staging()
+            opt.activate(self.plan)          # an eager step in between must not leak into the replay
             opt.prepare_replay()
             loss, logits = self._g.replay()
             opt.mark_launched()
         else:
             loss, logits = self._g.replay()
+            # an eager step in between (ragged last batch) re-pointed .grad at its own tensors:
+            # the optimizer must read the bucket views the graph has just written
+            for t, g in zip(self.targets, self.static_grads):
+                t.grad = g
             self.reducer.all_reduce_bucket(self.average)
             opt.step()
         return loss, logits

@@ -19,6 +19,22 @@ class BmnasError(RuntimeError):
     pass
 
 
+_NOTED = set()
+
+
+def note_off_path(where, why):
+    """A caller-side module (classifier, criterion, reshape layer) was given something the gfx950
+    kernels do not cover and is about to run its torch parent instead.  The fusion cell itself
+    never does this (it raises); here the parent class IS the reference behaviour, so the call
+    proceeds — but never silently: one warning per (where, why)."""
+    key = (where, why)
+    if key not in _NOTED:
+        _NOTED.add(key)
+        import warnings
+        warnings.warn(f'bmnas: {where} runs on the stock torch ops, not the HIP kernels: {why}', RuntimeWarning,
+                      stacklevel=3)
+
+
 class Dropout(C.Structure):
     """bmnas_dropout_t"""
     _fields_ = [('thr', C.c_uint32), ('scale', C.c_float), ('seed', C.c_uint64),
@@ -431,11 +447,12 @@ def arch_softmax_multi(a_list, dw_list, out_list, backward, n_shards=1, shard_st
 _PROF = None
 
 
-def profile_begin(algo):
+def profile_begin(algo, events=True):
     """algo: {wrapper name: fn(*args) -> (bound, units)} with bound in {'hbm', 'mfma'} and
-    units = algorithmic bytes / flops of that launch.  Only the named wrappers are timed."""
+    units = algorithmic bytes / flops of that launch.  Only the named wrappers are recorded.
+    events=False: no HIP events, only the ordered list of (wrapper, bound, units) — profile_end_calls()."""
     global _PROF
-    _PROF = {'algo': algo, 'records': {}}
+    _PROF = {'algo': algo, 'records': {}, 'calls': [], 'events': events}
     g = globals()
     for n in _TIMED_NAMES:
         if n in algo and n not in _PLAIN:
@@ -468,6 +485,17 @@ def profile_end():
     return out, overhead
 
 
+def profile_end_calls():
+    """-> [(wrapper, bound, units), ...] in launch order (profile_begin(algo, events=False))."""
+    global _PROF
+    prof, _PROF = _PROF, None
+    g = globals()
+    for n, fn in list(_PLAIN.items()):
+        g[n] = fn
+    _PLAIN.clear()
+    return prof['calls']
+
+
 _TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa',
@@ -483,6 +511,9 @@ def _timed(name, fn):
         if prof is None or name not in prof['algo']:
             return fn(*a, **k)
         bound, units = prof['algo'][name](*a, **k)
+        prof['calls'].append((name, bound, units))
+        if not prof['events']:
+            return fn(*a, **k)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         r = fn(*a, **k)

@@ -1,11 +1,13 @@
 """Drop-in nn.Module replacements for the two callers right after the fusion cell: the
 central classifier (nn.Linear) and the criterion, both on the gfx950 kernels of
 csrc/linear.hip.  Same constructor signatures, parameter names and state_dict keys as the torch
-classes they subclass; option combinations the kernels do not cover defer to the torch parent
-(the reference never uses them)."""
+classes they subclass.  Option combinations the kernels do not cover (the reference never uses
+them) run the torch parent class after a one-time RuntimeWarning (bmnas.lib.note_off_path):
+nothing leaves the HIP path silently."""
 import torch
 import torch.nn as nn
 
+from . import lib
 from .functions import BCEWithLogitsFn, CrossEntropyFn, LinearFn
 
 
@@ -17,6 +19,8 @@ class Linear(nn.Linear):
         if (x.is_cuda and x.dim() == 2 and self.bias is not None and self.out_features <= 128
                 and self.in_features % 16 == 0 and x.dtype == torch.float32):
             return LinearFn.apply(x, self.weight, self.bias)
+        lib.note_off_path('bmnas.nn.Linear', f'input {tuple(x.shape)} {x.dtype} on {x.device}, out_features '
+                          f'{self.out_features}, in_features {self.in_features}, bias {self.bias is not None}')
         return super().forward(x)
 
 
@@ -26,6 +30,8 @@ class BCEWithLogitsLoss(nn.BCEWithLogitsLoss):
                 and input.dtype == torch.float32 and target.dtype == torch.float32
                 and input.shape == target.shape):
             return BCEWithLogitsFn.apply(input, target)
+        lib.note_off_path('bmnas.nn.BCEWithLogitsLoss', f'input {tuple(input.shape)} {input.dtype} on {input.device}, '
+                          f'target {tuple(target.shape)} {target.dtype}, reduction {self.reduction}')
         return super().forward(input, target)
 
 
@@ -35,4 +41,6 @@ class CrossEntropyLoss(nn.CrossEntropyLoss):
                 and self.label_smoothing == 0.0 and self.ignore_index == -100
                 and target.dtype == torch.int64 and target.dim() == 1 and input.dtype == torch.float32):
             return CrossEntropyFn.apply(input, target)
+        lib.note_off_path('bmnas.nn.CrossEntropyLoss', f'input {tuple(input.shape)} {input.dtype} on {input.device}, '
+                          f'target {tuple(target.shape)} {target.dtype}, reduction {self.reduction}')
         return super().forward(input, target)

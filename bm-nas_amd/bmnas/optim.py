@@ -30,6 +30,7 @@ class Adam(torch.optim.Adam):
             raise lib.BmnasError('bmnas.optim.Adam: amsgrad is not on the reference path')
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False)
         self._plan = None
+        self._gen = 0            # bumped whenever the state tensors are replaced (load_state_dict)
 
     # ------------------------------------------------------------------ plan
     def _active(self):
@@ -79,7 +80,7 @@ class Adam(torch.optim.Adam):
         tab['numel'] = [p.numel() for p, _ in active]
         tab['hyp_row'] = row_of
         devbuf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-        self._plan = dict(ids=tuple(id(p) for p, _ in active), active=active, row_of=row_of,
+        self._plan = dict(ids=tuple(id(p) for p, _ in active), active=active, row_of=row_of, gen=self._gen,
                           groups=[gi for gi, _ in rows], count=[t for _, t in rows],
                           pin=pin, hyp=host[:len(rows) * 32].view(np.float32).reshape(len(rows), 8), tab=tab,
                           dev=devbuf, dev_hyp=devbuf[:hyp_bytes], dev_tab=devbuf[hyp_bytes:],
@@ -136,8 +137,17 @@ class Adam(torch.optim.Adam):
             self._plan['active'] = active
             self._launch()                      # scalars are refreshed by prepare_replay()
             return loss
-        if self._plan is None or self._plan['ids'] != tuple(id(p) for p, _ in active):
-            self._build(active)
+        ids = tuple(id(p) for p, _ in active)
+        if self._plan is None or self._plan.get('captured') or self._plan['ids'] != ids:
+            # never stage an eager step through a captured plan: its graph re-reads those buffers
+            eager = getattr(self, '_eager_plan', None)
+            if eager is not None and eager['ids'] == ids:
+                self._switch(eager)
+            else:
+                self._build(active)
+                self._eager_plan = self._plan
+        if self._plan['gen'] != self._gen:
+            self._switch(self._plan)
         self.wait_staging()
         self._stage(active)
         self._launch()
@@ -153,17 +163,67 @@ class Adam(torch.optim.Adam):
         for st in self.state.values():
             if torch.is_tensor(st.get('step')) and st['step'].is_cuda:
                 st['step'] = st['step'].cpu()
+        # the moment tensors are new objects: eager steps rebuild their plan, a captured plan
+        # (held by its GraphedTrainStep) re-reads pointers and counts in activate()
         self._plan = None
+        self._eager_plan = None
+        self._gen += 1
 
     # ------------------------------------------------------------------ hipGraph support
     def capture_safe(self):
-        """Build the plan from the gradients that exist NOW (static tensors of the step being
-        captured) so that step() inside `torch.cuda.graph` issues only stream work: one pinned
-        H2D copy and one launch.  Before every replay call prepare_replay()."""
+        """Build a plan OF ITS OWN from the gradients that exist NOW (static tensors of the step
+        being captured) so that step() inside `torch.cuda.graph` issues only stream work: one
+        pinned H2D copy and one launch.  The captured graph keeps reading this plan's staging
+        buffers, so the plan is never reused for eager steps: take it with `captured_plan()` after
+        the capture and call `activate(plan)` + `prepare_replay()` before every replay."""
         active = self._active()
         self.wait_staging()
         self._build(active)
         self._write_ptrs(active)
+        self._plan['captured'] = True
+
+    def captured_plan(self):
+        """The plan a capture has just baked into a graph, with the pointer table as captured
+        (parameters, static gradient tensors) snapshotted."""
+        pl = self._plan
+        if pl is None or not pl.get('captured'):
+            raise lib.BmnasError('bmnas.optim.Adam: no captured plan (capture_safe() + a captured step() first)')
+        pl['snap_param'] = pl['tab']['param'].copy()
+        pl['snap_grad'] = pl['tab']['grad'].copy()
+        pl['static_grads'] = [p.grad for p, _ in pl['active']]       # keeps the static tensors alive
+        return pl
+
+    def _switch(self, plan):
+        """Make `plan` current: step counts travel through the per-parameter `step` tensors, the
+        moment pointers are re-read when load_state_dict() replaced the state tensors."""
+        if self._plan is not plan:
+            self._flush_counts()
+            counts = {}
+            for (p, _), r in zip(plan['active'], plan['row_of']):
+                c = float(self._init_state(p)['step'])
+                if counts.setdefault(r, c) != c:
+                    raise lib.BmnasError('bmnas.optim.Adam: parameters that shared a step count when this plan was '
+                                         'built have diverged (an eager step on a subset?); re-capture the graph')
+            for r, c in counts.items():
+                plan['count'][r] = c
+            self._plan = plan
+        self.wait_staging()                  # the plan's last launch has consumed its pinned buffer
+        if plan['gen'] != self._gen:
+            plan['tab']['exp_avg'] = [self._init_state(p)['exp_avg'].data_ptr() for p, _ in plan['active']]
+            plan['tab']['exp_avg_sq'] = [self.state[p]['exp_avg_sq'].data_ptr() for p, _ in plan['active']]
+            plan['gen'] = self._gen
+
+    def activate(self, plan):
+        """Make `plan` (from captured_plan()) the current one before its graph is replayed.  Eager
+        steps in between — a ragged last batch, the Architect's eager path — run on a plan of their
+        own, so the staging buffers the graph reads are intact; but they advanced the step counts
+        and re-pointed `.grad`.  The counts are carried over, the capture-time parameter / gradient
+        pointers are restored and `.grad` is re-attached to the static tensors the graph writes."""
+        self._switch(plan)
+        plan['tab']['param'] = plan['snap_param']
+        plan['tab']['grad'] = plan['snap_grad']
+        for (p, _), gr in zip(plan['active'], plan['static_grads']):
+            p.grad = gr
 
     def prepare_replay(self):
         """Advance the step count and publish the current learning rates for the next replay

@@ -46,6 +46,9 @@ class _ReshapeBase(nn.Module):
             return ConvBnActFn.apply('relu', self.dropout.p, self.training, bn.running_mean, bn.running_var,
                                      bn.num_batches_tracked, self.conv.weight, self.conv.bias, bn.weight,
                                      bn.bias, pooled.contiguous())
+        from bmnas import lib
+        lib.note_off_path(type(self).__name__, f'pooled input {tuple(pooled.shape)} on {pooled.device} '
+                          f'(needs HIP device, C_in % 16 == 0, C % 16 == 0, L in 4/8/16)')
         return self.dropout(F.relu(bn(self.conv(pooled))))
 
 

@@ -1,18 +1,18 @@
 """Searcher facades (reference models/darts_searchable.py:25-90): build the datasets / DataLoaders
 and hand over to the per-dataset train_darts_model.  Datasets (`datasets/*`) and `models.utils` are
 out of scope and are imported from the reference checkout on sys.path.  With data parallelism
-(`--parallel` under torch.distributed.run) every rank draws its own shard through a
+(any launch under torch.distributed.run, WORLD_SIZE > 1) every rank draws its own shard through a
 DistributedSampler instead of DataParallel's scatter."""
 import torch
 from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
 from bmnas import dist as bdist
-from models.search._common import parallel_flag
+from models.search._common import data_parallel_world
 
 
 def _loaders(datasets, args):
-    world = bdist.env_world() if parallel_flag(args) else 1
+    world = data_parallel_world(args)
     loaders = {}
     for split, ds in datasets.items():
         if world > 1:

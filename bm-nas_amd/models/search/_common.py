@@ -21,6 +21,15 @@ def parallel_flag(args):
     return bool(getattr(args, 'parallel', getattr(args, 'use_dataparallel', False)))
 
 
+def data_parallel_world(args=None):
+    """Number of data-parallel replicas.  The reference turns nn.DataParallel on with
+    `args.parallel` when several GPUs are visible (mmimdb_darts_searchable.py:36); here the
+    replicas are processes, so the launch itself is the request: WORLD_SIZE > 1 (torchrun /
+    torch.distributed.run) means data parallel, whatever the flag says — N independent full
+    searches writing the same checkpoint directory are never what the launch meant."""
+    return bdist.env_world()
+
+
 class HyperNetBase(nn.Module):
     """backbones (set by the subclass) -> reshape_layers -> fusion_net -> central_classifier.
     Attribute names are the reference's: trainers reach into .reshape_layers / .fusion_net."""
@@ -96,9 +105,16 @@ def search_setup(model, args, criterion, device, num_batches_per_epoch, weight_d
                                               num_batches_per_epoch)
     arch_optimizer = Adam(model.arch_parameters(), lr=args.arch_learning_rate, betas=(0.5, 0.999),
                              weight_decay=args.arch_weight_decay)
+    if data_parallel_world(args) > 1:
+        # one process per GPU: the unchanged mains pass cuda:0 to every rank
+        # (main_darts_searchable_mmimdb.py:86), so the rank's own device comes from LOCAL_RANK,
+        # BEFORE the model moves; the trainer loops follow the model's device (_loop.run)
+        _, local, _ = bdist.init_from_env()
+        if torch.device(device).type == 'cuda':
+            device = torch.device('cuda', local)
+            torch.cuda.set_device(device)
     model.to(device)
-    if parallel_flag(args) and bdist.env_world() > 1:
-        bdist.init_from_env()
+    if data_parallel_world(args) > 1:
         bdist.broadcast_state(model, model.arch_parameters())
         bdist.attach(optimizer)
         bdist.attach(arch_optimizer)

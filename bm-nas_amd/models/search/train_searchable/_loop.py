@@ -33,8 +33,39 @@ def _rank():
 
 def _all_sum(t):
     if _world() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        from bmnas import dist as bdist
+        bdist.all_reduce(t, dist.ReduceOp.SUM)
     return t
+
+
+def _model_device(model, device):
+    """Under data parallelism every rank's replica sits on its own GPU (search_setup places it by
+    LOCAL_RANK) while the unchanged mains hand `cuda:0` to every rank: follow the model."""
+    if _world() > 1:
+        for p in model.parameters():
+            return p.device
+    return device
+
+
+def _is_sharded(loader):
+    from torch.utils.data.distributed import DistributedSampler
+    return isinstance(getattr(loader, 'sampler', None), DistributedSampler)
+
+
+def _shard_batch(inputs, labels):
+    """A loader without a DistributedSampler yields the GLOBAL batch on every rank: keep this
+    rank's contiguous slice (what DataParallel's scatter does; equal slices, so the mean of the
+    per-rank mean losses is the global mean — a remainder of n % world samples is dropped)."""
+    world, rank = _world(), _rank()
+    per = labels.shape[0] // world
+    if per == 0:
+        raise ValueError(f'batch of {labels.shape[0]} samples cannot be split over {world} ranks')
+    cut = lambda t: t.narrow(0, rank * per, per) if torch.is_tensor(t) and t.dim() > 0 else t
+    if isinstance(inputs, (tuple, list)):
+        inputs = type(inputs)(cut(t) for t in inputs)
+    else:
+        inputs = cut(inputs)
+    return inputs, cut(labels)
 
 
 class AccuracyMeter:
@@ -87,6 +118,7 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
         nan_escape=False):
     """-> dict(best_dev, best_dev_genotype, best_test, best_test_genotype, last_genotype, nan_abort)."""
     cosine = isinstance(scheduler, sc.LRCosineAnnealingScheduler)
+    device = _model_device(model, device)
     from bmnas.graph import GraphedTrainStep
     use_graph = GraphedTrainStep.enabled(args)
     w_graph, w_attempts = None, 0
@@ -112,9 +144,17 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 model.eval()
             meter.reset(device)
             loss_sum = torch.zeros((), device=device, dtype=torch.float64)
+            seen = 0
             learn = phase == 'train' or (phase == 'dev' and status == 'eval')
-            for data in dataloaders[phase]:
+            loader = dataloaders[phase]
+            split = _world() > 1 and not _is_sharded(loader)
+            if _world() > 1 and _is_sharded(loader):
+                loader.sampler.set_epoch(epoch)          # a new shuffle per epoch, the same on every rank
+            for data in loader:
                 inputs, labels = unpack(data, device)
+                if split:
+                    inputs, labels = _shard_batch(inputs, labels)
+                seen += labels.size(0)
                 # nothing of the previous batch's autograd graph may stay referenced while a step is
                 # being captured (see GraphedTrainStep._live_graph_tensors)
                 output = loss = None
@@ -150,6 +190,9 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 loss_sum += loss.detach().double() * labels.size(0)
                 meter.update(output.detach(), labels)
             n = dataset_sizes[phase]
+            if _world() > 1:
+                # what the ranks processed together (a DistributedSampler pads, a split drops a remainder)
+                n = int(_all_sum(torch.tensor(float(seen), device=device, dtype=torch.float64)))
             epoch_loss = float(_all_sum(loss_sum)) / n
             epoch_metric = meter.compute(n)
             logger.info('{} Loss: {:.4f}, {}: {:.4f}'.format(phase, epoch_loss, meter.name, epoch_metric))
@@ -187,15 +230,23 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
 def evaluate(model, criterion, loader, n, device, logger, args, unpack, meter, phase='test'):
     model.eval()
     logger.info('EXP: {}'.format(args.save))
+    device = _model_device(model, device)
     meter.reset(device)
     loss_sum = torch.zeros((), device=device, dtype=torch.float64)
+    split = _world() > 1 and not _is_sharded(loader)
+    seen = 0
     for data in loader:
         inputs, labels = unpack(data, device)
+        if split:
+            inputs, labels = _shard_batch(inputs, labels)
+        seen += labels.size(0)
         output = model(inputs)
         if isinstance(output, tuple):
             output = output[-1]
         loss_sum += criterion(output, labels).double() * labels.size(0)
         meter.update(output, labels)
+    if _world() > 1:
+        n = int(_all_sum(torch.tensor(float(seen), device=device, dtype=torch.float64)))
     epoch_loss = float(_all_sum(loss_sum)) / n
     metric = meter.compute(n)
     logger.info('{} Loss: {:.4f}, {}: {:.4f}'.format(phase, epoch_loss, meter.name, metric))

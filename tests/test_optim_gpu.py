@@ -114,3 +114,61 @@ def test_adam_refuses_cpu_parameters():
     p.grad = torch.ones(4)
     with pytest.raises(lib.BmnasError):
         Adam([p]).step()
+
+
+def test_eager_step_between_replays_does_not_poison_the_graph():
+    """graph replay, eager step() with fresh gradient tensors (same parameters), graph replay:
+    the captured plan keeps its own staging buffers and pointer table."""
+    from bmnas.optim import Adam
+    init = _make(4, SHAPES)
+    cpu = [t.clone().requires_grad_(True) for t in init]
+    gpu = [t.clone().to(dev()).requires_grad_(True) for t in init]
+    ref = torch.optim.Adam(cpu, lr=1e-2, weight_decay=1e-3)
+    opt = Adam(gpu, lr=1e-2, weight_decay=1e-3)
+    static = [torch.zeros_like(g_) for g_ in gpu]
+    for g_, s_ in zip(gpu, static):
+        g_.grad = s_
+    opt.capture_safe()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.cuda.graph(graph, stream=s):
+        opt.step()
+    torch.cuda.current_stream().wait_stream(s)
+    plan = opt.captured_plan()
+    for step in range(6):
+        grads = _make(90 + step, SHAPES)
+        for c, gr in zip(cpu, grads):
+            c.grad = gr.clone()
+        ref.step()
+        if step in (2, 4):                       # eager, on brand-new gradient tensors
+            for g_, gr in zip(gpu, grads):
+                g_.grad = gr.clone().to(dev())
+            opt.step()
+        else:
+            for s_, gr in zip(static, grads):
+                s_.copy_(gr)
+            opt.activate(plan)
+            opt.prepare_replay()
+            graph.replay()
+            opt.mark_launched()
+    torch.cuda.synchronize()
+    for c, g_ in zip(cpu, gpu):
+        assert float((g_.detach().cpu() - c.detach()).abs().max()) <= 2e-6 * (float(c.detach().abs().max()) + 1e-3)
+    assert float(opt.state_dict()['state'][0]['step']) == 6.0
+    # a checkpoint restored after the capture: the replay must follow the NEW moment tensors
+    sd = copy.deepcopy(opt.state_dict())
+    opt.load_state_dict(sd)
+    grads = _make(200, SHAPES)
+    for c, s_, gr in zip(cpu, static, grads):
+        c.grad = gr.clone()
+        s_.copy_(gr)
+    ref.step()
+    opt.activate(plan)
+    opt.prepare_replay()
+    graph.replay()
+    opt.mark_launched()
+    torch.cuda.synchronize()
+    for c, g_ in zip(cpu, gpu):
+        assert float((g_.detach().cpu() - c.detach()).abs().max()) <= 2e-6 * (float(c.detach().abs().max()) + 1e-3)
+    assert float(opt.state_dict()['state'][0]['step']) == 7.0
