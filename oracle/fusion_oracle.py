@@ -72,21 +72,24 @@ def num_node_edges(cfg) -> int:
     return sum(2 + t for t in range(cfg.ns))
 
 
-def arch_shapes(cfg) -> List[tuple]:
+def arch_shapes(cfg, primitives=None) -> List[tuple]:
     """Shapes of arch_parameters(): [alphas_edges, betas_0, gammas_0, betas_1, ...]
-    (model_search.py:91, model_search.py:44-48, node_search.py:87)."""
-    shapes = [(num_cell_edges(cfg), len(PRIMITIVES))]
+    (model_search.py:91, model_search.py:44-48, node_search.py:87).  ``primitives``: an edited
+    cell-level PRIMITIVES list (genotypes.py:6-9), default ['none', 'skip']."""
+    shapes = [(num_cell_edges(cfg), len(primitives or PRIMITIVES))]
     for _ in range(cfg.S):
         shapes.append((num_node_edges(cfg), len(STEP_EDGE_PRIMITIVES)))
         shapes.append((cfg.ns, len(STEP_STEP_PRIMITIVES)))
     return shapes
 
 
-def param_shapes(cfg) -> "Dict[str, tuple]":
+def param_shapes(cfg, primitives=None) -> "Dict[str, tuple]":
     """state_dict() key -> shape of the search FusionNetwork, in registration order
     (module construction order of model_search.py:20-35, node_search.py:20-46,
     node_operations.py:88-90,25-27,44-46).  ``num_batches_tracked`` entries are
-    int64 scalars (shape ())."""
+    int64 scalars (shape ()).  With an edited cell-level ``primitives`` list every mixed edge
+    ``cell._ops.{e}`` also owns the parameters of its fc_relu / fc_mish primitives
+    (operations.py:22-27, 48-54, 97-102), appended after the default entries."""
     C, L = cfg.C, cfg.L
     out: Dict[str, tuple] = {}
     out['cell.ln.weight'] = (cfg.M * C, L)
@@ -117,6 +120,12 @@ def param_shapes(cfg) -> "Dict[str, tuple]":
             bn(f'{nc}.bn', C)
         out[f'{nc}.ln.weight'] = (C, L)
         out[f'{nc}.ln.bias'] = (C, L)
+    for e in range(num_cell_edges(cfg)):
+        for pi, prim in enumerate(primitives or PRIMITIVES):
+            if prim in ('fc_relu', 'fc_mish'):
+                out[f'cell._ops.{e}._ops.{pi}.linear.weight'] = (C, C)
+                out[f'cell._ops.{e}._ops.{pi}.linear.bias'] = (C,)
+                bn(f'cell._ops.{e}._ops.{pi}.bn', C)
     return out
 
 
@@ -142,6 +151,33 @@ def mixed_edge_sum(states: Sequence[torch.Tensor], W, offset: int):
     acc = 0
     for j, h in enumerate(states):
         acc = acc + mixed_edge(h, W[offset + j])
+    return acc
+
+
+def op_fc(x, p, prefix, kind, training, drpt):
+    """FC_Relu.forward (operations.py:30-38) / FC_Mish.forward (operations.py:56-65):
+    Linear(C, C) over the channel dim (transpose, linear, transpose) -> ReLU | Mish
+    (x * tanh(softplus(x)), operations.py:44-46) -> BatchNorm1d(C) -> Dropout(drpt)."""
+    out = F.linear(x.transpose(1, 2), p[prefix + '.linear.weight'], p[prefix + '.linear.bias']).transpose(1, 2)
+    out = F.relu(out) if kind == 'fc_relu' else out * torch.tanh(F.softplus(out))
+    out = F.batch_norm(out, p[prefix + '.bn.running_mean'], p[prefix + '.bn.running_var'],
+                       p[prefix + '.bn.weight'], p[prefix + '.bn.bias'], training, BN_MOMENTUM, EPS)
+    _bump_nbt(p, prefix + '.bn.num_batches_tracked', training)
+    return _dropout(out, drpt, training)
+
+
+def mixed_edge_general(x, w, p, prefix, primitives, training, drpt):
+    """FusionMixedOp.forward (operations.py:104-105) for an edited PRIMITIVES list:
+    sum(w_p * OPS[p](x)) in list order (Python's sum starts from 0)."""
+    acc = 0
+    for pi, prim in enumerate(primitives):
+        if prim == 'none':
+            o = x.mul(0.)
+        elif prim == 'skip':
+            o = x
+        else:
+            o = op_fc(x, p, f'{prefix}._ops.{pi}', prim, training, drpt)
+        acc = acc + w[pi] * o
     return acc
 
 
@@ -240,7 +276,7 @@ def node_cell(x, y, beta_w, gamma_w, p, prefix, cfg, training, attn_drop=ATTN_DR
 
 
 def fusion_cell(inputs: Sequence[torch.Tensor], arch: Sequence[torch.Tensor], p, cfg,
-                training: bool, attn_drop: float = ATTN_DROP):
+                training: bool, attn_drop: float = ATTN_DROP, primitives=None):
     """FusionNetwork.forward + FusionCell.forward (model_search.py:93-97, 50-68) and
     FusionNode.forward (node_search.py:101-105).  ``arch`` is the arch_parameters()
     list (raw alphas/betas/gammas; the softmaxes are applied here)."""
@@ -249,7 +285,13 @@ def fusion_cell(inputs: Sequence[torch.Tensor], arch: Sequence[torch.Tensor], p,
     states = list(inputs)
     offset = 0
     for i in range(cfg.S):
-        sif = mixed_edge_sum(states, W, offset)
+        if primitives is None or list(primitives) == PRIMITIVES:
+            sif = mixed_edge_sum(states, W, offset)
+        else:
+            sif = 0
+            for j, h in enumerate(states):
+                sif = sif + mixed_edge_general(h, W[offset + j], p, f'cell._ops.{offset + j}', primitives,
+                                               training, cfg.drpt)
         beta_w = F.softmax(arch[1 + 2 * i], dim=-1)
         gamma_w = F.softmax(arch[2 + 2 * i], dim=-1)
         s = node_cell(sif, sif, beta_w, gamma_w, p, f'cell._step_nodes.{i}.node_cell', cfg,
@@ -263,9 +305,9 @@ def fusion_cell(inputs: Sequence[torch.Tensor], arch: Sequence[torch.Tensor], p,
     return out.view(out.size(0), -1)
 
 
-def hypernet_logits(inputs, arch, p, cls_w, cls_b, cfg, training, attn_drop=ATTN_DROP):
+def hypernet_logits(inputs, arch, p, cls_w, cls_b, cfg, training, attn_drop=ATTN_DROP, primitives=None):
     """fusion_net + central_classifier (mmimdb_darts_searchable.py:113-114)."""
-    return F.linear(fusion_cell(inputs, arch, p, cfg, training, attn_drop), cls_w, cls_b)
+    return F.linear(fusion_cell(inputs, arch, p, cfg, training, attn_drop, primitives), cls_w, cls_b)
 
 
 def loss_fn(kind: str):
@@ -279,7 +321,7 @@ def loss_fn(kind: str):
 
 
 def search_step(inputs, labels, arch, p, cls_w, cls_b, cfg, loss_kind, training=True,
-                attn_drop=ATTN_DROP):
+                attn_drop=ATTN_DROP, primitives=None):
     """One forward + backward of the hypernet (the benchmarked 'search step'):
     returns (logits, loss, grads) with grads for every float param in ``p``, the
     classifier, the arch list and the N inputs.  Buffers in ``p`` are updated in
@@ -296,7 +338,7 @@ def search_step(inputs, labels, arch, p, cls_w, cls_b, cfg, loss_kind, training=
     xs = [t.detach().requires_grad_(True) for t in inputs]
     cw = cls_w.detach().requires_grad_(True)
     cb = cls_b.detach().requires_grad_(True)
-    logits = hypernet_logits(xs, a, pp, cw, cb, cfg, training, attn_drop)
+    logits = hypernet_logits(xs, a, pp, cw, cb, cfg, training, attn_drop, primitives)
     loss = loss_fn(loss_kind)(logits, labels)
     loss.backward()
     grads = {k[2:]: t.grad for k, t in leaves.items()}
@@ -452,12 +494,13 @@ def node_genotype(betas, gammas, cfg) -> StepGenotype:
     return StepGenotype(inner_edges=edge_gene, inner_steps=node_gene, inner_concat=concat)
 
 
-def network_genotype(arch, cfg) -> Genotype:
+def network_genotype(arch, cfg, primitives=None) -> Genotype:
     """FusionNetwork.genotype (model_search.py:111-182): per step pick the pair (j<k) of
     ORIGINAL input nodes, at least one not selected before, maximising the product of
     their best non-none weights (first maximum wins)."""
     W_all = F.softmax(arch[0].detach().float().cpu(), dim=-1).numpy()
-    none = PRIMITIVES.index('none')
+    prims = list(primitives or PRIMITIVES)
+    none = prims.index('none')
     gene = []
     selected = set()
     start, n = 0, cfg.N
@@ -479,7 +522,7 @@ def network_genotype(arch, cfg) -> Genotype:
             raise IndexError('list index out of range')
         selected.update(best_pair)
         for j in best_pair:
-            gene.append((PRIMITIVES[_best_non_none(W[j], PRIMITIVES)], j))
+            gene.append((prims[_best_non_none(W[j], prims)], j))
         start += n
         n += 1
     steps = [node_genotype(arch[1 + 2 * i], arch[2 + 2 * i], cfg) for i in range(cfg.S)]

@@ -32,6 +32,10 @@ def _fill(rng, key, shape):
         return (rng.uniform(-1.0, 1.0, shape) / np.sqrt(fan_in)).astype(np.float32)
     if key.endswith('conv.bias'):
         return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    if key.endswith('linear.weight'):    # FC_Relu / FC_Mish (round-2 fixtures)
+        return (rng.uniform(-1.0, 1.0, shape) / np.sqrt(shape[1])).astype(np.float32)
+    if key.endswith('linear.bias'):
+        return (0.1 * rng.standard_normal(shape)).astype(np.float32)
     if key.endswith('.weight'):          # LN / BN scale
         return (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
     if key.endswith('.bias'):            # LN / BN shift
@@ -46,12 +50,12 @@ def make_params(cfg, seed, shapes=None):
     return {k: torch.from_numpy(_fill(rng, k, s)) for k, s in shapes.items()}
 
 
-def make_arch(cfg, seed, scale=0.5):
+def make_arch(cfg, seed, scale=0.5, primitives=None):
     """alphas/betas/gammas; scale 0.5 (not the reference's 1e-3 init) so the softmax
     weights are far from uniform and every arch-gradient term is exercised."""
     rng = _rng(seed + 1000003)
     return [torch.from_numpy((scale * rng.standard_normal(s)).astype(np.float32))
-            for s in fo.arch_shapes(cfg)]
+            for s in fo.arch_shapes(cfg, primitives)]
 
 
 def make_inputs(cfg, batch, seed):
