@@ -57,27 +57,47 @@ def make_args(c):
     return a
 
 
-class HyperNet(torch.nn.Module):
-    """fusion_net + central_classifier, wired like Searchable_* minus backbones/reshape layers."""
+# C_in of the backbone features each reshape layer receives (mmimdb_darts_searchable.py:86,
+# ntu_darts_searchable.py:104, ego_darts_searchable.py:104)
+C_INS = {'mmimdb': [512, 512, 512, 512, 64, 128],
+         'ntu': [512, 1024, 2048, 2048, 128, 256, 1024, 512],
+         'ego': [512, 1024, 2048, 2048, 512, 1024, 2048, 2048]}
 
-    def __init__(self, c):
+
+class HyperNet(torch.nn.Module):
+    """[reshape_layers ->] fusion_net -> central_classifier, wired like Searchable_* minus the
+    backbones.  tier 'F' (headline): the inputs ARE the (b, C, L) features.  tier 'R': the inputs
+    are pooled backbone features (b, C_in_i, L) and go through the Conv1d(k=1) + BatchNorm + ReLU +
+    Dropout tail of the reshape layers first (aux_models.py:61-76, 100-115; the adaptive max pool in
+    front of it is the backbone side of the boundary)."""
+
+    def __init__(self, c, tier='F', cname='mmimdb'):
         super().__init__()
         from models.search.darts.model_search import FusionNetwork
-        self.fusion_net = FusionNetwork(c['S'], c['M'], c['N'], 2, make_args(c), criterion=None)
+        args = make_args(c)
+        self.tier = tier
+        if tier == 'R':
+            import models.auxiliary.aux_models as aux
+            cls = aux.ReshapeInputLayer_MMIMDB if cname == 'mmimdb' else aux.ReshapeInputLayer
+            self.reshape_layers = torch.nn.ModuleList(cls(ci, c['C'], c['L'], args) for ci in C_INS[cname])
+        self.fusion_net = FusionNetwork(c['S'], c['M'], c['N'], 2, args, criterion=None)
         from bmnas import nn as bnn
         self.central_classifier = bnn.Linear(c['M'] * c['C'] * c['L'], c['nout'])
 
     def forward(self, xs):
+        if self.tier == 'R':
+            xs = [layer._tail(x) for layer, x in zip(self.reshape_layers, xs)]
         return self.central_classifier(self.fusion_net(xs))
 
     def arch_parameters(self):
         return self.fusion_net.arch_parameters()
 
 
-def synth_batch(c, batch, device, seed):
+def synth_batch(c, batch, device, seed, tier='F', cname='mmimdb'):
     g = torch.Generator(device='cpu').manual_seed(seed)
-    xs = [torch.relu(torch.randn(batch, c['C'], c['L'], generator=g)).to(device).requires_grad_(True)
-          for _ in range(c['N'])]
+    widths = [c['C']] * c['N'] if tier == 'F' else C_INS[cname]
+    xs = [torch.relu(torch.randn(batch, ci, c['L'], generator=g)).to(device).requires_grad_(True)
+          for ci in widths]
     if c['loss'] == 'bce':
         y = (torch.rand(batch, c['nout'], generator=g) < 0.2).float().to(device)
     else:
@@ -151,7 +171,8 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     if world > 1:
         bdist.attach(w_opt)
         bdist.attach(a_opt)
-    xv, yv = synth_batch(c, a.batch, device, seed=1000 + (torch.distributed.get_rank() if world > 1 else 0))
+    xv, yv = synth_batch(c, a.batch, device, 1000 + (torch.distributed.get_rank() if world > 1 else 0), a.tier,
+                         a.config)
     gw = GraphedTrainStep(model, crit, w_opt, xs, y)
     ga = GraphedTrainStep(model, crit, a_opt, xv, yv)
 
@@ -490,11 +511,11 @@ def main():
     c = CONFIGS[a.config]
 
     torch.manual_seed(2)                         # the mains' default --seed 2
-    model = HyperNet(c).to(device).train()
+    model = HyperNet(c, a.tier, a.config).to(device).train()
     from bmnas import nn as bnn
     from bmnas.functions import unit_grad
     crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
-    xs, y = synth_batch(c, a.batch, device, seed=rank)
+    xs, y = synth_batch(c, a.batch, device, rank, a.tier, a.config)
     params = [p for p in model.parameters()]
     arch = list(model.arch_parameters())
     leaves = params + arch + xs
@@ -599,8 +620,10 @@ def main():
         dt = float(t.item())
 
     result = {
-        'metric': 'search-steps/sec (fwd+bwd of fusion hypernet) on MM-IMDB synthetic'
-                  if a.config == 'mmimdb' else f'search-steps/sec (fwd+bwd of fusion hypernet) on {a.config} synthetic',
+        'metric': ('search-steps/sec (fwd+bwd of fusion hypernet) on MM-IMDB synthetic'
+                   if a.config == 'mmimdb' else
+                   f'search-steps/sec (fwd+bwd of fusion hypernet) on {a.config} synthetic')
+                  + (' [tier R: reshape layers + hypernet]' if a.tier == 'R' else ''),
         'value': round(world * a.steps / dt, 3),
         'unit': 'steps/s',
         'n_gpus': world,
@@ -615,6 +638,8 @@ def main():
         'config': {'workload': f'{a.config} fusion search, batch {a.batch} per GPU x {world} GPU(s), '
                                f'N{c["N"]} C{c["C"]} L{c["L"]} steps{c["S"]} node_steps{c["ns"]} '
                                f'node_multiplier{c["nm"]}, train mode, dropout {c["drpt"]}/0.1(attn)',
+                   'inputs': ('(b, C, L) features' if a.tier == 'F' else
+                              f'pooled backbone features (b, C_in, L), C_in = {C_INS[a.config]}, through the reshape layers'),
                    'global_batch': a.batch * world, 'per_gpu_batch': a.batch,
                    'parallelism': f'dp{world}', 'mode': a.mode,
                    'step': 'fwd+bwd (+ flat RCCL all-reduce of w- and arch-grads when n_gpus > 1)'},
@@ -639,7 +664,7 @@ def main():
             result['roofline_error'] = f'{type(e).__name__}: {e}'[:300]
             log(f'roofline pass failed: {e}')
     log('roofline pass done')
-    if rank == 0 and not a.no_cpu_baseline and world == 1:
+    if rank == 0 and not a.no_cpu_baseline and world == 1 and a.tier == 'F':
         try:
             result['cpu_baseline'] = cpu_baseline(a.config, c, a.batch)
             result['speedup_vs_cpu_baseline'] = round(result['value'] / result['cpu_baseline']['value'], 1)

@@ -75,6 +75,7 @@ SIGNATURES = {
                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P], _I),
     'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
+    'bmnas_conv_family_calls': ([C.POINTER(C.c_long), _I, _I], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
     'bmnas_node_mix_ln_fwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, _P],
@@ -313,6 +314,17 @@ def conv1x1_bwd_weight(dU, srcs, C_src, dW, ldw, dbias, dup_cols, b, L, M):
     _check(load().bmnas_conv1x1_bwd_weight(_ptr(dU), _ptrs(srcs), len(srcs), C_src, dW.data_ptr(), ldw,
                                            None if dbias is None else dbias.data_ptr(), dup_cols, b, L,
                                            M, _stream()), 'conv1x1_bwd_weight')
+
+
+def conv_family_calls(reset=False):
+    """{family name: calls since the last reset} of the conv GEMM dispatch (diagnostics)."""
+    lib = load()
+    n = lib.bmnas_conv_family_calls(None, 0, 0)
+    buf = (C.c_long * n)()
+    lib.bmnas_conv_family_calls(buf, n, int(reset))
+    lib.bmnas_conv_family_name.restype = C.c_char_p
+    lib.bmnas_conv_family_name.argtypes = [_I]
+    return {lib.bmnas_conv_family_name(i).decode(): int(buf[i]) for i in range(n)}
 
 
 def fold_weight(W, Weff, M, Cc):

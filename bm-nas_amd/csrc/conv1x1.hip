@@ -1171,6 +1171,13 @@ __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W
   }
 }
 
+// Which GEMM family a call was dispatched to (diagnostics for tests/test_dispatch_gpu.py: host-side
+// counters, never read by a kernel).  Order = bmnas_conv_family_name().
+enum ConvFamily { F_NJ, F_KSPLIT, F_PIPE_FWD, F_PIPE_BWD, F_LDS, F_FWD_SDPA_PIPE, F_FWD_SDPA_KSPLIT,
+                  F_BWD_SDPA_KSPLIT, F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_COUNT };
+long g_family_calls[F_COUNT] = {0};
+#define BMNAS_COUNT(f) (++g_family_calls[f])
+
 inline int conv_probe() {
   static const int v = []() { const char* e = getenv("BMNAS_CONV_PROBE"); return e ? atoi(e) : 0; }();
   return v;
@@ -1202,6 +1209,7 @@ bool launch_ksplit(const ConvArgs& a, hipStream_t st) {
   dim3 grid((unsigned)((a.n_groups + TN - 1) / TN), (unsigned)((a.J / 16 + TJ - 1) / TJ));
 #define KS_CASE(K)                                                                                   \
   if (kpw <= K) {                                                                                    \
+    BMNAS_COUNT(F_KSPLIT);                                                                           \
     hipLaunchKernelGGL((conv_ksplit_k<TRANS, TN, TJ, K>), grid, dim3(256), 0, st, a);                 \
     return true;                                                                                     \
   }
@@ -1221,6 +1229,7 @@ bool launch_ksplit_sdpa_fwd(const ConvArgs& a, const SdpaFwdArgs& s, hipStream_t
   dim3 grid((unsigned)(s.groups + gx * gy));
 #define KS_CASE(K)                                                                                   \
   if (kch == K) {                                                                                    \
+    BMNAS_COUNT(F_FWD_SDPA_KSPLIT);                                                                  \
     hipLaunchKernelGGL((conv_fwd_sdpa_k<TN, TJ, K>), grid, dim3(256),                                 \
                        std::max((size_t)kSdpaFwdLds, conv_ksplit_lds<TN, TJ>()), st, a, s, gx);       \
     return true;                                                                                     \
@@ -1240,6 +1249,7 @@ bool launch_ksplit_sdpa_bwd(const ConvArgs& a, const SdpaBwdArgs& s, hipStream_t
   const size_t lds = std::max(sdpa_bwd_lds(s.G.C), conv_ksplit_lds<TN, TJ>());
 #define KS_CASE(K)                                                                                   \
   if (kch == K) {                                                                                    \
+    BMNAS_COUNT(F_BWD_SDPA_KSPLIT);                                                                  \
     hipLaunchKernelGGL((conv_bwd_sdpa_k<TN, TJ, K>), grid, dim3(256), lds, st, a, s, gx);            \
     return true;                                                                                     \
   }
@@ -1264,10 +1274,12 @@ inline bool launch_pipe_fwd(const ConvArgs& a, hipStream_t st) {
   const int gx = (a.n_groups + 3) / 4, gy = (a.J + kPipeJ - 1) / kPipeJ;
   if (gx * gy < 96) return false;
   if (a.I % 48 == 0 && conv_pipe_lds<48, 4>(a.L) <= 65536) {     // (L = 4 pads rows to twice their size)
+    BMNAS_COUNT(F_PIPE_FWD);
     hipLaunchKernelGGL((conv_pipe_fwd_k<48, 4>), dim3((unsigned)(gx * gy)), dim3(256), (conv_pipe_lds<48, 4>(a.L)), st, a, gx);
     return true;
   }
   if (a.I % 32 == 0) {
+    BMNAS_COUNT(F_PIPE_FWD);
     hipLaunchKernelGGL((conv_pipe_fwd_k<32, 4>), dim3((unsigned)(gx * gy)), dim3(256), (conv_pipe_lds<32, 4>(a.L)), st, a, gx);
     return true;
   }
@@ -1281,6 +1293,7 @@ void launch_nj(const ConvArgs& a, hipStream_t st) {
   if (!TRANS && conv_pipe_mode() && a.I == a.Ci && a.fold == 0 && a.I % 48 == 0 && a.J % 16 == 0 && a.ldw % 4 == 0) {
     const int gx = (a.n_groups + 1) / 2, gy = (a.J + kPipeBJ - 1) / kPipeBJ;
     if (gx * gy >= 96) {
+      BMNAS_COUNT(F_PIPE_BWD);
       hipLaunchKernelGGL((conv_pipe_bwd_k<48, 2>), dim3((unsigned)(gx * gy)), dim3(256),
                          (conv_pipe_bwd_lds<48, 2>(a.L)), st, a, gx);
       return;
@@ -1301,6 +1314,7 @@ void launch_nj(const ConvArgs& a, hipStream_t st) {
   if (a.I >= 64 && ng * jt >= 256) {
     // production sizes: LDS-staged kernel; biggest tile that still yields >= ~400 workgroups
     const long wg64 = ((ng + 3) / 4) * ((jt + 3) / 4), wg3264 = ((ng + 1) / 2) * ((jt + 3) / 4);
+    BMNAS_COUNT(F_LDS);
     if (wg64 >= 400) {
       hipLaunchKernelGGL((conv_lds_k<TRANS, 64, 64>), dim3((unsigned)((ng + 3) / 4), (unsigned)((jt + 3) / 4)),
                          dim3(256), 0, st, a);
@@ -1313,6 +1327,7 @@ void launch_nj(const ConvArgs& a, hipStream_t st) {
     }
     return;
   }
+  BMNAS_COUNT(F_NJ);
   const long waves22 = ((ng + 1) / 2) * ((jt + 1) / 2);
   const long waves12 = ng * ((jt + 1) / 2);
   if (waves22 >= 2048) {
@@ -1413,6 +1428,7 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
 #define PF_CASE(KCv, K)                                                                                \
   if (!done && a.I % KCv == 0 && kch == K &&                                                           \
       (ngv == 2 ? conv_pipe_lds<KCv, 2>(a.L) : conv_pipe_lds<KCv, 4>(a.L)) <= 65536) {                 \
+    BMNAS_COUNT(F_FWD_SDPA_PIPE);                                                                      \
     if (ngv == 2)                                                                                      \
       hipLaunchKernelGGL((conv_pipe_fwd_sdpa_k<KCv, K, 2>), grid, dim3(256),                           \
                          std::max((size_t)kSdpaFwdLds, (conv_pipe_lds<KCv, 2>(a.L))), st, a, s, gx);        \
@@ -1525,6 +1541,7 @@ extern "C" int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* src
   dim3 grid;
   if (int e = fill_w_args(a, dU, srcs, n_src, C_src, dW, ldw, dbias, dup_cols, b, L, M, 8, &grid)) return e;
   if (b == 0) return 0;
+  BMNAS_COUNT(F_CONV_W);
   hipLaunchKernelGGL(conv_w_k, grid, dim3(512), 0, (hipStream_t)stream, a);
   BMNAS_CHECK_LAUNCH();
   return 0;
@@ -1577,6 +1594,7 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
       const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), (conv_pipe_bwd_lds<48, 2>(a.L)));
 #define PB_CASE(K)                                                                                     \
   if (!done && kch == K) {                                                                             \
+    BMNAS_COUNT(F_BWD_ALL_PIPE);                                                                       \
     if (ngv == 1)                                                                                      \
       hipLaunchKernelGGL((conv_bwd_all_pipe_k<48, K, 1>), grid, dim3(256), lds, st, a, s, w, gx, n_w,  \
                          (int)wgrid.x, (int)wgrid.y);                                                  \
@@ -1600,6 +1618,7 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
       const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), conv_ksplit_lds<2, 2>());
 #define ALL_CASE(T, K)                                                                                 \
   if (!done && TNv == T && kch == K) {                                                                 \
+    BMNAS_COUNT(F_BWD_ALL_KSPLIT);                                                                     \
     hipLaunchKernelGGL((conv_bwd_all_k<T, T, K>), grid, dim3(256), lds, st, a, s, w, gx, n_w,          \
                        (int)wgrid.x, (int)wgrid.y);                                                    \
     done = true;                                                                                       \
@@ -1620,6 +1639,21 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   }
   BMNAS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int bmnas_conv_family_calls(long* out, int n, int reset) {
+  if (!out && n > 0) return BMNAS_E_ARG;
+  for (int i = 0; i < n && i < F_COUNT; ++i) out[i] = g_family_calls[i];
+  if (reset)
+    for (int i = 0; i < F_COUNT; ++i) g_family_calls[i] = 0;
+  return F_COUNT;
+}
+
+extern "C" const char* bmnas_conv_family_name(int i) {
+  static const char* names[F_COUNT] = {"nj", "ksplit", "pipe_fwd", "pipe_bwd", "lds", "fwd_sdpa_pipe",
+                                       "fwd_sdpa_ksplit", "bwd_sdpa_ksplit", "bwd_all_pipe", "bwd_all_ksplit",
+                                       "conv_w"};
+  return (i >= 0 && i < F_COUNT) ? names[i] : nullptr;
 }
 
 extern "C" int bmnas_fold_weight(const float* W, float* Weff, int M, int C, void* stream) {

@@ -88,8 +88,15 @@ class NodeCell(nn.Module):
     def forward(self, x, y, edge_weights, node_weights):
         states = [x, y]
         offset = 0
+        default_edges = all(op._default for op in self.edge_ops)
         for i in range(self.node_steps):
-            z = mixed_edge_sum(states, edge_weights, offset)
+            if default_edges:
+                z = mixed_edge_sum(states, edge_weights, offset)
+            else:
+                # an edited PRIMITIVES list reaches the inner edges too (they are FusionMixedOps,
+                # reference node_search.py:31): composed op by op; zip() inside FusionMixedOp stops
+                # at the len(STEP_EDGE_PRIMITIVES) weights of the row, like the reference's
+                z = sum(self.edge_ops[offset + j](h, edge_weights[offset + j]) for j, h in enumerate(states))
             s = self.node_ops[i](z, z, node_weights[i])
             offset += len(states)
             states.append(s)

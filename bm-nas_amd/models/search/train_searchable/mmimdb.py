@@ -38,4 +38,5 @@ def test_mmimdb_track_f1(model, criterion, dataloaders, dataset_sizes, device, p
                          f1_type='weighted', init_f1=0.0, th_fscore=0.3):
     f1 = _loop.evaluate(model, criterion, dataloaders['test'], dataset_sizes['test'], device, logger, args,
                         _unpack, _loop.F1Meter(f1_type, th_fscore))
-    return f1, model.genotype()
+    logger.info(str(model.genotype()))
+    return f1                                  # the reference returns the bare score (mmimdb.py:285)

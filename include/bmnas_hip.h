@@ -206,6 +206,13 @@ int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* srcs, int n_sr
 /* Weff[m*C + c] = W[m*2C + c] + W[m*2C + C + c]: the conv applied to cat[z, z] (search mode,
  * NodeMixedOp(z, z) at node_search.py:55) equals Weff applied to z. */
 int bmnas_fold_weight(const float* W, float* Weff, int M, int C, void* stream);
+/* Diagnostics (tests/test_dispatch_gpu.py): how many calls each GEMM kernel family has served since
+ * the last reset — the conv entry points choose a family by shape (pipelined LDS tiles, split-K,
+ * whole-K LDS, direct; merged with the attention / weight-gradient workgroups or not).  Copies
+ * min(n, families) host counters to out, optionally resets them, returns the family count;
+ * bmnas_conv_family_name(i) names family i.  Host-side bookkeeping only: no kernel reads it. */
+int bmnas_conv_family_calls(long* out, int n, int reset);
+const char* bmnas_conv_family_name(int i);
 
 /* ---- BatchNorm1d bookkeeping ------------------------------------------------------------
  * Combines the GEMM's partial statistics (Chan's parallel variance), or uses the running

@@ -120,12 +120,17 @@ def param_shapes(cfg, primitives=None) -> "Dict[str, tuple]":
             bn(f'{nc}.bn', C)
         out[f'{nc}.ln.weight'] = (C, L)
         out[f'{nc}.ln.bias'] = (C, L)
-    for e in range(num_cell_edges(cfg)):
+    # FusionMixedOp is ALSO the class of NodeCell.edge_ops (node_search.py:10, 31), so an edited
+    # PRIMITIVES list puts the fc modules on the inner edges too
+    owners = [f'cell._ops.{e}' for e in range(num_cell_edges(cfg))]
+    owners += [f'cell._step_nodes.{i}.node_cell.edge_ops.{e}' for i in range(cfg.S)
+               for e in range(num_node_edges(cfg))]
+    for owner in owners:
         for pi, prim in enumerate(primitives or PRIMITIVES):
             if prim in ('fc_relu', 'fc_mish'):
-                out[f'cell._ops.{e}._ops.{pi}.linear.weight'] = (C, C)
-                out[f'cell._ops.{e}._ops.{pi}.linear.bias'] = (C,)
-                bn(f'cell._ops.{e}._ops.{pi}.bn', C)
+                out[f'{owner}._ops.{pi}.linear.weight'] = (C, C)
+                out[f'{owner}._ops.{pi}.linear.bias'] = (C,)
+                bn(f'{owner}._ops.{pi}.bn', C)
     return out
 
 
@@ -168,9 +173,12 @@ def op_fc(x, p, prefix, kind, training, drpt):
 
 def mixed_edge_general(x, w, p, prefix, primitives, training, drpt):
     """FusionMixedOp.forward (operations.py:104-105) for an edited PRIMITIVES list:
-    sum(w_p * OPS[p](x)) in list order (Python's sum starts from 0)."""
+    sum(w_p * OPS[p](x)) in list order (Python's sum starts from 0).  ``zip(weights, self._ops)``
+    stops at the shorter sequence: the inner edges of a NodeCell hand a row of
+    len(STEP_EDGE_PRIMITIVES) = 2 weights to a module with len(PRIMITIVES) ops, so only the
+    first two primitives take part there (node_search.py:54, 92)."""
     acc = 0
-    for pi, prim in enumerate(primitives):
+    for pi, prim in enumerate(primitives[:len(w)]):
         if prim == 'none':
             o = x.mul(0.)
         elif prim == 'skip':
@@ -250,12 +258,18 @@ def _bump_nbt(p, key, training):
         p[key] += 1
 
 
-def node_cell(x, y, beta_w, gamma_w, p, prefix, cfg, training, attn_drop=ATTN_DROP):
+def node_cell(x, y, beta_w, gamma_w, p, prefix, cfg, training, attn_drop=ATTN_DROP, primitives=None):
     """NodeCell.forward (node_search.py:48-70)."""
     states = [x, y]
     offset = 0
     for t in range(cfg.ns):
-        z = mixed_edge_sum(states, beta_w, offset)
+        if primitives is None or list(primitives) == PRIMITIVES:
+            z = mixed_edge_sum(states, beta_w, offset)
+        else:
+            z = 0
+            for j, h in enumerate(states):
+                z = z + mixed_edge_general(h, beta_w[offset + j], p, f'{prefix}.edge_ops.{offset + j}',
+                                           primitives, training, cfg.drpt)
         s = node_mixed_op(z, z, gamma_w[t], p, f'{prefix}.node_ops.{t}._ops', training,
                           cfg.drpt, attn_drop)
         _bump_nbt(p, f'{prefix}.node_ops.{t}._ops.2.bn.num_batches_tracked', training)
@@ -295,7 +309,7 @@ def fusion_cell(inputs: Sequence[torch.Tensor], arch: Sequence[torch.Tensor], p,
         beta_w = F.softmax(arch[1 + 2 * i], dim=-1)
         gamma_w = F.softmax(arch[2 + 2 * i], dim=-1)
         s = node_cell(sif, sif, beta_w, gamma_w, p, f'cell._step_nodes.{i}.node_cell', cfg,
-                      training, attn_drop)
+                      training, attn_drop, primitives)
         offset += len(states)
         states.append(s)
     out = torch.cat(states[-cfg.M:], dim=1)

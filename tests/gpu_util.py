@@ -82,3 +82,37 @@ def assert_close_scaled(name, got, want, rel=1e-4, floor=1e-6):
         i = int(np.argmax(err - tol))
         raise AssertionError(f'{name}: max|err|={np.nanmax(err):.3e} (scale {np.abs(want).max():.3e}) at flat {i}: '
                              f'got {got.reshape(-1)[i]!r} want {want.reshape(-1)[i]!r}')
+
+
+def assert_summary_scaled(name, got, want, rel=2e-4):
+    """Compare a tensor with a stored [sum, l2, first-k elements] float64 summary (the fixture form
+    of production-size tensors): l2 within rel, the sum within rel * l2 * sqrt(n) (cancellation),
+    the leading elements within rel * (|want| + l2 / sqrt(n))."""
+    g = got.detach().double().reshape(-1).cpu()
+    k = len(want) - 2
+    n = max(g.numel(), 1)
+    head = g[:k].numpy()
+    if head.size < k:
+        head = np.concatenate([head, np.zeros(k - head.size)])
+    l2 = max(abs(float(want[1])), 1e-12)
+    assert np.isfinite(g.numpy()).all(), name
+    assert abs(float(g.norm()) - want[1]) <= rel * l2 + 1e-7, (name, 'l2', float(g.norm()), want[1])
+    assert abs(float(g.sum()) - want[0]) <= rel * l2 * np.sqrt(n) + 1e-6, (name, 'sum', float(g.sum()), want[0])
+    assert np.all(np.abs(head - want[2:]) <= rel * (np.abs(want[2:]) + l2 / np.sqrt(n)) + 1e-7), \
+        (name, 'head', head, want[2:])
+
+
+def assert_close_either(name, got, want_a, want_b, rel=1e-4):
+    """Pass if `got` matches want_a OR want_b (per tensor).  Used where two legitimate evaluations
+    of the reference math exist — the fp32 op sequence and the same in float64 — and a ReLU /
+    dropout-free mask decision on a pre-activation within round-off of zero may fall either way:
+    such a flip moves whole gradient tensors by ~1e-2 of their scale (measured: the two CPU
+    evaluations differ from each other by that much at batch 128-250), which is not an error of
+    either side."""
+    try:
+        assert_close_scaled(name, got, want_a, rel)
+    except AssertionError as first:
+        try:
+            assert_close_scaled(name, got, want_b, rel)
+        except AssertionError as second:
+            raise AssertionError(f'{first}\n   and against the second evaluation: {second}') from None

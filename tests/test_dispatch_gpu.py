@@ -1,0 +1,110 @@
+"""-m gpu: which GEMM kernel family serves which shape ("prove reachable or delete").
+
+The conv entry points pick a family by shape; every family must be reached by a shape that the
+reference's configurations produce, and the parity of each case is checked against a plain
+fp32 torch contraction in the same test, so no family runs unverified:
+
+    pipe_fwd / pipe_bwd     LDS-tiled, K-chunked (standalone convs with >= 96 tiles: out_conv and
+                            reshape layers at production batch)
+    ksplit                  split-K, one memory round trip (small grids, K <= 1792)
+    lds                     whole-K LDS tiles (K = 2048 reshape layers at production batch)
+    nj                      direct (K = 2048 at small batch)
+    fwd_sdpa_pipe / _ksplit conv + attention in one launch (search NodeMixedOp, large / small batch)
+    bwd_all_pipe / _ksplit  data-gradient + weight-gradient + attention backward in one launch
+    bwd_sdpa_ksplit         data-gradient + attention backward (BMNAS_FUSE_BWD_ALL=0 path)
+    conv_w                  weight-gradient GEMM alone
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as fo
+from oracle import synth
+from gpu_util import assert_close_scaled, build_search_net, dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_case(b, C_in, M, L, seed=0):
+    """fwd + data-gradient + weight-gradient of one 1x1 conv through the C ABI vs torch fp32."""
+    from bmnas import lib
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, C_in, L, generator=g).to(dev())
+    W = (torch.randn(M, C_in, generator=g) / C_in ** 0.5).to(dev())
+    bias = torch.randn(M, generator=g).to(dev())
+    dU = torch.randn(b, M, L, generator=g).to(dev())
+    U = torch.empty(b, M, L, device=dev())
+    n_part = lib.conv1x1_num_partials(b, L)
+    part = torch.empty(n_part * M * 2, device=dev())
+    lib.conv1x1_fwd([x], C_in, W, C_in, bias, U, part, b, L, M, 0)
+    want = torch.einsum('mk,bkl->bml', W.double(), x.double()) + bias.double()[None, :, None]
+    assert_close_scaled('U', U, want.float())
+    dx = torch.empty_like(x)
+    lib.conv1x1_bwd_data(dU, W, C_in, [dx], C_in, 0, b, L, M, 0)
+    assert_close_scaled('dx', dx, torch.einsum('mk,bml->bkl', W.double(), dU.double()).float(), rel=2e-4)
+    dW = torch.zeros(M, C_in, device=dev())
+    db = torch.zeros(M, device=dev())
+    lib.conv1x1_bwd_weight(dU, [x], C_in, dW, C_in, db, 0, b, L, M)
+    assert_close_scaled('dW', dW, torch.einsum('bml,bkl->mk', dU.double(), x.double()).float(), rel=2e-4)
+    assert_close_scaled('db', db, dU.double().sum((0, 2)).float(), rel=2e-4)
+
+
+CASES = [
+    # (what, batch, C_in, M, L) -> families that must serve it (fwd, bwd-data)
+    ('out_conv NTU b512', 512, 256, 128, 8, {'pipe_fwd', 'ksplit'}),
+    ('reshape MM-IMDB C_in 512 b128', 128, 512, 192, 16, {'ksplit', 'pipe_bwd'}),
+    ('out_conv NTU b8', 8, 256, 128, 8, {'ksplit'}),
+    ('reshape NTU C_in 2048 b64', 64, 2048, 128, 8, {'lds'}),
+    ('reshape NTU C_in 2048 b6', 6, 2048, 128, 8, {'nj'}),
+]
+
+
+@pytest.mark.parametrize('what,b,C_in,M,L,expect', CASES, ids=[c[0] for c in CASES])
+def test_standalone_conv_families(what, b, C_in, M, L, expect):
+    from bmnas import lib
+    lib.conv_family_calls(reset=True)
+    _conv_case(b, C_in, M, L)
+    got = {k for k, v in lib.conv_family_calls().items() if v > 0}
+    assert expect <= got, (what, got)
+    assert 'conv_w' in got
+
+
+@pytest.mark.parametrize('name,batch,expect', [
+    ('mmimdb', 128, {'fwd_sdpa_pipe', 'bwd_all_pipe'}),
+    ('mmimdb', 8, {'fwd_sdpa_ksplit', 'bwd_all_ksplit'}),
+    ('ntu', 64, {'fwd_sdpa_ksplit', 'bwd_all_ksplit'}),
+])
+def test_merged_launch_families(name, batch, expect):
+    """One search step; the parity of these same shapes is pinned by test_network_gpu.py
+    (test_search_hypernet_matches_oracle_real_configs) — here: which kernels ran."""
+    from bmnas import lib
+    cfg = fo.Cfg({**fo.CONFIGS[name], 'drpt': 0.0})
+    net = build_search_net(cfg, 3, 'train_nodrop')
+    xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, 3)]
+    lib.conv_family_calls(reset=True)
+    net(xs).sum().backward()
+    torch.cuda.synchronize()
+    got = {k for k, v in lib.conv_family_calls().items() if v > 0}
+    assert expect <= got, (name, batch, got)
+
+
+def test_every_family_is_reachable(monkeypatch):
+    """Union over the cases above + the BMNAS_FUSE_BWD_ALL=0 route: no dead GEMM family."""
+    from bmnas import cell, lib
+    lib.conv_family_calls(reset=True)
+    for what, b, C_in, M, L, _ in CASES:
+        _conv_case(b, C_in, M, L)
+    for name, batch in (('mmimdb', 128), ('mmimdb', 8)):
+        cfg = fo.Cfg({**fo.CONFIGS[name], 'drpt': 0.0})
+        net = build_search_net(cfg, 3, 'train_nodrop')
+        xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, 3)]
+        net(xs).sum().backward()
+    monkeypatch.setattr(cell, 'FUSE_BWD_ALL', False)
+    cfg = fo.Cfg({**fo.CONFIGS['mmimdb'], 'drpt': 0.0})
+    net = build_search_net(cfg, 3, 'train_nodrop')
+    xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, 8, 3)]
+    net(xs).sum().backward()
+    torch.cuda.synchronize()
+    calls = lib.conv_family_calls()
+    dead = [k for k, v in calls.items() if v == 0]
+    assert not dead, (dead, calls)

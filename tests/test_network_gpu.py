@@ -8,7 +8,8 @@ import torch
 
 from oracle import fusion_oracle as fo
 from oracle import synth
-from gpu_util import (Args, assert_close_scaled, build_found_net, build_search_net, dev, set_mode)
+from gpu_util import (Args, assert_close_either, assert_close_scaled, assert_summary_scaled, build_found_net, build_search_net, dev,
+                      set_mode)
 from util import case_id, cfg_of, golden_files, load_npz, summarize
 
 pytestmark = pytest.mark.gpu
@@ -81,33 +82,48 @@ def test_search_hypernet_matches_reference_golden(path):
                                                       ('ego', 7, 83, 'ce'),
                                                       # BASELINE.json per-GPU sizes (configs 2-5)
                                                       ('mmimdb', 128, 23, 'bce'), ('ntu', 8, 60, 'ce'),
-                                                      ('ntu', 64, 60, 'ce'), ('ego', 6, 83, 'ce')])
+                                                      ('ntu', 64, 60, 'ce'), ('ego', 6, 83, 'ce'),
+                                                      # ragged production batches: the merged / pipelined
+                                                      # launches see partial tiles
+                                                      ('mmimdb', 100, 23, 'bce'), ('mmimdb', 250, 23, 'bce'),
+                                                      ('ntu', 250, 60, 'ce'), ('ego', 97, 83, 'ce')])
 def test_search_hypernet_matches_oracle_real_configs(name, batch, nout, loss_kind):
     """Full tensors (every gradient element) against the oracle at the three real configs,
-    train-mode BN, dropout identity; ragged batch for ego (odd batch with L=8 packs two
-    samples per MFMA tile)."""
+    train-mode BN, dropout identity; ragged batches (odd batch with L=8 packs two samples per
+    MFMA tile; 100 / 250 / 97 leave partial tiles in the merged and pipelined launches).
+
+    Two evaluations of the oracle are accepted per tensor: fp32 (the reference's own aten op
+    sequence) and float64.  Measured on the MI355X box (tools/diag_ntu250.py): the two CPU
+    evaluations differ from EACH OTHER by up to 2e-2 of a gradient tensor's scale at batch
+    128-250, because a ReLU pre-activation within round-off of zero takes the other branch; the HIP
+    path sits within 1e-6 of one of them (which one depends on the case)."""
     cfg = fo.Cfg({**fo.CONFIGS[name], 'drpt': 0.0})
     seed = 31
     meta = dict(cfg=dict(cfg), seed=seed, batch=batch, num_outputs=nout, loss=loss_kind,
                 mode='train_nodrop', has_grads=True)
     net, cls, xs, feat, logits, loss = _run_search_case(meta)
-    p = synth.make_params(cfg, seed)
+    f64 = lambda t: t.double() if t.is_floating_point() else t
     arch = synth.make_arch(cfg, seed)
     cw, cb = synth.make_classifier(cfg, nout, seed)
-    ologits, oloss, ograds = fo.search_step(synth.make_inputs(cfg, batch, seed),
-                                            synth.make_labels(loss_kind, batch, nout, seed), arch, p,
-                                            cw, cb, cfg, loss_kind, training=True, attn_drop=0.0)
+    labels = synth.make_labels(loss_kind, batch, nout, seed)
+    p = synth.make_params(cfg, seed)
+    ologits, oloss, ograds = fo.search_step(synth.make_inputs(cfg, batch, seed), labels, arch, p, cw, cb, cfg,
+                                            loss_kind, training=True, attn_drop=0.0)
+    p64 = {k: f64(v) for k, v in synth.make_params(cfg, seed).items()}
+    dlogits, dloss, dgrads = fo.search_step([f64(x) for x in synth.make_inputs(cfg, batch, seed)], labels,
+                                            [f64(a) for a in arch], p64, f64(cw), f64(cb), cfg, loss_kind,
+                                            training=True, attn_drop=0.0)
     assert_close_scaled('logits', logits, ologits)
     assert_close_scaled('loss', loss, oloss)
     for k, v in net.named_parameters():
         if k.endswith('conv.bias'):
             assert float(v.grad.abs().max()) < 1e-4, k
         else:
-            assert_close_scaled('grad:' + k, v.grad, ograds[k], rel=3e-4)
+            assert_close_either('grad:' + k, v.grad, ograds[k], dgrads[k], rel=2e-4)
     for i, a in enumerate(net.arch_parameters()):
-        assert_close_scaled(f'grad:arch.{i}', a.grad, ograds[f'arch.{i}'], rel=3e-4)
+        assert_close_either(f'grad:arch.{i}', a.grad, ograds[f'arch.{i}'], dgrads[f'arch.{i}'], rel=2e-4)
     for i, x in enumerate(xs):
-        assert_close_scaled(f'grad:input.{i}', x.grad, ograds[f'input.{i}'], rel=3e-4)
+        assert_close_either(f'grad:input.{i}', x.grad, ograds[f'input.{i}'], dgrads[f'input.{i}'], rel=2e-4)
     for k, v in net.state_dict().items():
         if fo.is_buffer(k):
             assert_close_scaled('buf:' + k, v.float(), p[k].float())
@@ -126,7 +142,10 @@ def test_found_network_matches_reference_golden(path):
     xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, seed)]
     with torch.set_grad_enabled(meta['has_grads']):
         feat = net(xs)
-    assert_close_scaled('feat', feat, z['feat'])
+    # found_mm / found_nt (round 2): production feature sizes C192/L16 and C128/L8, summary form
+    full = meta.get('full', True)
+    close = assert_close_scaled if full else assert_summary_scaled
+    close('feat', feat, z['feat'])
     if meta['has_grads']:
         w = torch.from_numpy(np.random.Generator(np.random.PCG64(seed))
                              .standard_normal(tuple(feat.shape)).astype(np.float32)).to(dev())
@@ -136,17 +155,88 @@ def test_found_network_matches_reference_golden(path):
             if k.startswith('grad:input.'):
                 x = xs[int(k.split('.')[-1])]
                 got = x.grad if x.grad is not None else torch.zeros_like(x)
-                assert_close_scaled(k, got, z[k], rel=2e-4)
+                close(k, got, z[k], rel=2e-4)
             elif k.startswith('grad:'):
                 t = params[k[5:]]
                 got = t.grad if t.grad is not None else torch.zeros_like(t)
                 if k.endswith('conv.bias') and meta['mode'] != 'eval':
                     assert float(got.abs().max()) < 1e-4, k
                 else:
-                    assert_close_scaled(k, got, z[k], rel=2e-4)
+                    close(k, got, z[k], rel=2e-4)
     for k, v in net.state_dict().items():
         if fo.is_buffer(k):
-            assert_close_scaled('buf:' + k, v.float(), z['buf:' + k])
+            if full or v.dim() == 0:
+                assert_close_scaled('buf:' + k, v.float(), z['buf:' + k])
+            else:
+                assert_summary_scaled('buf:' + k, v.float(), z['buf:' + k])
+
+
+@pytest.mark.parametrize('path', golden_files('prims_*.npz'), ids=case_id)
+def test_edited_primitives_match_reference_golden(path):
+    """PRIMITIVES edited to ['none', 'fc_relu', 'fc_mish', 'skip'] (reference
+    operations.py:9-10, 22-65).  The mixed edges leave the one-launch HIP path and are composed op
+    by op (FusionMixedOp's generic branch, FusionCell.forward's unfused loop, NodeCell's inner
+    edges); the step nodes' NodeMixedOps stay on the kernels.  Against the reference's outputs."""
+    import models.search.darts.genotypes as gt
+    from models.search.darts.model_search import FusionNetwork
+    meta, z = load_npz(path)
+    cfg = cfg_of(meta)
+    prims = meta['primitives']
+    saved = list(gt.PRIMITIVES)
+    gt.PRIMITIVES[:] = prims
+    try:
+        seed, batch, nout = meta['seed'], meta['batch'], meta['num_outputs']
+        net = FusionNetwork(cfg.S, cfg.M, cfg.N, 2, Args(cfg), criterion=None)
+        shapes = fo.param_shapes(cfg, prims)
+        assert set(net.state_dict().keys()) == set(shapes.keys())
+        net.load_state_dict(synth.make_params(cfg, seed, shapes))
+        for dst, src in zip(net.arch_parameters(), synth.make_arch(cfg, seed, 0.5, prims)):
+            assert dst.shape == src.shape
+            dst.data.copy_(src)
+        net.to(dev())
+        set_mode(net, meta['mode'])
+        cls = torch.nn.Linear(cfg.M * cfg.C * cfg.L, nout)
+        cw, cb = synth.make_classifier(cfg, nout, seed)
+        cls.weight.data.copy_(cw)
+        cls.bias.data.copy_(cb)
+        cls.to(dev())
+        xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, seed)]
+        y = synth.make_labels(meta['loss'], batch, nout, seed).to(dev())
+        crit = torch.nn.BCEWithLogitsLoss() if meta['loss'] == 'bce' else torch.nn.CrossEntropyLoss()
+        with torch.set_grad_enabled(meta['has_grads']):
+            feat = net(xs)
+            logits = cls(feat)
+            loss = crit(logits, y)
+        assert_close_scaled('feat', feat, z['feat'])
+        assert_close_scaled('logits', logits, z['logits'])
+        assert_close_scaled('loss', loss, z['loss'])
+        if meta['has_grads']:
+            loss.backward()
+            params = dict(net.named_parameters())
+            for k in z.files:
+                if not k.startswith('grad:'):
+                    continue
+                name = k[5:]
+                if name.startswith('arch.'):
+                    got = net.arch_parameters()[int(name.split('.')[1])].grad
+                elif name.startswith('input.'):
+                    got = xs[int(name.split('.')[1])].grad
+                elif name.startswith('central_classifier.'):
+                    got = getattr(cls, name.split('.')[1]).grad
+                else:
+                    got = params[name].grad
+                got = got if got is not None else torch.zeros(z[k].shape)
+                if (name.endswith('conv.bias') or name.endswith('linear.bias')) and meta['mode'] != 'eval' \
+                        and float(np.abs(z[k]).max()) < 1e-4:
+                    assert float(got.abs().max()) < 1e-4, k
+                else:
+                    assert_close_scaled(k, got, z[k], rel=3e-4)
+        for k, v in net.state_dict().items():
+            if fo.is_buffer(k):
+                assert_close_scaled('buf:' + k, v.float(), z['buf:' + k])
+        assert fo.genotype_to_jsonable(net.genotype()) == json.loads(str(z['genotype']))
+    finally:
+        gt.PRIMITIVES[:] = saved
 
 
 @pytest.mark.parametrize('optim', ['torch', 'bmnas', 'graph'])

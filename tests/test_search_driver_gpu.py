@@ -177,3 +177,86 @@ def test_hip_graph_falls_back_when_the_model_cannot_be_captured(tmp_path, monkey
     # the GPU is still usable afterwards
     x = torch.ones(4, device='cuda')
     assert float((x * 2).sum()) == 8.0
+
+
+def test_found_stage_trainer_and_tester_end_to_end(tmp_path, monkeypatch):
+    """the found-stage loop of main_darts_found_mmimdb.py:95-145 — a
+    Found_Image_Text_Net built from a genotype, trained with status='eval' (phases train, dev,
+    test; the dev phase also learns, train_searchable/mmimdb.py:38, 92), best-test checkpoint,
+    then test_mmimdb_track_f1 on the reloaded weights.  The tester's F1 must equal the F1
+    computed here directly from the model's outputs (sklearn, weighted, threshold 0.3)."""
+    from sklearn.metrics import f1_score
+    central = types.ModuleType('models.central')
+    fake = types.ModuleType('models.central.mmimdb')
+    fake.GP_VGG, fake.MaxOut_MLP = _CapturableVGG, _FakeMLP
+    central.mmimdb = fake
+    monkeypatch.setitem(sys.modules, 'models.central', central)
+    monkeypatch.setitem(sys.modules, 'models.central.mmimdb', fake)
+    import models.auxiliary.scheduler as sc
+    import models.search.mmimdb_darts_searchable as drv
+    import models.search.train_searchable._loop as loop
+    import models.search.train_searchable.mmimdb as tr
+    from bmnas import nn as bnn
+    from bmnas.optim import Adam
+    from models.search.darts.genotypes import Genotype, StepGenotype
+    from models.search.darts.utils import create_exp_dir
+    from models.search.plot_genotype import Plotter
+
+    class Args:
+        pass
+
+    a = Args()
+    a.C, a.L, a.drpt = 32, 16, 0.1
+    a.num_input_nodes, a.num_keep_edges, a.steps, a.multiplier = 6, 2, 2, 2
+    a.node_steps, a.node_multiplier, a.num_outputs = 2, 2, 23
+    a.batchsize, a.epochs = 8, 2
+    a.eta_max, a.eta_min, a.Ti, a.Tm = 1e-3, 1e-6, 1, 2
+    a.f1_type = 'weighted'
+    a.use_dataparallel = False
+    a.save = str(tmp_path / 'exp')
+    create_exp_dir(a.save)
+    genotype = Genotype(
+        edges=[('skip', 1), ('skip', 4), ('skip', 0), ('skip', 5)],
+        steps=[StepGenotype(inner_edges=[('skip', 0), ('skip', 1), ('skip', 2), ('skip', 0)],
+                            inner_steps=['ScaleDotAttn', 'LinearGLU'], inner_concat=[2, 3]),
+               StepGenotype(inner_edges=[('skip', 1), ('skip', 0), ('skip', 1), ('skip', 2)],
+                            inner_steps=['ConcatFC', 'Sum'], inner_concat=[2, 3])],
+        concat=[6, 7])
+    device = torch.device('cuda:0')
+    torch.manual_seed(5)
+    criterion = bnn.BCEWithLogitsLoss()
+    model = drv.Found_Image_Text_Net(a, criterion, genotype)
+    loaders = {k: DataLoader(_DS(n, s), batch_size=a.batchsize, shuffle=(k == 'train'), drop_last=False)
+               for k, n, s in (('train', 20, 1), ('dev', 12, 2), ('test', 11, 3))}
+    sizes = {k: len(v.dataset) for k, v in loaders.items()}
+    model.to(device)
+    optimizer = Adam(model.parameters(), lr=a.eta_max, weight_decay=1e-4)
+    scheduler = sc.LRCosineAnnealingScheduler(a.eta_max, a.eta_min, a.Ti, a.Tm, sizes['train'] / a.batchsize)
+    logger = logging.getLogger('bmnas-test')
+    w0 = model.central_classifier.weight.detach().clone()
+    test_f1, test_genotype = tr.train_mmimdb_track_f1(model, None, criterion, optimizer, scheduler, loaders, sizes,
+                                                      device, a.epochs, False, logger, Plotter(a), a, a.f1_type,
+                                                      0.0, 0.3, 'eval')
+    assert 0.0 <= test_f1 <= 1.0 and test_genotype == genotype
+    assert float((model.central_classifier.weight.detach() - w0).abs().max()) > 0      # it did train
+    # train AND dev phases learn in the found stage: 2 epochs x (3 + 2) batches
+    assert loop.run.stats['graph_replays'] + loop.run.stats['eager_steps'] >= 2 * (3 + 2)
+    ckpt = os.path.join(a.save, 'best', 'best_test_model.pt')
+    assert os.path.exists(ckpt)
+    # the tester on the reloaded best-test weights (main_darts_found_mmimdb.py:126-139)
+    model2 = drv.Found_Image_Text_Net(a, criterion, genotype)
+    model2.load_state_dict(torch.load(ckpt))
+    model2.to(device)
+    f1 = tr.test_mmimdb_track_f1(model2, criterion, loaders, sizes, device, False, logger, a, a.f1_type,
+                                 init_f1=0.0, th_fscore=0.3)
+    assert isinstance(f1, float)
+    model2.eval()
+    preds, labels = [], []
+    with torch.no_grad():
+        for d in loaders['test']:
+            out = model2((d['text'].to(device), d['image'].to(device)))
+            preds.append((torch.sigmoid(out) > 0.3).cpu())
+            labels.append(d['label'])
+    want = f1_score(torch.cat(labels).numpy(), torch.cat(preds).numpy(), average='weighted', zero_division=1)
+    assert abs(f1 - want) < 1e-12
+    assert abs(f1 - test_f1) < 1e-6        # the checkpoint holds the weights that scored the best test F1

@@ -62,7 +62,7 @@ def assert_close(name, got, want, rtol=1e-4, atol=1e-5):
 def assert_summary_close(name, got_tensor, want_summary, rtol=1e-4):
     """Compare against a [sum, l2, first-8] summary; sums of many terms get an atol scaled
     by the tensor's l2 norm (cancellation)."""
-    got = summarize(got_tensor)
+    got = summarize(got_tensor, len(want_summary) - 2)
     l2 = max(abs(float(want_summary[1])), 1e-12)
     n = got_tensor.numel()
     assert_close(name + ':sum', got[0], want_summary[0], rtol=rtol, atol=rtol * l2 * max(1.0, np.sqrt(n)) * 1e-1 + 1e-6)
