@@ -190,30 +190,63 @@ def mixsum_bwd(xs, slots, w_row0, g, dw_row0, w_stride=2, shards=1, shard_stride
 
 # -------------------------------------------------------------------- conv + BatchNorm
 class ConvBnSaved:
-    __slots__ = ('srcs', 'C_src', 'W', 'ldw', 'U', 'chan', 'M', 'training', 'dup', 'fold')
+    __slots__ = ('srcs', 'C_src', 'W', 'ldw', 'U', 'chan', 'M', 'training', 'dup', 'fold', 'fin')
 
 
-def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, dup=0, fold=0, attn=None):
+STAT_SHARDS = 8     # copies of the BatchNorm batch-sum buffers (same-address atomics serialise)
+
+
+class StatArena:
+    """The BatchNorm batch-sum buffers of one cell forward, carved out of ONE fp32 buffer that the
+    cell prologue launch zero-fills (bmnas_cell_prologue's scrub): the forward GEMMs add their
+    per-channel sums into them with atomics and the kernels that apply the BatchNorm finalise them
+    in place of a bmnas_bn_finalize launch per conv."""
+
+    def __init__(self, like, channel_counts):
+        self.sizes = [STAT_SHARDS * M * 2 for M in channel_counts]
+        self.buf = torch.empty(sum(self.sizes), device=like.device, dtype=torch.float32)
+        self.off = 0
+
+    def take(self, M):
+        n = STAT_SHARDS * M * 2
+        if self.off + n > self.buf.numel():
+            raise lib.BmnasError('StatArena: more BatchNorms in the forward than were planned')
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        return v
+
+
+def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, dup=0, fold=0, attn=None,
+                stats=None):
     """U = conv1x1(cat(srcs)) (+ batch statistics) and the fused BN affine `chan`.
-    W is (M, ldw) row-major with the first len(srcs)*C_src columns used."""
+    W is (M, ldw) row-major with the first len(srcs)*C_src columns used.
+    stats: a StatArena -> the statistics are finalised by the CONSUMER kernel (sv.fin is the
+    descriptor to hand to it; `chan` is written by that kernel); None -> bmnas_bn_finalize here."""
     x0 = srcs[0]
     b, L = x0.shape[0], x0.shape[2]
     M = bn_w.numel()
     U = _empty(x0, b, M, L)
-    part, n_part = None, 0
+    part, n_part, shards = None, 0, 0
     if training:
         if b * L < 2:
             raise ValueError('Expected more than 1 value per channel when training, got input size '
                              f'{[b, M, L]}')            # same refusal as nn.BatchNorm1d
-        n_part = lib.conv1x1_num_partials(b, L)
-        part = _empty(x0, n_part * M * 2)
+        if stats is not None:
+            part, shards = stats.take(M), STAT_SHARDS
+        else:
+            n_part = lib.conv1x1_num_partials(b, L)
+            part = _empty(x0, n_part * M * 2)
     if attn is None:
-        lib.conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold)
+        lib.conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold, shards)
     else:                                    # the attention branch rides in the same launch
-        lib.conv1x1_fwd_sdpa(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold, *attn)
+        lib.conv1x1_fwd_sdpa(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold, *attn, shards)
     chan = _empty(x0, 4 * M)
-    lib.bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan)
     sv = ConvBnSaved()
+    if stats is not None:
+        sv.fin = lib.make_bn_fin(part, shards, bias, bn_w, bn_b, rm, rv, nbt, training)
+    else:
+        sv.fin = lib.NO_FIN
+        lib.bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan)
     sv.srcs, sv.C_src, sv.W, sv.ldw, sv.U, sv.chan, sv.M = list(srcs), C_src, W, ldw, U, chan, M
     sv.training, sv.dup, sv.fold = training, dup, fold
     return U, chan, sv
@@ -265,7 +298,7 @@ class MixedSaved:
     pass
 
 
-def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None):
+def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None):
     """NodeMixedOp.forward (node_operations.py:118-120).  P: parameter pack of one NodeMixedOp
     (see models.search.darts.node_operations.NodeMixedOp.pack()).  x may be y (search).
     ln = (resid, ln_w, ln_b, stats): fuse the NodeCell tail `out += x; ln(out)` (node_search.py:67-68)
@@ -285,19 +318,21 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None):
     sv.merged = same and FUSE_ATTN_GEMM
     if sv.merged:
         U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C,
-                                  attn=(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, C, sv.d_attn), Weff=Weff)
+                                  attn=(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, C, sv.d_attn), Weff=Weff,
+                                  stats=stats)
     else:
         with _Fork(x.device) as fork:
             fork.side(lambda: lib.sdpa_ln_fwd(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, b, C, L, sv.d_attn))
-            U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C, Weff=Weff)
+            U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C, Weff=Weff, stats=stats)
     out = torch.empty_like(x)
+    fin = sv.conv.fin                        # BatchNorm finalised inside the mix kernel (or NO_FIN)
     if ln is None:
-        lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc)
+        lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc, fin)
     else:
-        resid, ln_w, ln_b, stats = ln
+        resid, ln_w, ln_b, ln_stats = ln
         sv.pre = torch.empty_like(x)
-        lib.node_mix_ln_fwd(x, y, p1, U, chan, gamma_row, resid, ln_w, ln_b, sv.pre, out, stats, b, C, L,
-                            sv.d_glu, sv.d_fc)
+        lib.node_mix_ln_fwd(x, y, p1, U, chan, gamma_row, resid, ln_w, ln_b, sv.pre, out, ln_stats, b, C, L,
+                            sv.d_glu, sv.d_fc, fin)
     return out, sv
 
 
@@ -309,9 +344,12 @@ FUSE_BWD_ALL = os.environ.get('BMNAS_FUSE_BWD_ALL', '1') != '0'
 FUSE_PROLOGUE = os.environ.get('BMNAS_FUSE_PROLOGUE', '1') != '0'
 # LayerNorm affine gradients + arch-softmax backward in one launch at the end of a cell's backward
 FUSE_EPILOGUE = os.environ.get('BMNAS_FUSE_EPILOGUE', '1') != '0'
+# BatchNorm statistics accumulated by the GEMM epilogues (atomics) and finalised inside the kernel
+# that applies the BatchNorm, instead of one bn_finalize launch per conv (needs FUSE_PROLOGUE)
+FUSE_BN_FINALIZE = os.environ.get('BMNAS_FUSE_BN_FINALIZE', '1') != '0'
 
 
-def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None, Weff=None):
+def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None, Weff=None, stats=None):
     # stacked [LinearGLU | ConcatFC] conv + BN
     if same:
         # conv(cat[z, z]) = (W[:, :C] + W[:, C:]) z: K is C instead of 2C.  The halves are added once
@@ -321,10 +359,12 @@ def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None, Weff=None):
             Weff = _empty(x, 3 * C, C)
             lib.fold_weight(P.stack_W, Weff, 3 * C, C)
         U, chan, sv.conv = conv_bn_fwd([x], C, Weff, C, P.stack_bias, P.stack_bn_w, P.stack_bn_b,
-                                       P.stack_rm, P.stack_rv, P.stack_nbt, training, dup=C, attn=attn)
+                                       P.stack_rm, P.stack_rv, P.stack_nbt, training, dup=C, attn=attn,
+                                       stats=stats)
     else:
         U, chan, sv.conv = conv_bn_fwd([x, y], C, P.stack_W, 2 * C, P.stack_bias, P.stack_bn_w,
-                                       P.stack_bn_b, P.stack_rm, P.stack_rv, P.stack_nbt, training)
+                                       P.stack_bn_b, P.stack_rm, P.stack_rv, P.stack_nbt, training,
+                                       stats=stats)
     return U, chan
 
 
@@ -405,7 +445,7 @@ FUSE_TAIL = True   # node_multiplier == 1: NodeMixedOp + residual + LayerNorm in
 FUSE_PAIR = True   # search mode: cell-level mixed sum + the node's first inner sum in one launch
 
 
-def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=None):
+def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=None, stats=None):
     """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
     device tensors.  NP: parameter pack of the NodeCell.  z0: the first inner mixed sum when the
     caller already formed it (bmnas_mixsum_pair_fwd)."""
@@ -423,7 +463,7 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
         last = sv.fused_tail and t == ns - 1
         s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
                                 (x, NP.ln_w, NP.ln_b, sv.stats) if last else None,
-                                None if weffs is None else weffs[t])
+                                None if weffs is None else weffs[t], stats)
         sv.zs.append(z)
         sv.mixed.append(msv)
         sv.offsets.append(offset)
@@ -437,10 +477,10 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
     if nm != 1:
         Wo = NP.out_conv_w.view(C, nm * C)
         V, chan, sv.oconv = conv_bn_fwd(tail, C, Wo, nm * C, NP.out_conv_b, NP.bn_w, NP.bn_b,
-                                        NP.bn_rm, NP.bn_rv, NP.bn_nbt, training)
+                                        NP.bn_rm, NP.bn_rv, NP.bn_nbt, training, stats=stats)
         sv.d_out = DROP.make(NP.out_p, x.numel(), training)
         o = torch.empty_like(x)
-        lib.bn_relu_fwd(V, chan, o, b, C, L, sv.d_out)
+        lib.bn_relu_fwd(V, chan, o, b, C, L, sv.d_out, sv.oconv.fin)
     else:
         o = tail[0]
     sv.o = o
@@ -499,7 +539,7 @@ class CellSaved:
     pass
 
 
-def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, weffs=None):
+def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, weffs=None, stats=None):
     """FusionCell.forward (model_search.py:50-68) with the step nodes in search mode
     (FusionNode(x, x), model_search.py:59).  alpha_w (k, 2) softmaxed device tensor."""
     N = len(xs)
@@ -516,7 +556,7 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
         else:
             sif, z0 = mixsum_fwd(states, alpha_w[offset:, 1]), None
         out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm, z0,
-                                 None if weffs is None else weffs[i * ns:(i + 1) * ns])
+                                 None if weffs is None else weffs[i * ns:(i + 1) * ns], stats)
         nsv.paired = z0 is not None
         sv.sifs.append(sif)
         sv.nodes.append(nsv)

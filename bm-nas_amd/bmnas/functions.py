@@ -249,13 +249,22 @@ class FusedCellFn(Function):
         # conv weight in ONE launch
         mixed = [m for n in CP.nodes for m in n.mixed]
         C_ = xs[0].shape[1]
-        weffs = None
+        weffs, stats = None, None
         if K.FUSE_PROLOGUE and 0 < len(mixed) <= 8:
             weffs = [torch.empty((3 * C_, C_), device=dev, dtype=torch.float32) for _ in mixed]
             # under capture the first prologue of the step also advances the dropout step counter
             # (bmnas.graph.GraphedStep), saving the separate add launch at the end of every replay
             adv, K.DROP.pending_advance = K.DROP.pending_advance, None
-            lib.cell_prologue(logits, ws, [m.stack_W for m in mixed], weffs, 3 * C_, C_, adv)
+            # the prologue also zero-fills the BatchNorm batch-sum buffers of this forward: the GEMM
+            # epilogues add into them, the mix / out_conv kernels finalise them (no bn_finalize launches)
+            if K.FUSE_BN_FINALIZE:
+                nm_ = cell.args.node_multiplier
+                counts = []
+                for n in CP.nodes:
+                    counts += [3 * C_] * len(n.mixed) + ([C_] if nm_ != 1 else [])
+                stats = K.StatArena(xs[0], counts)
+            lib.cell_prologue(logits, ws, [m.stack_W for m in mixed], weffs, 3 * C_, C_, adv,
+                              None if (stats is None or not training) else stats.buf)
         else:
             lib.arch_softmax_multi(logits, None, ws, False)      # every arch tensor, one launch
         if alpha_is_logits:
@@ -265,7 +274,8 @@ class FusedCellFn(Function):
         beta_ws, gamma_ws = ws[0::2], ws[1::2]
         ctx.alpha_is_logits = alpha_is_logits
         out, sv = K.fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S,
-                                    cell._multiplier, cell.args.node_steps, cell.args.node_multiplier, weffs)
+                                    cell._multiplier, cell.args.node_steps, cell.args.node_multiplier, weffs,
+                                    stats)
         ctx.cell, ctx.sv, ctx.beta_ws, ctx.gamma_ws, ctx.N, ctx.S = cell, sv, beta_ws, gamma_ws, N, S
         ctx.dev = dev
         return out

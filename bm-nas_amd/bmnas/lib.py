@@ -43,6 +43,25 @@ class Dropout(C.Structure):
 
 NO_DROP = Dropout(0, 1.0, 0, 0, None)
 
+
+class BnFin(C.Structure):
+    """bmnas_bn_fin_t"""
+    _fields_ = [('stat', C.c_void_p), ('conv_bias', C.c_void_p), ('bn_w', C.c_void_p), ('bn_b', C.c_void_p),
+                ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('num_batches_tracked', C.c_void_p),
+                ('shards', C.c_int), ('n_nbt', C.c_int), ('training', C.c_int), ('on', C.c_int)]
+
+
+NO_FIN = BnFin()
+
+
+def make_bn_fin(stat, shards, conv_bias, bn_w, bn_b, rm, rv, nbt, training):
+    """Descriptor for in-kernel BatchNorm finalisation (bmnas_bn_fin_t): the consumer of a conv output
+    derives scale / shift from the atomically accumulated batch sums `stat` (training) or from the
+    running statistics (eval) and writes `chan` for the backward kernels."""
+    p = lambda t: None if t is None else t.data_ptr()
+    return BnFin(p(stat), p(conv_bias), p(bn_w), p(bn_b), p(rm), p(rv), p(nbt), int(shards),
+                 0 if nbt is None else nbt.numel(), int(training), 1)
+
 _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _I = C.c_int
@@ -65,9 +84,9 @@ SIGNATURES = {
     'bmnas_sdpa_ln_fwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_sdpa_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, _I, _I, Dropout, _P], _I),
     'bmnas_conv1x1_num_partials': ([_I, _I], _I),
-    'bmnas_conv1x1_fwd': ([_PP, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P], _I),
+    'bmnas_conv1x1_fwd': ([_PP, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_conv1x1_bwd_data': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _P], _I),
-    'bmnas_conv1x1_fwd_sdpa': ([_PP, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I,
+    'bmnas_conv1x1_fwd_sdpa': ([_PP, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P, _I, Dropout, _P], _I),
     'bmnas_conv1x1_bwd_data_sdpa': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P], _I),
@@ -77,14 +96,14 @@ SIGNATURES = {
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_conv_family_calls': ([C.POINTER(C.c_long), _I, _I], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
-    'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
-    'bmnas_node_mix_ln_fwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, _P],
-                              _I),
+    'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
+    'bmnas_node_mix_ln_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout,
+                               Dropout, _P], _I),
     'bmnas_node_mix_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32, _P, _P, _I, _I, _I,
                             Dropout, Dropout, _P], _I),
     'bmnas_bn_glu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_glu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
-    'bmnas_bn_relu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_bn_relu_fwd': ([_P, _P, BnFin, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_bwd_apply': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_linear_fwd': ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
@@ -99,7 +118,7 @@ SIGNATURES = {
                                  _PP, _I, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  _PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I64, _P], _I),
     'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P, _P,
-                             _P], _I),
+                             _P, _I64, _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
                                  _P], _I),
 }
@@ -273,9 +292,10 @@ def conv1x1_num_partials(b, L):
     return n
 
 
-def conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold=0):
+def conv1x1_fwd(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold=0, stat_shards=0):
+    """stat_shards > 0: `part` is a zero-filled (stat_shards, M, 2) buffer of running batch sums."""
     _check(load().bmnas_conv1x1_fwd(_ptrs(srcs), len(srcs), C_src, W.data_ptr(), ldw, fold, _ptr(bias),
-                                    _ptr(U), _ptr(part), b, L, M, _stream()), 'conv1x1_fwd')
+                                    _ptr(U), _ptr(part), stat_shards, b, L, M, _stream()), 'conv1x1_fwd')
 
 
 def conv1x1_bwd_data(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold=0):
@@ -284,9 +304,9 @@ def conv1x1_bwd_data(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold=0):
 
 
 def conv1x1_fwd_sdpa(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold, x, y, ln_w, ln_b, out, xhat, stats, Cc,
-                     drop):
+                     drop, stat_shards=0):
     _check(load().bmnas_conv1x1_fwd_sdpa(_ptrs(srcs), len(srcs), C_src, W.data_ptr(), ldw, fold, _ptr(bias),
-                                         _ptr(U), _ptr(part), b, L, M, _ptr(x), _ptr(y), _ptr(ln_w),
+                                         _ptr(U), _ptr(part), stat_shards, b, L, M, _ptr(x), _ptr(y), _ptr(ln_w),
                                          _ptr(ln_b), _ptr(out), _ptr(xhat), _ptr(stats), Cc, drop, _stream()),
            'conv1x1_fwd_sdpa')
 
@@ -341,15 +361,17 @@ def bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan):
                                     chan.data_ptr(), _stream()), 'bn_finalize')
 
 
-def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc):
-    _check(load().bmnas_node_mix_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), gamma.data_ptr(),
+def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc, fin=NO_FIN):
+    _check(load().bmnas_node_mix_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin, gamma.data_ptr(),
                                      _ptr(out), b, Cc, L, dglu, dfc, _stream()), 'node_mix_fwd')
 
 
-def node_mix_ln_fwd(x, y, p1, U, chan, gamma, resid, ln_w, ln_b, pre, out, stats, b, Cc, L, dglu, dfc):
-    _check(load().bmnas_node_mix_ln_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), gamma.data_ptr(),
-                                        _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(pre), _ptr(out),
-                                        _ptr(stats), b, Cc, L, dglu, dfc, _stream()), 'node_mix_ln_fwd')
+def node_mix_ln_fwd(x, y, p1, U, chan, gamma, resid, ln_w, ln_b, pre, out, stats, b, Cc, L, dglu, dfc,
+                    fin=NO_FIN):
+    _check(load().bmnas_node_mix_ln_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin,
+                                        gamma.data_ptr(), _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(pre),
+                                        _ptr(out), _ptr(stats), b, Cc, L, dglu, dfc, _stream()),
+           'node_mix_ln_fwd')
 
 
 def node_mix_bwd(g, x, y, p1, U, chan, gamma, dgamma, dx, dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc,
@@ -369,8 +391,9 @@ def bn_glu_bwd(g, U, chan, dV, bn_grad, b, Cc, L, drop):
                                    _stream()), 'bn_glu_bwd')
 
 
-def bn_relu_fwd(U, chan, out, b, M, L, drop):
-    _check(load().bmnas_bn_relu_fwd(_ptr(U), _ptr(chan), _ptr(out), b, M, L, drop, _stream()), 'bn_relu_fwd')
+def bn_relu_fwd(U, chan, out, b, M, L, drop, fin=NO_FIN):
+    _check(load().bmnas_bn_relu_fwd(_ptr(U), _ptr(chan), fin, _ptr(out), b, M, L, drop, _stream()),
+           'bn_relu_fwd')
 
 
 def bn_relu_bwd(g, U, chan, dV, bn_grad, b, M, L, drop):
@@ -425,9 +448,10 @@ def adam_multi(table, chunks, n_chunks, hyp):
            'adam_multi')
 
 
-def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc, step=None):
+def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc, step=None, scrub=None):
     """Row softmax of every arch tensor + folded conv weights of every NodeMixedOp, one launch.
-    step = (counter, span): int64 device tensors; the launch also does counter += span."""
+    step = (counter, span): int64 device tensors; the launch also does counter += span.
+    scrub: flat fp32 tensor (numel % 4 == 0) the launch also zero-fills."""
     n = len(a_list)
     rows = (C.c_int * max(n, 1))(*[t.shape[0] for t in a_list])
     cols = (C.c_int * max(n, 1))(*[t.shape[1] for t in a_list])
@@ -437,7 +461,8 @@ def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc, step=None):
     pw = (C.c_void_p * max(nf, 1))(*[t.data_ptr() for t in Ws])
     pe = (C.c_void_p * max(nf, 1))(*[t.data_ptr() for t in Weffs])
     sc, sp = (None, None) if step is None else (step[0].data_ptr(), step[1].data_ptr())
-    _check(load().bmnas_cell_prologue(pa, po, rows, cols, n, pw, pe, nf, M, Cc, sc, sp, _stream()), 'cell_prologue')
+    _check(load().bmnas_cell_prologue(pa, po, rows, cols, n, pw, pe, nf, M, Cc, sc, sp, _ptr(scrub),
+                                      0 if scrub is None else scrub.numel(), _stream()), 'cell_prologue')
 
 
 def arch_softmax_multi(a_list, dw_list, out_list, backward, n_shards=1, shard_stride=0):

@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "../../include/bmnas_hip.h"
 #include "arch_body.hpp"
+#include "bn_fin.hpp"
 #include <cstdlib>
 
 namespace {
@@ -94,9 +95,13 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(
 // s = g0*(x+y) + g1*p1 + g2*drop(va*sigmoid(vg)) + g3*drop(relu(vf))
 __global__ __launch_bounds__(256) void node_mix_fwd_k(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ p1,
-    const float* __restrict__ U, const float* __restrict__ chan, const float* __restrict__ gamma,
+    const float* __restrict__ U, float* __restrict__ chan, BnFin fin, const float* __restrict__ gamma,
     float* __restrict__ out, int b, int C, int L, DropCfg dglu, DropCfg dfc) {
+  extern __shared__ float fin_lds[];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
+  float* sc = fin_lds;
+  float* sh = fin_lds + M;
+  bn_fin_fill<256>(fin, chan, M, b * L, sc, sh, blockIdx.x == 0);
   const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
   const int64_t total = (int64_t)b * cl4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -105,9 +110,9 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
     const int c = r / l4n;
     const int64_t e = i * 4;
     const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;      // (s, c, l) inside U's first C block
-    const float4 va = affine4(ld4(U + ub), chan[2 * M + c], chan[3 * M + c]);
-    const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), chan[2 * M + C + c], chan[3 * M + C + c]);
-    const float4 vf = affine4(ld4(U + ub + (int64_t)2 * C * L), chan[2 * M + 2 * C + c], chan[3 * M + 2 * C + c]);
+    const float4 va = affine4(ld4(U + ub), sc[c], sh[c]);
+    const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), sc[C + c], sh[C + c]);
+    const float4 vf = affine4(ld4(U + ub + (int64_t)2 * C * L), sc[2 * C + c], sh[2 * C + c]);
     const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
     const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e);
     float4 o;
@@ -127,37 +132,59 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
 template <int VPT, int BS>
 __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ p1,
-    const float* __restrict__ U, const float* __restrict__ chan, const float* __restrict__ gamma,
+    const float* __restrict__ U, float* __restrict__ chan, BnFin fin, const float* __restrict__ gamma,
     const float* __restrict__ resid, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-    float* __restrict__ pre, float* __restrict__ out, float* __restrict__ stats, int C, int L,
+    float* __restrict__ pre, float* __restrict__ out, float* __restrict__ stats, int b, int C, int L,
     DropCfg dglu, DropCfg dfc) {
   __shared__ float red[8];
+  extern __shared__ float fin_lds[];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   const int smp = blockIdx.x;
+  float* sc = fin_lds;
+  float* sh = fin_lds + M;
   const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
   float4 v[VPT], lw[VPT], lb[VPT];
-  float sum = 0.f;
+  // every global load of the sample first (raw conv outputs included), THEN the BatchNorm
+  // finalisation (its own memory round trip + a barrier), then the arithmetic: the two latencies
+  // overlap instead of adding up
+  float4 ua[VPT], ug[VPT], uf[VPT], xv[VPT], yv[VPT], pv[VPT], rv[VPT];
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int r = threadIdx.x + k * BS;
     v[k] = lw[k] = lb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ua[k] = ug[k] = uf[k] = xv[k] = yv[k] = pv[k] = rv[k] = v[k];
     if (r < cl4) {
-      lw[k] = ld4(ln_w + (int64_t)r * 4);            // with the first round of loads, not after
-      lb[k] = ld4(ln_b + (int64_t)r * 4);            // the reductions
-      const int c = r / l4n;
+      lw[k] = ld4(ln_w + (int64_t)r * 4);
+      lb[k] = ld4(ln_b + (int64_t)r * 4);
       const int64_t e = ((int64_t)smp * cl4 + r) * 4;
       const int64_t ub = ((int64_t)smp * M) * L + (int64_t)r * 4;
-      const float4 va = affine4(ld4(U + ub), chan[2 * M + c], chan[3 * M + c]);
-      const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), chan[2 * M + C + c], chan[3 * M + C + c]);
-      const float4 vf = affine4(ld4(U + ub + (int64_t)2 * C * L), chan[2 * M + 2 * C + c], chan[3 * M + 2 * C + c]);
+      ua[k] = ld4(U + ub);
+      ug[k] = ld4(U + ub + (int64_t)C * L);
+      uf[k] = ld4(U + ub + (int64_t)2 * C * L);
+      xv[k] = ld4(x + e);
+      yv[k] = ld4(y + e);
+      pv[k] = ld4(p1 + e);
+      rv[k] = ld4(resid + e);
+    }
+  }
+  bn_fin_fill<BS>(fin, chan, M, b * L, sc, sh, blockIdx.x == 0);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * BS;
+    if (r < cl4) {
+      const int c = r / l4n;
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      const float4 va = affine4(ua[k], sc[c], sh[c]);
+      const float4 vg = affine4(ug[k], sc[C + c], sh[C + c]);
+      const float4 vf = affine4(uf[k], sc[2 * C + c], sh[2 * C + c]);
       const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
-      const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e), rv = ld4(resid + e);
       float4 o;
-      o.x = g0 * (xv.x + yv.x) + g1 * pv.x + g2 * (va.x * sigmoidf(vg.x) * m2.x) + g3 * (fmaxf(vf.x, 0.f) * m3.x);
-      o.y = g0 * (xv.y + yv.y) + g1 * pv.y + g2 * (va.y * sigmoidf(vg.y) * m2.y) + g3 * (fmaxf(vf.y, 0.f) * m3.y);
-      o.z = g0 * (xv.z + yv.z) + g1 * pv.z + g2 * (va.z * sigmoidf(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
-      o.w = g0 * (xv.w + yv.w) + g1 * pv.w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
-      v[k] = f4_add(o, rv);
+      o.x = g0 * (xv[k].x + yv[k].x) + g1 * pv[k].x + g2 * (va.x * sigmoidf(vg.x) * m2.x) + g3 * (fmaxf(vf.x, 0.f) * m3.x);
+      o.y = g0 * (xv[k].y + yv[k].y) + g1 * pv[k].y + g2 * (va.y * sigmoidf(vg.y) * m2.y) + g3 * (fmaxf(vf.y, 0.f) * m3.y);
+      o.z = g0 * (xv[k].z + yv[k].z) + g1 * pv[k].z + g2 * (va.z * sigmoidf(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
+      o.w = g0 * (xv[k].w + yv[k].w) + g1 * pv[k].w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
+      v[k] = f4_add(o, rv[k]);
       st4(pre + e, v[k]);
       sum += f4_hsum(v[k]);
     }
@@ -396,15 +423,19 @@ __global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
 }
 
 __global__ __launch_bounds__(256) void bn_relu_fwd_k(const float* __restrict__ U,
-                                                     const float* __restrict__ chan,
+                                                     float* __restrict__ chan, BnFin fin,
                                                      float* __restrict__ out, int b, int M, int L,
                                                      DropCfg d) {
+  extern __shared__ float fin_lds[];
+  float* sc = fin_lds;
+  float* sh = fin_lds + M;
+  bn_fin_fill<256>(fin, chan, M, b * L, sc, sh, blockIdx.x == 0);
   const int ml4 = M * L / 4, l4n = L / 4;
   const int64_t total = (int64_t)b * ml4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i % ml4);
     const int c = r / l4n;
-    const float4 v = affine4(ld4(U + i * 4), chan[2 * M + c], chan[3 * M + c]);
+    const float4 v = affine4(ld4(U + i * 4), sc[c], sh[c]);
     const float4 m = drop_mult4(d, (uint64_t)(i * 4));
     st4(out + i * 4, make_float4(fmaxf(v.x, 0.f) * m.x, fmaxf(v.y, 0.f) * m.y,
                                   fmaxf(v.z, 0.f) * m.z, fmaxf(v.w, 0.f) * m.w));
@@ -557,6 +588,25 @@ inline DropCfg to_cfg(const bmnas_dropout_t& d) {
   return c;
 }
 
+// bmnas_bn_fin_t -> BnFin; < 0 on a bad descriptor
+inline int to_fin(const bmnas_bn_fin_t& f, BnFin* o) {
+  o->on = f.on ? 1 : 0;
+  if (!o->on) {
+    *o = BnFin{};
+    return 0;
+  }
+  if (!f.bn_w || !f.bn_b || f.shards < 0 || f.n_nbt < 0) return BMNAS_E_ARG;
+  if (f.shards > 8) return BMNAS_E_LIMIT;
+  if (f.training && (!f.stat || f.shards < 1)) return BMNAS_E_ARG;
+  if (!f.training && (!f.running_mean || !f.running_var)) return BMNAS_E_ARG;
+  if ((f.running_mean == nullptr) != (f.running_var == nullptr)) return BMNAS_E_ARG;
+  o->stat = f.stat; o->conv_bias = f.conv_bias; o->bn_w = f.bn_w; o->bn_b = f.bn_b;
+  o->running_mean = f.running_mean; o->running_var = f.running_var;
+  o->nbt = reinterpret_cast<long long*>(f.num_batches_tracked);
+  o->shards = f.shards; o->n_nbt = f.n_nbt; o->training = f.training ? 1 : 0;
+  return 0;
+}
+
 // samples walked per workgroup in the backward reductions: keep >= ~512 workgroups
 inline int pick_chunk(int b, int slots4) {
   // 4 sample lanes walk the chunk.  Measured (MM-IMDB b = 128, dgamma atomics sharded):
@@ -580,8 +630,13 @@ struct FoldPack {
 };
 
 __global__ __launch_bounds__(256) void cell_prologue_k(ArchPack P, FoldPack F, unsigned long long* step_counter,
-                                                       const unsigned long long* step_span) {
+                                                       const unsigned long long* step_span,
+                                                       float* __restrict__ scrub, int64_t scrub4) {
   const int nfb = F.n * F.blocks_per;
+  // side job: zero-fill the caller's forward accumulation buffers (BatchNorm batch sums that the GEMM
+  // epilogues add into with atomics, the head's logits) — instead of a memset launch
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < scrub4; i += (int64_t)gridDim.x * 256)
+    st4(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   // hipGraph replays: advance the dropout step counter once, here, before any kernel of this replay
   // reads it (one thread of the last workgroup; every later kernel is ordered after this launch)
   if (step_counter != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
@@ -635,30 +690,38 @@ extern "C" int bmnas_bn_finalize(const float* part, int n_part, int b, int L, in
 }
 
 extern "C" int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const float* U,
-                                  const float* chan, const float* gamma, float* out, int b, int C,
-                                  int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
-                                  void* stream) {
+                                  float* chan, bmnas_bn_fin_t fin, const float* gamma, float* out,
+                                  int b, int C, int L, bmnas_dropout_t drop_glu,
+                                  bmnas_dropout_t drop_fc, void* stream) {
   if (!x || !y || !p1 || !U || !chan || !gamma || !out || b < 0 || C < 1) return BMNAS_E_ARG;
   if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  BnFin f;
+  if (int e = to_fin(fin, &f)) return e;
+  if (f.on && f.training && b * L < 2) return BMNAS_E_ARG;
   if (b == 0) return 0;
   const int64_t total = (int64_t)b * C * L / 4;
-  hipLaunchKernelGGL(node_mix_fwd_k, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x,
-                     y, p1, U, chan, gamma, out, b, C, L, to_cfg(drop_glu), to_cfg(drop_fc));
+  hipLaunchKernelGGL(node_mix_fwd_k, dim3(stream_grid(total)), dim3(256), (size_t)6 * C * sizeof(float),
+                     (hipStream_t)stream, x, y, p1, U, chan, f, gamma, out, b, C, L, to_cfg(drop_glu),
+                     to_cfg(drop_fc));
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
 
 
 extern "C" int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float* p1, const float* U,
-                                     const float* chan, const float* gamma, const float* resid,
-                                     const float* ln_w, const float* ln_b, float* pre, float* out,
-                                     float* stats, int b, int C, int L, bmnas_dropout_t drop_glu,
-                                     bmnas_dropout_t drop_fc, void* stream) {
+                                     float* chan, bmnas_bn_fin_t fin, const float* gamma,
+                                     const float* resid, const float* ln_w, const float* ln_b,
+                                     float* pre, float* out, float* stats, int b, int C, int L,
+                                     bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream) {
   if (!x || !y || !p1 || !U || !chan || !gamma || !resid || !ln_w || !ln_b || !pre || !out || !stats ||
       b < 0 || C < 1)
     return BMNAS_E_ARG;
   if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  BnFin f;
+  if (int e = to_fin(fin, &f)) return e;
+  if (f.on && f.training && b * L < 2) return BMNAS_E_ARG;
   if (b == 0) return 0;
+  const size_t fin_lds = (size_t)6 * C * sizeof(float);
   const bool wide = b <= 256 && C * L / 4 >= 512;   // fewer samples than CUs: 8 waves per sample
   const int bs = wide ? 512 : 256;
   const int need = (C * L / 4 + bs - 1) / bs;
@@ -666,13 +729,13 @@ extern "C" int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float
 #define NML(V)                                                                                         \
   do {                                                                                                 \
     if (wide)                                                                                          \
-      hipLaunchKernelGGL((node_mix_ln_fwd_k<V, 512>), dim3(b), dim3(512), 0, st, x, y, p1, U, chan,    \
-                         gamma, resid, ln_w, ln_b, pre, out, stats, C, L, to_cfg(drop_glu),            \
-                         to_cfg(drop_fc));                                                             \
+      hipLaunchKernelGGL((node_mix_ln_fwd_k<V, 512>), dim3(b), dim3(512), fin_lds, st, x, y, p1, U,    \
+                         chan, f, gamma, resid, ln_w, ln_b, pre, out, stats, b, C, L,                  \
+                         to_cfg(drop_glu), to_cfg(drop_fc));                                           \
     else                                                                                               \
-      hipLaunchKernelGGL((node_mix_ln_fwd_k<V, 256>), dim3(b), dim3(256), 0, st, x, y, p1, U, chan,    \
-                         gamma, resid, ln_w, ln_b, pre, out, stats, C, L, to_cfg(drop_glu),            \
-                         to_cfg(drop_fc));                                                             \
+      hipLaunchKernelGGL((node_mix_ln_fwd_k<V, 256>), dim3(b), dim3(256), fin_lds, st, x, y, p1, U,    \
+                         chan, f, gamma, resid, ln_w, ln_b, pre, out, stats, b, C, L,                  \
+                         to_cfg(drop_glu), to_cfg(drop_fc));                                           \
   } while (0)
   if (need <= 1) NML(1);
   else if (need <= 2) NML(2);
@@ -735,14 +798,18 @@ extern "C" int bmnas_bn_glu_bwd(const float* g, const float* U, const float* cha
   return 0;
 }
 
-extern "C" int bmnas_bn_relu_fwd(const float* U, const float* chan, float* out, int b, int M, int L,
-                                 bmnas_dropout_t drop, void* stream) {
+extern "C" int bmnas_bn_relu_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, float* out, int b,
+                                 int M, int L, bmnas_dropout_t drop, void* stream) {
   if (!U || !chan || !out || b < 0 || M < 1) return BMNAS_E_ARG;
   if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (M > 4096) return BMNAS_E_LIMIT;                    // scale | shift of every channel sit in LDS
+  BnFin f;
+  if (int e = to_fin(fin, &f)) return e;
+  if (f.on && f.training && b * L < 2) return BMNAS_E_ARG;
   if (b == 0) return 0;
   const int64_t total = (int64_t)b * M * L / 4;
-  hipLaunchKernelGGL(bn_relu_fwd_k, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, U,
-                     chan, out, b, M, L, to_cfg(drop));
+  hipLaunchKernelGGL(bn_relu_fwd_k, dim3(stream_grid(total)), dim3(256), (size_t)2 * M * sizeof(float),
+                     (hipStream_t)stream, U, chan, f, out, b, M, L, to_cfg(drop));
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
@@ -814,8 +881,10 @@ extern "C" int bmnas_arch_softmax_multi(const float* const* a, const float* cons
 extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, const int* rows,
                                    const int* cols, int n_arch, const float* const* W,
                                    float* const* Weff, int n_fold, int M, int C,
-                                   uint64_t* step_counter, const uint64_t* step_span, void* stream) {
+                                   uint64_t* step_counter, const uint64_t* step_span, float* scrub,
+                                   int64_t scrub_n, void* stream) {
   if ((step_counter == nullptr) != (step_span == nullptr)) return BMNAS_E_ARG;
+  if (scrub_n < 0 || (scrub_n > 0 && !scrub) || scrub_n % 4) return BMNAS_E_ARG;
   if (n_arch < 0 || n_fold < 0 || (n_arch > 0 && (!a || !out || !rows || !cols)) ||
       (n_fold > 0 && (!W || !Weff || M < 1 || C < 1)))
     return BMNAS_E_ARG;
@@ -844,10 +913,11 @@ extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, con
   if (per > 128) per = 128;
   F.blocks_per = per;
   int blocks = n_fold * per + (total + 255) / 256;
-  if (blocks == 0 && step_counter != nullptr) blocks = 1;
+  if (blocks == 0 && (step_counter != nullptr || scrub_n > 0)) blocks = 1;
   if (blocks == 0) return 0;
   hipLaunchKernelGGL(cell_prologue_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, F,
-                     (unsigned long long*)step_counter, (const unsigned long long*)step_span);
+                     (unsigned long long*)step_counter, (const unsigned long long*)step_span, scrub,
+                     scrub_n / 4);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

@@ -28,6 +28,8 @@ struct ConvArgs {
   const float* W;
   const float* bias;     // per output col (fwd), nullable
   float* part;           // BN partial stats (fwd, training), nullable
+  float* stat;           // alternative to part: stat_shards x J x 2 running sums (atomics), nullable
+  int stat_shards;
   int ldw, Ci, Cj, I, J;
   int b, L, Lb, spw, n_groups, n_part;
   uint32_t acc_mask;
@@ -35,6 +37,56 @@ struct ConvArgs {
                          // (conv applied to cat[z, z], search mode: no separate folded copy)
   int probe;             // diagnostics only (BMNAS_CONV_PROBE): 1 = no MFMA, 2 = no loads
 };
+
+// BatchNorm batch statistics of the tile column group g (<= 16 valid columns) for output channel jj,
+// from the epilogue registers o (4 columns per lane, the channel's 16 columns spread over h = 0..3).
+//  * a.part:  one (sum, centred second moment) partial per (channel, n-group), combined later by
+//             bmnas_bn_finalize with Chan's rule;
+//  * a.stat:  running sums of d = u - bias and d^2 per channel, added with fp32 atomics into shard
+//             g % stat_shards (same-address atomics serialise: the shards spread them); the CONSUMER
+//             of the conv output turns them into mean / rstd itself (bn_fin.hpp), so no launch sits
+//             between the GEMM and the BatchNorm apply.  Shifting by the bias keeps E[d^2] - E[d]^2
+//             free of the cancellation a large bias would cause.
+__device__ __forceinline__ void bn_tile_stats(const ConvArgs& a, const float4 o, const float bj, const bool vo,
+                                              const int g, const int jj, const int h) {
+  if (a.stat != nullptr) {
+    float sum = 0.f, sq = 0.f;
+    if (vo) {
+      const float4 d = make_float4(o.x - bj, o.y - bj, o.z - bj, o.w - bj);
+      sum = f4_hsum(d);
+      sq = f4_dot(d, d);
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (h == 0) {
+      float* pp = a.stat + ((int64_t)(g % a.stat_shards) * a.J + jj) * 2;
+      atomicAdd(pp, sum);
+      atomicAdd(pp + 1, sq);
+    }
+    return;
+  }
+  if (a.part == nullptr) return;
+  float sum = vo ? f4_hsum(o) : 0.f;
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  int cnt = a.b * a.L - 16 * g;
+  cnt = cnt > 16 ? 16 : cnt;
+  const float mean = sum / (float)cnt;
+  float m2 = 0.f;
+  if (vo) {
+    const float4 c = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
+    m2 = f4_dot(c, c);
+  }
+  m2 += __shfl_xor(m2, 16, 64);
+  m2 += __shfl_xor(m2, 32, 64);
+  if (h == 0) {
+    float* pp = a.part + ((int64_t)jj * a.n_part + g) * 2;
+    pp[0] = sum;
+    pp[1] = m2;
+  }
+}
 
 // OUT[n][j] = sum_i ACT[i][n] * MAT(i, j);  TRANS: MAT(i,j) = W[j*ldw + i] (forward conv),
 // else MAT(i,j) = W[i*ldw + j] (data gradient).  A wave owns TN x TJ MFMA tiles
@@ -180,30 +232,8 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
         float* pp = d + ((int64_t)so[tn] * a.Cj + cj) * a.L + l0;
         st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
       }
-      if (a.part != nullptr) {
-        // per-channel partial statistics over this tile's (<= 16) valid columns (n-group g0+tn)
-        const int prow = g0 + tn;
-        if (prow < a.n_groups) {                         // wave-uniform
-          float sum = vo[tn] ? f4_hsum(o) : 0.f;
-          sum += __shfl_xor(sum, 16, 64);
-          sum += __shfl_xor(sum, 32, 64);
-          int cnt = a.b * a.L - 16 * prow;
-          cnt = cnt > 16 ? 16 : cnt;
-          const float mean = sum / (float)cnt;
-          float m2 = 0.f;
-          if (vo[tn]) {
-            const float4 c = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
-            m2 = f4_dot(c, c);
-          }
-          m2 += __shfl_xor(m2, 16, 64);
-          m2 += __shfl_xor(m2, 32, 64);
-          if (h == 0) {
-            float* pp = a.part + ((int64_t)jj * a.n_part + prow) * 2;
-            pp[0] = sum;
-            pp[1] = m2;
-          }
-        }
-      }
+      // per-channel batch statistics over this tile's (<= 16) valid columns (n-group g0 + tn)
+      if (g0 + tn < a.n_groups) bn_tile_stats(a, o, bj, vo[tn], g0 + tn, jj, h);      // wave-uniform guard
     }
   }
 }
@@ -340,26 +370,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
       float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
       st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
     }
-    if (a.part != nullptr) {
-      float sum = vo ? f4_hsum(o) : 0.f;
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      int cnt = a.b * a.L - 16 * g;
-      cnt = cnt > 16 ? 16 : cnt;
-      const float mean = sum / (float)cnt;
-      float m2 = 0.f;
-      if (vo) {
-        const float4 c = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
-        m2 = f4_dot(c, c);
-      }
-      m2 += __shfl_xor(m2, 16, 64);
-      m2 += __shfl_xor(m2, 32, 64);
-      if (h == 0) {
-        float* pp = a.part + ((int64_t)jj * a.n_part + g) * 2;
-        pp[0] = sum;
-        pp[1] = m2;
-      }
-    }
+    bn_tile_stats(a, o, bj, vo, g, jj, h);
   }
 }
 
@@ -514,26 +525,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
       const int so = g * a.spw + ((4 * h) >> a.Lb);
       const bool vo = so < a.b;
       if (vo) st4(a.dst.p[0] + ((int64_t)so * a.Cj + jj) * a.L + l0, o);
-      if (a.part != nullptr) {
-        float sum = vo ? f4_hsum(o) : 0.f;
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        int cnt = a.b * a.L - 16 * g;
-        cnt = cnt > 16 ? 16 : cnt;
-        const float mean = sum / (float)cnt;
-        float m2 = 0.f;
-        if (vo) {
-          const float4 cc = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
-          m2 = f4_dot(cc, cc);
-        }
-        m2 += __shfl_xor(m2, 16, 64);
-        m2 += __shfl_xor(m2, 32, 64);
-        if (h == 0) {
-          float* pp = a.part + ((int64_t)jj * a.n_part + g) * 2;
-          pp[0] = sum;
-          pp[1] = m2;
-        }
-      }
+      bn_tile_stats(a, o, bj, vo, g, jj, h);
     }
 }
 
@@ -935,26 +927,7 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
         float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
         st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
       }
-      if (a.part != nullptr) {
-        float sum = vo ? f4_hsum(o) : 0.f;
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        int cnt = a.b * a.L - 16 * g;
-        cnt = cnt > 16 ? 16 : cnt;
-        const float mean = sum / (float)cnt;
-        float m2 = 0.f;
-        if (vo) {
-          const float4 c = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
-          m2 = f4_dot(c, c);
-        }
-        m2 += __shfl_xor(m2, 16, 64);
-        m2 += __shfl_xor(m2, 32, 64);
-        if (h == 0) {
-          float* pp = a.part + ((int64_t)jj * a.n_part + g) * 2;
-          pp[0] = sum;
-          pp[1] = m2;
-        }
-      }
+      bn_tile_stats(a, o, bj, vo, g, jj, h);
     }
   }
 }
@@ -1345,8 +1318,9 @@ void launch_nj(const ConvArgs& a, hipStream_t st) {
 
 extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const float* W,
                                  int ldw, int fold_cols, const float* bias, float* U, float* part,
-                                 int b, int L, int M, void* stream) {
-  if (!srcs || !W || !U || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
+                                 int stat_shards, int b, int L, int M, void* stream) {
+  if (!srcs || !W || !U || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0 || stat_shards < 0)
+    return BMNAS_E_ARG;
   if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
   if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
   if (C_src % 16 || M % 16 || ldw % 4 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
@@ -1358,7 +1332,8 @@ extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src,
     a.act.p[q] = srcs[q];
   }
   a.dst.p[0] = U;
-  a.W = W; a.bias = bias; a.part = part; a.ldw = ldw;
+  a.W = W; a.bias = bias; a.ldw = ldw;
+  a.part = stat_shards ? nullptr : part; a.stat = stat_shards ? part : nullptr; a.stat_shards = stat_shards;
   a.Ci = C_src; a.I = n_src * C_src; a.Cj = M; a.J = M;
   a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = conv_probe(); a.fold = fold_cols;
   launch_nj<true>(a, (hipStream_t)stream);
@@ -1388,7 +1363,7 @@ extern "C" int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, 
 
 extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C_src, const float* W,
                                       int ldw, int fold_cols, const float* bias, float* U, float* part,
-                                      int b, int L, int M, const float* x, const float* y,
+                                      int stat_shards, int b, int L, int M, const float* x, const float* y,
                                       const float* ln_w, const float* ln_b, float* out, float* xhat,
                                       float* stats, int C, bmnas_dropout_t drop, void* stream) {
   if (!srcs || !W || !U || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
@@ -1406,7 +1381,8 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
     a.act.p[q] = srcs[q];
   }
   a.dst.p[0] = U;
-  a.W = W; a.bias = bias; a.part = part; a.ldw = ldw;
+  a.W = W; a.bias = bias; a.ldw = ldw;
+  a.part = stat_shards ? nullptr : part; a.stat = stat_shards ? part : nullptr; a.stat_shards = stat_shards;
   a.Ci = C_src; a.I = n_src * C_src; a.Cj = M; a.J = M;
   a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = 0; a.fold = fold_cols;
   s.x = x; s.y = y; s.ln_w = ln_w; s.ln_b = ln_b; s.out = out; s.xhat = xhat; s.stats = stats;

@@ -156,10 +156,14 @@ int bmnas_sdpa_ln_bwd(const float* g, const float* gscale, const float* x, const
  * of 16 (sample,l) columns; p < P = bmnas_conv1x1_num_partials(b, L). */
 int bmnas_conv1x1_num_partials(int b, int L);
 /* fold_cols > 0: the weight actually applied is W[m, k] + W[m, k + fold_cols] — the conv of
- * cat[z, z] (search mode, NodeMixedOp(z, z) at node_search.py:55) with n_src = 1. */
+ * cat[z, z] (search mode, NodeMixedOp(z, z) at node_search.py:55) with n_src = 1.
+ * stat_shards > 0 selects the other form of batch statistics: part is then a ZERO-FILLED buffer of
+ * stat_shards * M * 2 floats into which the launch adds, with fp32 atomics, the per-channel sums of
+ * d = U - bias and of d^2 (shard = column block % stat_shards).  The kernel that applies the
+ * BatchNorm finalises them itself (bmnas_bn_fin_t below): no bmnas_bn_finalize launch. */
 int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src, const float* W, int ldw,
-                      int fold_cols, const float* bias, float* U, float* part, int b, int L, int M,
-                      void* stream);
+                      int fold_cols, const float* bias, float* U, float* part, int stat_shards, int b,
+                      int L, int M, void* stream);
 /* dsrcs[q][s, c, l] (=|+=) sum_m Weff[m, q*C_src + c] * dU[s, m, l]   (dsrcs[q] NULL: skip;
  * Weff as above) */
 int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, int fold_cols,
@@ -170,8 +174,8 @@ int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, int fold_co
  * independent; K3's b*L/16 workgroups leave half the CUs idle, the GEMM tiles fill them.
  * Arguments = those of the two functions (same b, L). */
 int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C_src, const float* W, int ldw,
-                           int fold_cols, const float* bias, float* U, float* part, int b, int L,
-                           int M, const float* x, const float* y, const float* ln_w,
+                           int fold_cols, const float* bias, float* U, float* part, int stat_shards,
+                           int b, int L, int M, const float* x, const float* y, const float* ln_w,
                            const float* ln_b, float* out, float* xhat, float* stats, int C,
                            bmnas_dropout_t drop, void* stream);
 /* bmnas_conv1x1_bwd_data and bmnas_sdpa_ln_bwd in ONE launch.  The two halves run concurrently, so
@@ -226,20 +230,38 @@ int bmnas_bn_finalize(const float* part, int n_part, int b, int L, int M, const 
                       int64_t* num_batches_tracked, int n_nbt, int training, float* chan,
                       void* stream);
 
+/* BatchNorm finalisation INSIDE the kernel that applies it (bmnas_node_mix_fwd, bmnas_node_mix_ln_fwd,
+ * bmnas_bn_relu_fwd) instead of a bmnas_bn_finalize launch in front of it.  on = 0: `chan` already
+ * holds mean | rstd | scale | shift.  on = 1: every workgroup derives scale / shift in LDS —
+ * training: from `stat` (the sums a bmnas_conv1x1_fwd with stat_shards = shards accumulated; conv_bias
+ * is the shift they were taken about), eval: from the running statistics — and workgroup 0 writes
+ * `chan` (now an OUTPUT, for the backward kernels) and, in training mode, updates running_mean /
+ * running_var / the n_nbt counters like nn.BatchNorm1d. */
+typedef struct {
+  const float* stat;
+  const float* conv_bias;
+  const float* bn_w;
+  const float* bn_b;
+  float* running_mean;
+  float* running_var;
+  int64_t* num_batches_tracked;
+  int shards, n_nbt, training, on;
+} bmnas_bn_fin_t;
+
 /* ---- K2: the gamma-weighted NodeMixedOp combine -------------------------------------------
  * NodeMixedOp.forward node_operations.py:118-120 over [Sum, ScaleDotAttn, LinearGLU, ConcatFC]:
  *   s = g0*(x+y) + g1*p1 + g2*drop(glu(BN(U[:, 0:2C]))) + g3*drop(relu(BN(U[:, 2C:3C])))
  * gamma: 4 device floats (softmaxed row).  U: (b, 3C, L) stacked conv output [GLU | ConcatFC],
  * chan: its bn_finalize output (M = 3C).  p1 = attention branch output. */
-int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const float* U,
-                       const float* chan, const float* gamma, float* out, int b, int C, int L,
+int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const float* U, float* chan,
+                       bmnas_bn_fin_t fin, const float* gamma, float* out, int b, int C, int L,
                        bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
 /* K2 + K6 in one launch (node_multiplier == 1, last inner step; node_search.py:55,67-68):
  * pre = NodeMixedOp(...) + resid (saved for backward), out = LayerNorm_[C, L](pre), stats as in
  * cat_ln.  The backward is bmnas_cat_ln_bwd(srcs = {pre}, resid = NULL) with its input gradient
  * routed to both the mix and the residual, then bmnas_node_mix_bwd. */
 int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float* p1, const float* U,
-                          const float* chan, const float* gamma, const float* resid,
+                          float* chan, bmnas_bn_fin_t fin, const float* gamma, const float* resid,
                           const float* ln_w, const float* ln_b, float* pre, float* out, float* stats,
                           int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
                           void* stream);
@@ -263,7 +285,7 @@ int bmnas_bn_glu_bwd(const float* g, const float* U, const float* chan, float* d
 
 /* ---- BN + ReLU + dropout: ConcatFC tail (node_operations.py:53-55) and the NodeCell
  * out_conv tail (node_search.py:60-64) ---------------------------------------------------- */
-int bmnas_bn_relu_fwd(const float* U, const float* chan, float* out, int b, int M, int L,
+int bmnas_bn_relu_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, float* out, int b, int M, int L,
                       bmnas_dropout_t drop, void* stream);
 int bmnas_bn_relu_bwd(const float* g, const float* U, const float* chan, float* dV, float* bn_grad,
                       int b, int M, int L, bmnas_dropout_t drop, void* stream);
@@ -302,10 +324,14 @@ int bmnas_backward_epilogue(int n_prob, const float* const* g, const float* cons
  * Weff[q] (M, C) = W[q][:, :C] + W[q][:, C:] as bmnas_fold_weight does (W[q] is (M, 2C)).
  * step_counter / step_span (both or neither): *step_counter += *step_span, once, before anything
  * else of the step reads the dropout step counter (bmnas_dropout_t.step) — how a hipGraph replay
- * moves on to fresh dropout masks without a launch of its own. */
+ * moves on to fresh dropout masks without a launch of its own.
+ * scrub (scrub_n floats, % 4 == 0, nullable): zero-filled by the same launch — the forward
+ * accumulation buffers of the step (BatchNorm batch sums of bmnas_conv1x1_fwd(stat_shards > 0),
+ * the head's logits) instead of a memset launch. */
 int bmnas_cell_prologue(const float* const* a, float* const* out, const int* rows, const int* cols,
                         int n_arch, const float* const* W, float* const* Weff, int n_fold, int M,
-                        int C, uint64_t* step_counter, const uint64_t* step_span, void* stream);
+                        int C, uint64_t* step_counter, const uint64_t* step_span, float* scrub,
+                        int64_t scrub_n, void* stream);
 
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at
