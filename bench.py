@@ -87,7 +87,8 @@ class HyperNet(torch.nn.Module):
     def forward(self, xs):
         if self.tier == 'R':
             xs = [layer._tail(x) for layer, x in zip(self.reshape_layers, xs)]
-        return self.central_classifier(self.fusion_net(xs))
+        # = central_classifier(fusion_net(xs)), what Searchable_*.forward does (HyperNetBase.fuse)
+        return self.fusion_net.forward_classified(xs, self.central_classifier)
 
     def arch_parameters(self):
         return self.fusion_net.arch_parameters()
@@ -152,6 +153,10 @@ def algo_table(C, L):
         'bn_relu_bwd': lambda g, U, *_: ('hbm', 3 * T(U)),
         'bn_bwd_apply': lambda dV, U, *_: ('hbm', 3 * T(U)),
         'fold_weight': lambda W, We, *_: ('hbm', T(W) + T(We)),
+        # K7 + classifier: three accumulator sets (logits, A, B) forward; dfeat + dW backward
+        'head_fwd': lambda srcs, sums, lw, lb, W, bias, hb, st, b, Cc, L_, O: ('mfma', 6.0 * b * O * len(srcs) * Cc * L_),
+        'head_bwd': lambda srcs, sums, ds, m, lw, lb, W, hb, st, mode, g, gs, lab, loss, part, b, Cc, L_, O, *_:
+            ('mfma', 4.0 * b * O * len(srcs) * Cc * L_),
         'linear_fwd': lambda feat, W, bias, out, b, O, Kd: ('mfma', 2.0 * b * O * Kd),
         'linear_bwd': lambda g, gs, feat, W, df, dW, db, b, O, Kd: ('mfma', 4.0 * b * O * Kd),
     }
@@ -527,7 +532,8 @@ def main():
     def step():
         for t in leaves:
             t.grad = None
-        loss = crit(model(xs), y)
+        with bnn.fused_criterion():              # the loss is read only after backward
+            loss = crit(model(xs), y)
         loss.backward()
         return loss
 
@@ -552,7 +558,8 @@ def main():
         # same work as step(); gradients are taken with autograd.grad (no AccumulateGrad nodes,
         # whose streams are pinned at creation and do not follow the capture stream) and then
         # attached as .grad — the tensors are static, replays refresh them in place
-        loss = crit(model(xs), y)
+        with bnn.fused_criterion():
+            loss = crit(model(xs), y)
         if world > 1:
             if loss_scale != 1.0:
                 grads = torch.autograd.grad(loss * loss_scale, leaves, allow_unused=True)

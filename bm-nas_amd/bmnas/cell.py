@@ -129,6 +129,26 @@ class Pack:
         self.__dict__.update(kw)
 
 
+class HeadState(Pack):
+    """What the fused head (csrc/head.hip) shares between the cell's forward, the criterion and the
+    backward: classifier weights, the zero-filled hb = logits | A | B buffer, the loss scalar, and —
+    when the criterion was deferred into the backward launch (bmnas.nn.fused_criterion) — its kind
+    and labels.  `marker` stands in for dlogits in that case: the backward recognises it by address."""
+
+    deferred = None      # ('bce' | 'ce', labels)
+    gscale = None        # 0-dim device tensor multiplying dlogits (None: 1)
+
+    def resolve(self, g):
+        """-> (mode, dlogits, gscale, labels) for bmnas_head_bwd given the incoming gradient g."""
+        if self.deferred is not None and g.data_ptr() == self.marker.data_ptr():
+            kind, labels = self.deferred
+            return (1 if kind == 'bce' else 2), None, self.gscale, labels
+        return 0, (g if g.is_contiguous() else g.contiguous()), None, None
+
+
+LAST_HEAD = []           # FusedCellFn.forward leaves its HeadState here for the caller to pick up
+
+
 class GradSlot:
     """A lazily allocated gradient buffer that remembers whether it has been written
     (first writer overwrites, later writers accumulate)."""
@@ -202,10 +222,15 @@ class StatArena:
     per-channel sums into them with atomics and the kernels that apply the BatchNorm finalise them
     in place of a bmnas_bn_finalize launch per conv."""
 
-    def __init__(self, like, channel_counts):
+    def __init__(self, like, channel_counts, buf=None):
         self.sizes = [STAT_SHARDS * M * 2 for M in channel_counts]
-        self.buf = torch.empty(sum(self.sizes), device=like.device, dtype=torch.float32)
+        self.buf = torch.empty(sum(self.sizes), device=like.device, dtype=torch.float32) if buf is None else buf
+        assert self.buf.numel() >= sum(self.sizes)
         self.off = 0
+
+    @staticmethod
+    def numel_for(channel_counts):
+        return sum(STAT_SHARDS * M * 2 for M in channel_counts)
 
     def take(self, M):
         n = STAT_SHARDS * M * 2
@@ -329,10 +354,10 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None)
     if ln is None:
         lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc, fin)
     else:
-        resid, ln_w, ln_b, ln_stats = ln
+        resid, ln_w, ln_b, ln_stats, out_sums = ln
         sv.pre = torch.empty_like(x)
         lib.node_mix_ln_fwd(x, y, p1, U, chan, gamma_row, resid, ln_w, ln_b, sv.pre, out, ln_stats, b, C, L,
-                            sv.d_glu, sv.d_fc, fin)
+                            sv.d_glu, sv.d_fc, fin, out_sums)
     return out, sv
 
 
@@ -347,6 +372,8 @@ FUSE_EPILOGUE = os.environ.get('BMNAS_FUSE_EPILOGUE', '1') != '0'
 # BatchNorm statistics accumulated by the GEMM epilogues (atomics) and finalised inside the kernel
 # that applies the BatchNorm, instead of one bn_finalize launch per conv (needs FUSE_PROLOGUE)
 FUSE_BN_FINALIZE = os.environ.get('BMNAS_FUSE_BN_FINALIZE', '1') != '0'
+# the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
+FUSE_HEAD = os.environ.get('BMNAS_FUSE_HEAD', '1') != '0'
 
 
 def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None, Weff=None, stats=None):
@@ -445,7 +472,8 @@ FUSE_TAIL = True   # node_multiplier == 1: NodeMixedOp + residual + LayerNorm in
 FUSE_PAIR = True   # search mode: cell-level mixed sum + the node's first inner sum in one launch
 
 
-def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=None, stats=None):
+def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=None, stats=None,
+                  want_sums=False):
     """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
     device tensors.  NP: parameter pack of the NodeCell.  z0: the first inner mixed sum when the
     caller already formed it (bmnas_mixsum_pair_fwd)."""
@@ -458,11 +486,13 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
     offset = 0
     sv.fused_tail = nm == 1 and FUSE_TAIL
     sv.stats = _empty(x, b * 2)
+    # per-sample (sum, sum of squares) of the node output, for the head's K7 LayerNorm (head.hip)
+    sv.osum = _empty(x, b * 2) if want_sums else None
     for t in range(ns):
         z = z0 if (t == 0 and z0 is not None) else mixsum_fwd(states, beta_w[offset:, 1])
         last = sv.fused_tail and t == ns - 1
         s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
-                                (x, NP.ln_w, NP.ln_b, sv.stats) if last else None,
+                                (x, NP.ln_w, NP.ln_b, sv.stats, sv.osum) if last else None,
                                 None if weffs is None else weffs[t], stats)
         sv.zs.append(z)
         sv.mixed.append(msv)
@@ -485,7 +515,7 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
         o = tail[0]
     sv.o = o
     out = torch.empty_like(x)
-    lib.cat_ln_fwd([o], x, NP.ln_w, NP.ln_b, out, sv.stats, b, C, L, False)
+    lib.cat_ln_fwd([o], x, NP.ln_w, NP.ln_b, out, sv.stats, b, C, L, False, sv.osum)
     return out, sv
 
 
@@ -539,9 +569,12 @@ class CellSaved:
     pass
 
 
-def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, weffs=None, stats=None):
+def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, weffs=None, stats=None,
+                    head=None):
     """FusionCell.forward (model_search.py:50-68) with the step nodes in search mode
-    (FusionNode(x, x), model_search.py:59).  alpha_w (k, 2) softmaxed device tensor."""
+    (FusionNode(x, x), model_search.py:59).  alpha_w (k, 2) softmaxed device tensor.
+    head: Pack(W, bias, hb) -> the cell's LayerNorm tail continues into the central classifier in
+    ONE launch (bmnas_head_fwd) and the function returns the logits (b, O) = head.hb[0]."""
     N = len(xs)
     b, C, L = xs[0].shape
     sv = CellSaved()
@@ -556,7 +589,8 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
         else:
             sif, z0 = mixsum_fwd(states, alpha_w[offset:, 1]), None
         out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm, z0,
-                                 None if weffs is None else weffs[i * ns:(i + 1) * ns], stats)
+                                 None if weffs is None else weffs[i * ns:(i + 1) * ns], stats,
+                                 want_sums=head is not None)
         nsv.paired = z0 is not None
         sv.sifs.append(sif)
         sv.nodes.append(nsv)
@@ -564,8 +598,16 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
         offset += len(states)
         states.append(out)
     sv.states = states
-    out = _empty(xs[0], b, M * C * L)
     sv.stats = _empty(xs[0], b * 2)
+    sv.head = head
+    if head is not None:
+        if M > S:
+            raise lib.BmnasError('fused head: the cell concatenates input states (multiplier > steps)')
+        head.sums = [nsv.osum for nsv in sv.nodes[S - M:]]
+        lib.head_fwd(states[-M:], head.sums, CP.ln_w, CP.ln_b, head.W, head.bias, head.hb, sv.stats, b, C, L,
+                     head.W.shape[0])
+        return head.hb[0], sv
+    out = _empty(xs[0], b, M * C * L)
     lib.cat_ln_fwd(states[-M:], None, CP.ln_w, CP.ln_b, out, sv.stats, b, C, L, True)
     return out, sv
 
@@ -579,11 +621,26 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
     slots = [GradSlot(x0) if (j >= N or need_input_grads[j]) else None for j in range(N + S)]
     tail = slots[-M:]
     bufs, mask = _write_group(tail)
-    lib.cat_ln_bwd(g, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, bufs, None, mask, None, None,
-                   b, C, L, True, getattr(CG, 'scrub', None))
     deferred = Deferred()
-    _ln_affine(deferred, g, None, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, CG.dln_w, CG.dln_b,
-               b, C, L, True, False)
+    head, sums = sv.head, ()
+    if head is not None:
+        # classifier backward + (deferred) criterion + K7 backward in one launch; its batch reductions
+        # (dWcls, dbcls, the K7 affine gradients) leave as per-chunk partials summed by the epilogue
+        O, D = head.W.shape[0], M * C * L
+        n_chunk = lib.head_chunks(b)
+        part = _empty(x0, n_chunk * (O + 3) * D)
+        hsum = _empty(x0, (O + 3) * D)
+        mode, gten, gscale, labels = head.resolve(g)
+        lib.head_bwd(sv.states[-M:], head.sums, bufs, mask, CP.ln_w, CP.ln_b, head.W, head.hb, sv.stats, mode,
+                     gten, gscale, labels, head.loss, part, b, C, L, O, getattr(CG, 'scrub', None))
+        sums = ((part, hsum, n_chunk),)
+        head.dW, head.dbias = hsum[:O * D].view(O, D), hsum[(O + 2) * D:(O + 2) * D + O]
+        CG.dln_w, CG.dln_b = hsum[O * D:(O + 1) * D].view(M * C, L), hsum[(O + 1) * D:(O + 2) * D].view(M * C, L)
+    else:
+        lib.cat_ln_bwd(g, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, bufs, None, mask, None, None,
+                       b, C, L, True, getattr(CG, 'scrub', None))
+        _ln_affine(deferred, g, None, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, CG.dln_w, CG.dln_b,
+                   b, C, L, True, False)
     for i in reversed(range(S)):
         gn = slots[N + i].get()
         if gn is None:
@@ -606,10 +663,12 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
     if epilogue is not None and FUSE_EPILOGUE and 0 < len(deferred.probs) <= 8:
         # the LayerNorm affine reductions and the arch-softmax backward end the pass in ONE launch
         ws, dws, outs = epilogue
-        lib.backward_epilogue(deferred.probs, b, L, ws, dws, outs, CG.shards, CG.shard_stride)
+        lib.backward_epilogue(deferred.probs, b, L, ws, dws, outs, CG.shards, CG.shard_stride, sums)
         deferred.probs = []
         sv.epilogue_done = True
     else:
         deferred.flush(b, L)
+        for part, out, n_chunk in sums:
+            lib.sum_chunks(part, out, n_chunk)
         sv.epilogue_done = False
     return [s.get() if s is not None else None for s in slots[:N]]

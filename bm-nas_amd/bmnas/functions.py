@@ -235,7 +235,10 @@ class FusedCellFn(Function):
     the whole cell — mixed edges, step nodes, LayerNorm tail — as one autograd node."""
 
     @staticmethod
-    def forward(ctx, cell, training, alpha_is_logits, alpha, *tensors):
+    def forward(ctx, cell, training, alpha_is_logits, alpha, n_head, *tensors):
+        """tensors = N inputs, 2*S arch tensors, the cell's parameters and — n_head = 2 — the central
+        classifier's weight and bias: the cell then ends in the classifier (bmnas_head_fwd) and the
+        function returns the logits."""
         N, S = cell.num_input_nodes, cell._steps
         xs = [_c(_f32(t)) for t in tensors[:N]]
         _require_gpu(xs[0], 'FusionCell')
@@ -248,24 +251,38 @@ class FusedCellFn(Function):
         # every arch softmax and (search mode: conv applied to cat[z, z]) every NodeMixedOp's folded
         # conv weight in ONE launch
         mixed = [m for n in CP.nodes for m in n.mixed]
-        C_ = xs[0].shape[1]
-        weffs, stats = None, None
+        b, C_ = xs[0].shape[0], xs[0].shape[1]
+        # forward accumulation arena, zero-filled by the prologue launch: the BatchNorm batch sums that
+        # the GEMM epilogues add into (finalised by the mix / out_conv kernels: no bn_finalize
+        # launches) and the head's logits | A | B | loss
+        counts = []
+        if K.FUSE_BN_FINALIZE:
+            for n in CP.nodes:
+                counts += [3 * C_] * len(n.mixed) + ([C_] if cell.args.node_multiplier != 1 else [])
+        stat_n = K.StatArena.numel_for(counts)
+        head, head_n = None, 0
+        if n_head:
+            Wc, bc = _c(_f32(tensors[-2])), _c(_f32(tensors[-1]))
+            O = Wc.shape[0]
+            hb_n = (3 * b * O + 3) // 4 * 4
+            head_n = hb_n + 4
+        arena = torch.empty(stat_n + head_n, device=dev, dtype=torch.float32) if stat_n + head_n else None
+        stats = K.StatArena(xs[0], counts, arena[:stat_n]) if stat_n else None
+        if n_head:
+            head = K.HeadState(W=Wc, bias=bc, hb=arena[stat_n:stat_n + 3 * b * O].view(3, b, O),
+                               loss=arena[stat_n + hb_n:stat_n + hb_n + 1],
+                               marker=torch.empty((b, O), device=dev, dtype=torch.float32))
+        weffs = None
         if K.FUSE_PROLOGUE and 0 < len(mixed) <= 8:
             weffs = [torch.empty((3 * C_, C_), device=dev, dtype=torch.float32) for _ in mixed]
             # under capture the first prologue of the step also advances the dropout step counter
             # (bmnas.graph.GraphedStep), saving the separate add launch at the end of every replay
             adv, K.DROP.pending_advance = K.DROP.pending_advance, None
-            # the prologue also zero-fills the BatchNorm batch-sum buffers of this forward: the GEMM
-            # epilogues add into them, the mix / out_conv kernels finalise them (no bn_finalize launches)
-            if K.FUSE_BN_FINALIZE:
-                nm_ = cell.args.node_multiplier
-                counts = []
-                for n in CP.nodes:
-                    counts += [3 * C_] * len(n.mixed) + ([C_] if nm_ != 1 else [])
-                stats = K.StatArena(xs[0], counts)
-            lib.cell_prologue(logits, ws, [m.stack_W for m in mixed], weffs, 3 * C_, C_, adv,
-                              None if (stats is None or not training) else stats.buf)
+            lib.cell_prologue(logits, ws, [m.stack_W for m in mixed], weffs, 3 * C_, C_, adv, arena)
         else:
+            stats = None                                     # bn_finalize launches (no zero-filled sums)
+            if head is not None:
+                arena[stat_n:].zero_()
             lib.arch_softmax_multi(logits, None, ws, False)      # every arch tensor, one launch
         if alpha_is_logits:
             alpha_w, ws = ws[0], ws[1:]
@@ -275,16 +292,18 @@ class FusedCellFn(Function):
         ctx.alpha_is_logits = alpha_is_logits
         out, sv = K.fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S,
                                     cell._multiplier, cell.args.node_steps, cell.args.node_multiplier, weffs,
-                                    stats)
+                                    stats, head)
         ctx.cell, ctx.sv, ctx.beta_ws, ctx.gamma_ws, ctx.N, ctx.S = cell, sv, beta_ws, gamma_ws, N, S
-        ctx.dev = dev
+        ctx.dev, ctx.n_head = dev, n_head
+        if head is not None:
+            K.LAST_HEAD.append(head)
         return out
 
     @staticmethod
     def backward(ctx, g):
         cell, sv, N, S = ctx.cell, ctx.sv, ctx.N, ctx.S
         dev = ctx.dev
-        need_in = [ctx.needs_input_grad[4 + j] for j in range(N)]
+        need_in = [ctx.needs_input_grad[5 + j] for j in range(N)]
         # one zero-filled arena for every gradient that is accumulated with atomics
         CG, dalpha_w, dbeta_ws, dgamma_ws = cell.grad_pack(dev, sv.alpha_w, ctx.beta_ws, ctx.gamma_ws)
         ws, dws = [], []
@@ -294,7 +313,8 @@ class FusedCellFn(Function):
         if ctx.alpha_is_logits:
             ws, dws = [sv.alpha_w] + ws, [dalpha_w] + dws
         darch = [torch.empty_like(w) for w in ws]
-        dxs = K.fusion_cell_bwd(sv, _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws, CG, (ws, dws, darch))
+        dxs = K.fusion_cell_bwd(sv, g if sv.head is not None else _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws,
+                                CG, (ws, dws, darch))
         if not sv.epilogue_done:
             lib.arch_softmax_multi(ws, dws, darch, True, CG.shards, CG.shard_stride)
         if ctx.alpha_is_logits:
@@ -304,7 +324,8 @@ class FusedCellFn(Function):
             dalpha = torch.as_strided(dalpha_w, (CG.shards, *dalpha_w.shape),
                                       (CG.shard_stride, *dalpha_w.stride()),
                                       dalpha_w.storage_offset()).sum(0)
-        return (None, None, None, dalpha, *dxs, *darch, *cell.grads_in_param_order(CG))
+        head_grads = (sv.head.dW, sv.head.dbias) if ctx.n_head else ()
+        return (None, None, None, dalpha, None, *dxs, *darch, *cell.grads_in_param_order(CG), *head_grads)
 
 
 # ------------------------------------------------------- classifier + criterion epilogue
@@ -366,6 +387,28 @@ class _LossFn(Function):
         if u is not None and gl.data_ptr() == u.data_ptr():
             return dz, None                      # gradient of the loss is the constant 1
         return dz * gl, None
+
+
+class DeferredLossFn(Function):
+    """The criterion of a fused head, evaluated by the head's BACKWARD launch (bmnas_head_bwd modes
+    1 / 2): forward only records kind and labels and hands out the loss scalar that the backward
+    will fill — valid once backward has run, which is all a captured step needs (nothing can read a
+    value between two nodes of a hipGraph).  Enabled by bmnas.nn.fused_criterion()."""
+
+    @staticmethod
+    def forward(ctx, z, target, head, kind):
+        head.deferred = (kind, target if target.is_contiguous() else target.contiguous())
+        head.gscale = None
+        ctx.head = head
+        return head.loss.view(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        head = ctx.head
+        u = _UNIT.get((gl.device.type, gl.device.index))
+        if not (u is not None and gl.data_ptr() == u.data_ptr()):
+            head.gscale = gl.contiguous().float()          # d(loss)/d(loss) other than the constant 1
+        return head.marker, None, None, None
 
 
 class BCEWithLogitsFn(_LossFn):

@@ -134,11 +134,16 @@ class GraphedTrainStep:
         scale = 1.0 / reducer.world if (reducer is not None and not self.average) else 1.0
         armed = [False]
 
+        from . import nn as bnn
+
         def fn():
-            logits = model(self.inputs)
-            if isinstance(logits, tuple):
-                logits = logits[-1]
-            loss = criterion(logits, self.labels)
+            # the criterion of a fused head is evaluated by the head's backward launch: the static
+            # `loss` output is complete when the replay is (bmnas.nn.fused_criterion)
+            with bnn.fused_criterion():
+                logits = model(self.inputs)
+                if isinstance(logits, tuple):
+                    logits = logits[-1]
+                loss = criterion(logits, self.labels)
             if scale != 1.0:
                 grads = torch.autograd.grad(loss * scale, self.targets, allow_unused=True)
             else:

@@ -75,7 +75,7 @@ SIGNATURES = {
     'bmnas_mixsum_pair_fwd': ([_PP, _I, _P, _I, _P, _I, _P, _P, _I64, _P], _I),
     'bmnas_mixsum_pair_bwd': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _U32, _I64, _P],
                               _I),
-    'bmnas_cat_ln_fwd': ([_PP, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_cat_ln_fwd': ([_PP, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], _I),
     'bmnas_cat_ln_bwd': ([_P, _PP, _I, _P, _P, _P, _P, _PP, _P, _U32, _P, _P, _I, _I, _I, _I, _P, _I64, _P], _I),
     'bmnas_ln_affine_bwd': ([_P, _P, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     'bmnas_ln_affine_bwd_multi': ([_I, _PP, _PP, C.POINTER(_PP), C.POINTER(C.c_int), _PP, _PP, _PP, _PP, _PP,
@@ -98,7 +98,7 @@ SIGNATURES = {
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
     'bmnas_node_mix_ln_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout,
-                               Dropout, _P], _I),
+                               Dropout, _P, _P], _I),
     'bmnas_node_mix_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32, _P, _P, _I, _I, _I,
                             Dropout, Dropout, _P], _I),
     'bmnas_bn_glu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
@@ -116,7 +116,13 @@ SIGNATURES = {
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
     'bmnas_backward_epilogue': ([_I, _PP, _PP, C.POINTER(_PP), C.POINTER(C.c_int), _PP, _PP, _PP, _PP, _PP,
                                  _PP, _I, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                 _PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I64, _P], _I),
+                                 _PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I64,
+                                 _I, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int64), _P], _I),
+    'bmnas_head_chunks': ([_I], _I),
+    'bmnas_head_fwd': ([_PP, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_head_bwd': ([_PP, _PP, _PP, _I, _U32, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
+                        _P, _I64, _P], _I),
+    'bmnas_sum_chunks': ([_P, _P, _I, _I64, _P], _I),
     'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P, _P,
                              _P, _I64, _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
@@ -212,9 +218,11 @@ def mixsum_pair_bwd(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, acc
                                         gz.numel(), _stream()), 'mixsum_pair_bwd')
 
 
-def cat_ln_fwd(srcs, resid, ln_w, ln_b, out, stats, b, Cc, L, relu):
+def cat_ln_fwd(srcs, resid, ln_w, ln_b, out, stats, b, Cc, L, relu, out_sums=None):
+    """out_sums: optional (b, 2) buffer receiving each sample's (sum, sum of squares) of `out`."""
     _check(load().bmnas_cat_ln_fwd(_ptrs(srcs), len(srcs), _ptr(resid), _ptr(ln_w), _ptr(ln_b),
-                                   _ptr(out), _ptr(stats), b, Cc, L, int(relu), _stream()), 'cat_ln_fwd')
+                                   _ptr(out), _ptr(stats), b, Cc, L, int(relu), _ptr(out_sums), _stream()),
+           'cat_ln_fwd')
 
 
 def cat_ln_bwd(g, srcs, resid, ln_w, ln_b, stats, dsrcs, dresid, acc_mask, dln_w, dln_b, b, Cc, L, relu,
@@ -250,8 +258,9 @@ def ln_affine_bwd_multi(probs, b, L):
                                             _stream()), 'ln_affine_bwd_multi')
 
 
-def backward_epilogue(probs, b, L, ws, dws, outs, n_shards, shard_stride):
-    """ln_affine_bwd_multi(probs) + arch_softmax_multi(ws, dws, outs, backward) in one launch."""
+def backward_epilogue(probs, b, L, ws, dws, outs, n_shards, shard_stride, sums=()):
+    """ln_affine_bwd_multi(probs) + arch_softmax_multi(ws, dws, outs, backward) in one launch.
+    sums: up to two (part, out, n_chunk) — out[e] = sum_c part[c, e], the head's partials."""
     n = len(probs)
 
     def parr(key):
@@ -267,11 +276,44 @@ def backward_epilogue(probs, b, L, ws, dws, outs, n_shards, shard_stride):
     pw = (C.c_void_p * na)(*[t.data_ptr() for t in ws])
     pd = (C.c_void_p * na)(*[t.data_ptr() for t in dws])
     po = (C.c_void_p * na)(*[t.data_ptr() for t in outs])
+    ns = len(sums)
+    sp = (C.c_void_p * max(ns, 1))(*[t[0].data_ptr() for t in sums])
+    so = (C.c_void_p * max(ns, 1))(*[t[1].data_ptr() for t in sums])
+    sc = (C.c_int * max(ns, 1))(*[int(t[2]) for t in sums])
+    sn = (C.c_int64 * max(ns, 1))(*[t[1].numel() for t in sums])
+    for part, out, n_chunk in sums:
+        assert part.numel() == n_chunk * out.numel() and out.numel() % 4 == 0
     _check(load().bmnas_backward_epilogue(n, parr('g'), parr('gscale'), srcs, n_src, parr('resid'),
                                           parr('ln_w'), parr('ln_b'), parr('stats'), parr('dln_w'),
                                           parr('dln_b'), b, ints('C'), L, ints('relu'), ints('prenorm'),
-                                          pw, pd, po, rows, cols, na, n_shards, shard_stride, _stream()),
+                                          pw, pd, po, rows, cols, na, n_shards, shard_stride, ns, sp, so, sc,
+                                          sn, _stream()),
            'backward_epilogue')
+
+
+def head_chunks(b):
+    return load().bmnas_head_chunks(b)
+
+
+def head_fwd(srcs, sums, ln_w, ln_b, W, bias, hb, stats, b, Cc, L, O):
+    """K7 + central_classifier forward (csrc/head.hip); hb: zero-filled (3, b, O) = logits | A | B."""
+    _check(load().bmnas_head_fwd(_ptrs(srcs), _ptrs(sums), len(srcs), _ptr(ln_w), _ptr(ln_b), _ptr(W),
+                                 _ptr(bias), _ptr(hb), _ptr(stats), b, Cc, L, O, _stream()), 'head_fwd')
+
+
+def head_bwd(srcs, sums, dsrcs, acc_mask, ln_w, ln_b, W, hb, stats, mode, g, gscale, labels, loss, part,
+             b, Cc, L, O, scrub=None):
+    """mode 0: g = dlogits; 1: BCEWithLogits(mean) vs float labels; 2: CrossEntropy(mean) vs int64 labels."""
+    _check(load().bmnas_head_bwd(_ptrs(srcs), _ptrs(sums), _ptrs(dsrcs), len(srcs), acc_mask, _ptr(ln_w),
+                                 _ptr(ln_b), _ptr(W), _ptr(hb), _ptr(stats), mode, _ptr(g),
+                                 None if gscale is None else gscale.data_ptr(),
+                                 None if labels is None else labels.data_ptr(), _ptr(loss), _ptr(part),
+                                 b, Cc, L, O, _ptr(scrub),
+                                 0 if scrub is None else scrub.numel(), _stream()), 'head_bwd')
+
+
+def sum_chunks(part, out, n_chunk):
+    _check(load().bmnas_sum_chunks(_ptr(part), _ptr(out), n_chunk, out.numel(), _stream()), 'sum_chunks')
 
 
 def sdpa_ln_fwd(x, y, ln_w, ln_b, out, xhat, stats, b, Cc, L, drop):
@@ -367,10 +409,11 @@ def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc, fin=NO_FIN)
 
 
 def node_mix_ln_fwd(x, y, p1, U, chan, gamma, resid, ln_w, ln_b, pre, out, stats, b, Cc, L, dglu, dfc,
-                    fin=NO_FIN):
+                    fin=NO_FIN, out_sums=None):
     _check(load().bmnas_node_mix_ln_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin,
                                         gamma.data_ptr(), _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(pre),
-                                        _ptr(out), _ptr(stats), b, Cc, L, dglu, dfc, _stream()),
+                                        _ptr(out), _ptr(stats), b, Cc, L, dglu, dfc, _ptr(out_sums),
+                                        _stream()),
            'node_mix_ln_fwd')
 
 
@@ -533,7 +576,7 @@ def profile_end_calls():
     return prof['calls']
 
 
-_TIMED_NAMES = ('mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
+_TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',

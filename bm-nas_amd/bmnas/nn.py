@@ -7,8 +7,33 @@ nothing leaves the HIP path silently."""
 import torch
 import torch.nn as nn
 
+import contextlib
+
 from . import lib
-from .functions import BCEWithLogitsFn, CrossEntropyFn, LinearFn
+from .functions import BCEWithLogitsFn, CrossEntropyFn, DeferredLossFn, LinearFn
+
+_FUSED_CRITERION = [False]
+
+
+@contextlib.contextmanager
+def fused_criterion(on=True):
+    """Inside this context a criterion applied to the logits of a fused head (FusionNetwork with its
+    central classifier, csrc/head.hip) is evaluated by the head's backward launch instead of a
+    launch of its own: the returned loss tensor is filled when backward has run.  For code that
+    reads the loss only after backward — a captured training step (bmnas.graph.GraphedTrainStep
+    turns it on), the benchmark step."""
+    prev, _FUSED_CRITERION[0] = _FUSED_CRITERION[0], bool(on)
+    try:
+        yield
+    finally:
+        _FUSED_CRITERION[0] = prev
+
+
+def _deferrable(input):
+    head = getattr(input, '_bmnas_head', None)
+    if _FUSED_CRITERION[0] and head is not None and torch.is_grad_enabled() and input.requires_grad:
+        return head
+    return None
 
 
 class Linear(nn.Linear):
@@ -29,6 +54,9 @@ class BCEWithLogitsLoss(nn.BCEWithLogitsLoss):
         if (input.is_cuda and self.weight is None and self.pos_weight is None and self.reduction == 'mean'
                 and input.dtype == torch.float32 and target.dtype == torch.float32
                 and input.shape == target.shape):
+            head = _deferrable(input)
+            if head is not None:
+                return DeferredLossFn.apply(input, target, head, 'bce')
             return BCEWithLogitsFn.apply(input, target)
         lib.note_off_path('bmnas.nn.BCEWithLogitsLoss', f'input {tuple(input.shape)} {input.dtype} on {input.device}, '
                           f'target {tuple(target.shape)} {target.dtype}, reduction {self.reduction}')
@@ -40,6 +68,9 @@ class CrossEntropyLoss(nn.CrossEntropyLoss):
         if (input.is_cuda and input.dim() == 2 and self.weight is None and self.reduction == 'mean'
                 and self.label_smoothing == 0.0 and self.ignore_index == -100
                 and target.dtype == torch.int64 and target.dim() == 1 and input.dtype == torch.float32):
+            head = _deferrable(input)
+            if head is not None:
+                return DeferredLossFn.apply(input, target, head, 'ce')
             return CrossEntropyFn.apply(input, target)
         lib.note_off_path('bmnas.nn.CrossEntropyLoss', f'input {tuple(input.shape)} {input.dtype} on {input.device}, '
                           f'target {tuple(target.shape)} {target.dtype}, reduction {self.reduction}')

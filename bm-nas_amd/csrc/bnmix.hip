@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
     const float* __restrict__ U, float* __restrict__ chan, BnFin fin, const float* __restrict__ gamma,
     const float* __restrict__ resid, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
     float* __restrict__ pre, float* __restrict__ out, float* __restrict__ stats, int b, int C, int L,
-    DropCfg dglu, DropCfg dfc) {
+    DropCfg dglu, DropCfg dfc, float* __restrict__ osum) {
   __shared__ float red[8];
   extern __shared__ float fin_lds[];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
@@ -206,14 +206,26 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
     stats[2 * smp] = mean;
     stats[2 * smp + 1] = rstd;
   }
+  float os = 0.f, oq = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int r = threadIdx.x + k * BS;
     if (r < cl4) {
       const float4 w = lw[k], bb = lb[k];
-      st4(out + ((int64_t)smp * cl4 + r) * 4,
-          make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
-                      (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w));
+      const float4 o = make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
+                                   (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w);
+      st4(out + ((int64_t)smp * cl4 + r) * 4, o);
+      os += f4_hsum(o);
+      oq += f4_dot(o, o);
+    }
+  }
+  // (sum, sum of squares) of the node OUTPUT per sample for the K7 LayerNorm of the head (head.hip)
+  if (osum != nullptr) {
+    os = block_sum<BS / 64>(os, red);
+    oq = block_sum<BS / 64>(oq, red);
+    if (threadIdx.x == 0) {
+      osum[2 * smp] = os;
+      osum[2 * smp + 1] = oq;
     }
   }
 }
@@ -712,7 +724,8 @@ extern "C" int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float
                                      float* chan, bmnas_bn_fin_t fin, const float* gamma,
                                      const float* resid, const float* ln_w, const float* ln_b,
                                      float* pre, float* out, float* stats, int b, int C, int L,
-                                     bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream) {
+                                     bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, float* out_sums,
+                                     void* stream) {
   if (!x || !y || !p1 || !U || !chan || !gamma || !resid || !ln_w || !ln_b || !pre || !out || !stats ||
       b < 0 || C < 1)
     return BMNAS_E_ARG;
@@ -731,11 +744,11 @@ extern "C" int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float
     if (wide)                                                                                          \
       hipLaunchKernelGGL((node_mix_ln_fwd_k<V, 512>), dim3(b), dim3(512), fin_lds, st, x, y, p1, U,    \
                          chan, f, gamma, resid, ln_w, ln_b, pre, out, stats, b, C, L,                  \
-                         to_cfg(drop_glu), to_cfg(drop_fc));                                           \
+                         to_cfg(drop_glu), to_cfg(drop_fc), out_sums);                                 \
     else                                                                                               \
       hipLaunchKernelGGL((node_mix_ln_fwd_k<V, 256>), dim3(b), dim3(256), fin_lds, st, x, y, p1, U,    \
                          chan, f, gamma, resid, ln_w, ln_b, pre, out, stats, b, C, L,                  \
-                         to_cfg(drop_glu), to_cfg(drop_fc));                                           \
+                         to_cfg(drop_glu), to_cfg(drop_fc), out_sums);                                 \
   } while (0)
   if (need <= 1) NML(1);
   else if (need <= 2) NML(2);

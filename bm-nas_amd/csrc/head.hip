@@ -1,0 +1,466 @@
+// The head of a search step in two launches (forward, backward) instead of seven:
+//
+//   K7   out = relu(LayerNorm_[M*C, L](cat(states[-M:])))          model_search.py:63-67
+//        logits = out.view(b, -1) @ Wcls^T + bcls                  mmimdb_darts_searchable.py:82-83, 114
+//        loss = criterion(logits, labels)                          mmimdb_darts_searchable.py:22,
+//                                                                  ntu_darts_searchable.py:25, ego_...:24
+//   and their backward down to the gradients of the M states.
+//
+// What makes one launch each possible:
+//  * the LayerNorm statistics of a sample are not reduced here: every state that K7 concatenates is
+//    the output of a step node, whose kernel (node_mix_ln_fwd / cat_ln_fwd) already holds the whole
+//    sample in registers and hands over (sum, sum of squares) per sample; mean and rstd of the
+//    concatenation follow from M such pairs.  K7 thereby becomes elementwise and moves into the
+//    operand fetch of the classifier GEMM — `out` (b x 6144 floats) is never written or read;
+//  * the two per-sample reductions of the LayerNorm BACKWARD (mean of dxh, mean of dxh * xhat) are
+//    linear in dlogits:   m1[s] = sum_o dl[s,o] A[s,o] / D,   m2[s] = sum_o dl[s,o] B[s,o] / D   with
+//        A[s,o] = sum_k mask[s,k] lnw[k] W[o,k],    B[s,o] = sum_k mask[s,k] lnw[k] xhat[s,k] W[o,k],
+//    two more accumulator sets of the SAME forward GEMM (same W operand).  The backward is then
+//    elementwise per (sample, k) too, and tiles freely over the chip (a per-sample workgroup would
+//    read the whole 565 KB of Wcls per sample);
+//  * batch reductions (dWcls, dbcls, dlnw, dlnb) leave as per-16-sample-chunk partials with plain
+//    stores and are summed by the launch that ends the backward pass (bmnas_backward_epilogue):
+//    8 x fewer bytes than fp32 atomics would serialise at the memory side.
+//
+// Matrix products on v_mfma_f32_16x16x4_f32 (exact fp32).  Bound: latency / L2 (the whole head moves
+// ~15 MB at MM-IMDB batch 128); algorithmic FLOPs fwd 6 b O D (three accumulator sets), bwd 4 b O D.
+#include "common.hpp"
+#include "../../include/bmnas_hip.h"
+
+namespace {
+
+constexpr float kEpsLn = 1e-5f;
+constexpr int kHeadSrc = 4;
+constexpr int kMaxO = 128;
+
+struct HeadSrc {
+  const float* p[kHeadSrc];      // M states (b, C, L)
+  const float* sums[kHeadSrc];   // per state: (b, 2) = (sum, sum of squares) of each sample
+};
+
+__device__ __forceinline__ void sample_stats(const HeadSrc& src, int n_src, int s, int D, float* mean, float* rstd) {
+  float S = 0.f, Q = 0.f;
+  for (int q = 0; q < n_src; ++q) {
+    const float2 v = reinterpret_cast<const float2*>(src.sums[q])[s];
+    S += v.x;
+    Q += v.y;
+  }
+  const float inv = 1.f / (float)D;
+  const float m = S * inv;
+  const float var = fmaxf(Q * inv - m * m, 0.f);
+  *mean = m;
+  *rstd = 1.f / sqrtf(var + kEpsLn);
+}
+
+// ------------------------------------------------------------------------------ forward
+struct HeadFwdArgs {
+  HeadSrc src;
+  const float* ln_w;
+  const float* ln_b;
+  const float* W;        // (O, D)
+  const float* bias;     // (O)
+  float* hb;             // [3][b][O], zero-filled: logits | A | B (atomic adds)
+  float* stats;          // (b, 2): mean, rstd of the K7 LayerNorm (written by k-slice 0)
+  int b, O, D, CL, n_src, KS;
+};
+
+// grid = (KS k-slices, ceil(b / 16) sample tiles); 4 waves; wave w of slice ks takes the 16-k blocks
+// kb = (j * KS + ks) * 4 + w, j < J.  All operand loads of a wave are issued before its first MFMA.
+template <int J, int TJ>
+__global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a) {
+  __shared__ float4 red[3][3 * TJ][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, h = lane >> 4;
+  const int ks = blockIdx.x, st = blockIdx.y;
+  const int s = st * 16 + lo;
+  const int sc = s < a.b ? s : a.b - 1;                       // clamped rows are never stored
+  float mean, rstd;
+  sample_stats(a.src, a.n_src, sc, a.D, &mean, &rstd);
+  if (ks == 0 && wave == 0 && h == 0 && s < a.b) {
+    a.stats[2 * s] = mean;
+    a.stats[2 * s + 1] = rstd;
+  }
+  const int nkb = a.D / 16;
+  int oc[TJ];
+#pragma unroll
+  for (int t = 0; t < TJ; ++t) {
+    const int o = 16 * t + lo;
+    oc[t] = o < a.O ? o : a.O - 1;
+  }
+  float4 xv[J], lw[J], lb[J], wv[J][TJ];
+  bool valid[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int kb = (j * a.KS + ks) * 4 + wave;
+    valid[j] = kb < nkb;                                      // wave-uniform
+    const int kbc = valid[j] ? kb : nkb - 1;
+    const int k = kbc * 16 + 4 * h;
+    const int q = (kbc * 16) / a.CL;
+    xv[j] = ld4(a.src.p[q] + (int64_t)sc * a.CL + (k - q * a.CL));
+    lw[j] = ld4(a.ln_w + k);
+    lb[j] = ld4(a.ln_b + k);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) wv[j][t] = ld4(a.W + (int64_t)oc[t] * a.D + k);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[3][TJ];
+#pragma unroll
+  for (int v = 0; v < 3; ++v)
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) acc[v][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    if (!valid[j]) continue;
+    const float x4[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+    const float w4[4] = {lw[j].x, lw[j].y, lw[j].z, lw[j].w};
+    const float b4[4] = {lb[j].x, lb[j].y, lb[j].z, lb[j].w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xh = (x4[r] - mean) * rstd;
+      const float pre = xh * w4[r] + b4[r];
+      const bool on = pre > 0.f;
+      const float f = on ? pre : 0.f;                         // relu(LayerNorm(.))
+      const float a2 = on ? w4[r] : 0.f;                      // mask * lnw
+      const float a3 = a2 * xh;                               // mask * lnw * xhat
+#pragma unroll
+      for (int t = 0; t < TJ; ++t) {
+        const float wr = r == 0 ? wv[j][t].x : r == 1 ? wv[j][t].y : r == 2 ? wv[j][t].z : wv[j][t].w;
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f, wr, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, wr, acc[1][t], 0, 0, 0);
+        acc[2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, wr, acc[2][t], 0, 0, 0);
+      }
+    }
+  }
+  // acc[v][t][r] = OUT_v[sample st*16 + 4h + r][class 16 t + lo]; waves 1..3 hand theirs to wave 0
+  if (wave > 0) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int t = 0; t < TJ; ++t)
+        red[wave - 1][v * TJ + t][lane] = make_float4(acc[v][t][0], acc[v][t][1], acc[v][t][2], acc[v][t][3]);
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int v = 0; v < 3; ++v)
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+      const int o = 16 * t + lo;
+      if (o >= a.O) continue;
+      const float4 p0 = red[0][v * TJ + t][lane], p1 = red[1][v * TJ + t][lane], p2 = red[2][v * TJ + t][lane];
+      const float bo = (v == 0 && ks == 0) ? a.bias[o] : 0.f;
+      const float val[4] = {acc[v][t][0] + p0.x + p1.x + p2.x + bo, acc[v][t][1] + p0.y + p1.y + p2.y + bo,
+                            acc[v][t][2] + p0.z + p1.z + p2.z + bo, acc[v][t][3] + p0.w + p1.w + p2.w + bo};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = st * 16 + 4 * h + r;
+        if (m < a.b) atomicAdd(a.hb + ((int64_t)v * a.b + m) * a.O + o, val[r]);
+      }
+    }
+}
+
+// ----------------------------------------------------------------------------- backward
+struct HeadBwdArgs {
+  HeadSrc src;
+  float* dsrc[kHeadSrc];     // gradients of the M states (nullable)
+  uint32_t acc_mask;         // bit q: accumulate into dsrc[q]
+  const float* ln_w;
+  const float* ln_b;
+  const float* W;
+  const float* hb;           // [3][b][O] from the forward
+  const float* stats;        // (b, 2)
+  const float* g;            // mode 0: dlogits (b, O)
+  const float* gscale;       // nullable device scalar multiplying dlogits (all modes)
+  const float* labels_f;     // mode 1: (b, O) multi-hot floats
+  const long long* labels_i; // mode 2: (b) class ids
+  float* loss;               // modes 1, 2: += mean loss (zero-filled by the caller)
+  float* part;               // [n_chunk][O + 3][D] partials of each 16-sample chunk: rows 0..O-1 dW,
+                             // O dln_w, O+1 dln_b, O+2 dbias (first O entries)
+  float* scrub;              // side job: zero-fill (the caller's backward accumulation arena)
+  long long scrub4;
+  int b, O, D, CL, n_src, mode, tiles_per_wave;
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// grid = (k groups, 16-sample chunks).  Prologue: dl[16][O] (criterion gradient or the given one),
+// m1 / m2 / mean / rstd of the chunk's samples into LDS.  Then every wave walks its (16 samples x
+// 16 k) tiles:  dfeat^T = W^T dl^T on the matrix cores with k on the accumulator rows (float4 along k
+// per sample: LayerNorm backward and the state-gradient store are coalesced), and
+// dW = dl^T feat with feat recomputed in B-operand layout straight from the states.
+__global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
+  __shared__ float dl_s[16][kMaxO + 4];
+  __shared__ float ms[4][16];            // m1, m2, mean, rstd
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = lane & 15, h = lane >> 4;
+  const int chunk = blockIdx.y, s0 = chunk * 16;
+  for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < a.scrub4;
+       i += (long long)gridDim.x * gridDim.y * 256)
+    st4(a.scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+  const float gs = (a.gscale != nullptr) ? a.gscale[0] : 1.f;
+  const float invD = 1.f / (float)a.D;
+  // ---- prologue: wave w owns rows w, w + 4, w + 8, w + 12; lane owns classes lane, lane + 64
+  float loss_acc = 0.f;
+  for (int rr = wave; rr < 16; rr += 4) {
+    const int s = s0 + rr;
+    const bool vs = s < a.b;                                   // wave-uniform
+    const int sc = vs ? s : a.b - 1;
+    float dl[2] = {0.f, 0.f}, zz[2] = {0.f, 0.f};
+    bool vo[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int o = lane + 64 * u;
+      vo[u] = o < a.O;
+      const int oc = vo[u] ? o : a.O - 1;
+      if (a.mode == 0) dl[u] = vo[u] ? a.g[(int64_t)sc * a.O + oc] * gs : 0.f;
+      else zz[u] = a.hb[(int64_t)sc * a.O + oc];
+    }
+    if (a.mode == 1) {                                         // BCEWithLogits, reduction = mean
+      const float sc_ = gs / ((float)a.b * (float)a.O);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int o = lane + 64 * u;
+        const float y = a.labels_f[(int64_t)sc * a.O + (vo[u] ? o : a.O - 1)];
+        const float z = zz[u];
+        dl[u] = vo[u] ? (sigmoidf_(z) - y) * sc_ : 0.f;
+        if (vo[u] && vs) loss_acc += fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
+      }
+    } else if (a.mode == 2) {                                  // CrossEntropy, reduction = mean
+      float mx = fmaxf(vo[0] ? zz[0] : -INFINITY, vo[1] ? zz[1] : -INFINITY);
+#pragma unroll
+      for (int o_ = 32; o_ > 0; o_ >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o_, 64));
+      float e[2], den = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        e[u] = vo[u] ? __expf(zz[u] - mx) : 0.f;
+        den += e[u];
+      }
+      den = wave_sum(den);
+      const int lab = (int)a.labels_i[sc];
+      const float sc_ = gs / (float)a.b;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int o = lane + 64 * u;
+        dl[u] = vo[u] ? (e[u] / den - (o == lab ? 1.f : 0.f)) * sc_ : 0.f;
+        if (vo[u] && vs && o == lab) loss_acc += (mx + __logf(den)) - zz[u];
+      }
+    }
+    if (!vs) dl[0] = dl[1] = 0.f;
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int o = lane + 64 * u;
+      if (vo[u]) {
+        dl_s[rr][o] = dl[u];
+        p1 += dl[u] * a.hb[((int64_t)a.b + sc) * a.O + o];
+        p2 += dl[u] * a.hb[((int64_t)2 * a.b + sc) * a.O + o];
+      }
+    }
+    p1 = wave_sum(p1);
+    p2 = wave_sum(p2);
+    if (lane == 0) {
+      ms[0][rr] = p1 * invD;
+      ms[1][rr] = p2 * invD;
+      ms[2][rr] = a.stats[2 * sc];
+      ms[3][rr] = a.stats[2 * sc + 1];
+    }
+  }
+  if (a.mode != 0 && blockIdx.x == 0) {
+    loss_acc = wave_sum(loss_acc);
+    if (lane == 0) atomicAdd(a.loss, loss_acc / (a.mode == 1 ? (float)a.b * (float)a.O : (float)a.b));
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && (int)threadIdx.x < a.O) {              // dbias partial of this chunk
+    float t = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) t += dl_s[rr][threadIdx.x];
+    a.part[((int64_t)chunk * (a.O + 3) + a.O + 2) * a.D + threadIdx.x] = t;
+  }
+  // ---- tiles
+  const int nkt = a.D / 16;
+  const int osteps = (a.O + 3) / 4, otiles = (a.O + 15) / 16;
+  const float m1 = ms[0][lo], m2 = ms[1][lo], mean = ms[2][lo], rstd = ms[3][lo];
+  const int s = s0 + lo;
+  const bool vs = s < a.b;
+  const int sc = vs ? s : a.b - 1;
+  float* const part = a.part + (int64_t)chunk * (a.O + 3) * a.D;
+  for (int ti = 0; ti < a.tiles_per_wave; ++ti) {
+    const int kt = (blockIdx.x * a.tiles_per_wave + ti) * 4 + wave;
+    if (kt >= nkt) break;                                       // wave-uniform
+    const int k0 = kt * 16;
+    const int q = k0 / a.CL;                                    // wave-uniform: a tile never straddles states
+    const int kin = k0 - q * a.CL;
+    // GEMM 1: D[k = 4h + r][s = lo] = sum_o W[o][k0 + 4h + r] dl[s][o]
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = 0; t < osteps; ++t) {
+      const int o = 4 * t + h;
+      const int oc = o < a.O ? o : a.O - 1;
+      const float wv = a.W[(int64_t)oc * a.D + k0 + lo];         // clamped address + select (no branch)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o < a.O ? wv : 0.f, dl_s[lo][oc], acc, 0, 0, 0);
+    }
+    const float4 x = ld4(a.src.p[q] + (int64_t)sc * a.CL + kin + 4 * h);
+    const float4 lw = ld4(a.ln_w + k0 + 4 * h), lb = ld4(a.ln_b + k0 + 4 * h);
+    const float xq[4] = {x.x, x.y, x.z, x.w}, wq[4] = {lw.x, lw.y, lw.z, lw.w}, bq[4] = {lb.x, lb.y, lb.z, lb.w};
+    float dx[4], gw[4], gb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xh = (xq[r] - mean) * rstd;
+      const bool on = (xh * wq[r] + bq[r]) > 0.f;
+      const float gy = (on && vs) ? acc[r] : 0.f;               // gradient at the LayerNorm output
+      const float dxh = gy * wq[r];
+      dx[r] = rstd * (dxh - m1 - xh * m2);
+      gw[r] = gy * xh;
+      gb[r] = gy;
+    }
+    float* d = a.dsrc[q];
+    if (d != nullptr && vs) {
+      float* pp = d + (int64_t)s * a.CL + kin + 4 * h;
+      float4 o4 = make_float4(dx[0], dx[1], dx[2], dx[3]);
+      if (a.acc_mask & (1u << q)) o4 = f4_add(o4, ld4(pp));
+      st4(pp, o4);
+    }
+    // LayerNorm affine partials of this chunk: sum over the 16 samples (lanes lo) per k
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) {
+        gw[r] += __shfl_xor(gw[r], sh, 64);
+        gb[r] += __shfl_xor(gb[r], sh, 64);
+      }
+    }
+    if (lo == 0) {
+      st4(part + (int64_t)a.O * a.D + k0 + 4 * h, make_float4(gw[0], gw[1], gw[2], gw[3]));
+      st4(part + (int64_t)(a.O + 1) * a.D + k0 + 4 * h, make_float4(gb[0], gb[1], gb[2], gb[3]));
+    }
+    // GEMM 2: dW[o = 16 t + 4h + r][k0 + lo] = sum_s dl[s][o] feat[s][k0 + lo]; B operand = feat in
+    // (s = 4h + r, k = lo) layout, recomputed from the state (never stored)
+    float fr[4];
+    {
+      const float lwk = a.ln_w[k0 + lo], lbk = a.ln_b[k0 + lo];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int sr = s0 + 4 * h + r;
+        const int src_ = sr < a.b ? sr : a.b - 1;
+        const float xv = a.src.p[q][(int64_t)src_ * a.CL + kin + lo];
+        const float pre = (xv - ms[2][4 * h + r]) * ms[3][4 * h + r] * lwk + lbk;
+        fr[r] = (sr < a.b) ? fmaxf(pre, 0.f) : 0.f;
+      }
+    }
+    for (int t = 0; t < otiles; ++t) {
+      const int oa = 16 * t + lo;
+      const int oac = oa < a.O ? oa : a.O - 1;
+      f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa < a.O ? dl_s[4 * h + r][oac] : 0.f, fr[r], acc2, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * t + 4 * h + r;
+        if (o < a.O) part[(int64_t)o * a.D + k0 + lo] = acc2[r];
+      }
+    }
+  }
+}
+
+// Sum of per-chunk partials: out[e] = sum_c part[c][e]  (float4 stream).  Runs as a slice of the
+// backward epilogue launch; also callable on its own.
+__global__ __launch_bounds__(256) void sum_chunks_k(const float* __restrict__ part, float* __restrict__ out,
+                                                    int n_chunk, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 t = ld4(part + 4 * i);
+    for (int c = 1; c < n_chunk; ++c) t = f4_add(t, ld4(part + 4 * (i + (long long)c * n4)));
+    st4(out + 4 * i, t);
+  }
+}
+
+int fill_src(HeadSrc& s, const float* const* srcs, const float* const* sums, int n_src) {
+  if (!srcs || !sums || n_src < 1) return BMNAS_E_ARG;
+  if (n_src > kHeadSrc) return BMNAS_E_LIMIT;
+  for (int q = 0; q < n_src; ++q) {
+    if (!srcs[q] || !sums[q]) return BMNAS_E_ARG;
+    s.p[q] = srcs[q];
+    s.sums[q] = sums[q];
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int bmnas_head_chunks(int b) { return b < 1 ? BMNAS_E_ARG : (b + 15) / 16; }
+
+extern "C" int bmnas_head_fwd(const float* const* srcs, const float* const* sums, int n_src,
+                              const float* ln_w, const float* ln_b, const float* W, const float* bias,
+                              float* hb, float* stats, int b, int C, int L, int O, void* stream) {
+  if (!ln_w || !ln_b || !W || !bias || !hb || !stats || b < 0 || C < 1 || L < 1 || O < 1) return BMNAS_E_ARG;
+  if (O > kMaxO) return BMNAS_E_LIMIT;
+  if ((C * L) % 16) return BMNAS_E_SHAPE;
+  HeadFwdArgs a{};
+  if (int e = fill_src(a.src, srcs, sums, n_src)) return e;
+  if (b == 0) return 0;
+  a.ln_w = ln_w; a.ln_b = ln_b; a.W = W; a.bias = bias; a.hb = hb; a.stats = stats;
+  a.b = b; a.O = O; a.CL = C * L; a.D = n_src * C * L; a.n_src = n_src;
+  const int nkb = a.D / 16;
+  // three 16-k blocks per wave when the grid still fills the chip, else one or two
+  const int tiles = (b + 15) / 16;
+  int J = 3;
+  if ((nkb + 11) / 12 * tiles < 128) J = (nkb + 7) / 8 * tiles < 128 ? 1 : 2;
+  a.KS = (nkb + 4 * J - 1) / (4 * J);
+  dim3 grid((unsigned)a.KS, (unsigned)tiles);
+  const int TJ = (O + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+#define HF(Jv, Tv) hipLaunchKernelGGL((head_fwd_k<Jv, Tv>), grid, dim3(256), 0, st, a)
+#define HF_T(Jv)                                                                      \
+  do {                                                                                \
+    if (TJ <= 2) HF(Jv, 2); else if (TJ <= 4) HF(Jv, 4); else if (TJ <= 6) HF(Jv, 6); \
+    else HF(Jv, 8);                                                                   \
+  } while (0)
+  if (J == 3) HF_T(3); else if (J == 2) HF_T(2); else HF_T(1);
+#undef HF_T
+#undef HF
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_head_bwd(const float* const* srcs, const float* const* sums, float* const* dsrcs,
+                              int n_src, uint32_t accumulate_mask, const float* ln_w, const float* ln_b,
+                              const float* W, const float* hb, const float* stats, int mode, const float* g,
+                              const float* gscale, const void* labels, float* loss, float* part,
+                              int b, int C, int L, int O, float* scrub, int64_t scrub_n, void* stream) {
+  if (!dsrcs || !ln_w || !ln_b || !W || !hb || !stats || !part || b < 0 || C < 1 || L < 1 || O < 1)
+    return BMNAS_E_ARG;
+  if (mode < 0 || mode > 2 || (mode == 0 && !g) || (mode != 0 && (!labels || !loss))) return BMNAS_E_ARG;
+  if (scrub_n < 0 || (scrub_n > 0 && !scrub) || scrub_n % 4) return BMNAS_E_ARG;
+  if (O > kMaxO) return BMNAS_E_LIMIT;
+  if ((C * L) % 16) return BMNAS_E_SHAPE;
+  HeadBwdArgs a{};
+  if (int e = fill_src(a.src, srcs, sums, n_src)) return e;
+  if (b == 0) return 0;
+  for (int q = 0; q < n_src; ++q) a.dsrc[q] = dsrcs[q];
+  a.acc_mask = accumulate_mask; a.ln_w = ln_w; a.ln_b = ln_b; a.W = W; a.hb = hb; a.stats = stats;
+  a.g = g; a.gscale = gscale; a.mode = mode;
+  a.labels_f = mode == 1 ? (const float*)labels : nullptr;
+  a.labels_i = mode == 2 ? (const long long*)labels : nullptr;
+  a.loss = loss; a.part = part; a.scrub = scrub; a.scrub4 = scrub_n / 4;
+  a.b = b; a.O = O; a.CL = C * L; a.D = n_src * C * L; a.n_src = n_src;
+  const int nkt = a.D / 16, chunks = (b + 15) / 16;
+  // one tile per wave unless that gives far more workgroups than the chip holds at once
+  a.tiles_per_wave = 1;
+  while ((nkt + 4 * a.tiles_per_wave - 1) / (4 * a.tiles_per_wave) * chunks > 1024 && a.tiles_per_wave < 8)
+    a.tiles_per_wave *= 2;
+  dim3 grid((unsigned)((nkt + 4 * a.tiles_per_wave - 1) / (4 * a.tiles_per_wave)), (unsigned)chunks);
+  hipLaunchKernelGGL(head_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, a);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_sum_chunks(const float* part, float* out, int n_chunk, int64_t n, void* stream) {
+  if (!part || !out || n_chunk < 1 || n < 0 || n % 4) return BMNAS_E_ARG;
+  if (n == 0) return 0;
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sum_chunks_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, out, n_chunk,
+                     (long long)(n / 4));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}

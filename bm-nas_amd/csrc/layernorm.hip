@@ -32,7 +32,7 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
                                                     const float* __restrict__ ln_b,
                                                     float* __restrict__ out,
                                                     float* __restrict__ stats, int cl4, int d4,
-                                                    int relu) {
+                                                    int relu, float* __restrict__ osum) {
   __shared__ float red[8];
   const int s = blockIdx.x;
   float4 v[VPT], lw[VPT], lb[VPT];
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
     stats[2 * s] = mean;
     stats[2 * s + 1] = rstd;
   }
+  float os = 0.f, oq = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int i = threadIdx.x + k * BS;
@@ -81,6 +82,18 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
       }
       st4(out + ((int64_t)s * d4 + i) * 4, o);
+      os += f4_hsum(o);
+      oq += f4_dot(o, o);
+    }
+  }
+  // (sum, sum of squares) of this sample's OUTPUT: what a LayerNorm over a concatenation of such
+  // outputs (K7) needs, so that its statistics cost no pass of their own (head.hip)
+  if (osum != nullptr) {
+    os = block_sum<BS / 64>(os, red);
+    oq = block_sum<BS / 64>(oq, red);
+    if (threadIdx.x == 0) {
+      osum[2 * s] = os;
+      osum[2 * s + 1] = oq;
     }
   }
 }
@@ -251,11 +264,32 @@ __global__ __launch_bounds__(256) void ln_affine_bwd_k(LnAffineBatch B) {
   ln_affine_body(P, B.b, B.chunk, red);
 }
 
+// Partial sums left by the head's backward (head.hip): out[e] = sum_c part[c][e], float4 stream.
+constexpr int kMaxSums = 2;
+struct SumPack {
+  const float* part[kMaxSums];
+  float* out[kMaxSums];
+  long long n4[kMaxSums];
+  int n_chunk[kMaxSums];
+  int n;
+};
+
 // The two launches that end a fused cell's backward, as one: blockIdx.z < B.n are the LayerNorm
 // affine problems above, the z = B.n slice walks the rows of the architecture tensors (four rows
 // per workgroup, one wavefront each) for the row-softmax backward.  Independent work.
-__global__ __launch_bounds__(256) void backward_epilogue_k(LnAffineBatch B, ArchPack A, int arch_rows) {
+__global__ __launch_bounds__(256) void backward_epilogue_k(LnAffineBatch B, ArchPack A, int arch_rows, SumPack S) {
   __shared__ float4 red[2][3][64];
+  if ((int)blockIdx.z > B.n) {                                   // z = B.n + 1 + i: the i-th partial sum
+    const int i = (int)blockIdx.z - B.n - 1;
+    const long long n4 = S.n4[i], wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const float* __restrict__ part = S.part[i];
+    for (long long e = wg * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * gridDim.y * 256) {
+      float4 t = ld4(part + 4 * e);
+      for (int c = 1; c < S.n_chunk[i]; ++c) t = f4_add(t, ld4(part + 4 * (e + (long long)c * n4)));
+      st4(S.out[i] + 4 * e, t);
+    }
+    return;
+  }
   if ((int)blockIdx.z == B.n) {
     const int r = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + (int)(threadIdx.x >> 6);
     if (r < arch_rows) arch_softmax_bwd_row(A, r, threadIdx.x & 63);
@@ -292,7 +326,7 @@ inline int pick_vpt(int d4, int bs) {
 
 extern "C" int bmnas_cat_ln_fwd(const float* const* srcs, int n_src, const float* resid,
                                 const float* ln_w, const float* ln_b, float* out, float* stats,
-                                int b, int C, int L, int relu, void* stream) {
+                                int b, int C, int L, int relu, float* out_sums, void* stream) {
   if (!srcs || !ln_w || !ln_b || !out || !stats || n_src < 1 || b < 0 || C < 1 || L < 1)
     return BMNAS_E_ARG;
   if (n_src > 4) return BMNAS_E_LIMIT;
@@ -310,8 +344,8 @@ extern "C" int bmnas_cat_ln_fwd(const float* const* srcs, int n_src, const float
   hipStream_t st = (hipStream_t)stream;
 #define CALL(V)                                                                                         \
   do {                                                                                                  \
-    if (wide) hipLaunchKernelGGL((cat_ln_fwd_k<V, 512>), dim3(b), dim3(512), 0, st, s, resid, ln_w, ln_b, out, stats, cl4, d4, relu); \
-    else hipLaunchKernelGGL((cat_ln_fwd_k<V, 256>), dim3(b), dim3(256), 0, st, s, resid, ln_w, ln_b, out, stats, cl4, d4, relu);      \
+    if (wide) hipLaunchKernelGGL((cat_ln_fwd_k<V, 512>), dim3(b), dim3(512), 0, st, s, resid, ln_w, ln_b, out, stats, cl4, d4, relu, out_sums); \
+    else hipLaunchKernelGGL((cat_ln_fwd_k<V, 256>), dim3(b), dim3(256), 0, st, s, resid, ln_w, ln_b, out, stats, cl4, d4, relu, out_sums);      \
   } while (0)
   LN_DISPATCH(vpt, CALL)
 #undef CALL
@@ -430,10 +464,19 @@ extern "C" int bmnas_backward_epilogue(int n_prob, const float* const* g, const 
                                        int L, const int* relu, const int* prenorm,
                                        const float* const* arch_w, const float* const* arch_dw,
                                        float* const* arch_out, const int* arch_rows, const int* arch_cols,
-                                       int n_arch, int n_shards, int64_t shard_stride, void* stream) {
+                                       int n_arch, int n_shards, int64_t shard_stride, int n_sums,
+                                       const float* const* sum_part, float* const* sum_out,
+                                       const int* sum_chunks, const int64_t* sum_n, void* stream) {
   if (n_prob < 1 || b < 1 || !g || !srcs || !n_src || !dln_w || !dln_b || !C || !relu || !prenorm)
     return BMNAS_E_ARG;
-  if (n_prob > kMaxLnProbs) return BMNAS_E_LIMIT;
+  if (n_prob > kMaxLnProbs || n_sums > kMaxSums) return BMNAS_E_LIMIT;
+  if (n_sums < 0 || (n_sums > 0 && (!sum_part || !sum_out || !sum_chunks || !sum_n))) return BMNAS_E_ARG;
+  SumPack S{};
+  for (int i = 0; i < n_sums; ++i) {
+    if (!sum_part[i] || !sum_out[i] || sum_chunks[i] < 1 || sum_n[i] < 0 || sum_n[i] % 4) return BMNAS_E_ARG;
+    S.part[i] = sum_part[i]; S.out[i] = sum_out[i]; S.n_chunk[i] = sum_chunks[i]; S.n4[i] = sum_n[i] / 4;
+  }
+  S.n = n_sums;
   LnAffineBatch B{};
   for (int i = 0; i < n_prob; ++i)
     if (int e = fill_prob(B.p[i], g[i], gscale ? gscale[i] : nullptr, srcs[i], n_src[i],
@@ -449,12 +492,12 @@ extern "C" int bmnas_backward_epilogue(int n_prob, const float* const* g, const 
   B.chunk = 16;
   int maxd4 = 0;
   for (int i = 0; i < B.n; ++i) maxd4 = B.p[i].d4 > maxd4 ? B.p[i].d4 : maxd4;
-  dim3 grid((maxd4 + 63) / 64, (B.b + B.chunk - 1) / B.chunk, B.n + 1);
+  dim3 grid((maxd4 + 63) / 64, (B.b + B.chunk - 1) / B.chunk, B.n + 1 + n_sums);
   // the arch slice needs one wavefront per row, four per workgroup (LayerNorm workgroups past a
   // problem's width return at once, so widening the grid for tiny shapes costs nothing)
   const unsigned need_x = (unsigned)((total + 4 * (int)grid.y - 1) / (4 * (int)grid.y));
   if (grid.x < need_x) grid.x = need_x;
-  hipLaunchKernelGGL(backward_epilogue_k, grid, dim3(256), 0, (hipStream_t)stream, B, A, total);
+  hipLaunchKernelGGL(backward_epilogue_k, grid, dim3(256), 0, (hipStream_t)stream, B, A, total, S);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

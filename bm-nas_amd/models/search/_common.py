@@ -77,8 +77,10 @@ class HyperNetBase(nn.Module):
         return [layer(f) for layer, f in zip(self.reshape_layers, input_features)]
 
     def fuse(self, raw_features):
-        out = self.fusion_net(self.reshape_input_features(list(raw_features)))
-        return self.central_classifier(out)
+        feats = self.reshape_input_features(list(raw_features))
+        if hasattr(self.fusion_net, 'forward_classified'):        # search hypernet: K7 + classifier fused
+            return self.fusion_net.forward_classified(feats, self.central_classifier)
+        return self.central_classifier(self.fusion_net(feats))
 
     def genotype(self):
         if hasattr(self, '_genotype'):

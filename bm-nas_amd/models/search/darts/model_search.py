@@ -83,10 +83,22 @@ class FusionCell(nn.Module):
             gs += n.node_cell.grads_in_param_order(g)
         return gs + [CG.dln_w, CG.dln_b]
 
-    def forward(self, input_features, weights, weights_are_logits=False):
+    def head_fusable(self, classifier):
+        """Whether the cell's LayerNorm tail can continue into `classifier` in one launch
+        (csrc/head.hip): the concatenated states are all step-node outputs, <= 128 classes."""
+        from bmnas import cell as K
+        return (K.FUSE_HEAD and self._fusable and isinstance(classifier, nn.Linear)
+                and type(classifier).__module__.startswith('bmnas') and classifier.bias is not None
+                and classifier.out_features <= 128 and self._multiplier <= self._steps
+                and self._multiplier <= 4 and (self.C * self.L) % 16 == 0
+                and classifier.in_features == self._multiplier * self.C * self.L
+                and all(op._default for n in self._step_nodes for op in n.node_cell.node_ops))
+
+    def forward(self, input_features, weights, weights_are_logits=False, classifier=None):
         """weights: the softmaxed alphas (k, 2), as in the reference; FusionNetwork passes the
         raw alphas with weights_are_logits=True so that every arch softmax of the cell runs
-        in one kernel launch."""
+        in one kernel launch.  classifier (FusionNetwork.forward_classified): a bmnas.nn.Linear
+        the cell's output feeds — the call then returns ITS output, with K7 + Linear as one launch."""
         states = list(input_features)
         dev = states[0].device
         w = weights if weights.device == dev else weights.to(dev)
@@ -94,8 +106,15 @@ class FusionCell(nn.Module):
             arch = []
             for n in self._step_nodes:
                 arch += [t if t.device == dev else t.to(dev) for t in (n.betas, n.gammas)]
-            return FusedCellFn.apply(self, self.training, weights_are_logits, w, *states, *arch,
-                                     *self.param_list())
+            if classifier is not None and states[0].is_cuda and self.head_fusable(classifier):
+                from bmnas import cell as K
+                out = FusedCellFn.apply(self, self.training, weights_are_logits, w, 2, *states, *arch,
+                                        *self.param_list(), classifier.weight, classifier.bias)
+                out._bmnas_head = K.LAST_HEAD.pop()      # lets a fused criterion find its head
+                return out
+            out = FusedCellFn.apply(self, self.training, weights_are_logits, w, 0, *states, *arch,
+                                    *self.param_list())
+            return out if classifier is None else classifier(out)
         if weights_are_logits:
             w = arch_softmax(w, dev)
         # edited primitive lists: same dataflow, composed op by op
@@ -109,7 +128,8 @@ class FusionCell(nn.Module):
             offset += len(states)
             states.append(s)
         out = CatLnFn.apply(True, self.ln.weight, self.ln.bias, None, *states[-self._multiplier:])
-        return out.view(out.size(0), -1)
+        out = out.view(out.size(0), -1)
+        return out if classifier is None else classifier(out)
 
 
 class FusionNetwork(nn.Module):
@@ -145,6 +165,13 @@ class FusionNetwork(nn.Module):
         assert self._num_input_nodes == len(input_features)
         # softmax(alphas_edges) (reference :95) is folded into the fused cell call
         return self.cell(input_features, self.alphas_edges, weights_are_logits=True)
+
+    def forward_classified(self, input_features, classifier):
+        """classifier(self(input_features)) — what Searchable_*.forward does next
+        (mmimdb_darts_searchable.py:113-114) — with the cell's LayerNorm tail and the classifier as
+        one launch where the shapes allow (FusionCell.head_fusable), else exactly that composition."""
+        assert self._num_input_nodes == len(input_features)
+        return self.cell(input_features, self.alphas_edges, weights_are_logits=True, classifier=classifier)
 
     def _loss(self, input_features, labels):
         return self._criterion(self(input_features), labels)

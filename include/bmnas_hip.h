@@ -98,7 +98,7 @@ int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, int n_in, c
  * K6 = NodeCell.forward tail node_search.py:67-68 (n_src = 1, resid = x, relu = 0). */
 int bmnas_cat_ln_fwd(const float* const* srcs, int n_src, const float* resid, const float* ln_w,
                      const float* ln_b, float* out, float* stats, int b, int C, int L, int relu,
-                     void* stream);
+                     float* out_sums, void* stream);
 /* g: gradient of `out`.  dsrcs[q] (NULL to skip) / dresid (NULL to skip) receive the input
  * gradient (acc bits: bit q for dsrcs[q], bit 31 for dresid); dln_w / dln_b += (atomic per
  * sample; pass NULL and use bmnas_ln_affine_bwd, which needs 16x fewer atomics).
@@ -264,7 +264,7 @@ int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float* p1, const
                           float* chan, bmnas_bn_fin_t fin, const float* gamma, const float* resid,
                           const float* ln_w, const float* ln_b, float* pre, float* out, float* stats,
                           int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
-                          void* stream);
+                          float* out_sums, void* stream);
 /* Backward, phase A (elementwise + reductions):  g = grad of s.
  *   dgamma[shard*dgamma_shard_stride + q] += <g, p_q> (shards as in bmnas_mixsum_bwd);
  *   dx / dy (=|+=) g0*g (dy NULL: both into dx);
@@ -317,8 +317,9 @@ int bmnas_backward_epilogue(int n_prob, const float* const* g, const float* cons
                             float* const* dln_w, float* const* dln_b, int b, const int* C, int L,
                             const int* relu, const int* prenorm, const float* const* arch_w,
                             const float* const* arch_dw, float* const* arch_out, const int* arch_rows,
-                            const int* arch_cols, int n_arch, int n_shards, int64_t shard_stride,
-                            void* stream);
+                            const int* arch_cols, int n_arch, int n_shards, int64_t shard_stride, int n_sums,
+                            const float* const* sum_part, float* const* sum_out, const int* sum_chunks,
+                            const int64_t* sum_n, void* stream);
 /* The forward prologue of a FusionCell in ONE launch: the n_arch row softmaxes of
  * bmnas_arch_softmax_multi (forward) and, for each of n_fold (<= 8) NodeMixedOps of the cell,
  * Weff[q] (M, C) = W[q][:, :C] + W[q][:, C:] as bmnas_fold_weight does (W[q] is (M, 2C)).
@@ -332,6 +333,37 @@ int bmnas_cell_prologue(const float* const* a, float* const* out, const int* row
                         int n_arch, const float* const* W, float* const* Weff, int n_fold, int M,
                         int C, uint64_t* step_counter, const uint64_t* step_span, float* scrub,
                         int64_t scrub_n, void* stream);
+
+/* ---- the head of a search step: K7 + central_classifier (+ criterion) in two launches ----------
+ * Forward (model_search.py:63-67 + mmimdb_darts_searchable.py:114):
+ *   logits = relu(LayerNorm_[M*C, L](cat(srcs))).view(b, -1) @ W^T + bias
+ * without materialising the LayerNorm output: sums[q] = (b, 2) per-sample (sum, sum of squares) of
+ * state q as left by the kernel that produced it (out_sums of bmnas_node_mix_ln_fwd / bmnas_cat_ln_fwd)
+ * give the statistics, the normalisation happens in the operand fetch of the GEMM.
+ *   hb: ZERO-FILLED [3][b][O] — logits | A | B (A, B: the two extra products the backward's
+ *   LayerNorm reductions need, see csrc/head.hip); stats (b, 2) = mean | rstd (output).
+ * O <= 128, (C*L) % 16 == 0, n_src <= 4. */
+int bmnas_head_fwd(const float* const* srcs, const float* const* sums, int n_src, const float* ln_w,
+                   const float* ln_b, const float* W, const float* bias, float* hb, float* stats, int b,
+                   int C, int L, int O, void* stream);
+/* Backward of the same, down to dsrcs[q] (=|+=, bit q of accumulate_mask; NULL: skip).
+ *   mode 0: g = dlogits (b, O);  mode 1: BCEWithLogits(mean) of hb's logits against float labels
+ *   (b, O), *loss += the mean loss;  mode 2: CrossEntropy(mean) against int64 labels (b) — the
+ *   criterion (mmimdb_darts_searchable.py:22, ntu_darts_searchable.py:25) evaluated in the same launch.
+ *   gscale (nullable): device scalar multiplying dlogits.
+ * Batch reductions leave as per-16-sample-chunk partials (n_chunk = bmnas_head_chunks(b)):
+ *   part [n_chunk][O + 3][D]: rows 0..O-1 = dW, row O = dln_w, row O+1 = dln_b, row O+2 = dbias in its
+ *   first O entries (the rest of that row is never written);
+ * sum them with bmnas_backward_epilogue(n_sums ...) or bmnas_sum_chunks.
+ * scrub: optional zero-fill side job (the caller's backward accumulation arena). */
+int bmnas_head_chunks(int b);
+int bmnas_head_bwd(const float* const* srcs, const float* const* sums, float* const* dsrcs, int n_src,
+                   uint32_t accumulate_mask, const float* ln_w, const float* ln_b, const float* W,
+                   const float* hb, const float* stats, int mode, const float* g, const float* gscale,
+                   const void* labels, float* loss, float* part, int b, int C, int L, int O, float* scrub,
+                   int64_t scrub_n, void* stream);
+/* out[e] = sum_{c < n_chunk} part[c*n + e], e < n (n % 4 == 0) */
+int bmnas_sum_chunks(const float* part, float* out, int n_chunk, int64_t n, void* stream);
 
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at

@@ -15,31 +15,53 @@ from util import case_id, cfg_of, golden_files, load_npz, summarize
 pytestmark = pytest.mark.gpu
 
 
-def _run_search_case(meta):
+def _run_search_case(meta, head=None):
+    """head: None -> the reference's composition cls(net(xs)) with torch's Linear / criterion;
+    'fused' -> FusionNetwork.forward_classified with bmnas.nn.Linear (K7 + classifier in one launch,
+    csrc/head.hip) and the bmnas criterion kernel; 'deferred' -> the same with the criterion evaluated
+    by the head's backward launch (bmnas.nn.fused_criterion)."""
+    from bmnas import nn as bnn
     cfg = cfg_of(meta)
     seed, batch, nout = meta['seed'], meta['batch'], meta['num_outputs']
     net = build_search_net(cfg, seed, meta['mode'])
-    cls = torch.nn.Linear(cfg.M * cfg.C * cfg.L, nout)
+    cls = (torch.nn.Linear if head is None else bnn.Linear)(cfg.M * cfg.C * cfg.L, nout)
     cw, cb = synth.make_classifier(cfg, nout, seed)
     cls.weight.data.copy_(cw)
     cls.bias.data.copy_(cb)
     cls.to(dev())
     xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, seed)]
     y = synth.make_labels(meta['loss'], batch, nout, seed).to(dev())
-    crit = torch.nn.BCEWithLogitsLoss() if meta['loss'] == 'bce' else torch.nn.CrossEntropyLoss()
+    if head is None:
+        crit = torch.nn.BCEWithLogitsLoss() if meta['loss'] == 'bce' else torch.nn.CrossEntropyLoss()
+    else:
+        crit = bnn.BCEWithLogitsLoss() if meta['loss'] == 'bce' else bnn.CrossEntropyLoss()
     with torch.set_grad_enabled(meta['has_grads']):
-        feat = net(xs)
-        logits = cls(feat)
-        loss = crit(logits, y)
+        if head is None:
+            feat = net(xs)
+            logits = cls(feat)
+            loss = crit(logits, y)
+        else:
+            feat = None
+            assert net.cell.head_fusable(cls)
+            with bnn.fused_criterion(head == 'deferred'):
+                logits = net.forward_classified(xs, cls)
+                loss = crit(logits, y)
+            if head == 'deferred' and meta['has_grads']:
+                assert type(loss.grad_fn).__name__ == 'DeferredLossFnBackward'
     if meta['has_grads']:
         loss.backward()
     return net, cls, xs, feat, logits, loss
 
 
+@pytest.mark.parametrize('head', [None, 'fused', 'deferred'])
 @pytest.mark.parametrize('path', golden_files('hypernet_*.npz'), ids=case_id)
-def test_search_hypernet_matches_reference_golden(path):
+def test_search_hypernet_matches_reference_golden(path, head):
     meta, z = load_npz(path)
-    net, cls, xs, feat, logits, loss = _run_search_case(meta)
+    if head is not None and meta['cfg']['M'] > meta['cfg']['S']:
+        pytest.skip('the cell concatenates an input state: no fused head (FusionCell.head_fusable)')
+    if head == 'deferred' and not meta['has_grads']:
+        pytest.skip('a deferred criterion needs a backward pass')
+    net, cls, xs, feat, logits, loss = _run_search_case(meta, head)
     assert_close_scaled('logits', logits, z['logits'])
     assert_close_scaled('loss', loss, z['loss'])
     full = meta['full']
@@ -58,7 +80,7 @@ def test_search_hypernet_matches_reference_golden(path):
             got['buf:' + k] = v
     got['feat'] = feat
     for k in z.files:
-        if k in ('meta', 'logits', 'loss'):
+        if k in ('meta', 'logits', 'loss') or (k == 'feat' and feat is None):
             continue
         g = got[k]
         assert g is not None, k
@@ -87,7 +109,8 @@ def test_search_hypernet_matches_reference_golden(path):
                                                       # launches see partial tiles
                                                       ('mmimdb', 100, 23, 'bce'), ('mmimdb', 250, 23, 'bce'),
                                                       ('ntu', 250, 60, 'ce'), ('ego', 97, 83, 'ce')])
-def test_search_hypernet_matches_oracle_real_configs(name, batch, nout, loss_kind):
+@pytest.mark.parametrize('head', [None, 'fused', 'deferred'])
+def test_search_hypernet_matches_oracle_real_configs(name, batch, nout, loss_kind, head):
     """Full tensors (every gradient element) against the oracle at the three real configs,
     train-mode BN, dropout identity; ragged batches (odd batch with L=8 packs two samples per
     MFMA tile; 100 / 250 / 97 leave partial tiles in the merged and pipelined launches).
@@ -101,7 +124,7 @@ def test_search_hypernet_matches_oracle_real_configs(name, batch, nout, loss_kin
     seed = 31
     meta = dict(cfg=dict(cfg), seed=seed, batch=batch, num_outputs=nout, loss=loss_kind,
                 mode='train_nodrop', has_grads=True)
-    net, cls, xs, feat, logits, loss = _run_search_case(meta)
+    net, cls, xs, feat, logits, loss = _run_search_case(meta, head)
     f64 = lambda t: t.double() if t.is_floating_point() else t
     arch = synth.make_arch(cfg, seed)
     cw, cb = synth.make_classifier(cfg, nout, seed)
@@ -124,6 +147,9 @@ def test_search_hypernet_matches_oracle_real_configs(name, batch, nout, loss_kin
         assert_close_either(f'grad:arch.{i}', a.grad, ograds[f'arch.{i}'], dgrads[f'arch.{i}'], rel=2e-4)
     for i, x in enumerate(xs):
         assert_close_either(f'grad:input.{i}', x.grad, ograds[f'input.{i}'], dgrads[f'input.{i}'], rel=2e-4)
+    for k in ('weight', 'bias'):
+        kk = 'central_classifier.' + k
+        assert_close_either('grad:' + kk, getattr(cls, k).grad, ograds[kk], dgrads[kk], rel=2e-4)
     for k, v in net.state_dict().items():
         if fo.is_buffer(k):
             assert_close_scaled('buf:' + k, v.float(), p[k].float())
