@@ -68,7 +68,7 @@ struct HeadFwdArgs {
 // kb = (j * KS + ks) * 4 + w, j < J.  All operand loads of a wave are issued before its first MFMA.
 template <int J, int TJ>
 __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a) {
-  __shared__ float4 red[3][3 * TJ][64];
+  __shared__ float red[4][3][16][16 * TJ + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int ks = blockIdx.x, st = blockIdx.y;
@@ -131,32 +131,26 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a) {
       }
     }
   }
-  // acc[v][t][r] = OUT_v[sample st*16 + 4h + r][class 16 t + lo]; waves 1..3 hand theirs to wave 0
-  if (wave > 0) {
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-#pragma unroll
-      for (int t = 0; t < TJ; ++t)
-        red[wave - 1][v * TJ + t][lane] = make_float4(acc[v][t][0], acc[v][t][1], acc[v][t][2], acc[v][t][3]);
-  }
-  __syncthreads();
-  if (wave != 0) return;
+  // acc[v][t][r] = OUT_v[sample st*16 + 4h + r][class 16 t + lo].  All four waves lay their tiles out
+  // in LDS as [v][sample][class]; the workgroup then adds the four partials and issues the atomics in
+  // memory order — hb is [v][b][O] row-major, so a 16-sample tile is ONE contiguous run of 16 * O
+  // floats per v: full 256-byte wave-instructions instead of four 64-byte pieces each
 #pragma unroll
   for (int v = 0; v < 3; ++v)
 #pragma unroll
-    for (int t = 0; t < TJ; ++t) {
-      const int o = 16 * t + lo;
-      if (o >= a.O) continue;
-      const float4 p0 = red[0][v * TJ + t][lane], p1 = red[1][v * TJ + t][lane], p2 = red[2][v * TJ + t][lane];
-      const float bo = (v == 0 && ks == 0) ? a.bias[o] : 0.f;
-      const float val[4] = {acc[v][t][0] + p0.x + p1.x + p2.x + bo, acc[v][t][1] + p0.y + p1.y + p2.y + bo,
-                            acc[v][t][2] + p0.z + p1.z + p2.z + bo, acc[v][t][3] + p0.w + p1.w + p2.w + bo};
+    for (int t = 0; t < TJ; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = st * 16 + 4 * h + r;
-        if (m < a.b) atomicAdd(a.hb + ((int64_t)v * a.b + m) * a.O + o, val[r]);
-      }
-    }
+      for (int r = 0; r < 4; ++r) red[wave][v][4 * h + r][16 * t + lo] = acc[v][t][r];
+  __syncthreads();
+  const int rows = (a.b - st * 16) < 16 ? (a.b - st * 16) : 16;
+  const int per_v = rows * a.O;
+  for (int i = threadIdx.x; i < 3 * per_v; i += 256) {
+    const int v = i / per_v, e = i - v * per_v;
+    const int sr = e / a.O, o = e - sr * a.O;
+    float val = (red[0][v][sr][o] + red[1][v][sr][o]) + (red[2][v][sr][o] + red[3][v][sr][o]);
+    if (v == 0 && ks == 0) val += a.bias[o];
+    atomicAdd(a.hb + ((int64_t)v * a.b + st * 16) * a.O + e, val);
+  }
 }
 
 // ----------------------------------------------------------------------------- backward
@@ -174,144 +168,200 @@ struct HeadBwdArgs {
   const float* labels_f;     // mode 1: (b, O) multi-hot floats
   const long long* labels_i; // mode 2: (b) class ids
   float* loss;               // modes 1, 2: += mean loss (zero-filled by the caller)
-  float* part;               // [n_chunk][O + 3][D] partials of each 16-sample chunk: rows 0..O-1 dW,
+  float* part;               // [n_chunk][O + 3][D] partials of each sample chunk (bmnas_head_chunks): rows 0..O-1 dW,
                              // O dln_w, O+1 dln_b, O+2 dbias (first O entries)
   float* scrub;              // side job: zero-fill (the caller's backward accumulation arena)
   long long scrub4;
-  int b, O, D, CL, n_src, mode, tiles_per_wave;
+  int b, O, D, CL, n_src, mode;
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
-// grid = (k groups, 16-sample chunks).  Prologue: dl[16][O] (criterion gradient or the given one),
-// m1 / m2 / mean / rstd of the chunk's samples into LDS.  Then every wave walks its (16 samples x
-// 16 k) tiles:  dfeat^T = W^T dl^T on the matrix cores with k on the accumulator rows (float4 along k
-// per sample: LayerNorm backward and the state-gradient store are coalesced), and
-// dW = dl^T feat with feat recomputed in B-operand layout straight from the states.
+// grid = (D / 64 k-groups, sample chunks of 16 * SG); wave w of k-group x owns the (16 SG samples x
+// 16 k) tile kt = 4 x + w.  Every global load of the kernel is issued first — the tile's operands do
+// not depend on the criterion — then the prologue (dl[16 SG][O] = criterion gradient or the given
+// one, m1 / m2 / mean / rstd of the chunk's samples, into LDS; thread = (row, 16-class stripe),
+// reductions over a row = shuffles inside a 16-lane group), then the tile:  per group of 16 samples
+// dfeat^T = W^T dl^T on the matrix cores with k on the accumulator rows (float4 along k per sample:
+// LayerNorm backward and the state-gradient store are coalesced), and dW = dl^T feat accumulated
+// over the SG groups, with feat recomputed in B-operand layout straight from the states.
+// OT = class tiles of 16 the kernel is built for (O <= 16 OT).
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int sh = 1; sh < 16; sh <<= 1) v += __shfl_xor(v, sh, 64);
+  return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+  for (int sh = 1; sh < 16; sh <<= 1) v = fmaxf(v, __shfl_xor(v, sh, 64));
+  return v;
+}
+
+template <int OT, int SG>
 __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
-  __shared__ float dl_s[16][kMaxO + 4];
-  __shared__ float ms[4][16];            // m1, m2, mean, rstd
+  constexpr int kSteps = 4 * OT, kRows = 16 * SG;
+  __shared__ float dl_s[kRows][16 * OT + 4];
+  __shared__ float ms[4][kRows];         // m1, m2, mean, rstd
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
-  const int chunk = blockIdx.y, s0 = chunk * 16;
+  const int chunk = blockIdx.y, s0 = chunk * kRows;
   for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < a.scrub4;
        i += (long long)gridDim.x * gridDim.y * 256)
     st4(a.scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   const float gs = (a.gscale != nullptr) ? a.gscale[0] : 1.f;
   const float invD = 1.f / (float)a.D;
-  // ---- prologue: wave w owns rows w, w + 4, w + 8, w + 12; lane owns classes lane, lane + 64
-  float loss_acc = 0.f;
-  for (int rr = wave; rr < 16; rr += 4) {
-    const int s = s0 + rr;
-    const bool vs = s < a.b;                                   // wave-uniform
-    const int sc = vs ? s : a.b - 1;
-    float dl[2] = {0.f, 0.f}, zz[2] = {0.f, 0.f};
-    bool vo[2];
+  // ---- the tile's operand loads (independent of everything the prologue computes)
+  const int nkt = a.D / 16;
+  const int kt = blockIdx.x * 4 + wave;
+  const bool vt = kt < nkt;                                     // wave-uniform
+  const int k0 = (vt ? kt : nkt - 1) * 16;
+  const int q = k0 / a.CL;                                      // a tile never straddles two states
+  const int kin = k0 - q * a.CL;
+  const int osteps = (a.O + 3) / 4, otiles = (a.O + 15) / 16;
+  float wv[kSteps];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int o = lane + 64 * u;
-      vo[u] = o < a.O;
-      const int oc = vo[u] ? o : a.O - 1;
-      if (a.mode == 0) dl[u] = vo[u] ? a.g[(int64_t)sc * a.O + oc] * gs : 0.f;
-      else zz[u] = a.hb[(int64_t)sc * a.O + oc];
-    }
-    if (a.mode == 1) {                                         // BCEWithLogits, reduction = mean
-      const float sc_ = gs / ((float)a.b * (float)a.O);
+  for (int t = 0; t < kSteps; ++t) {
+    const int o = 4 * t + h;
+    wv[t] = a.W[(int64_t)(o < a.O ? o : a.O - 1) * a.D + k0 + lo];     // clamped address, selected below
+  }
+  const float4 lw = ld4(a.ln_w + k0 + 4 * h), lb = ld4(a.ln_b + k0 + 4 * h);
+  const float lwk = a.ln_w[k0 + lo], lbk = a.ln_b[k0 + lo];
+  float4 x[SG];
+  float xr[SG][4];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int o = lane + 64 * u;
-        const float y = a.labels_f[(int64_t)sc * a.O + (vo[u] ? o : a.O - 1)];
-        const float z = zz[u];
-        dl[u] = vo[u] ? (sigmoidf_(z) - y) * sc_ : 0.f;
-        if (vo[u] && vs) loss_acc += fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
-      }
-    } else if (a.mode == 2) {                                  // CrossEntropy, reduction = mean
-      float mx = fmaxf(vo[0] ? zz[0] : -INFINITY, vo[1] ? zz[1] : -INFINITY);
+  for (int g = 0; g < SG; ++g) {
+    const int s = s0 + 16 * g + lo;
+    x[g] = ld4(a.src.p[q] + (int64_t)(s < a.b ? s : a.b - 1) * a.CL + kin + 4 * h);
 #pragma unroll
-      for (int o_ = 32; o_ > 0; o_ >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o_, 64));
-      float e[2], den = 0.f;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        e[u] = vo[u] ? __expf(zz[u] - mx) : 0.f;
-        den += e[u];
-      }
-      den = wave_sum(den);
-      const int lab = (int)a.labels_i[sc];
-      const float sc_ = gs / (float)a.b;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int o = lane + 64 * u;
-        dl[u] = vo[u] ? (e[u] / den - (o == lab ? 1.f : 0.f)) * sc_ : 0.f;
-        if (vo[u] && vs && o == lab) loss_acc += (mx + __logf(den)) - zz[u];
-      }
-    }
-    if (!vs) dl[0] = dl[1] = 0.f;
-    float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int o = lane + 64 * u;
-      if (vo[u]) {
-        dl_s[rr][o] = dl[u];
-        p1 += dl[u] * a.hb[((int64_t)a.b + sc) * a.O + o];
-        p2 += dl[u] * a.hb[((int64_t)2 * a.b + sc) * a.O + o];
-      }
-    }
-    p1 = wave_sum(p1);
-    p2 = wave_sum(p2);
-    if (lane == 0) {
-      ms[0][rr] = p1 * invD;
-      ms[1][rr] = p2 * invD;
-      ms[2][rr] = a.stats[2 * sc];
-      ms[3][rr] = a.stats[2 * sc + 1];
+    for (int r = 0; r < 4; ++r) {
+      const int sr = s0 + 16 * g + 4 * h + r;
+      xr[g][r] = a.src.p[q][(int64_t)(sr < a.b ? sr : a.b - 1) * a.CL + kin + lo];
     }
   }
-  if (a.mode != 0 && blockIdx.x == 0) {
-    loss_acc = wave_sum(loss_acc);
-    if (lane == 0) atomicAdd(a.loss, loss_acc / (a.mode == 1 ? (float)a.b * (float)a.O : (float)a.b));
+  // ---- prologue: thread = (row tid / 16 of sample group g, class stripe lo + 16 u)
+  {
+    float zz[SG][OT], aa[SG][OT], bb[SG][OT], yy[SG][OT], st_mean[SG], st_rstd[SG];
+    int lab[SG];
+#pragma unroll
+    for (int g = 0; g < SG; ++g) {
+      const int sp = s0 + 16 * g + (threadIdx.x >> 4);
+      const int spc = sp < a.b ? sp : a.b - 1;
+#pragma unroll
+      for (int u = 0; u < OT; ++u) {
+        const int o = lo + 16 * u;
+        const int oc = o < a.O ? o : a.O - 1;
+        zz[g][u] = (a.mode == 0) ? a.g[(int64_t)spc * a.O + oc] : a.hb[(int64_t)spc * a.O + oc];
+        aa[g][u] = a.hb[((int64_t)a.b + spc) * a.O + oc];
+        bb[g][u] = a.hb[((int64_t)2 * a.b + spc) * a.O + oc];
+        yy[g][u] = (a.mode == 1) ? a.labels_f[(int64_t)spc * a.O + oc] : 0.f;
+      }
+      lab[g] = (a.mode == 2) ? (int)a.labels_i[spc] : 0;
+      st_mean[g] = a.stats[2 * spc];
+      st_rstd[g] = a.stats[2 * spc + 1];
+    }
+    float loss_acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < SG; ++g) {
+      const int rr = 16 * g + (threadIdx.x >> 4);
+      const bool vsp = s0 + rr < a.b;
+      float dl[OT];
+      float row_loss = 0.f;
+      if (a.mode == 0) {
+#pragma unroll
+        for (int u = 0; u < OT; ++u) dl[u] = (lo + 16 * u < a.O) ? zz[g][u] * gs : 0.f;
+      } else if (a.mode == 1) {                                 // BCEWithLogits, reduction = mean
+        const float sc_ = gs / ((float)a.b * (float)a.O);
+#pragma unroll
+        for (int u = 0; u < OT; ++u) {
+          const bool vo = lo + 16 * u < a.O;
+          const float z = zz[g][u], y = yy[g][u];
+          dl[u] = vo ? (sigmoidf_(z) - y) * sc_ : 0.f;
+          if (vo) row_loss += fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
+        }
+      } else {                                                  // CrossEntropy, reduction = mean
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < OT; ++u)
+          if (lo + 16 * u < a.O) mx = fmaxf(mx, zz[g][u]);
+        mx = group16_max(mx);
+        float e[OT], den = 0.f;
+#pragma unroll
+        for (int u = 0; u < OT; ++u) {
+          e[u] = (lo + 16 * u < a.O) ? __expf(zz[g][u] - mx) : 0.f;
+          den += e[u];
+        }
+        den = group16_sum(den);
+        const float sc_ = gs / (float)a.b;
+#pragma unroll
+        for (int u = 0; u < OT; ++u) {
+          const int o = lo + 16 * u;
+          dl[u] = (o < a.O) ? (e[u] / den - (o == lab[g] ? 1.f : 0.f)) * sc_ : 0.f;
+          if (o < a.O && o == lab[g]) row_loss += (mx + __logf(den)) - zz[g][u];
+        }
+      }
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < OT; ++u) {
+        if (!vsp) dl[u] = 0.f;
+        const int o = lo + 16 * u;
+        if (o < a.O) dl_s[rr][o] = dl[u];
+        p1 += dl[u] * aa[g][u];
+        p2 += dl[u] * bb[g][u];
+      }
+      p1 = group16_sum(p1);
+      p2 = group16_sum(p2);
+      if (lo == 0) {
+        ms[0][rr] = p1 * invD;
+        ms[1][rr] = p2 * invD;
+        ms[2][rr] = st_mean[g];
+        ms[3][rr] = st_rstd[g];
+      }
+      loss_acc += vsp ? row_loss : 0.f;
+    }
+    if (a.mode != 0 && blockIdx.x == 0) {
+      loss_acc = wave_sum(loss_acc);
+      if (lane == 0) atomicAdd(a.loss, loss_acc / (a.mode == 1 ? (float)a.b * (float)a.O : (float)a.b));
+    }
   }
   __syncthreads();
   if (blockIdx.x == 0 && (int)threadIdx.x < a.O) {              // dbias partial of this chunk
     float t = 0.f;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) t += dl_s[rr][threadIdx.x];
+    for (int rr = 0; rr < kRows; ++rr) t += dl_s[rr][threadIdx.x];
     a.part[((int64_t)chunk * (a.O + 3) + a.O + 2) * a.D + threadIdx.x] = t;
   }
-  // ---- tiles
-  const int nkt = a.D / 16;
-  const int osteps = (a.O + 3) / 4, otiles = (a.O + 15) / 16;
-  const float m1 = ms[0][lo], m2 = ms[1][lo], mean = ms[2][lo], rstd = ms[3][lo];
-  const int s = s0 + lo;
-  const bool vs = s < a.b;
-  const int sc = vs ? s : a.b - 1;
+  if (!vt) return;
+  // ---- the tile
   float* const part = a.part + (int64_t)chunk * (a.O + 3) * a.D;
-  for (int ti = 0; ti < a.tiles_per_wave; ++ti) {
-    const int kt = (blockIdx.x * a.tiles_per_wave + ti) * 4 + wave;
-    if (kt >= nkt) break;                                       // wave-uniform
-    const int k0 = kt * 16;
-    const int q = k0 / a.CL;                                    // wave-uniform: a tile never straddles states
-    const int kin = k0 - q * a.CL;
+  const float wq[4] = {lw.x, lw.y, lw.z, lw.w}, bq[4] = {lb.x, lb.y, lb.z, lb.w};
+  float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
+  float fr[SG][4];
+#pragma unroll
+  for (int g = 0; g < SG; ++g) {
+    const int rl = 16 * g + lo;
+    const int s = s0 + rl;
+    const bool vs = s < a.b;
+    const float m1 = ms[0][rl], m2 = ms[1][rl], mean = ms[2][rl], rstd = ms[3][rl];
     // GEMM 1: D[k = 4h + r][s = lo] = sum_o W[o][k0 + 4h + r] dl[s][o]
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int t = 0; t < osteps; ++t) {
-      const int o = 4 * t + h;
-      const int oc = o < a.O ? o : a.O - 1;
-      const float wv = a.W[(int64_t)oc * a.D + k0 + lo];         // clamped address + select (no branch)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o < a.O ? wv : 0.f, dl_s[lo][oc], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kSteps; ++t) {
+      if (t < osteps) {                                         // uniform
+        const int o = 4 * t + h;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o < a.O ? wv[t] : 0.f, dl_s[rl][o < a.O ? o : a.O - 1], acc,
+                                                   0, 0, 0);
+      }
     }
-    const float4 x = ld4(a.src.p[q] + (int64_t)sc * a.CL + kin + 4 * h);
-    const float4 lw = ld4(a.ln_w + k0 + 4 * h), lb = ld4(a.ln_b + k0 + 4 * h);
-    const float xq[4] = {x.x, x.y, x.z, x.w}, wq[4] = {lw.x, lw.y, lw.z, lw.w}, bq[4] = {lb.x, lb.y, lb.z, lb.w};
-    float dx[4], gw[4], gb[4];
+    const float xq[4] = {x[g].x, x[g].y, x[g].z, x[g].w};
+    float dx[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float xh = (xq[r] - mean) * rstd;
       const bool on = (xh * wq[r] + bq[r]) > 0.f;
       const float gy = (on && vs) ? acc[r] : 0.f;               // gradient at the LayerNorm output
-      const float dxh = gy * wq[r];
-      dx[r] = rstd * (dxh - m1 - xh * m2);
-      gw[r] = gy * xh;
-      gb[r] = gy;
+      dx[r] = rstd * (gy * wq[r] - m1 - xh * m2);
+      gw[r] += gy * xh;
+      gb[r] += gy;
     }
     float* d = a.dsrc[q];
     if (d != nullptr && vs) {
@@ -320,40 +370,37 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
       if (a.acc_mask & (1u << q)) o4 = f4_add(o4, ld4(pp));
       st4(pp, o4);
     }
-    // LayerNorm affine partials of this chunk: sum over the 16 samples (lanes lo) per k
+    // feat in (s = 4h + r, k = lo) layout for GEMM 2, recomputed from the state (never stored)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      const int rl2 = 16 * g + 4 * h + r;
+      const float pre = (xr[g][r] - ms[2][rl2]) * ms[3][rl2] * lwk + lbk;
+      fr[g][r] = (s0 + rl2 < a.b) ? fmaxf(pre, 0.f) : 0.f;
+    }
+  }
+  // LayerNorm affine partials of this chunk: sum over the samples (lanes lo, groups) per k
 #pragma unroll
-      for (int sh = 1; sh < 16; sh <<= 1) {
-        gw[r] += __shfl_xor(gw[r], sh, 64);
-        gb[r] += __shfl_xor(gb[r], sh, 64);
-      }
-    }
-    if (lo == 0) {
-      st4(part + (int64_t)a.O * a.D + k0 + 4 * h, make_float4(gw[0], gw[1], gw[2], gw[3]));
-      st4(part + (int64_t)(a.O + 1) * a.D + k0 + 4 * h, make_float4(gb[0], gb[1], gb[2], gb[3]));
-    }
-    // GEMM 2: dW[o = 16 t + 4h + r][k0 + lo] = sum_s dl[s][o] feat[s][k0 + lo]; B operand = feat in
-    // (s = 4h + r, k = lo) layout, recomputed from the state (never stored)
-    float fr[4];
-    {
-      const float lwk = a.ln_w[k0 + lo], lbk = a.ln_b[k0 + lo];
+  for (int r = 0; r < 4; ++r) {
+    gw[r] = group16_sum(gw[r]);
+    gb[r] = group16_sum(gb[r]);
+  }
+  if (lo == 0) {
+    st4(part + (int64_t)a.O * a.D + k0 + 4 * h, make_float4(gw[0], gw[1], gw[2], gw[3]));
+    st4(part + (int64_t)(a.O + 1) * a.D + k0 + 4 * h, make_float4(gb[0], gb[1], gb[2], gb[3]));
+  }
+  // GEMM 2: dW[o = 16 t + 4h + r][k0 + lo] = sum_s dl[s][o] feat[s][k0 + lo]
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int sr = s0 + 4 * h + r;
-        const int src_ = sr < a.b ? sr : a.b - 1;
-        const float xv = a.src.p[q][(int64_t)src_ * a.CL + kin + lo];
-        const float pre = (xv - ms[2][4 * h + r]) * ms[3][4 * h + r] * lwk + lbk;
-        fr[r] = (sr < a.b) ? fmaxf(pre, 0.f) : 0.f;
-      }
-    }
-    for (int t = 0; t < otiles; ++t) {
+  for (int t = 0; t < OT; ++t) {
+    if (t < otiles) {                                           // uniform
       const int oa = 16 * t + lo;
       const int oac = oa < a.O ? oa : a.O - 1;
       f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa < a.O ? dl_s[4 * h + r][oac] : 0.f, fr[r], acc2, 0, 0, 0);
+      for (int g = 0; g < SG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa < a.O ? dl_s[16 * g + 4 * h + r][oac] : 0.f, fr[g][r],
+                                                      acc2, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = 16 * t + 4 * h + r;
@@ -387,7 +434,15 @@ int fill_src(HeadSrc& s, const float* const* srcs, const float* const* sums, int
 
 }  // namespace
 
-extern "C" int bmnas_head_chunks(int b) { return b < 1 ? BMNAS_E_ARG : (b + 15) / 16; }
+// samples per partial-sum chunk of the backward: 32 (two MFMA sample groups per workgroup: the W
+// operand and the partial stores are shared) once the batch fills the chip that way, else 16
+static inline int head_sg(int b) { return b >= 64 ? 2 : 1; }
+
+extern "C" int bmnas_head_chunks(int b) {
+  if (b < 1) return BMNAS_E_ARG;
+  const int rows = 16 * head_sg(b);
+  return (b + rows - 1) / rows;
+}
 
 extern "C" int bmnas_head_fwd(const float* const* srcs, const float* const* sums, int n_src,
                               const float* ln_w, const float* ln_b, const float* W, const float* bias,
@@ -443,13 +498,17 @@ extern "C" int bmnas_head_bwd(const float* const* srcs, const float* const* sums
   a.labels_i = mode == 2 ? (const long long*)labels : nullptr;
   a.loss = loss; a.part = part; a.scrub = scrub; a.scrub4 = scrub_n / 4;
   a.b = b; a.O = O; a.CL = C * L; a.D = n_src * C * L; a.n_src = n_src;
-  const int nkt = a.D / 16, chunks = (b + 15) / 16;
-  // one tile per wave unless that gives far more workgroups than the chip holds at once
-  a.tiles_per_wave = 1;
-  while ((nkt + 4 * a.tiles_per_wave - 1) / (4 * a.tiles_per_wave) * chunks > 1024 && a.tiles_per_wave < 8)
-    a.tiles_per_wave *= 2;
-  dim3 grid((unsigned)((nkt + 4 * a.tiles_per_wave - 1) / (4 * a.tiles_per_wave)), (unsigned)chunks);
-  hipLaunchKernelGGL(head_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, a);
+  const int nkt = a.D / 16, sg = head_sg(b), chunks = bmnas_head_chunks(b);
+  dim3 grid((unsigned)((nkt + 3) / 4), (unsigned)chunks);
+  const int OT = (O + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+#define HB(OTv)                                                                        \
+  do {                                                                                 \
+    if (sg == 2) hipLaunchKernelGGL((head_bwd_k<OTv, 2>), grid, dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((head_bwd_k<OTv, 1>), grid, dim3(256), 0, st, a);          \
+  } while (0)
+  if (OT <= 2) HB(2); else if (OT <= 4) HB(4); else if (OT <= 6) HB(6); else HB(8);
+#undef HB
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

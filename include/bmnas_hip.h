@@ -351,7 +351,7 @@ int bmnas_head_fwd(const float* const* srcs, const float* const* sums, int n_src
  *   (b, O), *loss += the mean loss;  mode 2: CrossEntropy(mean) against int64 labels (b) — the
  *   criterion (mmimdb_darts_searchable.py:22, ntu_darts_searchable.py:25) evaluated in the same launch.
  *   gscale (nullable): device scalar multiplying dlogits.
- * Batch reductions leave as per-16-sample-chunk partials (n_chunk = bmnas_head_chunks(b)):
+ * Batch reductions leave as per-sample-chunk partials (16 or 32 samples; n_chunk = bmnas_head_chunks(b)):
  *   part [n_chunk][O + 3][D]: rows 0..O-1 = dW, row O = dln_w, row O+1 = dln_b, row O+2 = dbias in its
  *   first O entries (the rest of that row is never written);
  * sum them with bmnas_backward_epilogue(n_sums ...) or bmnas_sum_chunks.
