@@ -4,7 +4,7 @@
 // fp32 atomics (conv1x1.hip: bn_tile_stats, `stat_shards` copies to spread same-address atomics).
 // Every workgroup of the kernel that applies the BatchNorm (K2's mix, the out_conv / ConcatFC tail)
 // turns them into the fused affine scale[m] = bn_w * rstd, shift[m] = bn_b - mean * scale in LDS at
-// its start — M <= 2304 channels, a handful of loads and one rsqrt per thread — and workgroup 0 also
+// its start — four adjacent channels per thread, one memory round trip — and workgroup 0 also
 // writes chan = mean | rstd | scale | shift for the backward pass and updates the running
 // statistics exactly like nn.BatchNorm1d (momentum 0.1, unbiased variance, num_batches_tracked).
 // Eval mode: the same from the running statistics.  Replaces bmnas_bn_finalize on the search path
@@ -25,81 +25,93 @@ struct BnFin {
 };
 
 // sc / sh: LDS, M floats each.  Ends with a __syncthreads().
+// Thread t owns the four adjacent channels 4t .. 4t + 3 (M % 4 == 0, M <= 4 * BS): straight-line code,
+// every load a float4 and all of them issued before the first use — ONE memory round trip (an
+// earlier per-channel loop compiled into one load -> wait -> compute block per channel).
 template <int BS>
 __device__ __forceinline__ void bn_fin_fill(const BnFin& f, float* __restrict__ chan, const int M, const int N,
                                             float* sc, float* sh, const bool writer) {
   constexpr float kEpsBn = 1e-5f, kMom = 0.1f;
-  constexpr int kMaxShards = 8, kCh = 3;
+  constexpr int kMaxShards = 8;
   if (!f.on) {
-    for (int m = threadIdx.x; m < M; m += BS) {
-      sc[m] = chan[2 * M + m];
-      sh[m] = chan[3 * M + m];
+    for (int m0 = 4 * (int)threadIdx.x; m0 < M; m0 += 4 * BS) {   // one trip for M <= 4 * BS
+      const float4 a = ld4(chan + 2 * M + m0), b = ld4(chan + 3 * M + m0);
+      st4(sc + m0, a);
+      st4(sh + m0, b);
     }
     __syncthreads();
     return;
   }
-  const bool upd = writer && f.training && f.running_mean != nullptr;
-  for (int base = 0; base < M; base += kCh * BS) {
-    // every load of the (up to kCh) channels this thread owns first — shard sums, affine, running
-    // statistics; addresses are clamped, not predicated (a predicated load compiles to a branch and a
-    // wait per load) — then the arithmetic: ONE memory round trip per kCh * BS channels.
-    // (The sums were written by memory-side atomics: these loads miss L2.)
-    float2 v[kCh][kMaxShards];
-    float w[kCh], bb[kCh], cb[kCh], rm0[kCh], rv0[kCh];
+  const bool wr = writer && !(f.on & 2);                      // (bit 1: timing experiments only)
+  const bool upd = wr && f.training && f.running_mean != nullptr;
+  for (int m0 = 4 * (int)threadIdx.x; m0 < M; m0 += 4 * BS) {   // one trip for M <= 4 * BS
+    float4 v[kMaxShards][2];
+    if (f.training) {
+      const float4* st = reinterpret_cast<const float4*>(f.stat + 2 * m0);
 #pragma unroll
-    for (int i = 0; i < kCh; ++i) {
-      const int m = base + (int)threadIdx.x + i * BS;
-      const int mc = m < M ? m : M - 1;
-      if (f.training) {
-        const float2* st = reinterpret_cast<const float2*>(f.stat) + mc;
-#pragma unroll
-        for (int k = 0; k < kMaxShards; ++k) v[i][k] = st[(int64_t)(k < f.shards ? k : 0) * M];
-      }
-      w[i] = f.bn_w[mc];
-      bb[i] = f.bn_b[mc];
-      cb[i] = (f.training && f.conv_bias != nullptr) ? f.conv_bias[mc] : 0.f;
-      rm0[i] = 0.f;
-      rv0[i] = 1.f;
-      if (upd || !f.training) {
-        rm0[i] = f.running_mean[mc];
-        rv0[i] = f.running_var[mc];
+      for (int k = 0; k < kMaxShards; ++k) {                   // clamped shard index: no predicated loads
+        const float4* p = st + (int64_t)(k < f.shards ? k : 0) * (M / 2);
+        v[k][0] = p[0];                                        // (sum, sumsq) of channels m0, m0 + 1
+        v[k][1] = p[1];                                        //              of channels m0 + 2, m0 + 3
       }
     }
+    const float4 w4 = ld4(f.bn_w + m0), b4 = ld4(f.bn_b + m0);
+    float4 cb4 = make_float4(0.f, 0.f, 0.f, 0.f), rm4 = cb4, rv4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (f.training && f.conv_bias != nullptr) cb4 = ld4(f.conv_bias + m0);
+    if (upd || !f.training) {
+      rm4 = ld4(f.running_mean + m0);
+      rv4 = ld4(f.running_var + m0);
+    }
+    long long nb = 0;
+    const bool bump = wr && f.training && f.nbt != nullptr && m0 < f.n_nbt;
+    if (bump) nb = f.nbt[m0];                                  // (n_nbt <= 4: the counters of thread 0)
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (f.training) {
 #pragma unroll
-    for (int i = 0; i < kCh; ++i) {
-      const int m = base + (int)threadIdx.x + i * BS;
-      if (m >= M) continue;
-      float mean, rstd;
-      if (f.training) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int k = 0; k < kMaxShards; ++k) {
-          s += (k < f.shards) ? v[i][k].x : 0.f;
-          q += (k < f.shards) ? v[i][k].y : 0.f;
-        }
-        const float inv = 1.f / (float)N;
-        const float dm = s * inv;
-        const float var = fmaxf(q * inv - dm * dm, 0.f);
-        mean = dm + cb[i];
-        rstd = 1.f / sqrtf(var + kEpsBn);
-        if (upd) {
-          f.running_mean[m] = (1.f - kMom) * rm0[i] + kMom * mean;
-          f.running_var[m] = (1.f - kMom) * rv0[i] + kMom * (var * (float)N / (float)(N - 1));
-        }
-        if (writer && m < f.n_nbt && f.nbt != nullptr) f.nbt[m] += 1;
-      } else {
-        mean = rm0[i];
-        rstd = 1.f / sqrtf(rv0[i] + kEpsBn);
+      for (int k = 0; k < kMaxShards; ++k) {
+        const float on = k < f.shards ? 1.f : 0.f;
+        s[0] += on * v[k][0].x; q[0] += on * v[k][0].y;
+        s[1] += on * v[k][0].z; q[1] += on * v[k][0].w;
+        s[2] += on * v[k][1].x; q[2] += on * v[k][1].y;
+        s[3] += on * v[k][1].z; q[3] += on * v[k][1].w;
       }
-      const float scale = w[i] * rstd;
-      const float shift = bb[i] - mean * scale;
-      sc[m] = scale;
-      sh[m] = shift;
-      if (writer) {
-        chan[m] = mean;
-        chan[M + m] = rstd;
-        chan[2 * M + m] = scale;
-        chan[3 * M + m] = shift;
+    }
+    const float wq[4] = {w4.x, w4.y, w4.z, w4.w}, bq[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float cq[4] = {cb4.x, cb4.y, cb4.z, cb4.w}, rmq[4] = {rm4.x, rm4.y, rm4.z, rm4.w};
+    const float rvq[4] = {rv4.x, rv4.y, rv4.z, rv4.w};
+    float mean[4], rstd[4], scale[4], shift[4], nrm[4], nrv[4];
+    const float inv = 1.f / (float)N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (f.training) {
+        const float dm = s[j] * inv;
+        const float var = fmaxf(q[j] * inv - dm * dm, 0.f);
+        mean[j] = dm + cq[j];
+        rstd[j] = 1.f / sqrtf(var + kEpsBn);
+        nrm[j] = (1.f - kMom) * rmq[j] + kMom * mean[j];
+        nrv[j] = (1.f - kMom) * rvq[j] + kMom * (var * (float)N / (float)(N - 1));
+      } else {
+        mean[j] = rmq[j];
+        rstd[j] = 1.f / sqrtf(rvq[j] + kEpsBn);
+        nrm[j] = nrv[j] = 0.f;
+      }
+      scale[j] = wq[j] * rstd[j];
+      shift[j] = bq[j] - mean[j] * scale[j];
+    }
+    st4(sc + m0, make_float4(scale[0], scale[1], scale[2], scale[3]));
+    st4(sh + m0, make_float4(shift[0], shift[1], shift[2], shift[3]));
+    if (wr) {
+      st4(chan + m0, make_float4(mean[0], mean[1], mean[2], mean[3]));
+      st4(chan + M + m0, make_float4(rstd[0], rstd[1], rstd[2], rstd[3]));
+      st4(chan + 2 * M + m0, make_float4(scale[0], scale[1], scale[2], scale[3]));
+      st4(chan + 3 * M + m0, make_float4(shift[0], shift[1], shift[2], shift[3]));
+      if (upd) {
+        st4(f.running_mean + m0, make_float4(nrm[0], nrm[1], nrm[2], nrm[3]));
+        st4(f.running_var + m0, make_float4(nrv[0], nrv[1], nrv[2], nrv[3]));
+      }
+      if (bump) {
+        f.nbt[m0] = nb + 1;
+        for (int j = 1; j < 4 && m0 + j < f.n_nbt; ++j) f.nbt[m0 + j] += 1;
       }
     }
   }

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
     float* __restrict__ pre, float* __restrict__ out, float* __restrict__ stats, int b, int C, int L,
     DropCfg dglu, DropCfg dfc, float* __restrict__ osum) {
   __shared__ float red[8];
+  __shared__ float red6[8 * 6];
   extern __shared__ float fin_lds[];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   const int smp = blockIdx.x;
@@ -191,41 +192,49 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
   }
   const float inv_d = 1.f / (float)(cl4 * 4);
   const float mean = block_sum<BS / 64>(sum, red) * inv_d;
-  float sq = 0.f;
+  // second pass: the centred second moment and — same reduction round — what the per-sample sums of
+  // the OUTPUT o = c * rstd * w + b (c = v - mean) need:  sum o = rstd * S(c w) + S(b),
+  // sum o^2 = rstd^2 * S(c^2 w^2) + 2 rstd * S(c w b) + S(b^2)   (for the head's K7 LayerNorm)
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int r = threadIdx.x + k * BS;
     if (r < cl4) {
       const float4 cdev = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
-      sq += f4_dot(cdev, cdev);
+      acc[0] += f4_dot(cdev, cdev);
+      if (osum != nullptr) {
+        const float4 cw = f4_mul(cdev, lw[k]);
+        acc[1] += f4_hsum(cw);
+        acc[2] += f4_dot(cw, cw);
+        acc[3] += f4_dot(cw, lb[k]);
+        acc[4] += f4_hsum(lb[k]);
+        acc[5] += f4_dot(lb[k], lb[k]);
+      }
     }
   }
-  const float var = block_sum<BS / 64>(sq, red) * inv_d;
+  if (osum != nullptr) {
+    block_sum_lead<BS / 64, 6>(acc, red6);
+  } else {
+    acc[0] = block_sum<BS / 64>(acc[0], red);
+  }
+  const float var = acc[0] * inv_d;
   const float rstd = 1.f / sqrtf(var + kEps);
   if (threadIdx.x == 0) {
     stats[2 * smp] = mean;
     stats[2 * smp + 1] = rstd;
+    if (osum != nullptr) {
+      osum[2 * smp] = rstd * acc[1] + acc[4];
+      osum[2 * smp + 1] = rstd * rstd * acc[2] + 2.f * rstd * acc[3] + acc[5];
+    }
   }
-  float os = 0.f, oq = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int r = threadIdx.x + k * BS;
     if (r < cl4) {
       const float4 w = lw[k], bb = lb[k];
-      const float4 o = make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
-                                   (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w);
-      st4(out + ((int64_t)smp * cl4 + r) * 4, o);
-      os += f4_hsum(o);
-      oq += f4_dot(o, o);
-    }
-  }
-  // (sum, sum of squares) of the node OUTPUT per sample for the K7 LayerNorm of the head (head.hip)
-  if (osum != nullptr) {
-    os = block_sum<BS / 64>(os, red);
-    oq = block_sum<BS / 64>(oq, red);
-    if (threadIdx.x == 0) {
-      osum[2 * smp] = os;
-      osum[2 * smp + 1] = oq;
+      st4(out + ((int64_t)smp * cl4 + r) * 4,
+          make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
+                      (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w));
     }
   }
 }

@@ -82,6 +82,55 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// N sums at once over a block of NW waves (red must hold >= NW * N floats); every thread gets all N.
+template <int NW, int N>
+__device__ __forceinline__ void block_sum_n(float (&v)[N], float* red) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[w * N + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float t = red[i];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) t += red[k * N + i];
+    v[i] = t;
+  }
+}
+
+// As block_sum_n, but only v[0] is handed to every thread; v[1..N-1] are complete on thread 0 only
+// (the other threads skip their LDS reads).
+template <int NW, int N>
+__device__ __forceinline__ void block_sum_lead(float (&v)[N], float* red) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[i * NW + w] = v[i];
+  }
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) t += red[k];
+  v[0] = t;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+      float u = red[i * NW];
+#pragma unroll
+      for (int k = 1; k < NW; ++k) u += red[i * NW + k];
+      v[i] = u;
+    }
+  }
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
                                                     float* __restrict__ stats, int cl4, int d4,
                                                     int relu, float* __restrict__ osum) {
   __shared__ float red[8];
+  __shared__ float red6[8 * 6];
   const int s = blockIdx.x;
   float4 v[VPT], lw[VPT], lb[VPT];
   float sum = 0.f;
@@ -52,20 +53,40 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
   }
   const float inv_d = 1.f / (float)(d4 * 4);
   const float mean = block_sum<BS / 64>(sum, red) * inv_d;
-  float sq = 0.f;
+  // second pass: the centred second moment and — same reduction round, when asked for — what the
+  // per-sample sums of the OUTPUT need (see node_mix_ln_fwd_k; without ReLU only)
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool sums = osum != nullptr && !relu;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int i = threadIdx.x + k * BS;
     if (i < d4) {
       const float4 c = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
-      sq += f4_dot(c, c);
+      acc[0] += f4_dot(c, c);
+      if (sums) {
+        const float4 cw = f4_mul(c, lw[k]);
+        acc[1] += f4_hsum(cw);
+        acc[2] += f4_dot(cw, cw);
+        acc[3] += f4_dot(cw, lb[k]);
+        acc[4] += f4_hsum(lb[k]);
+        acc[5] += f4_dot(lb[k], lb[k]);
+      }
     }
   }
-  const float var = block_sum<BS / 64>(sq, red) * inv_d;
+  if (sums) {
+    block_sum_lead<BS / 64, 6>(acc, red6);
+  } else {
+    acc[0] = block_sum<BS / 64>(acc[0], red);
+  }
+  const float var = acc[0] * inv_d;
   const float rstd = 1.f / sqrtf(var + kEps);
   if (threadIdx.x == 0) {
     stats[2 * s] = mean;
     stats[2 * s + 1] = rstd;
+    if (sums) {
+      osum[2 * s] = rstd * acc[1] + acc[4];
+      osum[2 * s + 1] = rstd * rstd * acc[2] + 2.f * rstd * acc[3] + acc[5];
+    }
   }
   float os = 0.f, oq = 0.f;
 #pragma unroll
@@ -86,9 +107,8 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
       oq += f4_dot(o, o);
     }
   }
-  // (sum, sum of squares) of this sample's OUTPUT: what a LayerNorm over a concatenation of such
-  // outputs (K7) needs, so that its statistics cost no pass of their own (head.hip)
-  if (osum != nullptr) {
+  // with ReLU the sums cannot be derived from the moments: reduce the outputs themselves
+  if (osum != nullptr && relu) {
     os = block_sum<BS / 64>(os, red);
     oq = block_sum<BS / 64>(oq, red);
     if (threadIdx.x == 0) {
