@@ -213,7 +213,7 @@ class ConvBnSaved:
     __slots__ = ('srcs', 'C_src', 'W', 'ldw', 'U', 'chan', 'M', 'training', 'dup', 'fold', 'fin')
 
 
-STAT_SHARDS = int(os.environ.get('BMNAS_STAT_SHARDS', '8'))   # copies of the BatchNorm batch-sum buffers (same-address atomics serialise)
+STAT_SHARDS = int(os.environ.get('BMNAS_STAT_SHARDS', '4'))   # copies of the BatchNorm batch-sum buffers (same-address atomics serialise)
 
 
 class StatArena:

@@ -32,7 +32,7 @@ template <int BS>
 __device__ __forceinline__ void bn_fin_fill(const BnFin& f, float* __restrict__ chan, const int M, const int N,
                                             float* sc, float* sh, const bool writer) {
   constexpr float kEpsBn = 1e-5f, kMom = 0.1f;
-  constexpr int kMaxShards = 8;
+  constexpr int kMaxShards = 4;
   if (!f.on) {
     for (int m0 = 4 * (int)threadIdx.x; m0 < M; m0 += 4 * BS) {   // one trip for M <= 4 * BS
       const float4 a = ld4(chan + 2 * M + m0), b = ld4(chan + 3 * M + m0);

@@ -617,7 +617,7 @@ inline int to_fin(const bmnas_bn_fin_t& f, BnFin* o) {
     return 0;
   }
   if (!f.bn_w || !f.bn_b || f.shards < 0 || f.n_nbt < 0) return BMNAS_E_ARG;
-  if (f.shards > 8) return BMNAS_E_LIMIT;
+  if (f.shards > 4) return BMNAS_E_LIMIT;
   if (f.training && (!f.stat || f.shards < 1)) return BMNAS_E_ARG;
   if (!f.training && (!f.running_mean || !f.running_var)) return BMNAS_E_ARG;
   if ((f.running_mean == nullptr) != (f.running_var == nullptr)) return BMNAS_E_ARG;

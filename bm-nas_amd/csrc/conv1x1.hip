@@ -512,6 +512,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
 
   // epilogue: acc[tn][tj][r] = OUT[n = 16*g + 4h + r][j = jt + lo]
   const int l0 = (4 * h) & (a.L - 1);
+  float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};    // stat mode: this wave's n-groups together
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
@@ -525,8 +526,45 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
       const int so = g * a.spw + ((4 * h) >> a.Lb);
       const bool vo = so < a.b;
       if (vo) st4(a.dst.p[0] + ((int64_t)so * a.Cj + jj) * a.L + l0, o);
-      bn_tile_stats(a, o, bj, vo, g, jj, h);
+      if (a.stat == nullptr) {
+        bn_tile_stats(a, o, bj, vo, g, jj, h);
+      } else if (vo) {                                         // d = u - bias = the bare accumulator
+        ssum[tj] += (acc[tn][tj][0] + acc[tn][tj][1]) + (acc[tn][tj][2] + acc[tn][tj][3]);
+        ssq[tj] += acc[tn][tj][0] * acc[tn][tj][0] + acc[tn][tj][1] * acc[tn][tj][1] +
+                   acc[tn][tj][2] * acc[tn][tj][2] + acc[tn][tj][3] * acc[tn][tj][3];
+      }
     }
+  if (a.stat != nullptr) {
+    // ONE atomic pair per channel per WORKGROUP (the tile's NG n-groups together): waves 1 and 3 hand
+    // their sums to waves 0 and 2, which own the same channels, through the idle operand buffer.
+    // Same-address atomics serialise at the memory side: halving them again lets half as many shard
+    // copies do (the kernel that finalises the statistics reads every shard of every channel).
+    float2* xch = reinterpret_cast<float2*>(smem);               // [2][3][16]
+#pragma unroll
+    for (int tj = 0; tj < 3; ++tj) {
+      ssum[tj] += __shfl_xor(ssum[tj], 16, 64);
+      ssum[tj] += __shfl_xor(ssum[tj], 32, 64);
+      ssq[tj] += __shfl_xor(ssq[tj], 16, 64);
+      ssq[tj] += __shfl_xor(ssq[tj], 32, 64);
+    }
+    __syncthreads();                                           // every wave is done reading operands
+    if ((wave & 1) && h == 0) {
+#pragma unroll
+      for (int tj = 0; tj < 3; ++tj) xch[((wave >> 1) * 3 + tj) * 16 + lo] = make_float2(ssum[tj], ssq[tj]);
+    }
+    __syncthreads();
+    if (!(wave & 1) && h == 0) {
+#pragma unroll
+      for (int tj = 0; tj < 3; ++tj) {
+        const int jt = j0 + 16 * (jl0 + tj);
+        if (jt >= a.J) continue;
+        const float2 p = xch[((wave >> 1) * 3 + tj) * 16 + lo];
+        float* pp = a.stat + ((int64_t)(bx % a.stat_shards) * a.J + jt + lo) * 2;
+        atomicAdd(pp, ssum[tj] + p.x);
+        atomicAdd(pp + 1, ssq[tj] + p.y);
+      }
+    }
+  }
 }
 
 template <int KC, int NG>
