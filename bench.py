@@ -552,6 +552,10 @@ def main():
     # RCCL can average in the collective (ReduceOp.AVG): the captured step is then exactly the
     # single-GPU one; without it (gloo test harness) the loss is pre-scaled and the bucket summed
     use_avg = world > 1 and bdist.avg_supported(device)
+    # opt-in (BMNAS_NATIVE_RCCL=1): RCCL through the C ABI, captured INSIDE the step's hipGraph
+    native = world > 1 and bdist.native_rccl_enabled() and a.mode == 'graph'
+    comm = bdist.NativeComm.get() if native else None
+    use_avg = use_avg or native
     loss_scale = 1.0 if (world == 1 or use_avg) else 1.0 / world
 
     def step_for_capture():
@@ -566,6 +570,8 @@ def main():
             else:
                 grads = torch.autograd.grad(loss, leaves, grad_outputs=unit_grad(device), allow_unused=True)
             torch._foreach_copy_(flat_views, list(grads[:len(shared)]))
+            if native:
+                comm.all_reduce(flat, average=True)          # a launch on the capture stream
             for t, v in zip(shared, flat_views):
                 t.grad = v
             for t, g in zip(xs, grads[len(shared):]):
@@ -601,7 +607,7 @@ def main():
 
     def run():
         run_local()
-        if world > 1:
+        if world > 1 and not native:
             if a.mode == 'graph':
                 torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.AVG if use_avg
                                              else torch.distributed.ReduceOp.SUM)
@@ -649,7 +655,8 @@ def main():
                               f'pooled backbone features (b, C_in, L), C_in = {C_INS[a.config]}, through the reshape layers'),
                    'global_batch': a.batch * world, 'per_gpu_batch': a.batch,
                    'parallelism': f'dp{world}', 'mode': a.mode,
-                   'step': 'fwd+bwd (+ flat RCCL all-reduce of w- and arch-grads when n_gpus > 1)'},
+                   'step': 'fwd+bwd (+ flat RCCL all-reduce of w- and arch-grads when n_gpus > 1'
+                           + (', captured in the hipGraph via the C ABI)' if native else ')')},
         'samples_per_s': round(world * a.steps * a.batch / dt, 1),
     }
     if eager_ms is not None:

@@ -72,6 +72,46 @@ def broadcast(t, src=0, group=None):
     return t
 
 
+class NativeComm:
+    """RCCL through the C ABI (bmnas_comm_* / bmnas_allreduce_f32, csrc/comm.hip) instead of
+    torch.distributed's process group: the collective is a plain asynchronous launch on the current
+    HIP stream, which is what lets GraphedTrainStep capture it BETWEEN the backward and the Adam
+    launch — fwd + bwd + all-reduce + Adam as one hipGraph replay.  The unique id travels over the
+    already-initialised torch.distributed group (any backend).  Opt-in: BMNAS_NATIVE_RCCL=1."""
+
+    _instance = None
+
+    def __init__(self, group=None):
+        from . import lib
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = [lib.comm_get_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(uid, src=0, group=group)
+        self.comm = lib.comm_init_rank(self.world, self.rank, uid[0])
+
+    @classmethod
+    def get(cls, group=None):
+        if cls._instance is None:
+            cls._instance = cls(group)
+        return cls._instance
+
+    def all_reduce(self, flat, average=True):
+        from . import lib
+        lib.allreduce_f32(flat, self.comm, average)
+
+    def destroy(self):
+        from . import lib
+        if self.comm is not None:
+            lib.comm_destroy(self.comm)
+            self.comm = None
+            NativeComm._instance = None
+
+
+def native_rccl_enabled():
+    return os.environ.get('BMNAS_NATIVE_RCCL', '0') not in ('0', '', 'false', 'False')
+
+
 _AVG = {}
 
 
@@ -128,7 +168,10 @@ class FlatGradAllReducer:
         """average=False: the bucket holds gradients pre-scaled by 1/world (sum them);
         average=True: unscaled gradients, reduced with ReduceOp.AVG (see avg_supported)."""
         if self.world > 1:
-            all_reduce(self.flat, dist.ReduceOp.AVG if average else dist.ReduceOp.SUM, self.group)
+            if native_rccl_enabled() and self.flat.is_cuda and dist.get_backend(self.group) == 'nccl':
+                NativeComm.get(self.group).all_reduce(self.flat, average)      # capturable launch
+            else:
+                all_reduce(self.flat, dist.ReduceOp.AVG if average else dist.ReduceOp.SUM, self.group)
         self.reduced = True                      # the optimizer pre-hook must not average again
 
     def __call__(self):

@@ -126,12 +126,19 @@ class GraphedTrainStep:
         self.reducer = reducer
         self.inputs = [x.detach().clone().requires_grad_(x.requires_grad) for x in inputs]
         self.labels = labels.detach().clone()
-        self.in_graph_step = reducer is None
+        # RCCL through the C ABI (bmnas.dist.NativeComm, opt-in BMNAS_NATIVE_RCCL=1) is a plain launch
+        # on the capture stream: the all-reduce and the Adam step then live INSIDE the graph
+        from .dist import NativeComm, native_rccl_enabled
+        import torch.distributed as tdist
+        self.native = (reducer is not None and native_rccl_enabled() and self.labels.is_cuda
+                       and tdist.get_backend(reducer.group) == 'nccl')
+        self.in_graph_step = reducer is None or self.native
         views = reducer.ensure_bucket() if reducer is not None else None
         # with ReduceOp.AVG (RCCL) the captured step is the single-GPU one: unscaled loss, constant
         # unit gradient; otherwise the loss is pre-scaled by 1/world and the bucket is summed
-        self.average = reducer is not None and avg_supported(self.labels.device, reducer.group)
+        self.average = reducer is not None and (self.native or avg_supported(self.labels.device, reducer.group))
         scale = 1.0 / reducer.world if (reducer is not None and not self.average) else 1.0
+        comm = NativeComm.get(reducer.group) if self.native else None
         armed = [False]
 
         from . import nn as bnn
@@ -157,8 +164,13 @@ class GraphedTrainStep:
             else:
                 for t, g in zip(self.targets, grads):
                     t.grad = g
+            if self.native:
+                comm.all_reduce(reducer.flat, average=True)     # captured: a launch on this stream
+                reducer.reduced = True                          # the step pre-hook must not reduce again
             if self.in_graph_step and armed[0]:
                 optimizer.step()
+            if self.native:
+                reducer.reduced = False
             return loss, logits
 
         # The warm-up passes run WITHOUT the update (they settle allocations and lazy

@@ -123,6 +123,12 @@ SIGNATURES = {
     'bmnas_head_bwd': ([_PP, _PP, _PP, _I, _U32, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                         _P, _I64, _P], _I),
     'bmnas_sum_chunks': ([_P, _P, _I, _I64, _P], _I),
+    'bmnas_comm_available': ([], _I),
+    'bmnas_comm_unique_id_bytes': ([], _I),
+    'bmnas_comm_get_unique_id': ([_P], _I),
+    'bmnas_comm_init_rank': ([C.POINTER(C.c_void_p), _I, _I, _P], _I),
+    'bmnas_comm_destroy': ([_P], _I),
+    'bmnas_allreduce_f32': ([_P, _I64, _I, _P, _P], _I),
     'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P, _P,
                              _P, _I64, _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
@@ -151,7 +157,8 @@ def load():
 
 def _check(rc, name):
     if rc != 0:
-        kind = {-1: 'bad argument', -2: 'unsupported shape', -3: 'limit exceeded'}.get(rc, f'hipError {rc}')
+        kind = {-1: 'bad argument', -2: 'unsupported shape', -3: 'limit exceeded',
+                -4: 'librccl could not be loaded'}.get(rc, f'ncclResult {rc - 1000}' if rc > 1000 else f'hipError {rc}')
         raise BmnasError(f'{name} failed: {kind} (rc={rc})')
 
 
@@ -310,6 +317,34 @@ def head_bwd(srcs, sums, dsrcs, acc_mask, ln_w, ln_b, W, hb, stats, mode, g, gsc
                                  None if labels is None else labels.data_ptr(), _ptr(loss), _ptr(part),
                                  b, Cc, L, O, _ptr(scrub),
                                  0 if scrub is None else scrub.numel(), _stream()), 'head_bwd')
+
+
+def comm_available():
+    return bool(load().bmnas_comm_available())
+
+
+def comm_get_unique_id():
+    """-> bytes (rank 0 calls this and ships them to every rank)."""
+    buf = C.create_string_buffer(load().bmnas_comm_unique_id_bytes())
+    _check(load().bmnas_comm_get_unique_id(buf), 'comm_get_unique_id')
+    return buf.raw
+
+
+def comm_init_rank(world, rank, uid):
+    """Collective over all ranks; -> opaque communicator handle."""
+    comm = C.c_void_p()
+    _check(load().bmnas_comm_init_rank(C.byref(comm), world, rank, C.create_string_buffer(uid, len(uid))),
+           'comm_init_rank')
+    return comm
+
+
+def comm_destroy(comm):
+    _check(load().bmnas_comm_destroy(comm), 'comm_destroy')
+
+
+def allreduce_f32(buf, comm, average=False):
+    """In place, asynchronous on torch's current stream (capturable into a hipGraph)."""
+    _check(load().bmnas_allreduce_f32(_ptr(buf), buf.numel(), int(average), comm, _stream()), 'allreduce_f32')
 
 
 def sum_chunks(part, out, n_chunk):

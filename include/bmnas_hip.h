@@ -406,6 +406,24 @@ int bmnas_adam_chunk_elems(void);
 int bmnas_adam_multi(const bmnas_adam_tensor_t* tensors, const int32_t* chunks, int n_chunks,
                      const float* hyp, void* stream);
 
+/* ---- data parallelism: RCCL behind the C ABI ---------------------------------------------------
+ * One process per GPU; the data-path exchange of a search step is ONE in-place all-reduce of the flat
+ * fp32 gradient bucket (w-grads, or the alpha/beta/gamma vector) over xGMI — what replaces
+ * torch.nn.DataParallel at mmimdb_darts_searchable.py:36-37, ntu_darts_searchable.py:50-52,
+ * ego_darts_searchable.py:51-53.  librccl is bound lazily (dlopen): without it these return -4 and
+ * nothing else is affected.  Returns > 1000: RCCL's ncclResult_t + 1000.
+ *   rank 0:  bmnas_comm_get_unique_id(id)  -> ship the bmnas_comm_unique_id_bytes() bytes to every rank
+ *   all:     bmnas_comm_init_rank(&comm, world, rank, id)      (collective)
+ *   step:    bmnas_allreduce_f32(bucket, n, average, comm, stream)   — asynchronous on `stream`, so it
+ *            can be captured into the step's hipGraph between the backward and the Adam launch
+ *   end:     bmnas_comm_destroy(comm) */
+int bmnas_comm_available(void);
+int bmnas_comm_unique_id_bytes(void);
+int bmnas_comm_get_unique_id(void* id_out);
+int bmnas_comm_init_rank(void** comm_out, int world, int rank, const void* id);
+int bmnas_comm_destroy(void* comm);
+int bmnas_allreduce_f32(float* buf, int64_t count, int average, void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

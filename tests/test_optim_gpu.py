@@ -172,3 +172,44 @@ def test_eager_step_between_replays_does_not_poison_the_graph():
     for c, g_ in zip(cpu, gpu):
         assert float((g_.detach().cpu() - c.detach()).abs().max()) <= 2e-6 * (float(c.detach().abs().max()) + 1e-3)
     assert float(opt.state_dict()['state'][0]['step']) == 7.0
+
+
+def test_native_rccl_allreduce_single_rank_and_under_graph_capture():
+    """bmnas_comm_* / bmnas_allreduce_f32 (csrc/comm.hip): RCCL bound lazily behind the C ABI.  One GPU
+    is all a gpurun box has, so this is a world-size-1 communicator: the collective must run, leave the
+    bucket unchanged (sum and average over one rank), and be CAPTURABLE into a hipGraph next to other
+    launches on the stream — the property the in-graph all-reduce of a data-parallel step relies on."""
+    from bmnas import lib
+    if not lib.comm_available():
+        pytest.skip('librccl not loadable in this process')
+    uid = lib.comm_get_unique_id()
+    assert len(uid) == 128
+    comm = lib.comm_init_rank(1, 0, uid)
+    try:
+        x = torch.arange(4096, device=dev(), dtype=torch.float32)
+        want = x.clone()
+        lib.allreduce_f32(x, comm, average=False)
+        lib.allreduce_f32(x, comm, average=True)
+        torch.cuda.synchronize()
+        assert torch.equal(x, want)
+        # captured: y = 2 * x ; all-reduce(y) ; z = y + 1  replayed on fresh data
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            lib.allreduce_f32(y, comm, average=True)           # warm up RCCL's lazy setup outside capture
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                torch.mul(x, 2.0, out=y)
+                lib.allreduce_f32(y, comm, average=True)
+                torch.add(y, 1.0, out=z)
+        torch.cuda.current_stream().wait_stream(s)
+        for k in range(3):
+            x.fill_(float(k))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(z, torch.full_like(z, 2.0 * k + 1.0))
+    finally:
+        lib.comm_destroy(comm)
