@@ -116,6 +116,10 @@ def algo_table(C, L):
             ('hbm', (1 + (g2 is not None) + len(xs) + bin(acc).count('1')
                      + sum(d is not None for d in dxs)) * T(g)),
         'mixsum_pair_fwd': lambda xs, w, ws, w2, ws2, out, *_: ('hbm', (len(xs) + 2) * T(out)),
+        # the first pair sum with the cell prologue's jobs in the same launch: K1's bytes + the folds
+        'cell_prologue_pair': lambda al, ol, Ws, We, M, Cc, step, scrub, xs, a, bt, h, z:
+            ('hbm', (len(xs) + 2) * T(h) + sum(T(w) + T(e) for w, e in zip(Ws, We))
+             + (0 if scrub is None else T(scrub))),
         'mixsum_pair_bwd': lambda xs, dxs, w, ws, w2, ws2, h, gh, gz, dw, dw2, acc, sh=1, st=0, gz2=None:
             ('hbm', (2 + (gh is not None) + (gz2 is not None) + len(xs) + bin(acc).count('1')
                      + sum(d is not None for d in dxs)) * T(gz)),
@@ -194,7 +198,7 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            bdist.all_reduce(t, torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         return dt / n * 1e3
 
@@ -295,7 +299,8 @@ KERNELS_OF = {
     'linear_fwd': ('linear_fwd_k',), 'linear_bwd': ('linear_bwd_k',),
     'bce_logits': ('bce_logits_k',), 'cross_entropy': ('ce_rows_k',),
     'head_fwd': ('head_fwd_k',), 'head_bwd': ('head_bwd_k',), 'head_loss_bwd': ('head_loss_bwd_k',),
-    'cell_prologue': ('cell_prologue_k',), 'adam_multi': ('adam_multi_k',),
+    'cell_prologue': ('cell_prologue_k',), 'cell_prologue_pair': ('cell_prologue_pair_k',),
+    'adam_multi': ('adam_multi_k',),
 }
 
 
@@ -344,12 +349,19 @@ def profile_graph_replay(a, log, steps=60):
         shutil.rmtree(out, ignore_errors=True)
     rows.sort(key=lambda x: x[1])
     names = [x[0] for x in rows]
-    # the replays are the periodic tail of the trace: find the period from the last kernels
+    # the replays are the periodic tail of the trace.  Every step starts with exactly one cell prologue
+    # launch: the distance between its last occurrences is the period (a step that repeats an identical
+    # sub-sequence — six reshape layers in a row — would fool a shortest-repeat search); fallback: the
+    # shortest period whose last three repetitions agree
     period = None
-    for per in range(4, 400):
-        if len(names) > 3 * per + 3 and names[-per:] == names[-2 * per:-per] == names[-3 * per:-2 * per]:
-            period = per
-            break
+    marks = [i for i, n in enumerate(names) if 'cell_prologue_k' in n or 'cell_prologue_pair_k' in n]
+    if len(marks) >= 4 and marks[-1] - marks[-2] == marks[-2] - marks[-3]:
+        period = marks[-1] - marks[-2]        # (the trace ENDS with the last replay: cut from the end)
+    if period is None:
+        for per in range(4, 400):
+            if len(names) > 3 * per + 3 and names[-per:] == names[-2 * per:-per] == names[-3 * per:-2 * per]:
+                period = per
+                break
     if period is None:
         raise RuntimeError('no periodic replay pattern in the kernel trace')
     n_rep = 0
@@ -609,8 +621,8 @@ def main():
         run_local()
         if world > 1 and not native:
             if a.mode == 'graph':
-                torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.AVG if use_avg
-                                             else torch.distributed.ReduceOp.SUM)
+                bdist.all_reduce(flat, torch.distributed.ReduceOp.AVG if use_avg
+                                 else torch.distributed.ReduceOp.SUM)
             else:
                 red_all()
 
@@ -629,7 +641,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        bdist.all_reduce(t, torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
     result = {

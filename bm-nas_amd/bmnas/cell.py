@@ -372,6 +372,8 @@ FUSE_EPILOGUE = os.environ.get('BMNAS_FUSE_EPILOGUE', '1') != '0'
 # BatchNorm statistics accumulated by the GEMM epilogues (atomics) and finalised inside the kernel
 # that applies the BatchNorm, instead of one bn_finalize launch per conv (needs FUSE_PROLOGUE)
 FUSE_BN_FINALIZE = os.environ.get('BMNAS_FUSE_BN_FINALIZE', '1') != '0'
+# the cell prologue inside the launch of the first step's pair sum (needs FUSE_PROLOGUE and FUSE_PAIR)
+FUSE_PROLOGUE_PAIR = os.environ.get('BMNAS_FUSE_PROLOGUE_PAIR', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
 FUSE_HEAD = os.environ.get('BMNAS_FUSE_HEAD', '1') != '0'
 
@@ -570,7 +572,7 @@ class CellSaved:
 
 
 def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, weffs=None, stats=None,
-                    head=None):
+                    head=None, prologue=None):
     """FusionCell.forward (model_search.py:50-68) with the step nodes in search mode
     (FusionNode(x, x), model_search.py:59).  alpha_w (k, 2) softmaxed device tensor.
     head: Pack(W, bias, hb) -> the cell's LayerNorm tail continues into the central classifier in
@@ -585,7 +587,10 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
     for i in range(S):
         if FUSE_PAIR and len(states) <= 15:
             sif, z0 = torch.empty_like(xs[0]), torch.empty_like(xs[0])
-            lib.mixsum_pair_fwd(states, alpha_w[offset:, 1], 2, beta_ws[i][:, 1], 2, sif, z0)
+            if i == 0 and prologue is not None:
+                prologue(states, sif, z0)        # the cell prologue rides in this launch (bmnas_cell_prologue_pair)
+            else:
+                lib.mixsum_pair_fwd(states, alpha_w[offset:, 1], 2, beta_ws[i][:, 1], 2, sif, z0)
         else:
             sif, z0 = mixsum_fwd(states, alpha_w[offset:, 1]), None
         out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm, z0,

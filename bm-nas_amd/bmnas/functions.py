@@ -272,13 +272,24 @@ class FusedCellFn(Function):
             head = K.HeadState(W=Wc, bias=bc, hb=arena[stat_n:stat_n + 3 * b * O].view(3, b, O),
                                loss=arena[stat_n + hb_n:stat_n + hb_n + 1],
                                marker=torch.empty((b, O), device=dev, dtype=torch.float32))
-        weffs = None
+        weffs, prologue = None, None
         if K.FUSE_PROLOGUE and 0 < len(mixed) <= 8:
             weffs = [torch.empty((3 * C_, C_), device=dev, dtype=torch.float32) for _ in mixed]
             # under capture the first prologue of the step also advances the dropout step counter
             # (bmnas.graph.GraphedStep), saving the separate add launch at the end of every replay
             adv, K.DROP.pending_advance = K.DROP.pending_advance, None
-            lib.cell_prologue(logits, ws, [m.stack_W for m in mixed], weffs, 3 * C_, C_, adv, arena)
+            stackW = [m.stack_W for m in mixed]
+            if (K.FUSE_PROLOGUE_PAIR and K.FUSE_PAIR and alpha_is_logits and N <= 15
+                    and logits[0].shape[1] == 2 and logits[1].shape[1] == 2 and logits[1].shape[0] >= 2):
+                # the prologue's jobs ride in the launch of the first step's pair sum, which takes
+                # its edge weights straight from the alpha / beta logits
+                ws_all = ws                          # (`ws` is re-bound below: do not capture the name)
+
+                def prologue(states, sif, z0):
+                    lib.cell_prologue_pair(logits, ws_all, stackW, weffs, 3 * C_, C_, adv, arena, states,
+                                           logits[0], logits[1], sif, z0)
+            else:
+                lib.cell_prologue(logits, ws, stackW, weffs, 3 * C_, C_, adv, arena)
         else:
             stats = None                                     # bn_finalize launches (no zero-filled sums)
             if head is not None:
@@ -292,7 +303,7 @@ class FusedCellFn(Function):
         ctx.alpha_is_logits = alpha_is_logits
         out, sv = K.fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S,
                                     cell._multiplier, cell.args.node_steps, cell.args.node_multiplier, weffs,
-                                    stats, head)
+                                    stats, head, prologue)
         ctx.cell, ctx.sv, ctx.beta_ws, ctx.gamma_ws, ctx.N, ctx.S = cell, sv, beta_ws, gamma_ws, N, S
         ctx.dev, ctx.n_head = dev, n_head
         if head is not None:

@@ -131,6 +131,8 @@ SIGNATURES = {
     'bmnas_allreduce_f32': ([_P, _I64, _I, _P, _P], _I),
     'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P, _P,
                              _P, _I64, _P], _I),
+    'bmnas_cell_prologue_pair': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P,
+                                  _P, _P, _I64, _PP, _I, _P, _P, _P, _P, _I64, _P], _I),
     'bmnas_arch_softmax_multi': ([_PP, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I64,
                                  _P], _I),
 }
@@ -543,6 +545,23 @@ def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc, step=None, scrub=None):
                                       0 if scrub is None else scrub.numel(), _stream()), 'cell_prologue')
 
 
+def cell_prologue_pair(a_list, out_list, Ws, Weffs, M, Cc, step, scrub, xs, alpha_logits, beta_logits, h, z):
+    """cell_prologue(...) + mixsum_pair_fwd of the first step (weights from the raw logits), one launch."""
+    n = len(a_list)
+    rows = (C.c_int * max(n, 1))(*[t.shape[0] for t in a_list])
+    cols = (C.c_int * max(n, 1))(*[t.shape[1] for t in a_list])
+    pa = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in a_list])
+    po = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in out_list])
+    nf = len(Ws)
+    pw = (C.c_void_p * max(nf, 1))(*[t.data_ptr() for t in Ws])
+    pe = (C.c_void_p * max(nf, 1))(*[t.data_ptr() for t in Weffs])
+    sc, sp = (None, None) if step is None else (step[0].data_ptr(), step[1].data_ptr())
+    _check(load().bmnas_cell_prologue_pair(pa, po, rows, cols, n, pw, pe, nf, M, Cc, sc, sp, _ptr(scrub),
+                                           0 if scrub is None else scrub.numel(), _ptrs(xs), len(xs),
+                                           alpha_logits.data_ptr(), beta_logits.data_ptr(), _ptr(h), _ptr(z),
+                                           h.numel(), _stream()), 'cell_prologue_pair')
+
+
 def arch_softmax_multi(a_list, dw_list, out_list, backward, n_shards=1, shard_stride=0):
     """One launch for every architecture tensor (row softmax, or its backward)."""
     n = len(a_list)
@@ -611,7 +630,7 @@ def profile_end_calls():
     return prof['calls']
 
 
-_TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
+_TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'cell_prologue_pair', 'mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
     const float* __restrict__ gamma, float* dgamma, int dg_shards, int64_t dg_stride, float* dx,
     float* dy, uint32_t acc_mask, float* __restrict__ dV, float* bn_grad, int b, int C, int L,
     int chunk, DropCfg dglu, DropCfg dfc) {
-  __shared__ float red[4];
+  __shared__ float red16[16];
   __shared__ float csum[3][6][64];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;   // 64 slots x 4 sample lanes
@@ -343,13 +343,14 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
       atomicAdd(bn_grad + M + k * C + c, cs[3 + k]);
     }
   }
+  // the four dgamma sums in ONE reduction round (two barriers instead of eight); every workgroup adds
+  // into the same 4 scalars: same-address atomics serialise (~25 ns each), so they are spread over
+  // dg_shards copies (summed by the arch-softmax backward)
+  block_sum_lead<4, 4>(dgam, red16);
+  if (threadIdx.x == 0 && dgamma != nullptr) {
+    float* p = dgamma + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % dg_shards) * dg_stride;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float t = block_sum256(dgam[q], red);
-    // every workgroup adds into the same 4 scalars: same-address atomics serialise (~25 ns
-    // each), so spread them over dg_shards copies (summed by the arch-softmax backward)
-    if (threadIdx.x == 0 && dgamma != nullptr)
-      atomicAdd(dgamma + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % dg_shards) * dg_stride + q, t);
+    for (int q = 0; q < 4; ++q) atomicAdd(p + q, dgam[q]);
   }
 }
 
@@ -650,20 +651,23 @@ struct FoldPack {
   int n, M, C, blocks_per;
 };
 
-__global__ __launch_bounds__(256) void cell_prologue_k(ArchPack P, FoldPack F, unsigned long long* step_counter,
-                                                       const unsigned long long* step_span,
-                                                       float* __restrict__ scrub, int64_t scrub4) {
+// bid / nblocks: this workgroup's index among the prologue workgroups of the launch
+__device__ __forceinline__ void cell_prologue_body(const ArchPack& P, const FoldPack& F,
+                                                   unsigned long long* step_counter,
+                                                   const unsigned long long* step_span,
+                                                   float* __restrict__ scrub, int64_t scrub4, const int bid,
+                                                   const int nblocks) {
   const int nfb = F.n * F.blocks_per;
   // side job: zero-fill the caller's forward accumulation buffers (BatchNorm batch sums that the GEMM
   // epilogues add into with atomics, the head's logits) — instead of a memset launch
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < scrub4; i += (int64_t)gridDim.x * 256)
+  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < scrub4; i += (int64_t)nblocks * 256)
     st4(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   // hipGraph replays: advance the dropout step counter once, here, before any kernel of this replay
   // reads it (one thread of the last workgroup; every later kernel is ordered after this launch)
-  if (step_counter != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+  if (step_counter != nullptr && bid == nblocks - 1 && threadIdx.x == 0)
     step_counter[0] += step_span[0];
-  if ((int)blockIdx.x < nfb) {
-    const int q = blockIdx.x / F.blocks_per, bi = blockIdx.x - q * F.blocks_per;   // workgroup-uniform
+  if (bid < nfb) {
+    const int q = bid / F.blocks_per, bi = bid - q * F.blocks_per;   // workgroup-uniform
     const float* __restrict__ W = F.W[q];
     float* __restrict__ We = F.Weff[q];
     const int c4n = F.C / 4;
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(256) void cell_prologue_k(ArchPack P, FoldPack F, u
     }
     return;
   }
-  int r = (blockIdx.x - nfb) * 256 + threadIdx.x;
+  int r = (bid - nfb) * 256 + threadIdx.x;
   for (int t = 0; t < P.n; ++t) {
     if (r < P.rows[t]) {
       const int cols = P.cols[t];
@@ -689,6 +693,66 @@ __global__ __launch_bounds__(256) void cell_prologue_k(ArchPack P, FoldPack F, u
       return;
     }
     r -= P.rows[t];
+  }
+}
+
+__global__ __launch_bounds__(256) void cell_prologue_k(ArchPack P, FoldPack F, unsigned long long* step_counter,
+                                                       const unsigned long long* step_span,
+                                                       float* __restrict__ scrub, int64_t scrub4) {
+  cell_prologue_body(P, F, step_counter, step_span, scrub, scrub4, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// softmax(row)[1] of a two-column logits row, with the arithmetic of the prologue's row softmax (the
+// backward kernels read the prologue's stored weights: both must be the same bits)
+__device__ __forceinline__ float softmax2_col1(const float* a) {
+  const float a0 = a[0], a1 = a[1];
+  const float mx = fmaxf(a0, a1);
+  const float e0 = expf(a0 - mx), e1 = expf(a1 - mx);
+  return e1 / (e0 + e1);
+}
+
+// The prologue AND the first data kernel of the cell in one launch: workgroups [0, n_pro) do the
+// prologue's independent jobs, the rest stream the first step's mixed-edge pair sum
+//   h = sum_j softmax(alpha)[j, 1] x_j,   z = (softmax(beta)[0, 1] + softmax(beta)[1, 1]) h
+// (bmnas_mixsum_pair_fwd) with the edge weights computed from the raw logits in registers — nothing
+// of the prologue's output is needed before the NEXT launch.  One launch less per step.
+struct PairArgs {
+  PtrsIn xs;
+  const float* alpha;      // logits of the step's first edge, rows of 2
+  const float* beta;       // logits of the node's first two inner edges, rows of 2
+  float* out;
+  float* out2;
+  int64_t n4;
+};
+
+template <int NIN>
+__global__ __launch_bounds__(256) void cell_prologue_pair_k(ArchPack P, FoldPack F, unsigned long long* step_counter,
+                                                            const unsigned long long* step_span,
+                                                            float* __restrict__ scrub, int64_t scrub4, int n_pro,
+                                                            PairArgs A) {
+  if ((int)blockIdx.x < n_pro) {
+    cell_prologue_body(P, F, step_counter, step_span, scrub, scrub4, (int)blockIdx.x, n_pro);
+    return;
+  }
+  float wj[NIN];
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) wj[j] = softmax2_col1(A.alpha + 2 * j);
+  const float s2 = softmax2_col1(A.beta) + softmax2_col1(A.beta + 2);
+  const int64_t stride = (int64_t)(gridDim.x - n_pro) * 256;
+  for (int64_t i = (int64_t)(blockIdx.x - n_pro) * 256 + threadIdx.x; i < A.n4; i += stride) {
+    float4 v[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(A.xs.p[j])[i];
+    float4 acc = f4_scale(v[0], wj[0]);
+#pragma unroll
+    for (int j = 1; j < NIN; ++j) {
+      acc.x = fmaf(wj[j], v[j].x, acc.x);
+      acc.y = fmaf(wj[j], v[j].y, acc.y);
+      acc.z = fmaf(wj[j], v[j].z, acc.z);
+      acc.w = fmaf(wj[j], v[j].w, acc.w);
+    }
+    reinterpret_cast<float4*>(A.out)[i] = acc;
+    reinterpret_cast<float4*>(A.out2)[i] = f4_scale(acc, s2);
   }
 }
 
@@ -900,11 +964,16 @@ extern "C" int bmnas_arch_softmax_multi(const float* const* a, const float* cons
   return 0;
 }
 
-extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, const int* rows,
-                                   const int* cols, int n_arch, const float* const* W,
-                                   float* const* Weff, int n_fold, int M, int C,
-                                   uint64_t* step_counter, const uint64_t* step_span, float* scrub,
-                                   int64_t scrub_n, void* stream) {
+namespace {
+struct PrologueLaunch {
+  ArchPack P;
+  FoldPack F;
+  int blocks;
+};
+
+int fill_prologue(PrologueLaunch& L, const float* const* a, float* const* out, const int* rows, const int* cols,
+                  int n_arch, const float* const* W, float* const* Weff, int n_fold, int M, int C,
+                  const uint64_t* step_counter, const uint64_t* step_span, const float* scrub, int64_t scrub_n) {
   if ((step_counter == nullptr) != (step_span == nullptr)) return BMNAS_E_ARG;
   if (scrub_n < 0 || (scrub_n > 0 && !scrub) || scrub_n % 4) return BMNAS_E_ARG;
   if (n_arch < 0 || n_fold < 0 || (n_arch > 0 && (!a || !out || !rows || !cols)) ||
@@ -912,34 +981,88 @@ extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, con
     return BMNAS_E_ARG;
   if (n_arch > BMNAS_MAX_PTRS || n_fold > kMaxFold) return BMNAS_E_LIMIT;
   if (n_fold > 0 && C % 4) return BMNAS_E_SHAPE;
-  ArchPack P{};
+  L.P = ArchPack{};
   int total = 0;
   for (int t = 0; t < n_arch; ++t) {
     if (!a[t] || !out[t] || rows[t] < 1 || cols[t] < 1 || cols[t] > 4) return BMNAS_E_ARG;
-    P.a[t] = a[t];
-    P.o[t] = out[t];
-    P.rows[t] = rows[t];
-    P.cols[t] = cols[t];
+    L.P.a[t] = a[t];
+    L.P.o[t] = out[t];
+    L.P.rows[t] = rows[t];
+    L.P.cols[t] = cols[t];
     total += rows[t];
   }
-  P.n = n_arch;
-  P.n_shards = 1;
-  FoldPack F{};
+  L.P.n = n_arch;
+  L.P.n_shards = 1;
+  L.F = FoldPack{};
   for (int q = 0; q < n_fold; ++q) {
     if (!W[q] || !Weff[q]) return BMNAS_E_ARG;
-    F.W[q] = W[q];
-    F.Weff[q] = Weff[q];
+    L.F.W[q] = W[q];
+    L.F.Weff[q] = Weff[q];
   }
-  F.n = n_fold; F.M = M; F.C = C;
+  L.F.n = n_fold; L.F.M = M; L.F.C = C;
   int per = n_fold > 0 ? (int)(((int64_t)M * (C / 4) + 255) / 256) : 0;
   if (per > 128) per = 128;
-  F.blocks_per = per;
-  int blocks = n_fold * per + (total + 255) / 256;
-  if (blocks == 0 && (step_counter != nullptr || scrub_n > 0)) blocks = 1;
-  if (blocks == 0) return 0;
-  hipLaunchKernelGGL(cell_prologue_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, F,
+  L.F.blocks_per = per;
+  L.blocks = n_fold * per + (total + 255) / 256;
+  if (L.blocks == 0 && (step_counter != nullptr || scrub_n > 0)) L.blocks = 1;
+  return 0;
+}
+}  // namespace
+
+extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, const int* rows,
+                                   const int* cols, int n_arch, const float* const* W,
+                                   float* const* Weff, int n_fold, int M, int C,
+                                   uint64_t* step_counter, const uint64_t* step_span, float* scrub,
+                                   int64_t scrub_n, void* stream) {
+  PrologueLaunch L;
+  if (int e = fill_prologue(L, a, out, rows, cols, n_arch, W, Weff, n_fold, M, C, step_counter, step_span, scrub,
+                            scrub_n))
+    return e;
+  if (L.blocks == 0) return 0;
+  hipLaunchKernelGGL(cell_prologue_k, dim3(L.blocks), dim3(256), 0, (hipStream_t)stream, L.P, L.F,
                      (unsigned long long*)step_counter, (const unsigned long long*)step_span, scrub,
                      scrub_n / 4);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_cell_prologue_pair(const float* const* a, float* const* out, const int* rows,
+                                        const int* cols, int n_arch, const float* const* W,
+                                        float* const* Weff, int n_fold, int M, int C,
+                                        uint64_t* step_counter, const uint64_t* step_span, float* scrub,
+                                        int64_t scrub_n, const float* const* xs, int n_in,
+                                        const float* alpha_logits, const float* beta_logits, float* h,
+                                        float* z, int64_t n_elem, void* stream) {
+  PrologueLaunch L;
+  if (int e = fill_prologue(L, a, out, rows, cols, n_arch, W, Weff, n_fold, M, C, step_counter, step_span, scrub,
+                            scrub_n))
+    return e;
+  if (!xs || !alpha_logits || !beta_logits || !h || !z || n_in < 1 || n_elem < 0) return BMNAS_E_ARG;
+  if (n_in > BMNAS_MAX_PTRS - 1) return BMNAS_E_LIMIT;
+  if (n_elem % 4) return BMNAS_E_SHAPE;
+  PairArgs A{};
+  for (int j = 0; j < n_in; ++j) {
+    if (!xs[j]) return BMNAS_E_ARG;
+    A.xs.p[j] = xs[j];
+  }
+  A.alpha = alpha_logits; A.beta = beta_logits; A.out = h; A.out2 = z; A.n4 = n_elem / 4;
+  // one float4 per lane and input: the pair sum is a latency-floor kernel at the reference batches
+  int64_t pair_blocks = (A.n4 + 255) / 256;
+  if (pair_blocks > 2048) pair_blocks = 2048;                 // as bmnas_mixsum_pair_fwd
+  if (L.blocks + pair_blocks == 0) return 0;
+  dim3 grid((unsigned)(L.blocks + pair_blocks));
+  hipStream_t st = (hipStream_t)stream;
+#define PP(N)                                                                                          \
+  case N:                                                                                              \
+    hipLaunchKernelGGL(cell_prologue_pair_k<N>, grid, dim3(256), 0, st, L.P, L.F,                      \
+                       (unsigned long long*)step_counter, (const unsigned long long*)step_span, scrub, \
+                       scrub_n / 4, L.blocks, A);                                                      \
+    break;
+  switch (n_in) {
+    PP(1) PP(2) PP(3) PP(4) PP(5) PP(6) PP(7) PP(8) PP(9) PP(10) PP(11) PP(12) PP(13) PP(14) PP(15)
+    default: return BMNAS_E_LIMIT;
+  }
+#undef PP
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

@@ -334,6 +334,18 @@ int bmnas_cell_prologue(const float* const* a, float* const* out, const int* row
                         int C, uint64_t* step_counter, const uint64_t* step_span, float* scrub,
                         int64_t scrub_n, void* stream);
 
+/* bmnas_cell_prologue and the first data kernel of the cell in ONE launch: besides the prologue's jobs
+ * the grid streams the first step's mixed-edge pair sum (bmnas_mixsum_pair_fwd)
+ *   h = sum_j softmax(alpha_logits)[j, 1] xs[j],  z = (softmax(beta_logits)[0, 1] + softmax(beta_logits)[1, 1]) h
+ * (model_search.py:58 + node_search.py:54 at t = 0) with the edge weights taken from the raw two-column
+ * logits in registers — the prologue's outputs are only needed by the launches after this one.
+ * alpha_logits: first of n_in consecutive rows of alphas_edges; beta_logits: rows 0, 1 of the node's betas. */
+int bmnas_cell_prologue_pair(const float* const* a, float* const* out, const int* rows, const int* cols,
+                             int n_arch, const float* const* W, float* const* Weff, int n_fold, int M,
+                             int C, uint64_t* step_counter, const uint64_t* step_span, float* scrub,
+                             int64_t scrub_n, const float* const* xs, int n_in, const float* alpha_logits,
+                             const float* beta_logits, float* h, float* z, int64_t n_elem, void* stream);
+
 /* ---- the head of a search step: K7 + central_classifier (+ criterion) in two launches ----------
  * Forward (model_search.py:63-67 + mmimdb_darts_searchable.py:114):
  *   logits = relu(LayerNorm_[M*C, L](cat(srcs))).view(b, -1) @ W^T + bias

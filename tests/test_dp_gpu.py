@@ -110,3 +110,30 @@ def test_two_ranks_run_the_reference_call_chain(tmp_path):
     assert r1['files'] == []                        # only rank 0 writes checkpoints
     # 2 epochs x (2 full + 1 ragged) train batches; each rank sees half of every batch
     assert r0['stats']['graph_replays'] == 4 and r1['stats']['graph_replays'] == 4, (r0['stats'], r1['stats'])
+
+
+def test_bench_two_ranks_weak_scaling_line(tmp_path):
+    """bench.py's N > 1 path (what the driver launches with torch.distributed.run --nproc-per-node N):
+    every rank captures its step writing into the flat bucket, one all-reduce per step, barrier +
+    max-over-ranks timing, rank 0 prints ONE JSON line.  Two ranks on the one GPU of the box over
+    gloo stand in for two GPUs over RCCL."""
+    import json
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), BMNAS_FORCE_DEVICE='0', BMNAS_DIST_BACKEND='gloo',
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, bench, '--gpus', '2', '--steps', '5', '--warmup', '2',
+                                       '--batch', '32', '--no-full-step'], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f'rank {r}:\n{e[-3000:]}'
+    lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith('{')]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['config']['global_batch'] == 64 and d['config']['parallelism'] == 'dp2'
+    assert abs(d['value'] - 2 * 5 / (d['ms_per_step'] * 5e-3)) / d['value'] < 1e-3
