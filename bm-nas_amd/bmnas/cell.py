@@ -281,7 +281,11 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
     """dV (gradient w.r.t. the BN output, with bn_grad already reduced) -> in place dU;
     then data gradient into src_slots and weight/bias gradient (+=) into dW / dbias."""
     b, L = sv.U.shape[0], sv.U.shape[2]
-    lib.bn_bwd_apply(dV, sv.U, sv.chan, bn_grad, b, sv.M, L, sv.training)
+    # search mode: the merged backward launch applies the BatchNorm input gradient while it stages its
+    # operands (bmnas_conv1x1_bwd_all_sdpa, bn_U) — no launch in between
+    fold_bn = attn is not None and dW is not None and FUSE_BWD_ALL and FUSE_BN_APPLY
+    if not fold_bn:
+        lib.bn_bwd_apply(dV, sv.U, sv.chan, bn_grad, b, sv.M, L, sv.training)
     # destinations that alias each other inside ONE data-gradient launch would race:
     # give later duplicates a scratch buffer and add it afterwards (rare: node_multiplier
     # reaching back to the duplicated x/y inputs).
@@ -299,7 +303,8 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
     if attn is not None and dW is not None and FUSE_BWD_ALL:
         # data gradient, weight gradient and the attention backward share one grid
         lib.conv1x1_bwd_all_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, sv.srcs, dW,
-                                 dW.shape[1], dbias, sv.dup, *attn)
+                                 dW.shape[1], dbias, sv.dup, *attn,
+                                 (sv.U, sv.chan, bn_grad, sv.training) if fold_bn else None)
         for s, tmp in extra:
             s.buf().add_(tmp.buf())
         return
@@ -372,6 +377,8 @@ FUSE_EPILOGUE = os.environ.get('BMNAS_FUSE_EPILOGUE', '1') != '0'
 # BatchNorm statistics accumulated by the GEMM epilogues (atomics) and finalised inside the kernel
 # that applies the BatchNorm, instead of one bn_finalize launch per conv (needs FUSE_PROLOGUE)
 FUSE_BN_FINALIZE = os.environ.get('BMNAS_FUSE_BN_FINALIZE', '1') != '0'
+# BatchNorm input gradient applied inside the merged backward GEMM launch (no bn_bwd_apply launch)
+FUSE_BN_APPLY = os.environ.get('BMNAS_FUSE_BN_APPLY', '1') != '0'
 # the cell prologue inside the launch of the first step's pair sum (needs FUSE_PROLOGUE and FUSE_PAIR)
 FUSE_PROLOGUE_PAIR = os.environ.get('BMNAS_FUSE_PROLOGUE_PAIR', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)

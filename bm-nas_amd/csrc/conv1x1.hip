@@ -30,6 +30,14 @@ struct ConvArgs {
   float* part;           // BN partial stats (fwd, training), nullable
   float* stat;           // alternative to part: stat_shards x J x 2 running sums (atomics), nullable
   int stat_shards;
+  // data gradient with the BatchNorm input gradient folded into the operand staging: act.p[0] then
+  // holds dV (gradient w.r.t. the BatchNorm OUTPUT) and the tile kernel forms
+  //   dU = scale * (dV - kb - (U - mean) * rstd * kw),   kw = bn_grad[m] / N, kb = bn_grad[I + m] / N
+  // (training; eval: dU = scale * dV) while it moves the chunk into LDS — no bn_bwd_apply launch
+  const float* bn_U;     // conv output (b, I, L), nullable = no fold
+  const float* bn_chan;  // mean | rstd | scale | shift
+  const float* bn_grad;  // dBN.weight | dBN.bias
+  int bn_train;
   int ldw, Ci, Cj, I, J;
   int b, L, Lb, spw, n_groups, n_part;
   uint32_t acc_mask;
@@ -622,17 +630,45 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     boffg[i] = (int64_t)kr * a.ldw + 4 * j4;
     bsl[i] = ABUF + kr * JP + 4 * c4;
   }
-  float4 ra[NA], rb[NB];
+  // BatchNorm-backward fold: per-channel (scale, kb, mean, rstd * kw) of all K channels in LDS
+  // behind the two operand buffers
+  const bool fold_bn = a.bn_U != nullptr;
+  float4* coef = reinterpret_cast<float4*>(smem + 2 * BUF);
+  int chl[NA];                                                  // channel of ra[i] inside a chunk
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = t + 256 * i;
+    const int qq = q < A4 ? q : A4 - 1;
+    chl[i] = ((qq - (qq / cl4) * cl4) * 4) >> a.Lb;
+  }
+  float4 ra[NA], ru[NA], rb[NB];
   auto fetch = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
+    for (int i = 0; i < NA; ++i) {
+      ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
+      if (fold_bn && a.bn_train) ru[i] = ld4(a.bn_U + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[i] = ld4(a.W + boffg[i] + (int64_t)(c * KC) * a.ldw);
   };
-  auto stash = [&](float* buf) __attribute__((always_inline)) {
+  auto stash = [&](float* buf, int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      if (t + 256 * i < A4) st4(buf + asl[i], ra[i]);
+      if (t + 256 * i < A4) {
+        float4 v = ra[i];
+        if (fold_bn) {
+          const float4 cf = coef[c * KC + chl[i]];
+          if (a.bn_train) {
+            v.x = cf.x * (v.x - cf.y - (ru[i].x - cf.z) * cf.w);
+            v.y = cf.x * (v.y - cf.y - (ru[i].y - cf.z) * cf.w);
+            v.z = cf.x * (v.z - cf.y - (ru[i].z - cf.z) * cf.w);
+            v.w = cf.x * (v.w - cf.y - (ru[i].w - cf.z) * cf.w);
+          } else {
+            v = f4_scale(v, cf.x);
+          }
+        }
+        st4(buf + asl[i], v);
+      }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       if (t + 256 * i < B4) st4(buf + bsl[i], rb[i]);
@@ -646,7 +682,18 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
 #pragma unroll
   for (int tj = 0; tj < WJ; ++tj) acc[tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
   fetch(0);
-  stash(smem);
+  if (fold_bn) {
+    const float invN = 1.f / (float)(a.b * a.L);
+    for (int m = t; m < K; m += 256) {
+      const float sc = a.bn_chan[2 * K + m];
+      float4 cf = make_float4(sc, 0.f, 0.f, 0.f);
+      if (a.bn_train)
+        cf = make_float4(sc, a.bn_grad[K + m] * invN, a.bn_chan[m], a.bn_chan[K + m] * (a.bn_grad[m] * invN));
+      coef[m] = cf;
+    }
+    __syncthreads();
+  }
+  stash(smem, 0);
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     const float* cur = smem + (c & 1) * BUF;
@@ -676,7 +723,7 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
           acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][r], bv[kb][tj][r], acc[tj], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < nchunk) {
-      stash(smem + ((c + 1) & 1) * BUF);
+      stash(smem + ((c + 1) & 1) * BUF, c + 1);
       __syncthreads();
     }
   }
@@ -971,6 +1018,10 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
 }
 
 struct ConvWArgs {
+  const float* bn_U;     // as ConvArgs: dU then holds dV and the operand loads apply the BatchNorm backward
+  const float* bn_chan;
+  const float* bn_grad;
+  int bn_train;
   const float* dU;       // (b, M, L)
   ConvIn src;            // n_src sources (b, C_src, L); K = n_src * C_src
   float* dW;
@@ -1026,6 +1077,31 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
     for (int tk = 0; tk < 2; ++tk) acc[tm][tk] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum[2] = {0.f, 0.f};
 
+  // BatchNorm-backward fold (see ConvArgs): this lane's two dU rows are two fixed channels, their
+  // (scale, kb, mean, rstd * kw) live in registers for the whole walk over the batch
+  const bool fold_bn = a.bn_U != nullptr;
+  float4 cf[2] = {z4, z4};
+  if (fold_bn) {
+    const float invN = 1.f / (float)(a.b * a.L);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int mt = m0 + 16 * tm;
+      const int m = (mt < a.M ? mt : a.M - 16) + lo;
+      const float sc = a.bn_chan[2 * a.M + m];
+      cf[tm] = a.bn_train ? make_float4(sc, a.bn_grad[a.M + m] * invN, a.bn_chan[m],
+                                        a.bn_chan[a.M + m] * (a.bn_grad[m] * invN))
+                          : make_float4(sc, 0.f, 0.f, 0.f);
+    }
+  }
+  auto bn_fold = [&](float4 v, const float4 u, const float4 c) __attribute__((always_inline)) -> float4 {
+    if (!a.bn_train) return f4_scale(v, c.x);
+    v.x = c.x * (v.x - c.y - (u.x - c.z) * c.w);
+    v.y = c.x * (v.y - c.y - (u.y - c.z) * c.w);
+    v.z = c.x * (v.z - c.y - (u.z - c.z) * c.w);
+    v.w = c.x * (v.w - c.y - (u.w - c.z) * c.w);
+    return v;
+  };
+
   // loads are unconditional from clamped addresses; what must not contribute to the sum over
   // n (padded samples, groups past the split) is zeroed in the dU operand by a select
   float4 a0[2], b0[2], a1[2], b1[2];           // two statically named operand sets
@@ -1034,9 +1110,18 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
     const int s = gc * a.spw + sh;
     const int sc = s < a.b ? s : a.b - 1;
     const bool vs = (g < gend) && (s < a.b);
-    const float* ub = a.dU + (int64_t)sc * a.M * a.L + l0;
+    const int64_t uo = (int64_t)sc * a.M * a.L + l0;
     const int64_t xb = (int64_t)sc * a.C_src * a.L + l0;
-    const float4 u0 = ld4(ub + aoff0), u1 = ld4(ub + aoff1);
+    float4 u0 = ld4(a.dU + uo + aoff0), u1 = ld4(a.dU + uo + aoff1);
+    if (fold_bn) {
+      float4 r0 = z4, r1 = z4;
+      if (a.bn_train) {
+        r0 = ld4(a.bn_U + uo + aoff0);
+        r1 = ld4(a.bn_U + uo + aoff1);
+      }
+      u0 = bn_fold(u0, r0, cf[0]);
+      u1 = bn_fold(u1, r1, cf[1]);
+    }
     A[0] = vs ? u0 : z4;
     A[1] = vs ? u1 : z4;
     B[0] = ld4(bsrc0 + xb + boff0);
@@ -1561,6 +1646,9 @@ extern "C" int bmnas_conv1x1_bwd_weight(const float* dU, const float* const* src
   return 0;
 }
 
+extern "C" int bmnas_bn_bwd_apply(float* dV, const float* U, const float* chan, const float* bn_grad, int b,
+                                  int M, int L, int training, void* stream);
+
 extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int ldw, int fold_cols,
                                           float* const* dsrcs, int n_src, int C_src,
                                           uint32_t accumulate_mask, int b, int L, int M,
@@ -1569,7 +1657,9 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
                                           const float* gscale, const float* x, const float* y,
                                           const float* ln_w, const float* xhat, const float* stats,
                                           float* dx, float* dy, uint32_t sdpa_accumulate_mask, int C,
-                                          bmnas_dropout_t drop, void* stream) {
+                                          bmnas_dropout_t drop, const float* bn_U, const float* bn_chan,
+                                          const float* bn_grad, int bn_training, void* stream) {
+  if (bn_U != nullptr && (!bn_chan || (bn_training && !bn_grad))) return BMNAS_E_ARG;
   if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
   if (!g || !x || !y || !ln_w || !xhat || !stats || !dx) return BMNAS_E_ARG;
   if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
@@ -1597,15 +1687,27 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   hipStream_t st = (hipStream_t)stream;
   const int kch = sdpa_kch(C);
   bool done = false;
-  if (conv_pipe_mode() && a.I % 48 == 0 && a.fold == 0 && a.ldw % 4 == 0 && a.J % 16 == 0 && kch <= 4) {
-    static const int ng_forced = []() { const char* e = getenv("BMNAS_PIPE_BNG"); return e ? atoi(e) : 0; }();
-    const int gy = (a.J + kPipeBJ - 1) / kPipeBJ;
-    const int ngv = ng_forced ? ng_forced : 2;
-    const int gx = (a.n_groups + ngv - 1) / ngv;
-    if (gx * gy >= conv_pipe_min() / 2) {         // measured: pays from ~48 data-gradient tiles up
+  static const int ng_forced = []() { const char* e = getenv("BMNAS_PIPE_BNG"); return e ? atoi(e) : 0; }();
+  const int gy = (a.J + kPipeBJ - 1) / kPipeBJ;
+  const int ngv = ng_forced ? ng_forced : 2;
+  const int gx = (a.n_groups + ngv - 1) / ngv;
+  const bool pipe_ok = conv_pipe_mode() && a.I % 48 == 0 && a.fold == 0 && a.ldw % 4 == 0 && a.J % 16 == 0 &&
+                       kch <= 4 && gx * gy >= conv_pipe_min() / 2;   // measured: pays from ~48 data-gradient tiles up
+  if (bn_U != nullptr) {
+    if (pipe_ok) {                                  // the tile kernels apply the BatchNorm backward on the fly
+      a.bn_U = w.bn_U = bn_U; a.bn_chan = w.bn_chan = bn_chan; a.bn_grad = w.bn_grad = bn_grad;
+      a.bn_train = w.bn_train = bn_training;
+    } else {                                        // other kernel families: as its own launch, in place
+      if (int e = bmnas_bn_bwd_apply(const_cast<float*>(dU), bn_U, bn_chan, bn_grad, b, M, L, bn_training, stream))
+        return e;
+    }
+  }
+  if (pipe_ok) {
+    {
       const int n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
       dim3 grid((unsigned)(s.groups + n_w + gx * gy));
-      const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), (conv_pipe_bwd_lds<48, 2>(a.L)));
+      const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()),
+                                  (conv_pipe_bwd_lds<48, 2>(a.L)) + (a.bn_U ? (size_t)a.I * sizeof(float4) : 0));
 #define PB_CASE(K)                                                                                     \
   if (!done && kch == K) {                                                                             \
     BMNAS_COUNT(F_BWD_ALL_PIPE);                                                                       \

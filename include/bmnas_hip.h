@@ -192,7 +192,12 @@ int bmnas_conv1x1_bwd_data_sdpa(const float* dU, const float* W, int ldw, int fo
  * contraction of a NodeMixedOp's backward (search mode).  wsrcs: the conv's forward inputs
  * (n_src x (b, C_src, L)) for the weight gradient; dW / ldw_grad / dbias / dup_cols as in
  * bmnas_conv1x1_bwd_weight; the rest as in bmnas_conv1x1_bwd_data_sdpa.  Shapes outside the merged
- * kernels (M != 3C, C > 256) run as the three separate launches. */
+ * kernels (M != 3C, C > 256) run as the three separate launches. 
+ * bn_U != NULL folds the BatchNorm input gradient into the launch: dU then holds dV (the gradient
+ * w.r.t. the BatchNorm OUTPUT, bn_grad already reduced) and the tile kernels form
+ * scale * (dV - bn_grad[M+m]/N - u_hat * bn_grad[m]/N) (bmnas_bn_bwd_apply) while staging their operands;
+ * shapes served by the other kernel families get the same result from a bmnas_bn_bwd_apply launch
+ * issued first (dU is then overwritten in place). */
 int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int ldw, int fold_cols,
                                float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
                                int b, int L, int M, const float* const* wsrcs, float* dW,
@@ -200,7 +205,8 @@ int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int ldw, int fol
                                const float* gscale, const float* x, const float* y,
                                const float* ln_w, const float* xhat, const float* stats, float* dx,
                                float* dy, uint32_t sdpa_accumulate_mask, int C, bmnas_dropout_t drop,
-                               void* stream);
+                               const float* bn_U, const float* bn_chan, const float* bn_grad,
+                               int bn_training, void* stream);
 /* dW[m*ldw + k] += sum_{s,l} dU[s,m,l] * cat(srcs)[s,k,l];  dbias[m] += sum_{s,l} dU[s,m,l]
  * (atomic adds: caller zeroes; dbias may be NULL).  If dup_cols > 0 the same value is also
  * added at column k + dup_cols (folded x-is-y weights, see bmnas_fold_weight). */
