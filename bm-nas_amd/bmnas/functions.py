@@ -179,14 +179,17 @@ class ConvBnActFn(Function):
         b, M, L = U.shape
         g = _c(g)
         dV = torch.empty_like(U)
-        bn_grad = torch.zeros(2 * M, device=U.device, dtype=torch.float32)
+        # ONE zero-filled buffer for the three gradients that are accumulated with atomics (one memset
+        # launch instead of three: the reshape layers alone would otherwise pay 18 fills per step)
+        zero = torch.zeros(2 * M + M * sv.ldw + M, device=U.device, dtype=torch.float32)
+        bn_grad = zero[:2 * M]
+        dW = zero[2 * M:2 * M + M * sv.ldw].view(M, sv.ldw)
+        dbias = zero[2 * M + M * sv.ldw:]
         if act == 'glu':
             lib.bn_glu_bwd(g, U, sv.chan, dV, bn_grad, b, M // 2, L, ctx.drop)
         else:
             lib.bn_relu_bwd(g, U, sv.chan, dV, bn_grad, b, M, L, ctx.drop)
         slots = [K.GradSlot(s) if ctx.needs_input_grad[10 + q] else None for q, s in enumerate(sv.srcs)]
-        dW = torch.zeros((M, sv.ldw), device=U.device, dtype=torch.float32)
-        dbias = torch.zeros(M, device=U.device, dtype=torch.float32)
         K.conv_bn_bwd(sv, dV, bn_grad, slots, dW, dbias)
         dsrcs = [s.get() if s is not None else None for s in slots]
         return (None, None, None, None, None, None, dW.view(ctx.wshape), dbias, bn_grad[:M], bn_grad[M:],

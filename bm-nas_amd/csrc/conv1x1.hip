@@ -1367,8 +1367,17 @@ inline int conv_pipe_mode() {        // BMNAS_CONV_PIPE=0 falls back to the spli
 // pipelined tile kernel (forward); false when the shape is not covered
 inline bool launch_pipe_fwd(const ConvArgs& a, hipStream_t st) {
   if (!conv_pipe_mode() || a.I != a.Ci || a.fold != 0 || a.acc_mask != 0 || a.ldw % 4) return false;
-  const int gx = (a.n_groups + 3) / 4, gy = (a.J + kPipeJ - 1) / kPipeJ;
-  if (gx * gy < 96) return false;
+  const int gy = (a.J + kPipeJ - 1) / kPipeJ;
+  int gx = (a.n_groups + 3) / 4;
+  if (gx * gy < 96) {
+    // 32-column tiles when 64-column ones leave CUs idle (reshape layers at batch 128: K = 512 through
+    // the split-K kernel ran at 14 % of the MFMA peak, 18 us per layer)
+    gx = (a.n_groups + 1) / 2;
+    if (gx * gy < 96 || a.I % 32 != 0) return false;
+    BMNAS_COUNT(F_PIPE_FWD);
+    hipLaunchKernelGGL((conv_pipe_fwd_k<32, 2>), dim3((unsigned)(gx * gy)), dim3(256), (conv_pipe_lds<32, 2>(a.L)), st, a, gx);
+    return true;
+  }
   if (a.I % 48 == 0 && conv_pipe_lds<48, 4>(a.L) <= 65536) {     // (L = 4 pads rows to twice their size)
     BMNAS_COUNT(F_PIPE_FWD);
     hipLaunchKernelGGL((conv_pipe_fwd_k<48, 4>), dim3((unsigned)(gx * gy)), dim3(256), (conv_pipe_lds<48, 4>(a.L)), st, a, gx);

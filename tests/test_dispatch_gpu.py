@@ -52,7 +52,7 @@ def _conv_case(b, C_in, M, L, seed=0):
 CASES = [
     # (what, batch, C_in, M, L) -> families that must serve it (fwd, bwd-data)
     ('out_conv NTU b512', 512, 256, 128, 8, {'pipe_fwd', 'ksplit'}),
-    ('reshape MM-IMDB C_in 512 b128', 128, 512, 192, 16, {'ksplit', 'pipe_bwd'}),
+    ('reshape MM-IMDB C_in 512 b128', 128, 512, 192, 16, {'pipe_fwd', 'pipe_bwd'}),
     ('out_conv NTU b8', 8, 256, 128, 8, {'ksplit'}),
     ('reshape NTU C_in 2048 b64', 64, 2048, 128, 8, {'lds'}),
     ('reshape NTU C_in 2048 b6', 6, 2048, 128, 8, {'nj'}),

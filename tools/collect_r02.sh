@@ -38,9 +38,9 @@ for b in 32 64 128 256 512 1024; do
   python3 - $OUT/sweep_$b.json $b >> $OUT/${TAG}_k1_batch_sweep.txt <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-rows = [r for r in d.get('roofline_kernels', []) if r['kernel'].startswith('mixsum')]
+rows = [r for r in d.get('roofline_kernels', []) if r['kernel'].startswith(('mixsum', 'cell_prologue_pair'))]
 print(f"batch {int(sys.argv[2]):5d}: step {d['ms_per_step']:.4f} ms  " + '  '.join(
-    f"{r['kernel'].replace('mixsum_pair_', '')}: {r['avg_us']:.2f} us {r['algorithmic_units_per_launch'] / 1e6:.1f} MB frac {r['frac']:.3f}"
+    f"{r['kernel'].replace('mixsum_pair_', '').replace('cell_prologue_pair_k', 'fwd_k+prologue')}: {r['avg_us']:.2f} us {r['algorithmic_units_per_launch'] / 1e6:.1f} MB frac {r['frac']:.3f}"
     for r in sorted(rows, key=lambda r: r['kernel'])))
 PY
 done
