@@ -255,6 +255,9 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
 // waits once, runs its MFMAs back to back, and the four partial tiles are summed through
 // LDS.  Splitting K four ways also quadruples the number of waves, which is what hides the
 // latency at batch 128.
+template <int TN, int TJ>
+constexpr size_t conv_ksplit_lds();
+
 template <bool TRANS, int TN, int TJ, int KPW>
 __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx, const int by, char* lds) {
   // caller-provided LDS (conv_ksplit_lds<TN, TJ>() bytes): merged launches pay max(), not sum()
@@ -281,7 +284,9 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
   }
 
   const int nblk = a.I / 16;
-  float av[KPW][TN][4], bv[KPW][TJ][4];
+  // BatchNorm-backward fold (data gradient only, see ConvArgs): the raw conv outputs travel with dV
+  const bool fold_bn = !TRANS && a.bn_U != nullptr;
+  float av[KPW][TN][4], bv[KPW][TJ][4], uv[KPW][TN][4];
 #pragma unroll
   for (int kb = 0; kb < KPW; ++kb) {
     const int blk = wave * KPW + kb;
@@ -297,6 +302,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
       for (int r = 0; r < 4; ++r) {
         const float t = (a.probe & 2) ? (float)lane : pp[(int64_t)r * a.L];
         av[kb][tn][r] = vb ? t : 0.f;                    // blocks past the end contribute zero
+        if (fold_bn && a.bn_train) uv[kb][tn][r] = a.bn_U[abase[tn] + (int64_t)(ci + r) * a.L];
       }
     }
 #pragma unroll
@@ -317,6 +323,32 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
 #pragma unroll
           for (int r = 0; r < 4; ++r) bv[kb][tj][r] = pp[(int64_t)r * a.ldw];
         }
+      }
+    }
+  }
+  if (fold_bn) {
+    // per-channel (scale, kb, mean, rstd * kw) of all I channels through LDS (behind the partial tiles),
+    // then dU = scale * (dV - kb - (U - mean) * rstd * kw) on the operand registers
+    float4* coef = reinterpret_cast<float4*>(lds + conv_ksplit_lds<TN, TJ>());
+    const float invN = 1.f / (float)(a.b * a.L);
+    for (int m = threadIdx.x; m < a.I; m += 256) {
+      const float sc = a.bn_chan[2 * a.I + m];
+      coef[m] = a.bn_train ? make_float4(sc, a.bn_grad[a.I + m] * invN, a.bn_chan[m],
+                                         a.bn_chan[a.I + m] * (a.bn_grad[m] * invN))
+                           : make_float4(sc, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < KPW; ++kb) {
+      const int blk = wave * KPW + kb;
+      if (blk >= nblk) continue;                         // wave-uniform (those operands are zero)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 cf = coef[blk * 16 + 4 * h + r];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          av[kb][tn][r] = a.bn_train ? cf.x * (av[kb][tn][r] - cf.y - (uv[kb][tn][r] - cf.z) * cf.w)
+                                     : cf.x * av[kb][tn][r];
       }
     }
   }
@@ -1702,8 +1734,15 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   const int gx = (a.n_groups + ngv - 1) / ngv;
   const bool pipe_ok = conv_pipe_mode() && a.I % 48 == 0 && a.fold == 0 && a.ldw % 4 == 0 && a.J % 16 == 0 &&
                        kch <= 4 && gx * gy >= conv_pipe_min() / 2;   // measured: pays from ~48 data-gradient tiles up
+  // the split-K merged kernel (small grids): same conditions as its branch below
+  const long jt_ = a.J / 16, ng_ = a.n_groups;
+  const bool ks_big = ((ng_ + 1) / 2) * ((jt_ + 1) / 2) >= 1024 && 3 * kch * 16 + 16 <= 232;
+  const int ks_tn = ks_big ? 2 : 1;
+  const bool ks_ok = !pipe_ok && a.I == 3 * C && C % 64 == 0 && kch <= 4 &&
+                     3 * kch * 4 * (2 * ks_tn) + 4 * ks_tn * ks_tn <= 232 &&
+                     3 * kch * 4 * (3 * ks_tn) + 4 * ks_tn * ks_tn <= 232;   // (+ the raw-output registers of the fold)
   if (bn_U != nullptr) {
-    if (pipe_ok) {                                  // the tile kernels apply the BatchNorm backward on the fly
+    if (pipe_ok || ks_ok) {                         // the GEMM kernels apply the BatchNorm backward on the fly
       a.bn_U = w.bn_U = bn_U; a.bn_chan = w.bn_chan = bn_chan; a.bn_grad = w.bn_grad = bn_grad;
       a.bn_train = w.bn_train = bn_training;
     } else {                                        // other kernel families: as its own launch, in place
@@ -1740,7 +1779,8 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
       const int gx = (a.n_groups + TNv - 1) / TNv, gy = (a.J / 16 + TNv - 1) / TNv;
       const int n_data = gx * gy, n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
       dim3 grid((unsigned)(s.groups + n_data + n_w));
-      const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()), conv_ksplit_lds<2, 2>());
+      const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()),
+                                  conv_ksplit_lds<2, 2>() + (a.bn_U ? (size_t)a.I * sizeof(float4) : 0));
 #define ALL_CASE(T, K)                                                                                 \
   if (!done && TNv == T && kch == K) {                                                                 \
     BMNAS_COUNT(F_BWD_ALL_KSPLIT);                                                                     \
