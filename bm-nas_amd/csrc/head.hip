@@ -26,6 +26,7 @@
 // ~15 MB at MM-IMDB batch 128); algorithmic FLOPs fwd 6 b O D (three accumulator sets), bwd 4 b O D.
 #include "common.hpp"
 #include "../../include/bmnas_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -173,6 +174,7 @@ struct HeadBwdArgs {
   float* scrub;              // side job: zero-fill (the caller's backward accumulation arena)
   long long scrub4;
   int b, O, D, CL, n_src, mode;
+  int probe;                 // BMNAS_HEAD_PROBE: timing diagnostics only (results incomplete)
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
     for (int rr = 0; rr < kRows; ++rr) t += dl_s[rr][threadIdx.x];
     a.part[((int64_t)chunk * (a.O + 3) + a.O + 2) * a.D + threadIdx.x] = t;
   }
-  if (!vt) return;
+  if (!vt || (a.probe & 8)) return;
   // ---- the tile
   float* const part = a.part + (int64_t)chunk * (a.O + 3) * a.D;
   const float wq[4] = {lw.x, lw.y, lw.z, lw.w}, bq[4] = {lb.x, lb.y, lb.z, lb.w};
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
       gb[r] += gy;
     }
     float* d = a.dsrc[q];
-    if (d != nullptr && vs) {
+    if (d != nullptr && vs && !(a.probe & 2)) {
       float* pp = d + (int64_t)s * a.CL + kin + 4 * h;
       float4 o4 = make_float4(dx[0], dx[1], dx[2], dx[3]);
       if (a.acc_mask & (1u << q)) o4 = f4_add(o4, ld4(pp));
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
   // GEMM 2: dW[o = 16 t + 4h + r][k0 + lo] = sum_s dl[s][o] feat[s][k0 + lo]
 #pragma unroll
   for (int t = 0; t < OT; ++t) {
-    if (t < otiles) {                                           // uniform
+    if (t < otiles && !(a.probe & 1)) {                                           // uniform
       const int oa = 16 * t + lo;
       const int oac = oa < a.O ? oa : a.O - 1;
       f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -498,6 +500,8 @@ extern "C" int bmnas_head_bwd(const float* const* srcs, const float* const* sums
   a.labels_i = mode == 2 ? (const long long*)labels : nullptr;
   a.loss = loss; a.part = part; a.scrub = scrub; a.scrub4 = scrub_n / 4;
   a.b = b; a.O = O; a.CL = C * L; a.D = n_src * C * L; a.n_src = n_src;
+  static const int probe = []() { const char* e = getenv("BMNAS_HEAD_PROBE"); return e ? atoi(e) : 0; }();
+  a.probe = probe;
   const int nkt = a.D / 16, sg = head_sg(b), chunks = bmnas_head_chunks(b);
   dim3 grid((unsigned)((nkt + 3) / 4), (unsigned)chunks);
   const int OT = (O + 15) / 16;

@@ -107,6 +107,21 @@ def _worker(rank, world, port, tmp):
     assert red.reduced is False
     for v, b_ in zip(views, before):
         assert torch.equal(v, b_)
+    # ranks on different paths must still issue the SAME collective: rank 1 has no gradient for one
+    # tensor (e.g. it ran an eager step that did not touch it) — the eager reducer spans the whole
+    # bucket, a missing gradient travels as zeros
+    params = list(model.parameters())
+    for p_ in params:
+        p_.grad = torch.full_like(p_, float(rank + 1))
+    if rank == 1:
+        params[0].grad = None
+    red.reduced = False
+    red()
+    assert torch.allclose(params[1].grad, torch.full_like(params[1], 1.5))
+    if rank == 0:
+        assert torch.allclose(params[0].grad, torch.full_like(params[0], 0.5))      # (1 + 0) / 2
+    else:
+        assert params[0].grad is None
     dist.destroy_process_group()
     open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
 

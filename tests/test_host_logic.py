@@ -190,3 +190,54 @@ def test_live_autograd_graph_detector():
     assert GraphedTrainStep._live_graph_tensors(dev) == base + 1
     held = held.detach()
     assert GraphedTrainStep._live_graph_tensors(dev) == base
+
+
+def test_trainer_loop_shards_unsharded_batches(monkeypatch):
+    """Data parallelism through the reference's call chain: a loader without a DistributedSampler yields
+    the GLOBAL batch on every rank; the trainer loop keeps this rank's contiguous slice (what
+    DataParallel's scatter does), equal slices, remainder dropped."""
+    import torch
+    import models.search.train_searchable._loop as loop
+    x = (torch.arange(10).float().view(10, 1), torch.arange(20).float().view(10, 2))
+    y = torch.arange(10)
+    for rank in range(3):
+        monkeypatch.setattr(loop, '_world', lambda: 3)
+        monkeypatch.setattr(loop, '_rank', lambda r=rank: r)
+        (a, b), lab = loop._shard_batch(x, y)
+        assert lab.tolist() == [3 * rank, 3 * rank + 1, 3 * rank + 2]
+        assert a.shape == (3, 1) and b.shape == (3, 2) and float(a[0, 0]) == 3 * rank
+    monkeypatch.setattr(loop, '_world', lambda: 16)
+    with pytest.raises(ValueError):
+        loop._shard_batch(x, y)
+
+
+def test_world_size_alone_requests_data_parallelism(monkeypatch):
+    from models.search._common import data_parallel_world, parallel_flag
+
+    class A:
+        use_dataparallel = False
+
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    assert data_parallel_world(A()) == 1
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    assert data_parallel_world(A()) == 8 and parallel_flag(A()) is False
+
+
+def test_head_state_resolves_deferred_and_given_gradients():
+    import torch
+    from bmnas.cell import HeadState, StatArena
+    h = HeadState(marker=torch.zeros(4, 3))
+    g = torch.ones(4, 3)
+    assert h.resolve(g)[0] == 0 and h.resolve(g)[1] is g
+    labels = torch.zeros(4, 3)
+    h.deferred = ('bce', labels)
+    assert h.resolve(g)[0] == 0                       # a real dlogits tensor: the plain mode
+    mode, gt, gs, lab = h.resolve(h.marker)
+    assert (mode, gt, gs) == (1, None, None) and lab is labels
+    h.deferred = ('ce', labels)
+    assert h.resolve(h.marker)[0] == 2
+    a = StatArena(torch.zeros(1), [576, 576, 128])
+    v1, v2, v3 = a.take(576), a.take(576), a.take(128)
+    assert v1.numel() == v2.numel() and v3.numel() * 576 == v1.numel() * 128 and a.buf.numel() % 4 == 0
+    with pytest.raises(Exception):
+        a.take(16)
