@@ -147,6 +147,8 @@ def algo_table(C, L):
             ('mfma', 2.0 * M * len(ds) * Cs * b * L_ + 12.0 * b * L_ * L_ * Cs),
         'conv1x1_bwd_all_sdpa': lambda dU, W, ldw, ds, Cs, m, b, L_, M, *_:
             ('mfma', 4.0 * M * len(ds) * Cs * b * L_ + 12.0 * b * L_ * L_ * Cs),
+        'conv1x1_bwd_all': lambda dU, W, ldw, ds, Cs, m, b, L_, M, *_:
+            ('mfma', 4.0 * M * len(ds) * Cs * b * L_),
         'conv1x1_bwd_weight': lambda dU, srcs, Cs, dW, ldw, db, dup, b, L_, M, *_:
             ('mfma', 2.0 * M * len(srcs) * Cs * b * L_),
         'node_mix_fwd': lambda x, y, p1, U, ch, gm, out, *_: ('hbm', T(U) + 3 * T(out)),
@@ -291,6 +293,8 @@ KERNELS_OF = {
     'conv1x1_fwd_sdpa': ('conv_pipe_fwd_sdpa_k', 'conv_fwd_sdpa_k'),
     'conv1x1_bwd_data_sdpa': ('conv_pipe_bwd_sdpa_k', 'conv_bwd_sdpa_k'),
     'conv1x1_bwd_all_sdpa': ('conv_bwd_all_pipe_k', 'conv_bwd_all_k'),
+    # (large grids run as bn_bwd_apply + data + weight launches: the units go to the data-gradient kernel)
+    'conv1x1_bwd_all': ('conv_bwd_pair_k', 'conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_bwd_k'),
     'node_mix_fwd': ('node_mix_fwd_k',), 'node_mix_ln_fwd': ('node_mix_ln_fwd_k',),
     'node_mix_bwd': ('node_mix_bwd_k',), 'node_mix_ln_bwd': ('node_mix_ln_bwd_k',),
     'bn_relu_fwd': ('bn_relu_fwd_k',), 'bn_relu_bwd': ('bn_relu_bwd_k',),

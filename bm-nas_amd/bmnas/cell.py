@@ -284,7 +284,11 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
     # search mode: the merged backward launch applies the BatchNorm input gradient while it stages its
     # operands (bmnas_conv1x1_bwd_all_sdpa, bn_U) — no launch in between
     fold_bn = attn is not None and dW is not None and FUSE_BWD_ALL and FUSE_BN_APPLY
-    if not fold_bn:
+    # a conv with no attention beside it (out_conv): BatchNorm apply + both gradients behind one C-ABI
+    # call, which is one launch at small grids
+    pair = (attn is None and dW is not None and fork is None and FUSE_BWD_PAIR
+            and len({id(s) for s in src_slots if s is not None}) == len(src_slots))
+    if not fold_bn and not pair:
         lib.bn_bwd_apply(dV, sv.U, sv.chan, bn_grad, b, sv.M, L, sv.training)
     # destinations that alias each other inside ONE data-gradient launch would race:
     # give later duplicates a scratch buffer and add it afterwards (rare: node_multiplier
@@ -300,6 +304,10 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
                 seen[id(s)] = q
             slots.append(s)
     bufs, mask = _write_group(slots)
+    if pair:
+        lib.conv1x1_bwd_all(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, sv.srcs, dW,
+                            dW.shape[1], dbias, sv.dup, (sv.U, sv.chan, bn_grad, sv.training))
+        return
     if attn is not None and dW is not None and FUSE_BWD_ALL:
         # data gradient, weight gradient and the attention backward share one grid
         lib.conv1x1_bwd_all_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, sv.srcs, dW,
@@ -379,6 +387,8 @@ FUSE_EPILOGUE = os.environ.get('BMNAS_FUSE_EPILOGUE', '1') != '0'
 FUSE_BN_FINALIZE = os.environ.get('BMNAS_FUSE_BN_FINALIZE', '1') != '0'
 # BatchNorm input gradient applied inside the merged backward GEMM launch (no bn_bwd_apply launch)
 FUSE_BN_APPLY = os.environ.get('BMNAS_FUSE_BN_APPLY', '1') != '0'
+# out_conv backward (no attention beside it): BatchNorm apply + data + weight gradient as one launch at small grids
+FUSE_BWD_PAIR = os.environ.get('BMNAS_FUSE_BWD_PAIR', '1') != '0'
 # the cell prologue inside the launch of the first step's pair sum (needs FUSE_PROLOGUE and FUSE_PAIR)
 FUSE_PROLOGUE_PAIR = os.environ.get('BMNAS_FUSE_PROLOGUE_PAIR', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)

@@ -92,6 +92,8 @@ SIGNATURES = {
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P], _I),
     'bmnas_conv1x1_bwd_all_sdpa': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _PP, _P, _I, _P, _I,
                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P, _P, _P, _I, _P], _I),
+    'bmnas_conv1x1_bwd_all': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _PP, _P, _I, _P, _I,
+                               _P, _P, _P, _I, _P], _I),
     'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_conv_family_calls': ([C.POINTER(C.c_long), _I, _I], _I),
@@ -411,6 +413,17 @@ def conv1x1_bwd_all_sdpa(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, wsrc
                                              _ptr(ln_w), _ptr(xhat), _ptr(stats), _ptr(dx), _ptr(dy),
                                              sdpa_acc_mask, Cc, drop, _ptr(bU), _ptr(bchan), _ptr(bgrad),
                                              int(btrain), _stream()), 'conv1x1_bwd_all_sdpa')
+
+
+def conv1x1_bwd_all(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, wsrcs, dW, ldw_grad, dbias, dup_cols,
+                    bn=None):
+    """bn_bwd_apply (bn = (U, chan, bn_grad, training)) + data gradient + weight gradient of a conv
+    without an attention branch; one launch at small grids."""
+    bU, bchan, bgrad, btrain = (None, None, None, 0) if bn is None else bn
+    _check(load().bmnas_conv1x1_bwd_all(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs), C_src,
+                                        acc_mask, b, L, M, _ptrs(wsrcs), dW.data_ptr(), ldw_grad,
+                                        None if dbias is None else dbias.data_ptr(), dup_cols, _ptr(bU),
+                                        _ptr(bchan), _ptr(bgrad), int(btrain), _stream()), 'conv1x1_bwd_all')
 
 
 def conv1x1_bwd_weight(dU, srcs, C_src, dW, ldw, dbias, dup_cols, b, L, M):

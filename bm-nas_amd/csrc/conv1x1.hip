@@ -1265,6 +1265,23 @@ __global__ __launch_bounds__(256) void conv_bwd_all_k(ConvArgs a, SdpaBwdArgs s,
   }
 }
 
+// The backward of a conv + BatchNorm that has no attention branch beside it (NodeCell's out_conv,
+// node_search.py:63-66) at small grids: weight-gradient tiles, then data-gradient tiles, one launch; the
+// BatchNorm input gradient is applied while the operands are staged (ConvArgs::bn_U).
+template <int KPW>
+__global__ __launch_bounds__(256) void conv_bwd_pair_k(ConvArgs a, ConvWArgs w, int gx, int n_w, int wx,
+                                                       int wy) {
+  extern __shared__ __attribute__((aligned(16))) char merged_smem[];
+  const int blk = blockIdx.x;
+  if (blk < n_w) {
+    const int bz = blk / (wx * wy), r = blk - bz * wx * wy;
+    conv_w_body<4>(w, r % wx, r / wx, bz, merged_smem);
+  } else {
+    const int t = blk - n_w;
+    conv_ksplit_body<false, 1, 1, KPW>(a, t % gx, t / gx, merged_smem);
+  }
+}
+
 template <int KC, int KCH, int NG>
 __global__ __launch_bounds__(256) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
                                                            int n_w, int wx, int wy) {
@@ -1280,8 +1297,23 @@ __global__ __launch_bounds__(256) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdAr
                        s.drop, merged_smem);
   } else if (blk < s.groups + n_w) {
     const int t = blk - s.groups;
-    const int bz = t / (wx * wy), r = t - bz * wx * wy;
-    conv_w_body<4>(w, r % wx, r / wx, bz, merged_smem);
+    int bx, by, bz;
+    if (wx < 0) {
+      // XCD-aware order (workgroups go round-robin over the 8 XCDs, each with its own L2): XCD x owns
+      // batch split x / 2 and one half of the output-channel tiles, so its L2 fetches 1/8 of dU (and U)
+      // and 1/4 of the sources instead of every XCD fetching all of them.  Speed only: any
+      // placement gives the same tiles.
+      const int hw = (-wx) >> 1, x = blk & 7, q = t >> 3;
+      bz = x >> 1;
+      bx = (x & 1) * hw + q % hw;
+      by = q / hw;
+    } else {
+      bz = t / (wx * wy);
+      const int r = t - bz * wx * wy;
+      bx = r % wx;
+      by = r / wx;
+    }
+    conv_w_body<4>(w, bx, by, bz, merged_smem);
   } else {
     const int t = blk - s.groups - n_w;
     conv_pipe_bwd_body<KC, NG>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
@@ -1302,7 +1334,7 @@ __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W
 // Which GEMM family a call was dispatched to (diagnostics for tests/test_dispatch_gpu.py: host-side
 // counters, never read by a kernel).  Order = bmnas_conv_family_name().
 enum ConvFamily { F_NJ, F_KSPLIT, F_PIPE_FWD, F_PIPE_BWD, F_LDS, F_FWD_SDPA_PIPE, F_FWD_SDPA_KSPLIT,
-                  F_BWD_SDPA_KSPLIT, F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_COUNT };
+                  F_BWD_SDPA_KSPLIT, F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_BWD_PAIR, F_COUNT };
 long g_family_calls[F_COUNT] = {0};
 #define BMNAS_COUNT(f) (++g_family_calls[f])
 
@@ -1756,15 +1788,18 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
       dim3 grid((unsigned)(s.groups + n_w + gx * gy));
       const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()),
                                   (conv_pipe_bwd_lds<48, 2>(a.L)) + (a.bn_U ? (size_t)a.I * sizeof(float4) : 0));
+    // negative wx = XCD-aware weight-gradient tile order (see the kernel)
+    static const bool no_xcd = getenv("BMNAS_CONVW_XCD") && atoi(getenv("BMNAS_CONVW_XCD")) == 0;
+    const int wxa = (!no_xcd && wgrid.z == 4 && wgrid.x % 2 == 0) ? -(int)wgrid.x : (int)wgrid.x;
 #define PB_CASE(K)                                                                                     \
   if (!done && kch == K) {                                                                             \
     BMNAS_COUNT(F_BWD_ALL_PIPE);                                                                       \
     if (ngv == 1)                                                                                      \
       hipLaunchKernelGGL((conv_bwd_all_pipe_k<48, K, 1>), grid, dim3(256), lds, st, a, s, w, gx, n_w,  \
-                         (int)wgrid.x, (int)wgrid.y);                                                  \
+                         wxa, (int)wgrid.y);                                                  \
     else                                                                                               \
       hipLaunchKernelGGL((conv_bwd_all_pipe_k<48, K, 2>), grid, dim3(256), lds, st, a, s, w, gx, n_w,  \
-                         (int)wgrid.x, (int)wgrid.y);                                                  \
+                         wxa, (int)wgrid.y);                                                  \
     done = true;                                                                                       \
   }
       PB_CASE(1) PB_CASE(2) PB_CASE(3) PB_CASE(4)
@@ -1806,6 +1841,67 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   return 0;
 }
 
+extern "C" int bmnas_conv1x1_bwd_all(const float* dU, const float* W, int ldw, int fold_cols,
+                                     float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
+                                     int b, int L, int M, const float* const* wsrcs, float* dW,
+                                     int ldw_grad, float* dbias, int dup_cols, const float* bn_U,
+                                     const float* bn_chan, const float* bn_grad, int bn_training,
+                                     void* stream) {
+  if (bn_U != nullptr && (!bn_chan || (bn_training && !bn_grad))) return BMNAS_E_ARG;
+  if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
+  if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
+  if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
+  if (C_src % 16 || M % 16 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
+  ConvWArgs w{};
+  dim3 wgrid;
+  if (int e = fill_w_args(w, dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, 4, &wgrid))
+    return e;
+  ConvArgs a{};
+  if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
+  if (b == 0) return 0;
+  a.act.p[0] = dU;
+  for (int q = 0; q < n_src; ++q) a.dst.p[q] = dsrcs[q];
+  a.W = W; a.bias = nullptr; a.part = nullptr; a.ldw = ldw;
+  a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
+  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = conv_probe(); a.fold = fold_cols;
+  hipStream_t st = (hipStream_t)stream;
+  // merged where bmnas_conv1x1_bwd_data would take the 1x1-tile split-K kernel anyway (small grids:
+  // every launch there is at the ~4.5 us floor, so two launches fewer is the whole gain)
+  const long jt = a.J / 16, ng = a.n_groups;
+  const int kpw = (a.I / 16 + 3) / 4;
+  const bool pipe = conv_pipe_mode() && a.fold == 0 && a.I % 48 == 0 && a.ldw % 4 == 0 &&
+                    ((ng + 1) / 2) * ((a.J + kPipeBJ - 1) / kPipeBJ) >= 96;
+  const bool merged = !pipe && ((ng + 1) / 2) * ((jt + 1) / 2) < 1024 && kpw <= 4 &&
+                      kpw * 4 * 3 + 4 <= 232;
+  if (!merged) {
+    if (bn_U != nullptr)
+      if (int e = bmnas_bn_bwd_apply(const_cast<float*>(dU), bn_U, bn_chan, bn_grad, b, M, L, bn_training, stream))
+        return e;
+    if (int e = bmnas_conv1x1_bwd_data(dU, W, ldw, fold_cols, dsrcs, n_src, C_src, accumulate_mask, b, L, M,
+                                       stream))
+      return e;
+    return bmnas_conv1x1_bwd_weight(dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, stream);
+  }
+  if (bn_U != nullptr) {
+    a.bn_U = w.bn_U = bn_U; a.bn_chan = w.bn_chan = bn_chan; a.bn_grad = w.bn_grad = bn_grad;
+    a.bn_train = w.bn_train = bn_training;
+  }
+  const int gx = (int)ng, gy = (int)jt;
+  const int n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
+  dim3 grid((unsigned)(n_w + gx * gy));
+  const size_t lds = std::max(conv_w_lds<4>(), conv_ksplit_lds<1, 1>() + (a.bn_U ? (size_t)a.I * sizeof(float4) : 0));
+  BMNAS_COUNT(F_BWD_PAIR);
+#define BP_CASE(K)                                                                                     \
+  case K:                                                                                              \
+    hipLaunchKernelGGL((conv_bwd_pair_k<K>), grid, dim3(256), lds, st, a, w, gx, n_w, (int)wgrid.x,    \
+                       (int)wgrid.y);                                                                  \
+    break;
+  switch (kpw) { BP_CASE(1) BP_CASE(2) BP_CASE(3) BP_CASE(4) default: return BMNAS_E_LIMIT; }
+#undef BP_CASE
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int bmnas_conv_family_calls(long* out, int n, int reset) {
   if (!out && n > 0) return BMNAS_E_ARG;
   for (int i = 0; i < n && i < F_COUNT; ++i) out[i] = g_family_calls[i];
@@ -1817,7 +1913,7 @@ extern "C" int bmnas_conv_family_calls(long* out, int n, int reset) {
 extern "C" const char* bmnas_conv_family_name(int i) {
   static const char* names[F_COUNT] = {"nj", "ksplit", "pipe_fwd", "pipe_bwd", "lds", "fwd_sdpa_pipe",
                                        "fwd_sdpa_ksplit", "bwd_sdpa_ksplit", "bwd_all_pipe", "bwd_all_ksplit",
-                                       "conv_w"};
+                                       "conv_w", "bwd_pair"};
   return (i >= 0 && i < F_COUNT) ? names[i] : nullptr;
 }
 

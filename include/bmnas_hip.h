@@ -207,6 +207,17 @@ int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int ldw, int fol
                                float* dy, uint32_t sdpa_accumulate_mask, int C, bmnas_dropout_t drop,
                                const float* bn_U, const float* bn_chan, const float* bn_grad,
                                int bn_training, void* stream);
+/* The backward of a conv + BatchNorm with no attention branch beside it (NodeCell's out_conv + bn,
+ * reference models/search/darts/node_search.py:63-66): bmnas_bn_bwd_apply (when bn_U != NULL) +
+ * bmnas_conv1x1_bwd_data + bmnas_conv1x1_bwd_weight.  Small grids (where the data gradient would take
+ * the 1x1-tile split-K kernel) run as ONE launch with the BatchNorm input gradient applied while the
+ * operands are staged (dU is then left untouched); other shapes run as the three launches, dU
+ * overwritten in place by the first.  Arguments as in bmnas_conv1x1_bwd_all_sdpa. */
+int bmnas_conv1x1_bwd_all(const float* dU, const float* W, int ldw, int fold_cols, float* const* dsrcs,
+                          int n_src, int C_src, uint32_t accumulate_mask, int b, int L, int M,
+                          const float* const* wsrcs, float* dW, int ldw_grad, float* dbias,
+                          int dup_cols, const float* bn_U, const float* bn_chan, const float* bn_grad,
+                          int bn_training, void* stream);
 /* dW[m*ldw + k] += sum_{s,l} dU[s,m,l] * cat(srcs)[s,k,l];  dbias[m] += sum_{s,l} dU[s,m,l]
  * (atomic adds: caller zeroes; dbias may be NULL).  If dup_cols > 0 the same value is also
  * added at column k + dup_cols (folded x-is-y weights, see bmnas_fold_weight). */

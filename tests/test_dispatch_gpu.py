@@ -79,7 +79,7 @@ def test_standalone_conv_families(what, b, C_in, M, L, expect):
 @pytest.mark.parametrize('name,batch,expect', [
     ('mmimdb', 128, {'fwd_sdpa_pipe', 'bwd_all_pipe'}),
     ('mmimdb', 8, {'fwd_sdpa_ksplit', 'bwd_all_ksplit'}),
-    ('ntu', 64, {'fwd_sdpa_ksplit', 'bwd_all_ksplit'}),
+    ('ntu', 64, {'fwd_sdpa_ksplit', 'bwd_all_ksplit', 'bwd_pair'}),
 ])
 def test_merged_launch_families(name, batch, expect):
     """One search step; the parity of these same shapes is pinned by test_network_gpu.py
@@ -101,7 +101,7 @@ def test_every_family_is_reachable(monkeypatch):
     lib.conv_family_calls(reset=True)
     for what, b, C_in, M, L, _ in CASES:
         _conv_case(b, C_in, M, L)
-    for name, batch in (('mmimdb', 128), ('mmimdb', 8)):
+    for name, batch in (('mmimdb', 128), ('mmimdb', 8), ('ntu', 8)):      # ntu: out_conv -> bwd_pair
         cfg = fo.Cfg({**fo.CONFIGS[name], 'drpt': 0.0})
         net = build_search_net(cfg, 3, 'train_nodrop')
         xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, 3)]

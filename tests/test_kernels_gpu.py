@@ -324,6 +324,61 @@ def test_conv1x1_fwd_large_single_source(b, C, L, M, bias, stats):
             assert_close_scaled(f'm2[{gi}]', got[:, gi, 1].float(), m2.float(), rel=2e-4)
 
 
+@pytest.mark.parametrize('b,C,L,M,n_src,training,acc', [(8, 128, 8, 128, 2, True, 0), (6, 128, 8, 128, 2, True, 1),
+                                                        (64, 128, 8, 128, 2, True, 2), (48, 128, 8, 128, 3, False, 0),
+                                                        (7, 64, 4, 64, 2, True, 3), (5, 192, 16, 192, 2, True, 0),
+                                                        (128, 192, 16, 192, 2, True, 1), (250, 128, 8, 128, 2, True, 0)])
+def test_conv1x1_bwd_all_pair(b, C, L, M, n_src, training, acc):
+    """bmnas_conv1x1_bwd_all (out_conv + bn backward, node_search.py:63-66): BatchNorm input gradient,
+    data gradient and weight / bias gradient; merged launch at the small grids, three launches otherwise."""
+    from bmnas import lib
+    g = _gen(4100 + b + C + n_src)
+    dV, U = _rand(g, b, M, L), _rand(g, b, M, L) * 1.5 + 0.3
+    W = _rand(g, M, n_src * C) * 0.1
+    bn_w = _rand(g, M) * 0.3 + 1.0
+    srcs = [_rand(g, b, C, L) for _ in range(n_src)]
+    prev = [_rand(g, b, C, L) for _ in range(n_src)]
+    Ud, dVd = U.double(), dV.double()
+    N = b * L
+    if training:
+        mean = Ud.mean(dim=(0, 2))
+        rstd = 1.0 / torch.sqrt(Ud.var(dim=(0, 2), unbiased=False) + 1e-5)
+    else:
+        mean = _rand(g, M).double() * 0.2
+        rstd = 1.0 / torch.sqrt(_rand(g, M).double().abs() + 0.5)
+    xhat = (Ud - mean[None, :, None]) * rstd[None, :, None]
+    scale = rstd * bn_w.double()
+    s_dx, s_d = (dVd * xhat).sum(dim=(0, 2)), dVd.sum(dim=(0, 2))
+    if training:
+        dU = scale[None, :, None] * (dVd - s_d[None, :, None] / N - xhat * s_dx[None, :, None] / N)
+    else:
+        dU = scale[None, :, None] * dVd
+    chan = torch.cat([mean, rstd, scale, torch.zeros(M, dtype=torch.float64)]).float().to(dev())
+    bn_grad = torch.cat([s_dx, s_d]).float().to(dev())
+    dst = [p.clone().to(dev()) for p in prev]
+    dW0, db0 = _rand(g, M, n_src * C), _rand(g, M)
+    dW, db = dW0.clone().to(dev()), db0.clone().to(dev())
+    dV_dev = dV.to(dev())
+    before = lib.conv_family_calls(reset=True)
+    lib.conv1x1_bwd_all(dV_dev, W.to(dev()), n_src * C, dst, C, acc, b, L, M, 0, [x.to(dev()) for x in srcs], dW,
+                        n_src * C, db, 0, (U.to(dev()), chan, bn_grad, training))
+    fam = lib.conv_family_calls(reset=True)
+    import os
+    small = not (b == 128 and C == 192 and os.environ.get('BMNAS_CONV_PIPE', '1') != '0')
+    assert (fam['bwd_pair'] == 1) == small, fam
+    ref = torch.einsum('mc,bml->bcl', W.double(), dU)
+    for q in range(n_src):
+        want = ref[:, q * C:(q + 1) * C]
+        if acc & (1 << q):
+            want = want + prev[q].double()
+        assert_close_scaled(f'dsrc{q}', dst[q], want.float(), rel=5e-5)
+    cat = torch.cat([x.double() for x in srcs], dim=1)
+    assert_close_scaled('dW', dW, (dW0.double() + torch.einsum('bml,bkl->mk', dU, cat)).float(), rel=5e-5)
+    assert_close_scaled('dbias', db, (db0.double() + dU.sum(dim=(0, 2))).float(), rel=5e-5)
+    if small:
+        assert torch.equal(dV_dev.cpu(), dV)           # the merged launch leaves its dV operand alone
+
+
 @pytest.mark.parametrize('b,C,L,M,n_dst,acc', [(128, 192, 16, 576, 1, 1), (100, 192, 16, 576, 1, 1),
                                               (128, 192, 16, 576, 1, 0), (250, 128, 8, 384, 2, 3),
                                               (509, 64, 4, 192, 1, 1), (128, 128, 16, 128, 2, 0),
