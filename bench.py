@@ -158,6 +158,8 @@ def algo_table(C, L):
         'bn_relu_fwd': lambda U, *_: ('hbm', 2 * T(U)),
         'bn_relu_bwd': lambda g, U, *_: ('hbm', 3 * T(U)),
         'bn_bwd_apply': lambda dV, U, *_: ('hbm', 3 * T(U)),
+        'bn_relu_ln_fwd': lambda U, ch, resid, w, *_: ('hbm', 4 * T(U) + 2 * T(w)),
+        'bn_relu_ln_bwd': lambda g, o, resid, w, st, U, *_: ('hbm', 6 * T(U) + T(w)),
         'fold_weight': lambda W, We, *_: ('hbm', T(W) + T(We)),
         # K7 + classifier: three accumulator sets (logits, A, B) forward; dfeat + dW backward
         'head_fwd': lambda srcs, sums, lw, lb, W, bias, hb, st, b, Cc, L_, O: ('mfma', 6.0 * b * O * len(srcs) * Cc * L_),
@@ -298,6 +300,7 @@ KERNELS_OF = {
     'node_mix_fwd': ('node_mix_fwd_k',), 'node_mix_ln_fwd': ('node_mix_ln_fwd_k',),
     'node_mix_bwd': ('node_mix_bwd_k',), 'node_mix_ln_bwd': ('node_mix_ln_bwd_k',),
     'bn_relu_fwd': ('bn_relu_fwd_k',), 'bn_relu_bwd': ('bn_relu_bwd_k',),
+    'bn_relu_ln_fwd': ('bn_relu_ln_fwd_k',), 'bn_relu_ln_bwd': ('bn_relu_ln_bwd_k',),
     'bn_glu_fwd': ('bn_glu_fwd_k',), 'bn_glu_bwd': ('bn_glu_bwd_k',),
     'bn_bwd_apply': ('bn_bwd_apply_k',), 'bn_finalize': ('bn_finalize_k',), 'fold_weight': ('fold_weight_k',),
     'linear_fwd': ('linear_fwd_k',), 'linear_bwd': ('linear_bwd_k',),

@@ -389,6 +389,11 @@ FUSE_BN_FINALIZE = os.environ.get('BMNAS_FUSE_BN_FINALIZE', '1') != '0'
 FUSE_BN_APPLY = os.environ.get('BMNAS_FUSE_BN_APPLY', '1') != '0'
 # out_conv backward (no attention beside it): BatchNorm apply + data + weight gradient as one launch at small grids
 FUSE_BWD_PAIR = os.environ.get('BMNAS_FUSE_BWD_PAIR', '1') != '0'
+# NodeCell tail with node_multiplier != 1: BatchNorm + ReLU + dropout + residual + LayerNorm as one launch per
+# direction (one workgroup per sample; above BN_TAIL_MAX_B samples the per-sample BatchNorm atomics of its
+# backward would serialise, and the streaming kernels take over)
+FUSE_BN_TAIL = os.environ.get('BMNAS_FUSE_BN_TAIL', '1') != '0'
+BN_TAIL_MAX_B = 128
 # the cell prologue inside the launch of the first step's pair sum (needs FUSE_PROLOGUE and FUSE_PAIR)
 FUSE_PROLOGUE_PAIR = os.environ.get('BMNAS_FUSE_PROLOGUE_PAIR', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
@@ -529,6 +534,13 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
                                         NP.bn_rm, NP.bn_rv, NP.bn_nbt, training, stats=stats)
         sv.d_out = DROP.make(NP.out_p, x.numel(), training)
         o = torch.empty_like(x)
+        sv.fused_bn_tail = FUSE_BN_TAIL and b <= BN_TAIL_MAX_B and C <= 1024
+        if sv.fused_bn_tail:             # BatchNorm + ReLU + dropout + residual + LayerNorm: one launch
+            out = torch.empty_like(x)
+            lib.bn_relu_ln_fwd(V, chan, x, NP.ln_w, NP.ln_b, o, out, sv.stats, b, C, L, sv.d_out,
+                               sv.oconv.fin, sv.osum)
+            sv.o = o
+            return out, sv
         lib.bn_relu_fwd(V, chan, o, b, C, L, sv.d_out, sv.oconv.fin)
     else:
         o = tail[0]
@@ -551,13 +563,18 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
     tail = list(range(2 + ns - nm, 2 + ns))
     resid = None if sv.fused_tail else x                 # fused: sv.o already holds o + x
     if nm != 1:
-        d_o = GradSlot(x)
-        bufs, mask = _write_group([d_o])
-        racc = x_slot.acc_bit()
-        lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
-                       mask | (racc << 31), None, None, b, C, L, False)
         dV = _empty(x, b, C, L)
-        lib.bn_relu_bwd(d_o.buf(), sv.oconv.U, sv.oconv.chan, dV, NG.bn_grad, b, C, L, sv.d_out)
+        if sv.fused_bn_tail:
+            racc = x_slot.acc_bit()
+            lib.bn_relu_ln_bwd(g, sv.o, x, NP.ln_w, sv.stats, sv.oconv.U, sv.oconv.chan, dV, NG.bn_grad,
+                               x_slot.buf(), racc, b, C, L, sv.d_out)
+        else:
+            d_o = GradSlot(x)
+            bufs, mask = _write_group([d_o])
+            racc = x_slot.acc_bit()
+            lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
+                           mask | (racc << 31), None, None, b, C, L, False)
+            lib.bn_relu_bwd(d_o.buf(), sv.oconv.U, sv.oconv.chan, dV, NG.bn_grad, b, C, L, sv.d_out)
         conv_bn_bwd(sv.oconv, dV, NG.bn_grad, [slots[j] for j in tail],
                     NG.out_conv_dW.view(C, nm * C), NG.out_conv_db)
     else:

@@ -107,6 +107,8 @@ SIGNATURES = {
     'bmnas_bn_glu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_fwd': ([_P, _P, BnFin, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_bn_relu_ln_fwd': ([_P, _P, BnFin, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P, _P], _I),
+    'bmnas_bn_relu_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_bwd_apply': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_linear_fwd': ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
     'bmnas_linear_bwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
@@ -496,6 +498,18 @@ def bn_relu_fwd(U, chan, out, b, M, L, drop, fin=NO_FIN):
 def bn_relu_bwd(g, U, chan, dV, bn_grad, b, M, L, drop):
     _check(load().bmnas_bn_relu_bwd(_ptr(g), _ptr(U), _ptr(chan), _ptr(dV), _ptr(bn_grad), b, M, L, drop,
                                     _stream()), 'bn_relu_bwd')
+
+
+def bn_relu_ln_fwd(U, chan, resid, ln_w, ln_b, o, out, stats, b, Cc, L, drop, fin=NO_FIN, out_sums=None):
+    _check(load().bmnas_bn_relu_ln_fwd(_ptr(U), _ptr(chan), fin, _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(o),
+                                       _ptr(out), _ptr(stats), b, Cc, L, drop, _ptr(out_sums), _stream()),
+           'bn_relu_ln_fwd')
+
+
+def bn_relu_ln_bwd(g, o, resid, ln_w, stats, U, chan, dV, bn_grad, dresid, acc_resid, b, Cc, L, drop):
+    _check(load().bmnas_bn_relu_ln_bwd(_ptr(g), _ptr(o), _ptr(resid), _ptr(ln_w), _ptr(stats), _ptr(U),
+                                       _ptr(chan), _ptr(dV), _ptr(bn_grad), _ptr(dresid), int(acc_resid), b, Cc,
+                                       L, drop, _stream()), 'bn_relu_ln_bwd')
 
 
 def bn_bwd_apply(dV, U, chan, bn_grad, b, M, L, training):

@@ -512,6 +512,172 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g
   }
 }
 
+// NodeCell's tail with node_multiplier != 1 (node_search.py:64-69) as ONE launch per direction:
+//   o = dropout(relu(bn(U)));  out = LayerNorm(o + resid)
+// One workgroup per sample (the LayerNorm's two reductions stay in registers); the BatchNorm is
+// finalised by every workgroup at its start (bn_fin.hpp).  o is written out as well: the batched
+// LayerNorm-affine gradient of the backward epilogue reads the LayerNorm input from it.
+template <int VPT, int BS>
+__global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
+    const float* __restrict__ U, float* __restrict__ chan, BnFin fin, const float* __restrict__ resid,
+    const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* __restrict__ o_out,
+    float* __restrict__ out, float* __restrict__ stats, int b, int C, int L, DropCfg d,
+    float* __restrict__ osum) {
+  __shared__ float red[8];
+  __shared__ float red6[8 * 6];
+  extern __shared__ float fin_lds[];
+  const int cl4 = C * L / 4, l4n = L / 4;
+  const int smp = blockIdx.x;
+  float* sc = fin_lds;
+  float* sh = fin_lds + C;
+  float4 v[VPT], lw[VPT], lb[VPT], rv[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {                     // every global load first, then the finalisation
+    const int r = threadIdx.x + k * BS;
+    v[k] = lw[k] = lb[k] = rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < cl4) {
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      lw[k] = ld4(ln_w + (int64_t)r * 4);
+      lb[k] = ld4(ln_b + (int64_t)r * 4);
+      v[k] = ld4(U + e);
+      rv[k] = ld4(resid + e);
+    }
+  }
+  bn_fin_fill<BS>(fin, chan, C, b * L, sc, sh, blockIdx.x == 0);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * BS;
+    if (r < cl4) {
+      const int c = r / l4n;
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      const float4 a = affine4(v[k], sc[c], sh[c]);
+      const float4 m = drop_mult4(d, (uint64_t)e);
+      const float4 o = make_float4(fmaxf(a.x, 0.f) * m.x, fmaxf(a.y, 0.f) * m.y, fmaxf(a.z, 0.f) * m.z,
+                                   fmaxf(a.w, 0.f) * m.w);
+      st4(o_out + e, o);
+      v[k] = f4_add(o, rv[k]);
+      sum += f4_hsum(v[k]);
+    }
+  }
+  const float inv_d = 1.f / (float)(cl4 * 4);
+  const float mean = block_sum<BS / 64>(sum, red) * inv_d;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // see node_mix_ln_fwd_k
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * BS;
+    if (r < cl4) {
+      const float4 cdev = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
+      acc[0] += f4_dot(cdev, cdev);
+      if (osum != nullptr) {
+        const float4 cw = f4_mul(cdev, lw[k]);
+        acc[1] += f4_hsum(cw);
+        acc[2] += f4_dot(cw, cw);
+        acc[3] += f4_dot(cw, lb[k]);
+        acc[4] += f4_hsum(lb[k]);
+        acc[5] += f4_dot(lb[k], lb[k]);
+      }
+    }
+  }
+  if (osum != nullptr) {
+    block_sum_lead<BS / 64, 6>(acc, red6);
+  } else {
+    acc[0] = block_sum<BS / 64>(acc[0], red);
+  }
+  const float var = acc[0] * inv_d;
+  const float rstd = 1.f / sqrtf(var + kEps);
+  if (threadIdx.x == 0) {
+    stats[2 * smp] = mean;
+    stats[2 * smp + 1] = rstd;
+    if (osum != nullptr) {
+      osum[2 * smp] = rstd * acc[1] + acc[4];
+      osum[2 * smp + 1] = rstd * rstd * acc[2] + 2.f * rstd * acc[3] + acc[5];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * BS;
+    if (r < cl4) {
+      const float4 w = lw[k], bb = lb[k];
+      st4(out + ((int64_t)smp * cl4 + r) * 4,
+          make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
+                      (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w));
+    }
+  }
+}
+
+// Backward of the same tail: LayerNorm input gradient dx (added to / written as the residual's
+// gradient), then through dropout and ReLU to dV (the gradient w.r.t. the BatchNorm output) plus the
+// BatchNorm reductions bn_grad = (sum dV * u_hat | sum dV) — one atomic pair per channel per sample.
+template <int VPT, int BS>
+__global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
+    const float* __restrict__ g, const float* __restrict__ o, const float* __restrict__ resid,
+    const float* __restrict__ ln_w, const float* __restrict__ stats, const float* __restrict__ U,
+    const float* __restrict__ chan, float* __restrict__ dV, float* bn_grad, float* dresid, int acc_resid,
+    int b, int C, int L, DropCfg d) {
+  __shared__ float red[8];
+  const int cl4 = C * L / 4, l4n = L / 4;
+  const int smp = blockIdx.x;
+  const float mean = stats[2 * smp], rstd = stats[2 * smp + 1];
+  float4 xh[VPT], dxh[VPT], u[VPT], old[VPT];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * BS;
+    xh[k] = dxh[k] = u[k] = old[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < cl4) {
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      const float4 x = f4_add(ld4(o + e), ld4(resid + e));
+      const float4 w = ld4(ln_w + (int64_t)r * 4);
+      const float4 gy = ld4(g + e);
+      u[k] = ld4(U + e);
+      if (acc_resid) old[k] = ld4(dresid + e);
+      xh[k] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+      dxh[k] = f4_mul(gy, w);
+      s1 += f4_hsum(dxh[k]);
+      s2 += f4_dot(dxh[k], xh[k]);
+    }
+  }
+  const float inv_d = 1.f / (float)(cl4 * 4);
+  const float m1 = block_sum<BS / 64>(s1, red) * inv_d;
+  const float m2 = block_sum<BS / 64>(s2, red) * inv_d;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int r = threadIdx.x + k * BS;
+    const bool act = r < cl4;
+    const int c = act ? r / l4n : 0;
+    float sw = 0.f, sb = 0.f;
+    if (act) {
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      float4 dx;
+      dx.x = rstd * (dxh[k].x - m1 - xh[k].x * m2);
+      dx.y = rstd * (dxh[k].y - m1 - xh[k].y * m2);
+      dx.z = rstd * (dxh[k].z - m1 - xh[k].z * m2);
+      dx.w = rstd * (dxh[k].w - m1 - xh[k].w * m2);
+      if (dresid != nullptr) st4(dresid + e, f4_add(dx, old[k]));
+      const float mu = chan[c], rs = chan[C + c], scv = chan[2 * C + c], shv = chan[3 * C + c];
+      const float4 m = drop_mult4(d, (uint64_t)e);
+      const float uq[4] = {u[k].x, u[k].y, u[k].z, u[k].w}, gq[4] = {dx.x, dx.y, dx.z, dx.w},
+                  mq[4] = {m.x, m.y, m.z, m.w};
+      float dv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float a = fmaf(uq[t], scv, shv);
+        dv[t] = (a > 0.f) ? gq[t] * mq[t] : 0.f;
+        sw += dv[t] * (uq[t] - mu) * rs;
+        sb += dv[t];
+      }
+      st4(dV + e, make_float4(dv[0], dv[1], dv[2], dv[3]));
+    }
+    sw = row_sum(sw, l4n);
+    sb = row_sum(sb, l4n);
+    if (act && (r % l4n) == 0) {
+      atomicAdd(bn_grad + c, sw);
+      atomicAdd(bn_grad + C + c, sb);
+    }
+  }
+}
+
 // dU = scale * (dV - db/N - u_hat * dw/N)   (training);  dU = scale * dV  (eval)
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(float* __restrict__ dV,
                                                       const float* __restrict__ U,
@@ -911,6 +1077,75 @@ extern "C" int bmnas_bn_relu_bwd(const float* g, const float* U, const float* ch
   dim3 grid((ml4 + 63) / 64, (b + chunk - 1) / chunk);
   hipLaunchKernelGGL(bn_relu_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, U, chan, dV, bn_grad,
                      b, M, L, chunk, to_cfg(drop));
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_bn_relu_ln_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, const float* resid,
+                                    const float* ln_w, const float* ln_b, float* o, float* out, float* stats,
+                                    int b, int C, int L, bmnas_dropout_t drop, float* out_sums,
+                                    void* stream) {
+  if (!U || !chan || !resid || !ln_w || !ln_b || !o || !out || !stats || b < 0 || C < 1) return BMNAS_E_ARG;
+  if (L % 4 || L > 16 || C % 4) return BMNAS_E_SHAPE;
+  BnFin f;
+  if (int e = to_fin(fin, &f)) return e;
+  if (f.on && f.training && b * L < 2) return BMNAS_E_ARG;
+  if (b == 0) return 0;
+  const size_t fin_lds = (size_t)2 * C * sizeof(float);
+  const bool wide = b <= 256 && C * L / 4 >= 512;
+  const int bs = wide ? 512 : 256;
+  const int need = (C * L / 4 + bs - 1) / bs;
+  if (C > 4 * bs) return BMNAS_E_LIMIT;                 // bn_fin_fill: one trip
+  hipStream_t st = (hipStream_t)stream;
+#define BRL(V)                                                                                          \
+  do {                                                                                                  \
+    if (wide)                                                                                           \
+      hipLaunchKernelGGL((bn_relu_ln_fwd_k<V, 512>), dim3(b), dim3(512), fin_lds, st, U, chan, f, resid, \
+                         ln_w, ln_b, o, out, stats, b, C, L, to_cfg(drop), out_sums);                   \
+    else                                                                                                \
+      hipLaunchKernelGGL((bn_relu_ln_fwd_k<V, 256>), dim3(b), dim3(256), fin_lds, st, U, chan, f, resid, \
+                         ln_w, ln_b, o, out, stats, b, C, L, to_cfg(drop), out_sums);                   \
+  } while (0)
+  if (need <= 1) BRL(1);
+  else if (need <= 2) BRL(2);
+  else if (need <= 3) BRL(3);
+  else if (need <= 4) BRL(4);
+  else if (need <= 8) BRL(8);
+  else return BMNAS_E_LIMIT;
+#undef BRL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_bn_relu_ln_bwd(const float* g, const float* o, const float* resid, const float* ln_w,
+                                    const float* stats, const float* U, const float* chan, float* dV,
+                                    float* bn_grad, float* dresid, int accumulate_resid, int b, int C,
+                                    int L, bmnas_dropout_t drop, void* stream) {
+  if (!g || !o || !resid || !ln_w || !stats || !U || !chan || !dV || !bn_grad || b < 0 || C < 1)
+    return BMNAS_E_ARG;
+  if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
+  if (accumulate_resid && !dresid) return BMNAS_E_ARG;
+  if (b == 0) return 0;
+  const bool wide = b <= 256 && C * L / 4 >= 512;
+  const int bs = wide ? 512 : 256;
+  const int need = (C * L / 4 + bs - 1) / bs;
+  hipStream_t st = (hipStream_t)stream;
+#define BRL(V)                                                                                          \
+  do {                                                                                                  \
+    if (wide)                                                                                           \
+      hipLaunchKernelGGL((bn_relu_ln_bwd_k<V, 512>), dim3(b), dim3(512), 0, st, g, o, resid, ln_w, stats, \
+                         U, chan, dV, bn_grad, dresid, accumulate_resid, b, C, L, to_cfg(drop));        \
+    else                                                                                                \
+      hipLaunchKernelGGL((bn_relu_ln_bwd_k<V, 256>), dim3(b), dim3(256), 0, st, g, o, resid, ln_w, stats, \
+                         U, chan, dV, bn_grad, dresid, accumulate_resid, b, C, L, to_cfg(drop));        \
+  } while (0)
+  if (need <= 1) BRL(1);
+  else if (need <= 2) BRL(2);
+  else if (need <= 3) BRL(3);
+  else if (need <= 4) BRL(4);
+  else if (need <= 8) BRL(8);
+  else return BMNAS_E_LIMIT;
+#undef BRL
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

@@ -307,6 +307,22 @@ int bmnas_bn_relu_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, float* ou
 int bmnas_bn_relu_bwd(const float* g, const float* U, const float* chan, float* dV, float* bn_grad,
                       int b, int M, int L, bmnas_dropout_t drop, void* stream);
 
+/* NodeCell's whole tail for node_multiplier != 1 (reference node_search.py:64-69) as one launch per
+ * direction:  o = dropout(relu(bn(U)));  out = LayerNorm_[C,L](o + resid).
+ * fwd: U (b, C, L) raw out_conv output; chan / fin as in bmnas_bn_relu_fwd; o and out (b, C, L) written;
+ * stats (b, 2) = per-sample (mean, rstd) of the LayerNorm; out_sums (b, 2) nullable = per-sample
+ * (sum, sum of squares) of out (for bmnas_head_fwd).
+ * bwd: g = grad of out.  dresid (=|+= by accumulate_resid; nullable) gets the LayerNorm input gradient,
+ * dV (b, C, L) the gradient w.r.t. the BatchNorm output, bn_grad (2C, caller-zeroed) += (sum dV * u_hat |
+ * sum dV) by atomics.  Replaces bmnas_cat_ln_bwd + bmnas_bn_relu_bwd. */
+int bmnas_bn_relu_ln_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, const float* resid,
+                         const float* ln_w, const float* ln_b, float* o, float* out, float* stats, int b,
+                         int C, int L, bmnas_dropout_t drop, float* out_sums, void* stream);
+int bmnas_bn_relu_ln_bwd(const float* g, const float* o, const float* resid, const float* ln_w,
+                         const float* stats, const float* U, const float* chan, float* dV, float* bn_grad,
+                         float* dresid, int accumulate_resid, int b, int C, int L, bmnas_dropout_t drop,
+                         void* stream);
+
 /* Backward, phase B: BatchNorm input gradient, in place on dV (b, M, L):
  *   training: dU = scale*(dV - bn_grad[M+m]/N - u_hat*bn_grad[m]/N), N = b*L;  eval: dU = scale*dV. */
 int bmnas_bn_bwd_apply(float* dV, const float* U, const float* chan, const float* bn_grad, int b,

@@ -324,6 +324,52 @@ def test_conv1x1_fwd_large_single_source(b, C, L, M, bias, stats):
             assert_close_scaled(f'm2[{gi}]', got[:, gi, 1].float(), m2.float(), rel=2e-4)
 
 
+@pytest.mark.parametrize('b,C,L,acc,sums', [(8, 128, 8, 0, True), (6, 128, 8, 1, False), (64, 128, 8, 1, True),
+                                            (5, 192, 16, 0, True), (3, 16, 4, 1, False), (100, 256, 16, 0, True)])
+def test_bn_relu_ln_tail(b, C, L, acc, sums):
+    """bmnas_bn_relu_ln_fwd / _bwd (NodeCell tail, node_search.py:64-69, dropout off) against
+    float64 autograd: o = relu(bn(U)), out = LN(o + x); dV, the BatchNorm reductions, the residual gradient."""
+    from bmnas import lib
+    g = _gen(7700 + b + C)
+    U, x, gy = _rand(g, b, C, L), _rand(g, b, C, L), _rand(g, b, C, L)
+    ln_w, ln_b = _rand(g, C, L) * 0.3 + 1.0, _rand(g, C, L) * 0.2
+    bn_w, bn_b = _rand(g, C) * 0.3 + 1.0, _rand(g, C) * 0.2
+    prev = _rand(g, b, C, L)
+    Ud = U.double()
+    mean = Ud.mean(dim=(0, 2))
+    rstd = 1.0 / torch.sqrt(Ud.var(dim=(0, 2), unbiased=False) + 1e-5)
+    scale = rstd * bn_w.double()
+    shift = bn_b.double() - mean * scale
+    V = (Ud * scale[None, :, None] + shift[None, :, None]).requires_grad_(True)
+    xd = x.double().requires_grad_(True)
+    o_ref = torch.relu(V)
+    out_ref = F.layer_norm(o_ref + xd, [C, L], ln_w.double(), ln_b.double(), 1e-5)
+    out_ref.backward(gy.double())
+    chan = torch.cat([mean, rstd, scale, shift]).float().to(dev())
+    o, out = torch.empty(b, C, L, device=dev()), torch.empty(b, C, L, device=dev())
+    stats = torch.empty(b, 2, device=dev())
+    osum = torch.empty(b, 2, device=dev()) if sums else None
+    nodrop = lib.NO_DROP
+    lib.bn_relu_ln_fwd(U.to(dev()), chan, x.to(dev()), ln_w.to(dev()), ln_b.to(dev()), o, out, stats, b, C, L,
+                       nodrop, lib.NO_FIN, osum)
+    assert_close_scaled('o', o, o_ref.detach().float(), rel=2e-5)
+    assert_close_scaled('out', out, out_ref.detach().float(), rel=5e-5)
+    if sums:
+        want = torch.stack([out_ref.detach().sum(dim=(1, 2)), (out_ref.detach() ** 2).sum(dim=(1, 2))], dim=1)
+        assert_close_scaled('out_sums', osum, want.float(), rel=1e-4)
+    dV = torch.empty(b, C, L, device=dev())
+    bn_grad = torch.zeros(2 * C, device=dev())
+    dres = prev.clone().to(dev())
+    lib.bn_relu_ln_bwd(gy.to(dev()), o, x.to(dev()), ln_w.to(dev()), stats, U.to(dev()), chan, dV, bn_grad, dres,
+                       acc, b, C, L, nodrop)
+    assert_close_scaled('dV', dV, V.grad.float(), rel=1e-4)
+    want_res = xd.grad + (prev.double() if acc else 0.0)
+    assert_close_scaled('dresid', dres, want_res.float(), rel=1e-4)
+    xhat = (Ud - mean[None, :, None]) * rstd[None, :, None]
+    want_bn = torch.cat([(V.grad * xhat).sum(dim=(0, 2)), V.grad.sum(dim=(0, 2))])
+    assert_close_scaled('bn_grad', bn_grad, want_bn.float(), rel=1e-4)
+
+
 @pytest.mark.parametrize('b,C,L,M,n_src,training,acc', [(8, 128, 8, 128, 2, True, 0), (6, 128, 8, 128, 2, True, 1),
                                                         (64, 128, 8, 128, 2, True, 2), (48, 128, 8, 128, 3, False, 0),
                                                         (7, 64, 4, 64, 2, True, 3), (5, 192, 16, 192, 2, True, 0),
