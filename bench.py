@@ -151,10 +151,12 @@ def algo_table(C, L):
             ('mfma', 4.0 * M * len(ds) * Cs * b * L_),
         'conv1x1_bwd_weight': lambda dU, srcs, Cs, dW, ldw, db, dup, b, L_, M, *_:
             ('mfma', 2.0 * M * len(srcs) * Cs * b * L_),
-        'node_mix_fwd': lambda x, y, p1, U, ch, gm, out, *_: ('hbm', T(U) + 3 * T(out)),
+        'node_mix_fwd': lambda x, y, p1, U, ch, gm, out, b, Cc, L_, dg, df, fin=None, nxt=None:
+            ('hbm', T(U) + 3 * T(out) + (0 if nxt is None else (len(nxt[0]) + 1) * T(out))),
         'node_mix_ln_fwd': lambda x, y, p1, U, ch, gm, resid, w, b_, pre, out, *_:
             ('hbm', T(U) + 5 * T(out) + 2 * T(w)),
-        'node_mix_bwd': lambda g, x, y, p1, U, *_: ('hbm', 2 * T(U) + 4 * T(g)),
+        'node_mix_bwd': lambda g, x, y, p1, U, ch, gm, dgm, dx, dy, m, dV, bg, b, Cc, L_, dg, df, sh=1, st=0, nxt=None:
+            ('hbm', 2 * T(U) + 4 * T(x) + (0 if nxt is None else (2 * len(nxt[0]) + 4) * T(x))),
         'bn_relu_fwd': lambda U, *_: ('hbm', 2 * T(U)),
         'bn_relu_bwd': lambda g, U, *_: ('hbm', 3 * T(U)),
         'bn_bwd_apply': lambda dV, U, *_: ('hbm', 3 * T(U)),

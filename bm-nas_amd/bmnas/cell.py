@@ -336,7 +336,7 @@ class MixedSaved:
     pass
 
 
-def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None):
+def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None, nxt=None):
     """NodeMixedOp.forward (node_operations.py:118-120).  P: parameter pack of one NodeMixedOp
     (see models.search.darts.node_operations.NodeMixedOp.pack()).  x may be y (search).
     ln = (resid, ln_w, ln_b, stats): fuse the NodeCell tail `out += x; ln(out)` (node_search.py:67-68)
@@ -365,7 +365,7 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None)
     out = torch.empty_like(x)
     fin = sv.conv.fin                        # BatchNorm finalised inside the mix kernel (or NO_FIN)
     if ln is None:
-        lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc, fin)
+        lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc, fin, nxt)
     else:
         resid, ln_w, ln_b, ln_stats, out_sums = ln
         sv.pre = torch.empty_like(x)
@@ -394,6 +394,9 @@ FUSE_BWD_PAIR = os.environ.get('BMNAS_FUSE_BWD_PAIR', '1') != '0'
 # backward would serialise, and the streaming kernels take over)
 FUSE_BN_TAIL = os.environ.get('BMNAS_FUSE_BN_TAIL', '1') != '0'
 BN_TAIL_MAX_B = 128
+# the next inner step's mixed sum (and its backward) inside the previous step's mix launch
+FUSE_INNER_SUM = os.environ.get('BMNAS_FUSE_INNER_SUM', '1') != '0'
+MIX_PREV_MAX = 5
 # the cell prologue inside the launch of the first step's pair sum (needs FUSE_PROLOGUE and FUSE_PAIR)
 FUSE_PROLOGUE_PAIR = os.environ.get('BMNAS_FUSE_PROLOGUE_PAIR', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
@@ -449,9 +452,9 @@ def _attn_affine_bwd(sv, g, G, deferred=None):
                False, True)
 
 
-def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=0, deferred=None):
-    """g: grad of the mixed output.  dgamma_row (4 floats, +=), x_slot / y_slot: GradSlots
-    (y_slot None when x is y).  G: gradient pack (stack_dW, stack_dbias, stack_bn_grad,
+def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=0, deferred=None, nxt=None):
+    """g: grad of the mixed output (None with nxt: nothing accumulated yet).  nxt: see lib.node_mix_bwd.
+    dgamma_row (4 floats, +=), x_slot / y_slot: GradSlots (y_slot None when x is y).  G: gradient pack (stack_dW, stack_dbias, stack_bn_grad,
     dln_w, dln_b), all += ."""
     x, y = sv.x, sv.y
     b, C, L = x.shape
@@ -462,7 +465,9 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
         if sv.same:
             dxb, acc = x_slot.buf(), x_slot.acc_bit()
             lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
-                             dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
+                             dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride, nxt)
+            if nxt is not None:
+                g = nxt[-1]                  # the launch completed this step's gradient there
             if sv.merged and x_slot.extra is None:
                 # the attention gradient is produced next to the data-gradient GEMM, into its own
                 # buffer; whoever consumes x_slot adds the two parts (g2 / gz2 of the K1 backward)
@@ -478,7 +483,9 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
             dxb, dyb = x_slot.buf(), y_slot.buf()
             acc = x_slot.acc_bit() | (y_slot.acc_bit() << 1)
             lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, dyb, acc,
-                             dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
+                             dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride, nxt)
+            if nxt is not None:
+                g = nxt[-1]
             conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot, y_slot], G.stack_dW, G.stack_dbias, fork)
             lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, dyb, 3, b, C, L,
                             sv.d_attn)
@@ -512,12 +519,22 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
     sv.stats = _empty(x, b * 2)
     # per-sample (sum, sum of squares) of the node output, for the head's K7 LayerNorm (head.hip)
     sv.osum = _empty(x, b * 2) if want_sums else None
+    sv.next_fused = []
+    z_next = None
     for t in range(ns):
-        z = z0 if (t == 0 and z0 is not None) else mixsum_fwd(states, beta_w[offset:, 1])
+        if z_next is not None:
+            z = z_next                                   # formed by the previous step's mix launch
+        else:
+            z = z0 if (t == 0 and z0 is not None) else mixsum_fwd(states, beta_w[offset:, 1])
         last = sv.fused_tail and t == ns - 1
+        nxt, z_next = None, None
+        if FUSE_INNER_SUM and t + 1 < ns and len(states) <= MIX_PREV_MAX:
+            z_next = torch.empty_like(x)
+            nxt = (list(states), beta_w[offset + len(states):, 1], 2, z_next)
+        sv.next_fused.append(nxt is not None)
         s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
                                 (x, NP.ln_w, NP.ln_b, sv.stats, sv.osum) if last else None,
-                                None if weffs is None else weffs[t], stats)
+                                None if weffs is None else weffs[t], stats, nxt)
         sv.zs.append(z)
         sv.mixed.append(msv)
         sv.offsets.append(offset)
@@ -584,17 +601,30 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
                        mask | (racc << 31), None, None, b, C, L, False)
     _ln_affine(deferred, g, None, [sv.o], resid, NP.ln_w, NP.ln_b, sv.stats, NG.dln_w, NG.dln_b, b, C, L,
                False, False)
+    pending = None               # (gz, gz2, offset, n_in) of step t + 1's mixed sum, folded into step t's mix backward
     for t in reversed(range(ns)):
         gs = slots[2 + t].get()
-        if gs is None:
+        if gs is None and pending is None:
             continue                                    # this inner state feeds nothing
         z_slot = GradSlot(x)
+        nxt = None
+        if pending is not None:
+            gz, gz2, off_n, n_in = pending              # states[:n_in - 1] + this step's output states[n_in - 1]
+            bufs, mask = _write_group(slots[:n_in - 1])
+            g_out = slots[2 + t].buf()                  # in place when something was accumulated already
+            slots[2 + t].written = True
+            nxt = (sv.states[:n_in - 1], bufs, mask, sv.beta_w[off_n:, 1], 2, dbeta_w[off_n:, 1], NG.shards,
+                   NG.shard_stride, sv.states[n_in - 1], gz, gz2, g_out)
+            pending = None
         node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t], NG.shards, NG.shard_stride,
-                       deferred)
+                       deferred, nxt)
         if t == 0 and defer_first:
             return z_slot.buf(), z_slot.extra
         off = sv.offsets[t]
         n_in = 2 + t
+        if t >= 1 and sv.next_fused[t - 1]:
+            pending = (z_slot.buf(), z_slot.extra, off, n_in)
+            continue
         mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.beta_w[off:, 1], z_slot.buf(),
                    dbeta_w[off:, 1], 2, NG.shards, NG.shard_stride, g2=z_slot.extra)
     return None

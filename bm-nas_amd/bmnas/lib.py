@@ -99,6 +99,10 @@ SIGNATURES = {
     'bmnas_conv_family_calls': ([C.POINTER(C.c_long), _I, _I], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
+    'bmnas_node_mix_fwd_next': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _I, _I, _I, Dropout, Dropout, _PP, _I, _P, _I,
+                                 _P, _P], _I),
+    'bmnas_node_mix_bwd_next': ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32, _P, _P, _I, _I, _I,
+                                 Dropout, Dropout, _PP, _PP, _I, _U32, _P, _I, _P, _I, _I64, _P, _P, _P, _P, _P], _I),
     'bmnas_node_mix_ln_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout,
                                Dropout, _P, _P], _I),
     'bmnas_node_mix_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32, _P, _P, _I, _I, _I,
@@ -459,9 +463,16 @@ def bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan):
                                     chan.data_ptr(), _stream()), 'bn_finalize')
 
 
-def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc, fin=NO_FIN):
-    _check(load().bmnas_node_mix_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin, gamma.data_ptr(),
-                                     _ptr(out), b, Cc, L, dglu, dfc, _stream()), 'node_mix_fwd')
+def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc, fin=NO_FIN, nxt=None):
+    """nxt = (prev states, w_row0, w_stride, z_next): the next inner step's mixed sum in the same launch."""
+    if nxt is None:
+        _check(load().bmnas_node_mix_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin, gamma.data_ptr(),
+                                         _ptr(out), b, Cc, L, dglu, dfc, _stream()), 'node_mix_fwd')
+        return
+    prev, w, ws, z = nxt
+    _check(load().bmnas_node_mix_fwd_next(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin, gamma.data_ptr(),
+                                          _ptr(out), b, Cc, L, dglu, dfc, _ptrs(prev), len(prev), w.data_ptr(),
+                                          ws, _ptr(z), _stream()), 'node_mix_fwd_next')
 
 
 def node_mix_ln_fwd(x, y, p1, U, chan, gamma, resid, ln_w, ln_b, pre, out, stats, b, Cc, L, dglu, dfc,
@@ -474,11 +485,22 @@ def node_mix_ln_fwd(x, y, p1, U, chan, gamma, resid, ln_w, ln_b, pre, out, stats
 
 
 def node_mix_bwd(g, x, y, p1, U, chan, gamma, dgamma, dx, dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc,
-                 dg_shards=1, dg_stride=0):
-    _check(load().bmnas_node_mix_bwd(_ptr(g), _ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan),
-                                     gamma.data_ptr(), None if dgamma is None else dgamma.data_ptr(),
-                                     dg_shards, dg_stride, _ptr(dx), _ptr(dy), acc_mask, _ptr(dV),
-                                     _ptr(bn_grad), b, Cc, L, dglu, dfc, _stream()), 'node_mix_bwd')
+                 dg_shards=1, dg_stride=0, nxt=None):
+    """nxt = (prev, dprev, prev_acc_mask, w_row0, w_stride, dw_row0, dw_shards, dw_stride, s, gz, gz2, g_out):
+    the backward of the next inner step's mixed sum in the same launch (g: nullable, earlier contributions)."""
+    if nxt is None:
+        _check(load().bmnas_node_mix_bwd(_ptr(g), _ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan),
+                                         gamma.data_ptr(), None if dgamma is None else dgamma.data_ptr(),
+                                         dg_shards, dg_stride, _ptr(dx), _ptr(dy), acc_mask, _ptr(dV),
+                                         _ptr(bn_grad), b, Cc, L, dglu, dfc, _stream()), 'node_mix_bwd')
+        return
+    prev, dprev, pacc, w, ws, dw, dws, dwst, s, gz, gz2, g_out = nxt
+    _check(load().bmnas_node_mix_bwd_next(_ptr(g), _ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan),
+                                          gamma.data_ptr(), None if dgamma is None else dgamma.data_ptr(),
+                                          dg_shards, dg_stride, _ptr(dx), _ptr(dy), acc_mask, _ptr(dV),
+                                          _ptr(bn_grad), b, Cc, L, dglu, dfc, _ptrs(prev), _ptrs(dprev), len(prev),
+                                          pacc, w.data_ptr(), ws, dw.data_ptr(), dws, dwst, _ptr(s), _ptr(gz),
+                                          _ptr(gz2), _ptr(g_out), _stream()), 'node_mix_bwd_next')
 
 
 def bn_glu_fwd(U, chan, out, b, Cc, L, drop):
@@ -663,7 +685,8 @@ def profile_end_calls():
 
 _TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'cell_prologue_pair', 'mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
-                'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa',
+                'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa', 'conv1x1_bwd_all',
+                'bn_relu_ln_fwd', 'bn_relu_ln_bwd',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',
                 'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy', 'adam_multi')

@@ -92,11 +92,37 @@ __device__ __forceinline__ float4 affine4(float4 u, float sc, float sh) {
 }
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
 
+// The NEXT inner step's mixed sum riding in this step's mix kernel (NodeCell, node_search.py:54):
+// z_next = sum_{j < n} w_j prev_j + w_n s, with s the state this kernel produces — one launch and one
+// read of s fewer per inner step.  Backward: MixNextB (the whole bmnas_mixsum_bwd of that sum).
+constexpr int kMixPrev = 5;
+struct MixNextF {
+  const float* prev[kMixPrev];
+  const float* w;            // w[j * ws], j = 0 .. n
+  float* z;
+  int n, ws;
+};
+struct MixNextB {
+  const float* prev[kMixPrev];
+  float* dprev[kMixPrev];    // (=|+= by acc bit j) w_j G; nullable
+  const float* w;
+  float* dw;                 // dw[j * ws] += <G, prev_j> (j < n), dw[n * ws] += <G, s>; sharded like bmnas_mixsum_bwd
+  const float* s;            // the state this step produced (forward output)
+  const float* gz;           // G = gz + gz2: gradient of z_next
+  const float* gz2;          // nullable
+  const float* g_in;         // what other consumers of s already accumulated; nullable
+  float* g_out;              // g_in + w_n G: the gradient this kernel (and the attention backward after it) uses
+  int64_t dw_stride;
+  int n, ws, dw_shards;
+  uint32_t acc;
+};
+
 // s = g0*(x+y) + g1*p1 + g2*drop(va*sigmoid(vg)) + g3*drop(relu(vf))
+template <int NP>
 __global__ __launch_bounds__(256) void node_mix_fwd_k(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ p1,
     const float* __restrict__ U, float* __restrict__ chan, BnFin fin, const float* __restrict__ gamma,
-    float* __restrict__ out, int b, int C, int L, DropCfg dglu, DropCfg dfc) {
+    float* __restrict__ out, int b, int C, int L, DropCfg dglu, DropCfg dfc, MixNextF N) {
   extern __shared__ float fin_lds[];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   float* sc = fin_lds;
@@ -121,6 +147,16 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
     o.z = g0 * (xv.z + yv.z) + g1 * pv.z + g2 * (va.z * sigmoidf(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
     o.w = g0 * (xv.w + yv.w) + g1 * pv.w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
     st4(out + e, o);
+    if (NP > 0) {
+      float4 z = f4_scale(o, N.w[NP * N.ws]);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const float wj = N.w[j * N.ws];
+        const float4 pj = ld4(N.prev[j] + e);
+        z.x = fmaf(wj, pj.x, z.x); z.y = fmaf(wj, pj.y, z.y); z.z = fmaf(wj, pj.z, z.z); z.w = fmaf(wj, pj.w, z.w);
+      }
+      st4(N.z + e, z);
+    }
   }
 }
 
@@ -246,13 +282,21 @@ __device__ __forceinline__ float row_sum(float v, int l4n) {
   return v;
 }
 
+template <int NP>
 __global__ __launch_bounds__(256) void node_mix_bwd_k(
     const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ p1, const float* __restrict__ U, const float* __restrict__ chan,
     const float* __restrict__ gamma, float* dgamma, int dg_shards, int64_t dg_stride, float* dx,
     float* dy, uint32_t acc_mask, float* __restrict__ dV, float* bn_grad, int b, int C, int L,
-    int chunk, DropCfg dglu, DropCfg dfc) {
+    int chunk, DropCfg dglu, DropCfg dfc, MixNextB N) {
   __shared__ float red16[16];
+  __shared__ float redn[4 * (NP + 1)];
+  float part[NP + 1], wn[NP + 1];
+#pragma unroll
+  for (int j = 0; j <= NP; ++j) {
+    part[j] = 0.f;
+    wn[j] = (NP > 0) ? N.w[j * N.ws] : 0.f;
+  }
   __shared__ float csum[3][6][64];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;   // 64 slots x 4 sample lanes
@@ -278,7 +322,28 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
       const int64_t e = ((int64_t)s * cl4 + r) * 4;
       const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
       const float4 ua = ld4(U + ub), ug = ld4(U + ub + (int64_t)C * L), uf = ld4(U + ub + (int64_t)2 * C * L);
-      const float4 gv = ld4(g + e), xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e);
+      float4 gv;
+      if (NP > 0) {
+        // the backward of the next step's mixed sum first: it completes this step's own gradient
+        float4 G = ld4(N.gz + e);
+        if (N.gz2 != nullptr) G = f4_add(G, ld4(N.gz2 + e));
+        gv = f4_scale(G, wn[NP]);
+        if (N.g_in != nullptr) gv = f4_add(gv, ld4(N.g_in + e));
+        st4(N.g_out + e, gv);
+        part[NP] += f4_dot(G, ld4(N.s + e));
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {                     // in order: destinations may alias each other
+          part[j] += f4_dot(G, ld4(N.prev[j] + e));
+          float* d = N.dprev[j];
+          if (d == nullptr) continue;
+          float4 rr = f4_scale(G, wn[j]);
+          if (N.acc & (1u << j)) rr = f4_add(rr, ld4(d + e));
+          st4(d + e, rr);
+        }
+      } else {
+        gv = ld4(g + e);
+      }
+      const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e);
       const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
       const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
       const float uaq[4] = {ua.x, ua.y, ua.z, ua.w}, ugq[4] = {ug.x, ug.y, ug.z, ug.w},
@@ -351,6 +416,14 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
     float* p = dgamma + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % dg_shards) * dg_stride;
 #pragma unroll
     for (int q = 0; q < 4; ++q) atomicAdd(p + q, dgam[q]);
+  }
+  if (NP > 0) {
+    block_sum_lead<4, NP + 1>(part, redn);
+    if (threadIdx.x == 0) {
+      float* p = N.dw + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % N.dw_shards) * N.dw_stride;
+#pragma unroll
+      for (int j = 0; j <= NP; ++j) atomicAdd(p + j * N.ws, part[j]);
+    }
   }
 }
 
@@ -940,22 +1013,46 @@ extern "C" int bmnas_bn_finalize(const float* part, int n_part, int b, int L, in
   return 0;
 }
 
-extern "C" int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const float* U,
-                                  float* chan, bmnas_bn_fin_t fin, const float* gamma, float* out,
-                                  int b, int C, int L, bmnas_dropout_t drop_glu,
-                                  bmnas_dropout_t drop_fc, void* stream) {
-  if (!x || !y || !p1 || !U || !chan || !gamma || !out || b < 0 || C < 1) return BMNAS_E_ARG;
+extern "C" int bmnas_node_mix_fwd_next(const float* x, const float* y, const float* p1, const float* U,
+                                       float* chan, bmnas_bn_fin_t fin, const float* gamma, float* out,
+                                       int b, int C, int L, bmnas_dropout_t drop_glu,
+                                       bmnas_dropout_t drop_fc, const float* const* prev, int n_prev,
+                                       const float* w, int w_stride, float* z_next, void* stream) {
+  if (!x || !y || !p1 || !U || !chan || !gamma || !out || b < 0 || C < 1 || n_prev < 0) return BMNAS_E_ARG;
   if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (n_prev > kMixPrev) return BMNAS_E_LIMIT;
+  MixNextF N{};
+  if (n_prev > 0) {
+    if (!prev || !w || !z_next || w_stride < 1) return BMNAS_E_ARG;
+    for (int j = 0; j < n_prev; ++j) {
+      if (!prev[j]) return BMNAS_E_ARG;
+      N.prev[j] = prev[j];
+    }
+    N.w = w; N.ws = w_stride; N.z = z_next; N.n = n_prev;
+  }
   BnFin f;
   if (int e = to_fin(fin, &f)) return e;
   if (f.on && f.training && b * L < 2) return BMNAS_E_ARG;
   if (b == 0) return 0;
   const int64_t total = (int64_t)b * C * L / 4;
-  hipLaunchKernelGGL(node_mix_fwd_k, dim3(stream_grid(total)), dim3(256), (size_t)6 * C * sizeof(float),
-                     (hipStream_t)stream, x, y, p1, U, chan, f, gamma, out, b, C, L, to_cfg(drop_glu),
-                     to_cfg(drop_fc));
+#define NMF(NPv)                                                                                          \
+  case NPv:                                                                                               \
+    hipLaunchKernelGGL(node_mix_fwd_k<NPv>, dim3(stream_grid(total)), dim3(256), (size_t)6 * C * sizeof(float), \
+                       (hipStream_t)stream, x, y, p1, U, chan, f, gamma, out, b, C, L, to_cfg(drop_glu),   \
+                       to_cfg(drop_fc), N);                                                               \
+    break;
+  switch (n_prev) { NMF(0) NMF(1) NMF(2) NMF(3) NMF(4) NMF(5) default: return BMNAS_E_LIMIT; }
+#undef NMF
   BMNAS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int bmnas_node_mix_fwd(const float* x, const float* y, const float* p1, const float* U,
+                                  float* chan, bmnas_bn_fin_t fin, const float* gamma, float* out,
+                                  int b, int C, int L, bmnas_dropout_t drop_glu,
+                                  bmnas_dropout_t drop_fc, void* stream) {
+  return bmnas_node_mix_fwd_next(x, y, p1, U, chan, fin, gamma, out, b, C, L, drop_glu, drop_fc, nullptr, 0,
+                                 nullptr, 0, nullptr, stream);
 }
 
 
@@ -1000,26 +1097,60 @@ extern "C" int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float
   return 0;
 }
 
+extern "C" int bmnas_node_mix_bwd_next(const float* g, const float* x, const float* y, const float* p1,
+                                       const float* U, const float* chan, const float* gamma,
+                                       float* dgamma, int dgamma_shards, int64_t dgamma_shard_stride,
+                                       float* dx, float* dy, uint32_t accumulate_mask, float* dV,
+                                       float* bn_grad, int b, int C, int L, bmnas_dropout_t drop_glu,
+                                       bmnas_dropout_t drop_fc, const float* const* prev,
+                                       float* const* dprev, int n_prev, uint32_t prev_accumulate_mask,
+                                       const float* w, int w_stride, float* dw, int dw_shards,
+                                       int64_t dw_shard_stride, const float* s, const float* gz,
+                                       const float* gz2, float* g_out, void* stream) {
+  if (!x || !y || !p1 || !U || !chan || !gamma || !dV || !bn_grad || b < 0 || C < 1 || dgamma_shards < 1 ||
+      n_prev < 0)
+    return BMNAS_E_ARG;
+  if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
+  if (n_prev > kMixPrev) return BMNAS_E_LIMIT;
+  MixNextB N{};
+  if (n_prev > 0) {
+    // g (nullable here) is what other consumers of s accumulated; g_out receives the complete gradient
+    if (!prev || !dprev || !w || !dw || !s || !gz || !g_out || w_stride < 1 || dw_shards < 1) return BMNAS_E_ARG;
+    for (int j = 0; j < n_prev; ++j) {
+      if (!prev[j]) return BMNAS_E_ARG;
+      N.prev[j] = prev[j];
+      N.dprev[j] = dprev[j];
+    }
+    N.w = w; N.ws = w_stride; N.dw = dw; N.dw_shards = dw_shards; N.dw_stride = dw_shard_stride;
+    N.s = s; N.gz = gz; N.gz2 = gz2; N.g_in = g; N.g_out = g_out; N.n = n_prev; N.acc = prev_accumulate_mask;
+  } else if (!g) {
+    return BMNAS_E_ARG;
+  }
+  if (b == 0) return 0;
+  const int cl4 = C * L / 4;
+  const int chunk = pick_chunk(b, cl4);
+  dim3 grid((cl4 + 63) / 64, (b + chunk - 1) / chunk);
+#define NMB(NPv)                                                                                          \
+  case NPv:                                                                                               \
+    hipLaunchKernelGGL(node_mix_bwd_k<NPv>, grid, dim3(256), 0, (hipStream_t)stream, g, x, y, p1, U, chan, \
+                       gamma, dgamma, dgamma_shards, dgamma_shard_stride, dx, dy, accumulate_mask, dV,     \
+                       bn_grad, b, C, L, chunk, to_cfg(drop_glu), to_cfg(drop_fc), N);                     \
+    break;
+  switch (n_prev) { NMB(0) NMB(1) NMB(2) NMB(3) NMB(4) NMB(5) default: return BMNAS_E_LIMIT; }
+#undef NMB
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int bmnas_node_mix_bwd(const float* g, const float* x, const float* y, const float* p1,
                                   const float* U, const float* chan, const float* gamma,
                                   float* dgamma, int dgamma_shards, int64_t dgamma_shard_stride,
                                   float* dx, float* dy, uint32_t accumulate_mask, float* dV,
                                   float* bn_grad, int b, int C, int L, bmnas_dropout_t drop_glu,
                                   bmnas_dropout_t drop_fc, void* stream) {
-  if (!g || !x || !y || !p1 || !U || !chan || !gamma || !dV || !bn_grad || b < 0 || C < 1 ||
-      dgamma_shards < 1)
-    return BMNAS_E_ARG;
-  if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
-  if (b == 0) return 0;
-  const int cl4 = C * L / 4;
-  const int chunk = pick_chunk(b, cl4);
-  dim3 grid((cl4 + 63) / 64, (b + chunk - 1) / chunk);
-  hipLaunchKernelGGL(node_mix_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, x, y, p1, U, chan,
-                     gamma, dgamma, dgamma_shards, dgamma_shard_stride, dx, dy, accumulate_mask, dV, bn_grad, b, C,
-                     L, chunk,
-                     to_cfg(drop_glu), to_cfg(drop_fc));
-  BMNAS_CHECK_LAUNCH();
-  return 0;
+  return bmnas_node_mix_bwd_next(g, x, y, p1, U, chan, gamma, dgamma, dgamma_shards, dgamma_shard_stride, dx, dy,
+                                 accumulate_mask, dV, bn_grad, b, C, L, drop_glu, drop_fc, nullptr, nullptr, 0,
+                                 0, nullptr, 0, nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 

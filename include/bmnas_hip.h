@@ -293,6 +293,31 @@ int bmnas_node_mix_bwd(const float* g, const float* x, const float* y, const flo
                        uint32_t accumulate_mask, float* dV, float* bn_grad, int b, int C, int L,
                        bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
 
+/* K2 with the NEXT inner step's mixed sum riding along (NodeCell.forward, reference
+ * models/search/darts/node_search.py:52-57: step t+1 starts with z = sum_j beta_j states[j], and
+ * states[-1] is the s this launch produces):
+ *   z_next = sum_{j < n_prev} w[j*w_stride] * prev[j] + w[n_prev*w_stride] * s      (n_prev <= 5)
+ * one launch fewer per inner step; n_prev == 0: exactly bmnas_node_mix_fwd. */
+int bmnas_node_mix_fwd_next(const float* x, const float* y, const float* p1, const float* U, float* chan,
+                            bmnas_bn_fin_t fin, const float* gamma, float* out, int b, int C, int L,
+                            bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, const float* const* prev,
+                            int n_prev, const float* w, int w_stride, float* z_next, void* stream);
+/* Backward of the same: bmnas_mixsum_bwd of the next step's sum, then bmnas_node_mix_bwd, one launch.
+ * G = gz + gz2 (gz2 nullable) is the gradient of z_next; dprev[j] (=|+= by bit j of
+ * prev_accumulate_mask, nullable, may alias each other: in-order read-modify-write) gets w_j * G;
+ * dw[shard*dw_shard_stride + j*w_stride] += <G, prev_j> (j < n_prev) and <G, s> (j = n_prev);
+ * g (nullable) is what other consumers of s accumulated so far, g_out (may be g) receives the complete
+ * gradient g + w_n * G, which this launch then uses as bmnas_node_mix_bwd's g (and the attention
+ * backward launched after it must read g_out). */
+int bmnas_node_mix_bwd_next(const float* g, const float* x, const float* y, const float* p1, const float* U,
+                            const float* chan, const float* gamma, float* dgamma, int dgamma_shards,
+                            int64_t dgamma_shard_stride, float* dx, float* dy, uint32_t accumulate_mask,
+                            float* dV, float* bn_grad, int b, int C, int L, bmnas_dropout_t drop_glu,
+                            bmnas_dropout_t drop_fc, const float* const* prev, float* const* dprev,
+                            int n_prev, uint32_t prev_accumulate_mask, const float* w, int w_stride,
+                            float* dw, int dw_shards, int64_t dw_shard_stride, const float* s,
+                            const float* gz, const float* gz2, float* g_out, void* stream);
+
 /* ---- standalone LinearGLU tail (Found nets): out = drop(glu(BN(U))), U (b, 2C, L) --------
  * node_operations.py:34-38.  Backward phase A like bmnas_node_mix_bwd (M = 2C). */
 int bmnas_bn_glu_fwd(const float* U, const float* chan, float* out, int b, int C, int L,

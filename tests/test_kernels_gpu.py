@@ -324,6 +324,74 @@ def test_conv1x1_fwd_large_single_source(b, C, L, M, bias, stats):
             assert_close_scaled(f'm2[{gi}]', got[:, gi, 1].float(), m2.float(), rel=2e-4)
 
 
+@pytest.mark.parametrize('b,C,L,n_prev,have_g,alias', [(8, 128, 8, 2, True, True), (6, 128, 8, 3, False, True),
+                                                       (64, 128, 8, 2, True, False), (5, 192, 16, 4, True, False),
+                                                       (3, 16, 4, 1, False, False), (100, 64, 8, 5, True, True)])
+def test_node_mix_next_sum_matches_separate_launches(b, C, L, n_prev, have_g, alias):
+    """bmnas_node_mix_fwd_next / _bwd_next (the next inner step's mixed sum inside the mix launch,
+    node_search.py:52-57) against the separate launches they replace (bmnas_node_mix_fwd + bmnas_mixsum_fwd;
+    bmnas_mixsum_bwd + bmnas_node_mix_bwd), which the oracle tests pin."""
+    from bmnas import lib
+    g = _gen(9900 + b + C + n_prev)
+    d = dev()
+    x, p1, U = _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d), _rand(g, b, 3 * C, L).to(d)
+    gamma = torch.softmax(_rand(g, 4), 0).to(d)
+    M = 3 * C
+    Ud = U.double()
+    mean = Ud.mean(dim=(0, 2))
+    rstd = 1.0 / torch.sqrt(Ud.var(dim=(0, 2), unbiased=False) + 1e-5)
+    bn_w, bn_b = (_rand(g, M) * 0.3 + 1.0).to(d).double(), (_rand(g, M) * 0.2).to(d).double()
+    scale = rstd * bn_w
+    chan = torch.cat([mean, rstd, scale, bn_b - mean * scale]).float()
+    prev = [_rand(g, b, C, L).to(d) for _ in range(n_prev)]
+    if alias and n_prev >= 2:
+        prev[1] = prev[0]                       # search mode: x is y
+    w = torch.softmax(_rand(g, n_prev + 1, 2), -1).to(d)          # (k, 2): column 1 is the edge weight
+    nd = lib.NO_DROP
+    # forward
+    s0, z0 = torch.empty_like(x), torch.empty_like(x)
+    lib.node_mix_fwd(x, x, p1, U, chan, gamma, s0, b, C, L, nd, nd)
+    lib.mixsum_fwd(prev + [s0], w[:, 1], 2, z0)
+    s1, z1 = torch.empty_like(x), torch.empty_like(x)
+    lib.node_mix_fwd(x, x, p1, U, chan, gamma, s1, b, C, L, nd, nd, lib.NO_FIN, (prev, w[:, 1], 2, z1))
+    assert torch.equal(s0, s1)
+    assert_close_scaled('z_next', z1, z0.cpu(), rel=2e-6)
+    # backward
+    gz, gz2 = _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d)
+    g_prev = _rand(g, b, C, L).to(d) if have_g else None
+    old = [_rand(g, b, C, L).to(d) for _ in range(n_prev)]
+    if alias and n_prev >= 2:
+        old[1] = old[0]
+    acc = 0b10101 & ((1 << n_prev) - 1)
+    if alias and n_prev >= 2:
+        acc |= 2                                 # the second writer of an aliased destination accumulates
+
+    def run(fused):
+        dst = [o.clone() for o in old]
+        if alias and n_prev >= 2:
+            dst[1] = dst[0]
+        dw = torch.zeros(n_prev + 1, 2, device=d)
+        dgam = torch.zeros(4, device=d)
+        dx, dV, bn_grad = torch.empty_like(x), torch.empty(b, M, L, device=d), torch.zeros(2 * M, device=d)
+        gs = g_prev.clone() if have_g else torch.empty_like(x)
+        if fused:
+            lib.node_mix_bwd(gs if have_g else None, x, x, p1, U, chan, gamma, dgam, dx, None, 0, dV, bn_grad, b, C,
+                             L, nd, nd, 1, 0, (prev, dst, acc, w[:, 1], 2, dw[:, 1], 1, 0, s0, gz, gz2, gs))
+        else:
+            sd = torch.empty_like(x)
+            lib.mixsum_bwd(prev + [s0], dst + [gs if have_g else sd], w[:, 1], 2, gz, dw[:, 1],
+                           acc | ((1 << n_prev) if have_g else 0), 1, 0, gz2)
+            gs = gs if have_g else sd
+            lib.node_mix_bwd(gs, x, x, p1, U, chan, gamma, dgam, dx, None, 0, dV, bn_grad, b, C, L, nd, nd)
+        torch.cuda.synchronize()
+        return dict(g=gs, dx=dx, dV=dV, bn_grad=bn_grad, dgamma=dgam, dw=dw,
+                    **{f'dprev{j}': t for j, t in enumerate(dst)})
+
+    want, got = run(False), run(True)
+    for k in want:
+        assert_close_scaled(k, got[k], want[k].cpu(), rel=1e-5)
+
+
 @pytest.mark.parametrize('b,C,L,acc,sums', [(8, 128, 8, 0, True), (6, 128, 8, 1, False), (64, 128, 8, 1, True),
                                             (5, 192, 16, 0, True), (3, 16, 4, 1, False), (100, 256, 16, 0, True)])
 def test_bn_relu_ln_tail(b, C, L, acc, sums):
