@@ -1176,7 +1176,10 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
   };
   // two-set software pipeline, straight-line steady state (groups past the split are clamped +
   // zeroed by load_ops, so running one extra masked group is harmless).  Measured: 12.5 us vs
-  // 15.9 us for issuing all of a wave's loads up front.
+  // 15.9 us for issuing all of a wave's loads up front; a three-set ring with the BatchNorm fold
+  // moved to the point of use: no gain (13.6 vs 13.9 us alone, 24.4 vs 24.0 us merged).  NB: that
+  // variant with `break`s out of the ring loop was MISCOMPILED by hipcc 7.2 (wrong accumulators on
+  // the exit paths) — keep exits out of MFMA pipeline loops, predicate the tail instead.
   int g = gbeg + wave;
   load_ops(a0, b0, g);
   for (; g + NW < gend; g += 2 * NW) {
@@ -1250,6 +1253,10 @@ __global__ __launch_bounds__(256) void conv_bwd_all_k(ConvArgs a, SdpaBwdArgs s,
   constexpr int KPW = 3 * KCH;
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   const int blk = blockIdx.x;
+  // BMNAS_CONV_PROBE bits 16 / 32 / 64: as in conv_bwd_all_pipe_k (timing diagnostics only)
+  if ((a.probe & 16) && blk < s.groups) return;
+  if ((a.probe & 32) && blk >= s.groups && blk < s.groups + n_w) return;
+  if ((a.probe & 64) && blk >= s.groups + n_w) return;
   if (blk < s.groups) {
     sdpa_bwd_body<KCH>(blk, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask, s.G,
                        s.drop, merged_smem);
