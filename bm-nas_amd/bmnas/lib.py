@@ -96,6 +96,7 @@ SIGNATURES = {
                                _P, _P, _P, _I, _P], _I),
     'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
+    'bmnas_probe_read': ([_P, _I64, _I, _I, _P, _P], _I),
     'bmnas_conv_family_calls': ([C.POINTER(C.c_long), _I, _I], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
@@ -447,6 +448,11 @@ def conv_family_calls(reset=False):
     lib.bmnas_conv_family_name.restype = C.c_char_p
     lib.bmnas_conv_family_name.argtypes = [_I]
     return {lib.bmnas_conv_family_name(i).decode(): int(buf[i]) for i in range(n)}
+
+
+def probe_read(p, width, sink, row_stride=0):
+    """FETCH_SIZE calibration read of the whole tensor p (diagnostics, tools/calibrate_fetch.py)."""
+    _check(load().bmnas_probe_read(_ptr(p), p.numel(), width, row_stride, _ptr(sink), _stream()), 'probe_read')
 
 
 def fold_weight(W, Weff, M, Cc):

@@ -494,6 +494,12 @@ int bmnas_comm_init_rank(void** comm_out, int world, int rank, const void* id);
 int bmnas_comm_destroy(void* comm);
 int bmnas_allreduce_f32(float* buf, int64_t count, int average, void* comm, void* stream);
 
+/* ---- diagnostics: read-width calibration for rocprofv3's FETCH_SIZE (tools/calibrate_fetch.sh) ----
+ * Reads p[0 .. n_floats) exactly once with `width` bytes per lane per load (4, 8, 16), or (width 64) as
+ * 64-byte rows at row_stride floats — the operand pattern of the split-K GEMM kernels, which then reads
+ * 64 bytes of every row_stride * 4.  Not part of the hypernet path. */
+int bmnas_probe_read(const float* p, int64_t n_floats, int width, int row_stride, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

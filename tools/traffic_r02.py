@@ -1,9 +1,11 @@
 """profiles/<tag>_traffic.json, keyed by kernel (short name as in bench.py's roofline_kernels), from two
 rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes: TCC has 4 slots, FETCH_SIZE costs 3).
-Counter units are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly
-half the bytes of a wide coalesced 16-B-per-lane streaming read, so the read side is doubled for the
-float4-streaming kernels; WRITE_SIZE is exact for 16-B streaming stores and float atomics.  Kernels
-whose loads are mostly dword-wide (MFMA operand fetches) are uncalibrated: raw value kept, noted.
+Counter units are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the L2's
+128-byte fabric requests at 64 bytes, so the read side is doubled — for EVERY kernel: the calibration in
+profiles/r02_fetch_calibration.txt (tools/calibrate_fetch.sh: a 256 MiB buffer read once with 4 / 8 / 16
+bytes per lane and as the GEMM kernels' 64-byte operand rows) gives x2.000 for all dense patterns, and
+shows that rows using 64 of every 128 bytes still move whole 128-byte lines.  WRITE_SIZE is exact for
+16-B streaming stores and float atomics.
 usage: traffic_r02.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
 import collections
 import csv
@@ -11,8 +13,6 @@ import json
 import sys
 
 fetch_csv, write_csv, out = sys.argv[1:4]
-STREAMING = ('mixsum', 'cat_ln', 'ln_affine', 'node_mix', 'bn_', 'fold_weight', 'adam', 'backward_epilogue',
-             'cell_prologue', 'sum_chunks')
 
 
 def short(n):
@@ -37,11 +37,9 @@ for k in sorted(f):
     n = len(f[k])
     fetch = sum(f[k]) / n * 1024
     write = sum(w.get(k, [0.0])) / max(len(w.get(k, [0.0])), 1) * 1024
-    streaming = any(k.startswith(s) for s in STREAMING)
     res[k] = {'fetch_raw_bytes': round(fetch), 'write_bytes': round(write),
-              'traffic_bytes': round((2 * fetch if streaming else fetch) + write),
-              'read_correction': 'x2 (16-B/lane streaming reads, gfx950)' if streaming else
-                                 'none (dword / mixed-width operand loads: uncalibrated, could be up to x2)',
+              'traffic_bytes': round(2 * fetch + write),
+              'read_correction': 'x2 (128-B fabric requests tallied at 64 B; profiles/r02_fetch_calibration.txt)',
               'launches_sampled': n}
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
 for k, v in sorted(res.items()):
