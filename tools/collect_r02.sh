@@ -31,6 +31,7 @@ run ego_b6 --config ego --batch 6 --steps 200 --no-cpu-baseline
 run ego_b48 --config ego --batch 48 --steps 200 --no-cpu-baseline
 run mmimdb_b128_tierR --tier R --steps 200
 run ntu_b64_tierR --config ntu --batch 64 --tier R --steps 100
+run mmimdb_b1024 --batch 1024 --steps 100 --no-cpu-baseline
 # K1 (the MixedOp kernel) against the HBM roofline over the batch: launch-inclusive rocprofv3 durations
 echo "# K1 = mixsum_pair_{fwd,bwd}_k: algorithmic bytes / rocprofv3 duration / 8 TB/s, per-GPU batch sweep (MM-IMDB shapes)" > $OUT/${TAG}_k1_batch_sweep.txt
 for b in 32 64 128 256 512 1024; do
