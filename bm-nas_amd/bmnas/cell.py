@@ -286,8 +286,9 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
     fold_bn = attn is not None and dW is not None and FUSE_BWD_ALL and FUSE_BN_APPLY
     # a conv with no attention beside it (out_conv): BatchNorm apply + both gradients behind one C-ABI
     # call, which is one launch at small grids
+    live = [s for s in src_slots if s is not None]
     pair = (attn is None and dW is not None and fork is None and FUSE_BWD_PAIR
-            and len({id(s) for s in src_slots if s is not None}) == len(src_slots))
+            and len({id(s) for s in live}) == len(live))
     if not fold_bn and not pair:
         lib.bn_bwd_apply(dV, sv.U, sv.chan, bn_grad, b, sv.M, L, sv.training)
     # destinations that alias each other inside ONE data-gradient launch would race:

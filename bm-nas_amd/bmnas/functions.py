@@ -145,6 +145,45 @@ class SdpaLnFn(Function):
 
 
 # ------------------------------------------------- conv1x1 + BN + {GLU | ReLU} + dropout
+class _ZeroPool:
+    """Zero-filled scratch for the gradients that the standalone conv + BatchNorm modules accumulate with
+    atomics (bn_grad | dW | dbias per module): ONE torch.zeros per backward pass instead of one per module
+    (the six reshape layers of a step paid six ~5 us fills).  Forward calls announce their need; the first
+    backward call of a pass allocates for all of them — also inside a hipGraph capture, where the fill
+    becomes one memset node.  Anything unexpected (a second backward over the same graph, a module that
+    never announced) gets its own torch.zeros, as before."""
+
+    def __init__(self):
+        self.pending = 0          # floats announced by forwards since the last backward pass began
+        self.chunk = None
+        self.off = 0
+        self.in_backward = False
+
+    @staticmethod
+    def _round(n):
+        return (n + 3) // 4 * 4   # slices stay 16-byte aligned
+
+    def announce(self, n):
+        if self.in_backward:      # a new step's forward: the previous pass is over
+            self.in_backward, self.pending, self.chunk = False, 0, None
+        self.pending += self._round(n)
+
+    def take(self, n, device):
+        n = self._round(n)
+        if not self.in_backward:
+            self.in_backward = True
+            self.chunk = torch.zeros(max(self.pending, n), device=device, dtype=torch.float32)
+            self.off = 0
+        if self.chunk is None or self.chunk.device != device or self.off + n > self.chunk.numel():
+            return torch.zeros(n, device=device, dtype=torch.float32)
+        v = self.chunk[self.off:self.off + n]
+        self.off += n
+        return v
+
+
+ZERO_POOL = _ZeroPool()
+
+
 class ConvBnActFn(Function):
     """cat(srcs) -> Conv1d(k=1) -> BatchNorm1d -> glu(dim=1) | relu -> Dropout(p).
     LinearGLU (node_operations.py:30-39), ConcatFC (:49-56), NodeCell out_conv
@@ -170,6 +209,8 @@ class ConvBnActFn(Function):
             drop = K.DROP.make(p, out.numel(), training)
             lib.bn_relu_fwd(U, chan, out, b, M, L, drop)
         ctx.act, ctx.sv, ctx.drop, ctx.wshape = act, sv, drop, tuple(conv_w.shape)
+        if any(ctx.needs_input_grad):
+            ZERO_POOL.announce(2 * M + M * sv.ldw + M)
         return out
 
     @staticmethod
@@ -179,9 +220,9 @@ class ConvBnActFn(Function):
         b, M, L = U.shape
         g = _c(g)
         dV = torch.empty_like(U)
-        # ONE zero-filled buffer for the three gradients that are accumulated with atomics (one memset
-        # launch instead of three: the reshape layers alone would otherwise pay 18 fills per step)
-        zero = torch.zeros(2 * M + M * sv.ldw + M, device=U.device, dtype=torch.float32)
+        # ONE zero-filled buffer for the three gradients that are accumulated with atomics, carved out of
+        # one fill per backward pass (_ZeroPool)
+        zero = ZERO_POOL.take(2 * M + M * sv.ldw + M, U.device)
         bn_grad = zero[:2 * M]
         dW = zero[2 * M:2 * M + M * sv.ldw].view(M, sv.ldw)
         dbias = zero[2 * M + M * sv.ldw:]

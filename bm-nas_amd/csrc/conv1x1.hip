@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
 template <int TN, int TJ>
 constexpr size_t conv_ksplit_lds();
 
-template <bool TRANS, int TN, int TJ, int KPW>
+// MULTI: contractions longer than the 4 * KPW blocks a workgroup holds in registers at once (the K = 2048
+// reshape layers) run as several rounds of [all loads, then all MFMAs] into the same accumulators.
+template <bool TRANS, int TN, int TJ, int KPW, bool MULTI = false>
 __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx, const int by, char* lds) {
   // caller-provided LDS (conv_ksplit_lds<TN, TJ>() bytes): merged launches pay max(), not sum()
   float4 (*part)[TN * TJ][64] = reinterpret_cast<float4 (*)[TN * TJ][64]>(lds);
@@ -285,14 +287,22 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
 
   const int nblk = a.I / 16;
   // BatchNorm-backward fold (data gradient only, see ConvArgs): the raw conv outputs travel with dV
-  const bool fold_bn = !TRANS && a.bn_U != nullptr;
+  const bool fold_bn = !TRANS && !MULTI && a.bn_U != nullptr;
+  f32x4 acc[TN][TJ];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < (MULTI ? nblk : 1); base += 4 * KPW) {
   float av[KPW][TN][4], bv[KPW][TJ][4], uv[KPW][TN][4];
 #pragma unroll
   for (int kb = 0; kb < KPW; ++kb) {
-    const int blk = wave * KPW + kb;
+    const int blk = base + wave * KPW + kb;
     const bool vb = blk < nblk;                          // wave-uniform
     const int i0 = (vb ? blk : nblk - 1) * 16;
-    const int q = i0 / a.Ci;
+    // MULTI: one source, no weight fold, no probes (host-checked) — nothing wave-uniform-but-runtime is left
+    // inside the round loop, where hipcc would turn it into a branch + s_waitcnt per block
+    const int q = MULTI ? 0 : i0 / a.Ci;
     const int ci = i0 - q * a.Ci + 4 * h;
     const float* src = a.act.p[q];
 #pragma unroll
@@ -300,23 +310,23 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
       const float* pp = src + abase[tn] + (int64_t)ci * a.L;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float t = (a.probe & 2) ? (float)lane : pp[(int64_t)r * a.L];
+        const float t = (!MULTI && (a.probe & 2)) ? (float)lane : pp[(int64_t)r * a.L];
         av[kb][tn][r] = vb ? t : 0.f;                    // blocks past the end contribute zero
         if (fold_bn && a.bn_train) uv[kb][tn][r] = a.bn_U[abase[tn] + (int64_t)(ci + r) * a.L];
       }
     }
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
-      if (a.probe & 2) {
+      if (!MULTI && (a.probe & 2)) {
         bv[kb][tj][0] = bv[kb][tj][1] = bv[kb][tj][2] = bv[kb][tj][3] = (float)lo;
       } else if (TRANS) {
         const float* pp = a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h;
         float4 w4 = ld4(pp);
-        if (a.fold > 0) w4 = f4_add(w4, ld4(pp + a.fold));   // wave-uniform; W is L2-resident
+        if (!MULTI && a.fold > 0) w4 = f4_add(w4, ld4(pp + a.fold));   // wave-uniform; W is L2-resident
         bv[kb][tj][0] = w4.x; bv[kb][tj][1] = w4.y; bv[kb][tj][2] = w4.z; bv[kb][tj][3] = w4.w;
       } else {
         const float* pp = a.W + (int64_t)(i0 + 4 * h) * a.ldw + jcl[tj];
-        if (a.fold > 0) {
+        if (!MULTI && a.fold > 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) bv[kb][tj][r] = pp[(int64_t)r * a.ldw] + pp[(int64_t)r * a.ldw + a.fold];
         } else {
@@ -340,7 +350,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < KPW; ++kb) {
-      const int blk = wave * KPW + kb;
+      const int blk = base + wave * KPW + kb;
       if (blk >= nblk) continue;                         // wave-uniform (those operands are zero)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -355,12 +365,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
   // keep every load above this line: without the fence hipcc sinks the loads next to their
   // MFMAs to save registers, which re-serialises load -> wait -> multiply per block
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 acc[TN][TJ];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (a.probe & 1) {
+  if (!MULTI && (a.probe & 1)) {
 #pragma unroll
     for (int kb = 0; kb < KPW; ++kb)
 #pragma unroll
@@ -380,6 +385,8 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
           for (int tj = 0; tj < TJ; ++tj)
             acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][r], bv[kb][tj][r], acc[tn][tj], 0, 0, 0);
   }
+  if (MULTI) __builtin_amdgcn_sched_barrier(0);
+  }  // rounds
 
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn)
@@ -421,6 +428,15 @@ template <bool TRANS, int TN, int TJ, int KPW>
 __global__ __launch_bounds__(256) void conv_ksplit_k(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[conv_ksplit_lds<TN, TJ>()];
   conv_ksplit_body<TRANS, TN, TJ, KPW>(a, blockIdx.x, blockIdx.y, lds);
+}
+
+// long contractions at small grids (C_in = 2048 reshape layers at <= 64 samples per GPU): rounds of 12
+// blocks per wave instead of the whole-K LDS kernel, whose 64 workgroups walked K serially (44.7 us for
+// NTU b = 64, 3 % of the MFMA peak)
+template <bool TRANS>
+__global__ __launch_bounds__(256) void conv_ksplit_multi_k(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[conv_ksplit_lds<1, 1>()];
+  conv_ksplit_body<TRANS, 1, 1, 12, true>(a, blockIdx.x, blockIdx.y, lds);
 }
 
 // ---- pipelined LDS tile kernel (forward) -----------------------------------------------------------
@@ -1372,8 +1388,17 @@ template <bool TRANS, int TN, int TJ>
 bool launch_ksplit(const ConvArgs& a, hipStream_t st) {
   const int nblk = a.I / 16;
   const int kpw = (nblk + 3) / 4;
-  if (kpw * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;       // operand + accumulator VGPRs
   dim3 grid((unsigned)((a.n_groups + TN - 1) / TN), (unsigned)((a.J / 16 + TJ - 1) / TJ));
+  static const bool multi_on = !(getenv("BMNAS_KSPLIT_MULTI") && atoi(getenv("BMNAS_KSPLIT_MULTI")) == 0);
+  // longer contractions (K > 768: the C_in = 1024 / 2048 reshape layers) at small grids: several register
+  // rounds in one launch; large grids keep the LDS tile kernels (operand reuse)
+  if (multi_on && TN == 1 && TJ == 1 && kpw > 12 && a.bn_U == nullptr && a.fold == 0 && a.I == a.Ci &&
+      (long)grid.x * grid.y <= 512) {
+    BMNAS_COUNT(F_KSPLIT);
+    hipLaunchKernelGGL((conv_ksplit_multi_k<TRANS>), grid, dim3(256), 0, st, a);
+    return true;
+  }
+  if (kpw * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;       // operand + accumulator VGPRs
 #define KS_CASE(K)                                                                                   \
   if (kpw <= K) {                                                                                    \
     BMNAS_COUNT(F_KSPLIT);                                                                           \
@@ -1880,14 +1905,40 @@ extern "C" int bmnas_conv1x1_bwd_all(const float* dU, const float* W, int ldw, i
                     ((ng + 1) / 2) * ((a.J + kPipeBJ - 1) / kPipeBJ) >= 96;
   const bool merged = !pipe && ((ng + 1) / 2) * ((jt + 1) / 2) < 1024 && kpw <= 4 &&
                       kpw * 4 * 3 + 4 <= 232;
-  if (!merged) {
-    if (bn_U != nullptr)
+  bool want_data = false;
+  for (int q = 0; q < n_src; ++q) want_data = want_data || dsrcs[q] != nullptr;
+  if (!merged || !want_data) {
+    // separate launches.  The pipelined data-gradient kernel and the weight-gradient kernel both apply the
+    // BatchNorm input gradient while staging their operands, so only the other data-gradient families
+    // (whole-K LDS / direct kernels of the K = 2048 reshape layers) need the in-place launch first
+    const bool fold_here = bn_U != nullptr && (pipe || !want_data);
+    if (bn_U != nullptr && !fold_here)
       if (int e = bmnas_bn_bwd_apply(const_cast<float*>(dU), bn_U, bn_chan, bn_grad, b, M, L, bn_training, stream))
         return e;
-    if (int e = bmnas_conv1x1_bwd_data(dU, W, ldw, fold_cols, dsrcs, n_src, C_src, accumulate_mask, b, L, M,
-                                       stream))
+    if (want_data) {
+      if (fold_here) {
+        a.bn_U = bn_U; a.bn_chan = bn_chan; a.bn_grad = bn_grad; a.bn_train = bn_training;
+        const int pgx = (a.n_groups + 1) / 2, pgy = (a.J + kPipeBJ - 1) / kPipeBJ;
+        BMNAS_COUNT(F_PIPE_BWD);
+        hipLaunchKernelGGL((conv_pipe_bwd_k<48, 2>), dim3((unsigned)(pgx * pgy)), dim3(256),
+                           (conv_pipe_bwd_lds<48, 2>(a.L)) + (size_t)a.I * sizeof(float4), st, a, pgx);
+        BMNAS_CHECK_LAUNCH();
+      } else if (int e = bmnas_conv1x1_bwd_data(dU, W, ldw, fold_cols, dsrcs, n_src, C_src, accumulate_mask, b,
+                                                L, M, stream)) {
+        return e;
+      }
+    }
+    ConvWArgs w8{};
+    dim3 grid8;
+    if (int e = fill_w_args(w8, dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, 8, &grid8))
       return e;
-    return bmnas_conv1x1_bwd_weight(dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, stream);
+    if (fold_here) {
+      w8.bn_U = bn_U; w8.bn_chan = bn_chan; w8.bn_grad = bn_grad; w8.bn_train = bn_training;
+    }
+    BMNAS_COUNT(F_CONV_W);
+    hipLaunchKernelGGL(conv_w_k, grid8, dim3(512), 0, st, w8);
+    BMNAS_CHECK_LAUNCH();
+    return 0;
   }
   if (bn_U != nullptr) {
     a.bn_U = w.bn_U = bn_U; a.bn_chan = w.bn_chan = bn_chan; a.bn_grad = w.bn_grad = bn_grad;

@@ -211,8 +211,10 @@ int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int ldw, int fol
  * reference models/search/darts/node_search.py:63-66): bmnas_bn_bwd_apply (when bn_U != NULL) +
  * bmnas_conv1x1_bwd_data + bmnas_conv1x1_bwd_weight.  Small grids (where the data gradient would take
  * the 1x1-tile split-K kernel) run as ONE launch with the BatchNorm input gradient applied while the
- * operands are staged (dU is then left untouched); other shapes run as the three launches, dU
- * overwritten in place by the first.  Arguments as in bmnas_conv1x1_bwd_all_sdpa. */
+ * operands are staged; grids served by the pipelined tile kernel, and calls that want no data gradient
+ * (every dsrcs[q] NULL: frozen backbones in front of the reshape layers), run as two / one launch(es) with
+ * the same fold (dU is left untouched in all these cases); the remaining shapes run as the three launches,
+ * dU overwritten in place by the first.  Arguments as in bmnas_conv1x1_bwd_all_sdpa. */
 int bmnas_conv1x1_bwd_all(const float* dU, const float* W, int ldw, int fold_cols, float* const* dsrcs,
                           int n_src, int C_src, uint32_t accumulate_mask, int b, int L, int M,
                           const float* const* wsrcs, float* dW, int ldw_grad, float* dbias,

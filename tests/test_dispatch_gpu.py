@@ -6,9 +6,13 @@ fp32 torch contraction in the same test, so no family runs unverified:
 
     pipe_fwd / pipe_bwd     LDS-tiled, K-chunked (standalone convs with >= 96 tiles: out_conv and
                             reshape layers at production batch)
-    ksplit                  split-K, one memory round trip (small grids, K <= 1792)
-    lds                     whole-K LDS tiles (K = 2048 reshape layers at production batch)
-    nj                      direct (K = 2048 at small batch)
+    ksplit                  split-K, one memory round trip (small grids, K <= 768) or several register rounds
+                            in one launch (longer K at <= 512 workgroups: the C_in = 1024 / 2048 reshape layers
+                            at <= 64 samples per GPU)
+    lds                     whole-K LDS tiles: generic large-grid fallback (channel counts that the pipelined
+                            kernels do not take, e.g. not a multiple of 32) — no reference shape needs it
+    nj                      direct kernel: generic small-grid fallback (e.g. a fused torch.cat of two sources
+                            with K > 1792) — no reference shape needs it
     fwd_sdpa_pipe / _ksplit conv + attention in one launch (search NodeMixedOp, large / small batch)
     bwd_all_pipe / _ksplit  data-gradient + weight-gradient + attention backward in one launch
     bwd_sdpa_ksplit         data-gradient + attention backward (BMNAS_FUSE_BWD_ALL=0 path)
@@ -26,17 +30,20 @@ import os
 
 # the expectations below describe the DEFAULT dispatch; tools/test_matrix.sh forces other kernel families
 # through these switches on purpose (their results are checked by the parity tests, not here)
-_FORCED = [k for k in ('BMNAS_CONV_PIPE', 'BMNAS_FUSE_ATTN_GEMM', 'BMNAS_FUSE_BWD_ALL', 'BMNAS_PIPE_MIN',
+_FORCED = [k for k in ('BMNAS_KSPLIT_MULTI', 'BMNAS_CONV_PIPE', 'BMNAS_FUSE_ATTN_GEMM', 'BMNAS_FUSE_BWD_ALL', 'BMNAS_PIPE_MIN',
                        'BMNAS_PIPE_NG', 'BMNAS_PIPE_BNG', 'BMNAS_FUSE_BWD_PAIR') if os.environ.get(k) is not None]
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(bool(_FORCED), reason=f'kernel family forced by {_FORCED}')]
 
 
-def _conv_case(b, C_in, M, L, seed=0):
-    """fwd + data-gradient + weight-gradient of one 1x1 conv through the C ABI vs torch fp32."""
+def _conv_case(b, C_in, M, L, seed=0, n_src=1):
+    """fwd + data-gradient + weight-gradient of one 1x1 conv through the C ABI vs torch fp32.
+    n_src > 1: the input is handed over as n_src channel slices (torch.cat fused into the GEMM)."""
     from bmnas import lib
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(b, C_in, L, generator=g).to(dev())
+    if n_src > 1:
+        return _conv_case_cat(lib, g, x, b, C_in, M, L, n_src)
     W = (torch.randn(M, C_in, generator=g) / C_in ** 0.5).to(dev())
     bias = torch.randn(M, generator=g).to(dev())
     dU = torch.randn(b, M, L, generator=g).to(dev())
@@ -56,13 +63,28 @@ def _conv_case(b, C_in, M, L, seed=0):
     assert_close_scaled('db', db, dU.double().sum((0, 2)).float(), rel=2e-4)
 
 
+def _conv_case_cat(lib, g, x, b, C_in, M, L, n_src):
+    Cs = C_in // n_src
+    xs = [x[:, q * Cs:(q + 1) * Cs].contiguous() for q in range(n_src)]
+    W = (torch.randn(M, C_in, generator=g) / C_in ** 0.5).to(dev())
+    bias = torch.randn(M, generator=g).to(dev())
+    U = torch.empty(b, M, L, device=dev())
+    part = torch.empty(lib.conv1x1_num_partials(b, L) * M * 2, device=dev())
+    lib.conv1x1_fwd(xs, Cs, W, C_in, bias, U, part, b, L, M, 0)
+    want = torch.einsum('mk,bkl->bml', W.double(), x.double()) + bias.double()[None, :, None]
+    assert_close_scaled('U', U, want.float())
+
+
 CASES = [
     # (what, batch, C_in, M, L) -> families that must serve it (fwd, bwd-data)
     ('out_conv NTU b512', 512, 256, 128, 8, {'pipe_fwd', 'ksplit'}),
     ('reshape MM-IMDB C_in 512 b128', 128, 512, 192, 16, {'pipe_fwd', 'pipe_bwd'}),
     ('out_conv NTU b8', 8, 256, 128, 8, {'ksplit'}),
-    ('reshape NTU C_in 2048 b64', 64, 2048, 128, 8, {'lds'}),
-    ('reshape NTU C_in 2048 b6', 6, 2048, 128, 8, {'nj'}),
+    ('reshape NTU C_in 2048 b64', 64, 2048, 128, 8, {'ksplit'}),        # multi-round split-K (10.7 us; lds: 51 us)
+    ('reshape NTU C_in 2048 b6', 6, 2048, 128, 8, {'ksplit'}),          # (10.7 us; nj: 23 us)
+    ('reshape NTU C_in 2048 b256', 256, 2048, 128, 8, {'pipe_fwd'}),
+    # generic fallbacks for shapes outside the reference's configurations:
+    ('channels not a multiple of 32, large grid: C_in 2064 b512', 512, 2064, 128, 8, {'lds'}),
 ]
 
 
@@ -95,10 +117,21 @@ def test_merged_launch_families(name, batch, expect):
     assert expect <= got, (name, batch, got)
 
 
+def test_cat_of_two_sources_with_long_contraction_takes_the_direct_kernel():
+    """nj: the generic direct kernel — here a two-source (fused torch.cat) K = 2048 contraction at a tiny
+    grid, which the multi-round split-K kernel (single source) does not cover."""
+    from bmnas import lib
+    lib.conv_family_calls(reset=True)
+    _conv_case(6, 2048, 128, 8, n_src=2)
+    got = {k for k, v in lib.conv_family_calls().items() if v > 0}
+    assert 'nj' in got, got
+
+
 def test_every_family_is_reachable(monkeypatch):
     """Union over the cases above + the BMNAS_FUSE_BWD_ALL=0 route: no dead GEMM family."""
     from bmnas import cell, lib
     lib.conv_family_calls(reset=True)
+    _conv_case(6, 2048, 128, 8, n_src=2)
     for what, b, C_in, M, L, _ in CASES:
         _conv_case(b, C_in, M, L)
     for name, batch in (('mmimdb', 128), ('mmimdb', 8), ('ntu', 8)):      # ntu: out_conv -> bwd_pair

@@ -441,7 +441,9 @@ def test_bn_relu_ln_tail(b, C, L, acc, sums):
 @pytest.mark.parametrize('b,C,L,M,n_src,training,acc', [(8, 128, 8, 128, 2, True, 0), (6, 128, 8, 128, 2, True, 1),
                                                         (64, 128, 8, 128, 2, True, 2), (48, 128, 8, 128, 3, False, 0),
                                                         (7, 64, 4, 64, 2, True, 3), (5, 192, 16, 192, 2, True, 0),
-                                                        (128, 192, 16, 192, 2, True, 1), (250, 128, 8, 128, 2, True, 0)])
+                                                        (128, 192, 16, 192, 2, True, 1), (250, 128, 8, 128, 2, True, 0),
+                                                        (128, 512, 16, 192, 1, True, -1), (64, 2048, 8, 128, 1, True, 0),
+                                                        (6, 2048, 8, 128, 1, True, -1)])
 def test_conv1x1_bwd_all_pair(b, C, L, M, n_src, training, acc):
     """bmnas_conv1x1_bwd_all (out_conv + bn backward, node_search.py:63-66): BatchNorm input gradient,
     data gradient and weight / bias gradient; merged launch at the small grids, three launches otherwise."""
@@ -469,7 +471,9 @@ def test_conv1x1_bwd_all_pair(b, C, L, M, n_src, training, acc):
         dU = scale[None, :, None] * dVd
     chan = torch.cat([mean, rstd, scale, torch.zeros(M, dtype=torch.float64)]).float().to(dev())
     bn_grad = torch.cat([s_dx, s_d]).float().to(dev())
-    dst = [p.clone().to(dev()) for p in prev]
+    want_data = acc >= 0                        # acc = -1: no data gradient asked for (frozen inputs)
+    acc = max(acc, 0)
+    dst = [p.clone().to(dev()) if want_data else None for p in prev]
     dW0, db0 = _rand(g, M, n_src * C), _rand(g, M)
     dW, db = dW0.clone().to(dev()), db0.clone().to(dev())
     dV_dev = dV.to(dev())
@@ -478,10 +482,14 @@ def test_conv1x1_bwd_all_pair(b, C, L, M, n_src, training, acc):
                         n_src * C, db, 0, (U.to(dev()), chan, bn_grad, training))
     fam = lib.conv_family_calls(reset=True)
     import os
-    small = not (b == 128 and C == 192 and os.environ.get('BMNAS_CONV_PIPE', '1') != '0')
-    assert (fam['bwd_pair'] == 1) == small, fam
+    pipe_on = os.environ.get('BMNAS_CONV_PIPE', '1') != '0'
+    ng, jt = (b * L + 15) // 16, n_src * C // 16
+    pipe = pipe_on and M % 48 == 0 and ((ng + 1) // 2) * ((n_src * C + 63) // 64) >= 96
+    merged = want_data and not pipe and ((ng + 1) // 2) * ((jt + 1) // 2) < 1024
+    assert (fam['bwd_pair'] == 1) == merged, fam
+    untouched = merged or pipe or not want_data         # else bn_bwd_apply ran in place first
     ref = torch.einsum('mc,bml->bcl', W.double(), dU)
-    for q in range(n_src):
+    for q in range(n_src if want_data else 0):
         want = ref[:, q * C:(q + 1) * C]
         if acc & (1 << q):
             want = want + prev[q].double()
@@ -489,8 +497,10 @@ def test_conv1x1_bwd_all_pair(b, C, L, M, n_src, training, acc):
     cat = torch.cat([x.double() for x in srcs], dim=1)
     assert_close_scaled('dW', dW, (dW0.double() + torch.einsum('bml,bkl->mk', dU, cat)).float(), rel=5e-5)
     assert_close_scaled('dbias', db, (db0.double() + dU.sum(dim=(0, 2))).float(), rel=5e-5)
-    if small:
-        assert torch.equal(dV_dev.cpu(), dV)           # the merged launch leaves its dV operand alone
+    if untouched:
+        assert torch.equal(dV_dev.cpu(), dV)           # the folding launches leave their dV operand alone
+    else:
+        assert_close_scaled('dU in place', dV_dev, dU.float(), rel=5e-5)
 
 
 @pytest.mark.parametrize('b,C,L,M,n_dst,acc', [(128, 192, 16, 576, 1, 1), (100, 192, 16, 576, 1, 1),
