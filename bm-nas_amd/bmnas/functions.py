@@ -172,6 +172,7 @@ class _ZeroPool:
         n = self._round(n)
         if not self.in_backward:
             self.in_backward = True
+            FWD_STAT_POOL.close()
             self.chunk = torch.zeros(max(self.pending, n), device=device, dtype=torch.float32)
             self.off = 0
         if self.chunk is None or self.chunk.device != device or self.off + n > self.chunk.numel():
@@ -182,6 +183,46 @@ class _ZeroPool:
 
 
 ZERO_POOL = _ZeroPool()
+
+
+class _FwdStatPool:
+    """Zero-filled BatchNorm batch-sum buffers (StatArena layout) for the standalone conv + BatchNorm + ReLU
+    modules, so that their statistics are finalised inside bn_relu_fwd like on the search path instead of by
+    a bn_finalize launch per module.  A forward pass cannot announce its needs, so the chunk is sized by the
+    previous pass (a pass ends when a backward pass begins); the first pass, and anything beyond the chunk,
+    gets a fill of its own."""
+    CAP = 1 << 24                 # floats: never carry more than 64 MB from a run of forwards without backward
+
+    def __init__(self):
+        self.open = False
+        self.chunk = None
+        self.off = 0
+        self.total = 0
+        self.last_total = 0
+
+    def close(self):              # a backward pass began (called by the first ZERO_POOL.take of the pass)
+        if self.open:
+            self.open = False
+            self.last_total = min(self.total, self.CAP)
+
+    def take(self, M):
+        """-> zero-filled view of STAT_SHARDS * M * 2 floats (the interface conv_bn_fwd expects of `stats`)."""
+        n = (K.STAT_SHARDS * M * 2 + 3) // 4 * 4
+        dev = self.device
+        if not self.open:
+            self.open, self.off, self.total = True, 0, 0
+            self.chunk = torch.zeros(self.last_total, device=dev, dtype=torch.float32) if self.last_total else None
+        self.total += n
+        if self.chunk is None or self.chunk.device != dev or self.off + n > self.chunk.numel():
+            return torch.zeros(n, device=dev, dtype=torch.float32)
+        v = self.chunk[self.off:self.off + n]
+        self.off += n
+        return v
+
+
+FWD_STAT_POOL = _FwdStatPool()
+# BMNAS_FUSE_BN_FINALIZE=0: bn_finalize launches, as in round 1
+FUSE_STANDALONE_BN = K.FUSE_BN_FINALIZE
 
 
 class ConvBnActFn(Function):
@@ -197,8 +238,12 @@ class ConvBnActFn(Function):
         M = conv_w.shape[0]
         K_in = len(srcs) * C_src
         W = _c(conv_w).view(M, K_in)
+        pool = None
+        if act != 'glu' and training and FUSE_STANDALONE_BN:
+            pool = FWD_STAT_POOL             # statistics finalised inside bn_relu_fwd (no bn_finalize launch)
+            pool.device = srcs[0].device
         U, chan, sv = K.conv_bn_fwd(srcs, C_src, W, K_in, _c(conv_b), _c(bn_w), _c(bn_b), rm, rv, nbt,
-                                    training)
+                                    training, stats=pool)
         if act == 'glu':
             Cout = M // 2
             out = torch.empty((b, Cout, L), device=U.device, dtype=torch.float32)
@@ -207,7 +252,7 @@ class ConvBnActFn(Function):
         else:
             out = torch.empty((b, M, L), device=U.device, dtype=torch.float32)
             drop = K.DROP.make(p, out.numel(), training)
-            lib.bn_relu_fwd(U, chan, out, b, M, L, drop)
+            lib.bn_relu_fwd(U, chan, out, b, M, L, drop, sv.fin)
         ctx.act, ctx.sv, ctx.drop, ctx.wshape = act, sv, drop, tuple(conv_w.shape)
         if any(ctx.needs_input_grad):
             ZERO_POOL.announce(2 * M + M * sv.ldw + M)
