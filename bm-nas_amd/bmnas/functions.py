@@ -173,7 +173,8 @@ class _ZeroPool:
         if not self.in_backward:
             self.in_backward = True
             FWD_STAT_POOL.close()
-            self.chunk = torch.zeros(max(self.pending, n), device=device, dtype=torch.float32)
+            # (capped: forwards that were never followed by a backward must not inflate the fill)
+            self.chunk = torch.zeros(max(min(self.pending, 1 << 24), n), device=device, dtype=torch.float32)
             self.off = 0
         if self.chunk is None or self.chunk.device != device or self.off + n > self.chunk.numel():
             return torch.zeros(n, device=device, dtype=torch.float32)

@@ -241,3 +241,46 @@ def test_head_state_resolves_deferred_and_given_gradients():
     assert v1.numel() == v2.numel() and v3.numel() * 576 == v1.numel() * 128 and a.buf.numel() % 4 == 0
     with pytest.raises(Exception):
         a.take(16)
+
+
+def test_zero_pool_one_fill_per_backward_pass():
+    """bmnas.functions._ZeroPool: forwards announce, the first backward take allocates for all of them,
+    slices are disjoint, zero and 16-byte aligned; the next forward starts a new pass; unexpected takes
+    get their own fill."""
+    from bmnas.functions import _ZeroPool
+    dev = torch.device('cpu')
+    pool = _ZeroPool()
+    for n in (10, 7, 33):
+        pool.announce(n)
+    a, b, c = pool.take(33, dev), pool.take(7, dev), pool.take(10, dev)
+    base = pool.chunk.data_ptr()
+    assert pool.chunk.numel() == 12 + 8 + 36
+    assert [t.data_ptr() - base for t in (a, b, c)] == [0, 36 * 4, 44 * 4]
+    assert all(float(t.abs().sum()) == 0.0 and t.data_ptr() % 16 == 0 for t in (a, b, c))
+    extra = pool.take(5, dev)                          # beyond what was announced (second backward, ...)
+    assert extra.numel() == 8 and not (base <= extra.data_ptr() < base + pool.chunk.numel() * 4)
+    pool.announce(4)                                   # next step's forward
+    assert not pool.in_backward and pool.pending == 4
+    d = pool.take(4, dev)
+    assert pool.chunk.numel() == 4 and d.data_ptr() == pool.chunk.data_ptr()
+    lone = _ZeroPool().take(6, dev)                    # a module that never announced
+    assert lone.numel() == 8
+
+
+def test_forward_stat_pool_sizes_a_pass_by_the_previous_one():
+    from bmnas import cell
+    from bmnas.functions import _FwdStatPool
+    pool = _FwdStatPool()
+    pool.device = torch.device('cpu')
+    n = lambda M: (cell.STAT_SHARDS * M * 2 + 3) // 4 * 4
+    first = [pool.take(16), pool.take(32)]             # first pass: nothing known, one fill each
+    assert pool.chunk is None and [t.numel() for t in first] == [n(16), n(32)]
+    pool.close()                                       # a backward pass began
+    assert pool.last_total == n(16) + n(32)
+    a, b = pool.take(16), pool.take(32)                # second pass: one chunk
+    assert pool.chunk.numel() == n(16) + n(32)
+    assert a.data_ptr() == pool.chunk.data_ptr() and b.data_ptr() == a.data_ptr() + n(16) * 4
+    c = pool.take(64)                                  # more than last time: own fill, remembered for the next pass
+    assert c.numel() == n(64) and float(c.abs().sum()) == 0.0
+    pool.close()
+    assert pool.last_total == n(16) + n(32) + n(64)
