@@ -157,6 +157,10 @@ def algo_table(C, L):
             ('hbm', T(U) + 5 * T(out) + 2 * T(w)),
         'node_mix_bwd': lambda g, x, y, p1, U, ch, gm, dgm, dx, dy, m, dV, bg, b, Cc, L_, dg, df, sh=1, st=0, nxt=None:
             ('hbm', 2 * T(U) + 4 * T(x) + (0 if nxt is None else (2 * len(nxt[0]) + 4) * T(x))),
+        # K6 backward + K2 backward: gy, pre, x, p1, U read; g_in, dresid, dx, dV written (rmw where accumulated)
+        'node_mix_ln_bwd': lambda g, pre, w, st, g_in, dres, racc, x, y, p1, U, ch, gm, dgm, dx, dy, m, dV, *_:
+            ('hbm', 2 * T(U) + (4 + (g_in is not None) + (dres is not None) + bool(racc) + (dx is not None)
+                                + bin(m).count('1')) * T(x) + T(w)),
         'bn_relu_fwd': lambda U, *_: ('hbm', 2 * T(U)),
         'bn_relu_bwd': lambda g, U, *_: ('hbm', 3 * T(U)),
         'bn_bwd_apply': lambda dV, U, *_: ('hbm', 3 * T(U)),

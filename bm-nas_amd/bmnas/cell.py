@@ -400,6 +400,8 @@ FUSE_INNER_SUM = os.environ.get('BMNAS_FUSE_INNER_SUM', '1') != '0'
 MIX_PREV_MAX = 5
 # the cell prologue inside the launch of the first step's pair sum (needs FUSE_PROLOGUE and FUSE_PAIR)
 FUSE_PROLOGUE_PAIR = os.environ.get('BMNAS_FUSE_PROLOGUE_PAIR', '1') != '0'
+# node_multiplier == 1, <= 128 samples: the node's LayerNorm backward inside the mix-backward launch
+FUSE_LN_BWD = os.environ.get('BMNAS_FUSE_LN_BWD', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
 FUSE_HEAD = os.environ.get('BMNAS_FUSE_HEAD', '1') != '0'
 
@@ -453,10 +455,14 @@ def _attn_affine_bwd(sv, g, G, deferred=None):
                False, True)
 
 
-def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=0, deferred=None, nxt=None):
+def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=0, deferred=None, nxt=None,
+                   ln=None):
     """g: grad of the mixed output (None with nxt: nothing accumulated yet).  nxt: see lib.node_mix_bwd.
     dgamma_row (4 floats, +=), x_slot / y_slot: GradSlots (y_slot None when x is y).  G: gradient pack (stack_dW, stack_dbias, stack_bn_grad,
-    dln_w, dln_b), all += ."""
+    dln_w, dln_b), all += .
+    ln = (gy, pre, ln_w, stats, resid_slot, g_slot): the mixed output went through `+ resid -> LayerNorm`
+    (node_multiplier == 1) and gy is the gradient of THAT output; the launch does the LayerNorm backward
+    first (bmnas_node_mix_ln_bwd), writes its input gradient to g_slot and resid_slot.  x is y only."""
     x, y = sv.x, sv.y
     b, C, L = x.shape
     M = 3 * C
@@ -464,9 +470,19 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
     bn_grad = G.stack_bn_grad            # [dW_bn (3C) | dB_bn (3C)], zero-initialised by caller
     with _Fork(x.device) as fork:
         if sv.same:
+            if ln is not None:
+                gy, pre, ln_w, stats, r_slot, g_slot = ln
+                g = g_slot.buf()
+                g_slot.written = True
+                rbuf, racc = r_slot.buf(), r_slot.acc_bit()
             dxb, acc = x_slot.buf(), x_slot.acc_bit()
-            lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
-                             dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride, nxt)
+            if ln is not None:
+                lib.node_mix_ln_bwd(gy, pre, ln_w, stats, g, rbuf, racc, x, y, sv.p1, sv.conv.U, sv.conv.chan,
+                                    sv.gamma, dgamma_row, dxb, None, acc, dV, bn_grad, b, C, L, sv.d_glu,
+                                    sv.d_fc, shards, shard_stride)
+            else:
+                lib.node_mix_bwd(g, x, y, sv.p1, sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc,
+                                 dV, bn_grad, b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride, nxt)
             if nxt is not None:
                 g = nxt[-1]                  # the launch completed this step's gradient there
             if sv.merged and x_slot.extra is None:
@@ -580,6 +596,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
     slots = [x_slot, y_slot] + [GradSlot(x) for _ in range(ns)]
     tail = list(range(2 + ns - nm, 2 + ns))
     resid = None if sv.fused_tail else x                 # fused: sv.o already holds o + x
+    ln_job = None
     if nm != 1:
         dV = _empty(x, b, C, L)
         if sv.fused_bn_tail:
@@ -595,6 +612,10 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
             lib.bn_relu_bwd(d_o.buf(), sv.oconv.U, sv.oconv.chan, dV, NG.bn_grad, b, C, L, sv.d_out)
         conv_bn_bwd(sv.oconv, dV, NG.bn_grad, [slots[j] for j in tail],
                     NG.out_conv_dW.view(C, nm * C), NG.out_conv_db)
+    elif (FUSE_LN_BWD and sv.fused_tail and sv.mixed[ns - 1].same and slots[tail[0]].get() is None
+          and lib.node_mix_ln_bwd_ok(b, C, L)):
+        # the LayerNorm backward rides in the last inner step's mix-backward launch
+        ln_job = (g, sv.o, NP.ln_w, sv.stats, x_slot, slots[tail[0]])
     else:
         bufs, mask = _write_group([slots[tail[0]]])
         racc = x_slot.acc_bit()
@@ -604,8 +625,9 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
                False, False)
     pending = None               # (gz, gz2, offset, n_in) of step t + 1's mixed sum, folded into step t's mix backward
     for t in reversed(range(ns)):
-        gs = slots[2 + t].get()
-        if gs is None and pending is None:
+        ln = ln_job if t == ns - 1 else None
+        gs = None if ln is not None else slots[2 + t].get()
+        if gs is None and pending is None and ln is None:
             continue                                    # this inner state feeds nothing
         z_slot = GradSlot(x)
         nxt = None
@@ -618,7 +640,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
                    NG.shard_stride, sv.states[n_in - 1], gz, gz2, g_out)
             pending = None
         node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t], NG.shards, NG.shard_stride,
-                       deferred, nxt)
+                       deferred, nxt, ln)
         if t == 0 and defer_first:
             return z_slot.buf(), z_slot.extra
         off = sv.offsets[t]

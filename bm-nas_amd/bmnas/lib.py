@@ -108,6 +108,9 @@ SIGNATURES = {
                                Dropout, _P, _P], _I),
     'bmnas_node_mix_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32, _P, _P, _I, _I, _I,
                             Dropout, Dropout, _P], _I),
+    'bmnas_node_mix_ln_bwd_ok': ([_I, _I, _I], _I),
+    'bmnas_node_mix_ln_bwd': ([_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32,
+                               _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
     'bmnas_bn_glu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_glu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_fwd': ([_P, _P, BnFin, _P, _I, _I, _I, Dropout, _P], _I),
@@ -509,6 +512,20 @@ def node_mix_bwd(g, x, y, p1, U, chan, gamma, dgamma, dx, dy, acc_mask, dV, bn_g
                                           _ptr(gz2), _ptr(g_out), _stream()), 'node_mix_bwd_next')
 
 
+def node_mix_ln_bwd_ok(b, Cc, L):
+    return bool(load().bmnas_node_mix_ln_bwd_ok(b, Cc, L))
+
+
+def node_mix_ln_bwd(g, pre, ln_w, stats, g_in, dresid, acc_resid, x, y, p1, U, chan, gamma, dgamma, dx, dy,
+                    acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc, dg_shards=1, dg_stride=0):
+    """K6 backward + K2 backward in one launch (bmnas_node_mix_ln_bwd)."""
+    _check(load().bmnas_node_mix_ln_bwd(_ptr(g), _ptr(pre), _ptr(ln_w), _ptr(stats), _ptr(g_in), _ptr(dresid),
+                                        int(acc_resid), _ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan),
+                                        gamma.data_ptr(), None if dgamma is None else dgamma.data_ptr(),
+                                        dg_shards, dg_stride, _ptr(dx), _ptr(dy), acc_mask, _ptr(dV),
+                                        _ptr(bn_grad), b, Cc, L, dglu, dfc, _stream()), 'node_mix_ln_bwd')
+
+
 def bn_glu_fwd(U, chan, out, b, Cc, L, drop):
     _check(load().bmnas_bn_glu_fwd(_ptr(U), _ptr(chan), _ptr(out), b, Cc, L, drop, _stream()), 'bn_glu_fwd')
 
@@ -693,7 +710,7 @@ _TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'cell_prologue_pair', '
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa', 'conv1x1_bwd_all',
                 'bn_relu_ln_fwd', 'bn_relu_ln_bwd',
-                'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
+                'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'node_mix_ln_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',
                 'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy', 'adam_multi')
 _PLAIN = {}

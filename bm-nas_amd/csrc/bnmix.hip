@@ -428,6 +428,158 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
 }
 
 
+// K6 backward + K2 backward in ONE launch (node_multiplier == 1, small batches): the LayerNorm input
+// gradient of the node output never makes a round trip of its own.  TWO workgroups per sample so that
+// 128 samples still cover 256 CUs: both reduce the sample's two LayerNorm sums (the 24 KB of a sample's
+// gy / pre-norm rows are read twice — against a 5 us launch), then each takes one half of the sample's
+// channels through LayerNorm backward -> gamma-mix backward (the arithmetic of node_mix_bwd_k).
+// A thread's element k of the first phase (k < VPT2) IS its element of the second phase: half h
+// starts its walk over the sample at its own half.  BatchNorm reductions: one atomic pair per
+// channel per sample (as bn_relu_ln_bwd_k), which is why the launcher keeps this to b <= 128.
+template <int VPT1, int VPT2, int BS>
+__global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
+    const float* __restrict__ gy, const float* __restrict__ pre, const float* __restrict__ ln_w,
+    const float* __restrict__ stats, float* __restrict__ gbuf, float* dresid, int acc_resid,
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ p1,
+    const float* __restrict__ U, const float* __restrict__ chan, const float* __restrict__ gamma,
+    float* dgamma, int dg_shards, int64_t dg_stride, float* dx, float* dy, uint32_t acc_mask,
+    float* __restrict__ dV, float* bn_grad, int b, int C, int L, DropCfg dglu, DropCfg dfc) {
+  constexpr int NW = BS / 64;
+  __shared__ float red2[NW * 2];
+  __shared__ float red4[NW * 4];
+  const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C, h4 = cl4 / 2;
+  const int smp = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const bool same = (x == y);
+  // second-phase operands first: they do not depend on the sums
+  float4 ua[VPT2], ug[VPT2], uf[VPT2], xv[VPT2], yv[VPT2], pv[VPT2], oldr[VPT2], oldx[VPT2], oldy[VPT2];
+  float csc[VPT2][3], csh[VPT2][3], cmu[VPT2][3], crs[VPT2][3];
+#pragma unroll
+  for (int k = 0; k < VPT2; ++k) {
+    const int idx = threadIdx.x + k * BS;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    ua[k] = ug[k] = uf[k] = xv[k] = yv[k] = pv[k] = oldr[k] = oldx[k] = oldy[k] = zero;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) csc[k][q] = csh[k][q] = cmu[k][q] = crs[k][q] = 0.f;
+    if (idx < h4) {
+      const int r = half * h4 + idx;
+      const int c = r / l4n;
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      const int64_t ub = ((int64_t)smp * M) * L + (int64_t)r * 4;
+      ua[k] = ld4(U + ub);
+      ug[k] = ld4(U + ub + (int64_t)C * L);
+      uf[k] = ld4(U + ub + (int64_t)2 * C * L);
+      xv[k] = ld4(x + e);
+      yv[k] = same ? xv[k] : ld4(y + e);
+      pv[k] = ld4(p1 + e);
+      if (acc_resid) oldr[k] = ld4(dresid + e);
+      if (dx != nullptr && (acc_mask & 1u)) oldx[k] = ld4(dx + e);
+      if (dy != nullptr && (acc_mask & 2u)) oldy[k] = ld4(dy + e);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        cmu[k][q] = chan[q * C + c];
+        crs[k][q] = chan[M + q * C + c];
+        csc[k][q] = chan[2 * M + q * C + c];
+        csh[k][q] = chan[3 * M + q * C + c];
+      }
+    }
+  }
+  const float g0 = gamma[0], g2 = gamma[2], g3 = gamma[3];
+  const float mean = stats[2 * smp], rstd = stats[2 * smp + 1];
+  // first phase: the whole sample's sum(gy w) and sum(gy w xhat)
+  float4 xh[VPT1], dxh[VPT1];
+  float s12[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < VPT1; ++k) {
+    const int idx = threadIdx.x + k * BS;
+    xh[k] = dxh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < cl4) {
+      int r = half * h4 + idx;
+      r = r >= cl4 ? r - cl4 : r;
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      const float4 pr = ld4(pre + e), w = ld4(ln_w + (int64_t)r * 4), g = ld4(gy + e);
+      xh[k] = make_float4((pr.x - mean) * rstd, (pr.y - mean) * rstd, (pr.z - mean) * rstd, (pr.w - mean) * rstd);
+      dxh[k] = f4_mul(g, w);
+      s12[0] += f4_hsum(dxh[k]);
+      s12[1] += f4_dot(dxh[k], xh[k]);
+    }
+  }
+  block_sum_n<NW, 2>(s12, red2);
+  const float inv_d = 1.f / (float)(cl4 * 4);
+  const float m1 = s12[0] * inv_d, m2 = s12[1] * inv_d;
+  // second phase
+  float dgam[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < VPT2; ++k) {
+    const int idx = threadIdx.x + k * BS;
+    const bool act = idx < h4;
+    const int r = half * h4 + (act ? idx : 0);
+    const int c = r / l4n;
+    float sw[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+    if (act) {
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      const int64_t ub = ((int64_t)smp * M) * L + (int64_t)r * 4;
+      float4 gv;
+      gv.x = rstd * (dxh[k].x - m1 - xh[k].x * m2);
+      gv.y = rstd * (dxh[k].y - m1 - xh[k].y * m2);
+      gv.z = rstd * (dxh[k].z - m1 - xh[k].z * m2);
+      gv.w = rstd * (dxh[k].w - m1 - xh[k].w * m2);
+      if (gbuf != nullptr) st4(gbuf + e, gv);
+      if (dresid != nullptr) st4(dresid + e, f4_add(gv, oldr[k]));
+      const float4 m2d = drop_mult4(dglu, (uint64_t)e), m3d = drop_mult4(dfc, (uint64_t)e);
+      const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+      const float uaq[4] = {ua[k].x, ua[k].y, ua[k].z, ua[k].w}, ugq[4] = {ug[k].x, ug[k].y, ug[k].z, ug[k].w},
+                  ufq[4] = {uf[k].x, uf[k].y, uf[k].z, uf[k].w};
+      const float xq[4] = {xv[k].x + yv[k].x, xv[k].y + yv[k].y, xv[k].z + yv[k].z, xv[k].w + yv[k].w};
+      const float pq[4] = {pv[k].x, pv[k].y, pv[k].z, pv[k].w};
+      const float m2q[4] = {m2d.x, m2d.y, m2d.z, m2d.w}, m3q[4] = {m3d.x, m3d.y, m3d.z, m3d.w};
+      float da[4], dg[4], df[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float va = fmaf(uaq[t], csc[k][0], csh[k][0]), vg = fmaf(ugq[t], csc[k][1], csh[k][1]),
+                    vf = fmaf(ufq[t], csc[k][2], csh[k][2]);
+        const float sg = sigmoidf(vg);
+        dgam[0] += gq[t] * xq[t];
+        dgam[1] += gq[t] * pq[t];
+        dgam[2] += gq[t] * (va * sg * m2q[t]);
+        dgam[3] += gq[t] * (fmaxf(vf, 0.f) * m3q[t]);
+        const float gm2 = g2 * gq[t] * m2q[t];
+        da[t] = gm2 * sg;
+        dg[t] = gm2 * va * sg * (1.f - sg);
+        df[t] = (vf > 0.f) ? g3 * gq[t] * m3q[t] : 0.f;
+        sw[0] += da[t] * (uaq[t] - cmu[k][0]) * crs[k][0];
+        sw[1] += dg[t] * (ugq[t] - cmu[k][1]) * crs[k][1];
+        sw[2] += df[t] * (ufq[t] - cmu[k][2]) * crs[k][2];
+        sb[0] += da[t]; sb[1] += dg[t]; sb[2] += df[t];
+      }
+      st4(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
+      st4(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
+      st4(dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
+      const float4 d0 = f4_scale(gv, g0);
+      if (dx != nullptr) st4(dx + e, f4_add((dy == nullptr) ? f4_scale(d0, 2.f) : d0, oldx[k]));
+      if (dy != nullptr) st4(dy + e, f4_add(d0, oldy[k]));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      sw[q] = row_sum(sw[q], l4n);
+      sb[q] = row_sum(sb[q], l4n);
+    }
+    if (act && (r % l4n) == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        atomicAdd(bn_grad + q * C + c, sw[q]);
+        atomicAdd(bn_grad + M + q * C + c, sb[q]);
+      }
+    }
+  }
+  block_sum_lead<NW, 4>(dgam, red4);
+  if (threadIdx.x == 0 && dgamma != nullptr) {
+    float* p = dgamma + (int64_t)(blockIdx.x % dg_shards) * dg_stride;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(p + q, dgam[q]);
+  }
+}
+
+
 // standalone LinearGLU tail: out = drop(va * sigmoid(vg)), U is (b, 2C, L) = [a | gate]
 __global__ __launch_bounds__(256) void bn_glu_fwd_k(const float* __restrict__ U,
                                                     const float* __restrict__ chan,
@@ -1153,6 +1305,39 @@ extern "C" int bmnas_node_mix_bwd(const float* g, const float* x, const float* y
                                  0, nullptr, 0, nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
+
+extern "C" int bmnas_node_mix_ln_bwd_ok(int b, int C, int L) {
+  return b >= 1 && b <= 128 && (L == 4 || L == 8 || L == 16) && C >= 2 && C % 2 == 0 && C * L / 4 <= 2048;
+}
+
+extern "C" int bmnas_node_mix_ln_bwd(const float* g, const float* pre, const float* ln_w, const float* stats,
+                                     float* g_in, float* dresid, int accumulate_resid, const float* x,
+                                     const float* y, const float* p1, const float* U, const float* chan,
+                                     const float* gamma, float* dgamma, int dgamma_shards,
+                                     int64_t dgamma_shard_stride, float* dx, float* dy,
+                                     uint32_t accumulate_mask, float* dV, float* bn_grad, int b, int C, int L,
+                                     bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream) {
+  if (!g || !pre || !ln_w || !stats || !x || !y || !p1 || !U || !chan || !gamma || !dV || !bn_grad || b < 0 ||
+      C < 1 || dgamma_shards < 1)
+    return BMNAS_E_ARG;
+  if (accumulate_resid && !dresid) return BMNAS_E_ARG;
+  if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
+  if (b == 0) return 0;
+  if (!bmnas_node_mix_ln_bwd_ok(b, C, L)) return BMNAS_E_LIMIT;
+  const int cl4 = C * L / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define NMLB(V1, V2)                                                                                         \
+  hipLaunchKernelGGL((node_mix_ln_bwd_k<V1, V2, 512>), dim3(2 * b), dim3(512), 0, st, g, pre, ln_w, stats,   \
+                     g_in, dresid, accumulate_resid, x, y, p1, U, chan, gamma, dgamma, dgamma_shards,        \
+                     dgamma_shard_stride, dx, dy, accumulate_mask, dV, bn_grad, b, C, L, to_cfg(drop_glu),   \
+                     to_cfg(drop_fc))
+  if (cl4 <= 512) NMLB(1, 1);
+  else if (cl4 <= 1024) NMLB(2, 1);
+  else NMLB(4, 2);
+#undef NMLB
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int bmnas_bn_glu_fwd(const float* U, const float* chan, float* out, int b, int C, int L,
                                 bmnas_dropout_t drop, void* stream) {

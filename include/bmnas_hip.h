@@ -295,6 +295,21 @@ int bmnas_node_mix_bwd(const float* g, const float* x, const float* y, const flo
                        uint32_t accumulate_mask, float* dV, float* bn_grad, int b, int C, int L,
                        bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
 
+/* K6 backward + K2 backward in one launch (node_multiplier == 1; reference node_search.py:55,67-68 run
+ * backwards): g = grad of out = LayerNorm_[C, L](pre), pre / stats as saved by bmnas_node_mix_ln_fwd.
+ * g_in (nullable) receives the LayerNorm input gradient (the attention backward reads it), dresid (=|+= by
+ * accumulate_resid; nullable) the same values as the residual's gradient; everything else as
+ * bmnas_node_mix_bwd with that gradient as its g.  Two workgroups per sample; one BatchNorm atomic pair per
+ * channel per sample, hence b <= 128 and C*L <= 8192 (bmnas_node_mix_ln_bwd_ok; BMNAS_E_LIMIT otherwise).
+ * Replaces bmnas_cat_ln_bwd + bmnas_node_mix_bwd. */
+int bmnas_node_mix_ln_bwd_ok(int b, int C, int L);
+int bmnas_node_mix_ln_bwd(const float* g, const float* pre, const float* ln_w, const float* stats,
+                          float* g_in, float* dresid, int accumulate_resid, const float* x, const float* y,
+                          const float* p1, const float* U, const float* chan, const float* gamma,
+                          float* dgamma, int dgamma_shards, int64_t dgamma_shard_stride, float* dx, float* dy,
+                          uint32_t accumulate_mask, float* dV, float* bn_grad, int b, int C, int L,
+                          bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
+
 /* K2 with the NEXT inner step's mixed sum riding along (NodeCell.forward, reference
  * models/search/darts/node_search.py:52-57: step t+1 starts with z = sum_j beta_j states[j], and
  * states[-1] is the s this launch produces):

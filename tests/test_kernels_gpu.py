@@ -392,6 +392,65 @@ def test_node_mix_next_sum_matches_separate_launches(b, C, L, n_prev, have_g, al
         assert_close_scaled(k, got[k], want[k].cpu(), rel=1e-5)
 
 
+@pytest.mark.parametrize('b,C,L,racc,xacc,drop,same', [(128, 192, 16, 0, 0, True, True), (8, 128, 8, 1, 1, False, True),
+                                                         (5, 32, 16, 0, 1, True, True), (3, 16, 4, 1, 0, False, False),
+                                                         (100, 256, 16, 0, 0, True, True), (7, 512, 16, 1, 1, True, False),
+                                                         (1, 64, 8, 0, 0, False, True)])
+def test_node_mix_ln_bwd_matches_separate_launches(b, C, L, racc, xacc, drop, same):
+    """bmnas_node_mix_ln_bwd (K6 LayerNorm backward + K2 mix backward in one launch, two workgroups per
+    sample; node_search.py:55,67-68 backwards) against bmnas_cat_ln_bwd + bmnas_node_mix_bwd, which the
+    oracle tests pin.  All three instantiations (C*L/4 <= 512, <= 1024, <= 2048), dropout on and off,
+    accumulating and overwriting destinations, x is y and x != y."""
+    from bmnas import lib
+    assert lib.node_mix_ln_bwd_ok(b, C, L)
+    assert not lib.node_mix_ln_bwd_ok(129, C, L) and not lib.node_mix_ln_bwd_ok(4, 1024, 16)
+    g = _gen(4300 + b + C + L)
+    d = dev()
+    x, p1, U = _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d), _rand(g, b, 3 * C, L).to(d)
+    y = x if same else _rand(g, b, C, L).to(d)
+    pre, gy = (_rand(g, b, C, L) * 1.5 + 0.2).to(d), _rand(g, b, C, L).to(d)
+    ln_w, ln_b = (_rand(g, C, L) * 0.3 + 1.0).to(d), (_rand(g, C, L) * 0.2).to(d)
+    gamma = torch.softmax(_rand(g, 4), 0).to(d)
+    M = 3 * C
+    Ud = U.double()
+    mean = Ud.mean(dim=(0, 2))
+    rstd = 1.0 / torch.sqrt(Ud.var(dim=(0, 2), unbiased=False) + 1e-5)
+    bn_w, bn_b = (_rand(g, M) * 0.3 + 1.0).to(d).double(), (_rand(g, M) * 0.2).to(d).double()
+    scale = rstd * bn_w
+    chan = torch.cat([mean, rstd, scale, bn_b - mean * scale]).float()
+    pd = pre.double()
+    smean = pd.mean(dim=(1, 2))
+    srstd = 1.0 / torch.sqrt(pd.var(dim=(1, 2), unbiased=False) + 1e-5)
+    stats = torch.stack([smean, srstd], dim=1).float().contiguous()
+    dglu = lib.make_dropout(0.1, 1234, 0) if drop else lib.NO_DROP
+    dfc = lib.make_dropout(0.2, 1234, b * C * L // 4) if drop else lib.NO_DROP
+    old_r, old_x, old_y = _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d)
+
+    def run(fused):
+        dres, dx, dy = old_r.clone(), old_x.clone(), (None if same else old_y.clone())
+        gin = torch.empty_like(x)
+        dgam = torch.zeros(4, device=d)
+        dV, bn_grad = torch.empty(b, M, L, device=d), torch.zeros(2 * M, device=d)
+        acc = xacc | (0 if same else (xacc << 1))
+        if fused:
+            lib.node_mix_ln_bwd(gy, pre, ln_w, stats, gin, dres, racc, x, y, p1, U, chan, gamma, dgam, dx, dy, acc,
+                                dV, bn_grad, b, C, L, dglu, dfc)
+        else:
+            lib.cat_ln_bwd(gy, [pre], None, ln_w, ln_b, stats, [gin], dres, racc << 31, None, None, b, C, L, False)
+            lib.node_mix_bwd(gin, x, y, p1, U, chan, gamma, dgam, dx, dy, acc, dV, bn_grad, b, C, L, dglu, dfc)
+        torch.cuda.synchronize()
+        out = dict(g_in=gin, dresid=dres, dx=dx, dV=dV, bn_grad=bn_grad, dgamma=dgam)
+        if dy is not None:
+            out['dy'] = dy
+        return out
+
+    want, got = run(False), run(True)
+    for k in want:
+        assert_close_scaled(k, got[k], want[k].cpu(), rel=2e-5)
+    if drop:                                                    # the masks really were on, and identical
+        assert float((want['dV'] == 0).float().mean()) > 0.05
+
+
 @pytest.mark.parametrize('b,C,L,acc,sums', [(8, 128, 8, 0, True), (6, 128, 8, 1, False), (64, 128, 8, 1, True),
                                             (5, 192, 16, 0, True), (3, 16, 4, 1, False), (100, 256, 16, 0, True)])
 def test_bn_relu_ln_tail(b, C, L, acc, sums):
