@@ -443,7 +443,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ p1,
     const float* __restrict__ U, const float* __restrict__ chan, const float* __restrict__ gamma,
     float* dgamma, int dg_shards, int64_t dg_stride, float* dx, float* dy, uint32_t acc_mask,
-    float* __restrict__ dV, float* bn_grad, int b, int C, int L, DropCfg dglu, DropCfg dfc) {
+    float* __restrict__ dV, float* bn_grad, int b, int C, int L, DropCfg dglu, DropCfg dfc, int probe) {
   constexpr int NW = BS / 64;
   __shared__ float red2[NW * 2];
   __shared__ float red4[NW * 4];
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
   for (int k = 0; k < VPT1; ++k) {
     const int idx = threadIdx.x + k * BS;
     xh[k] = dxh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < cl4) {
+    if (idx < cl4 && !((probe & 2) && idx >= h4)) {
       int r = half * h4 + idx;
       r = r >= cl4 ? r - cl4 : r;
       const int64_t e = ((int64_t)smp * cl4 + r) * 4;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
       sw[q] = row_sum(sw[q], l4n);
       sb[q] = row_sum(sb[q], l4n);
     }
-    if (act && (r % l4n) == 0) {
+    if (act && (r % l4n) == 0 && !(probe & 1)) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         atomicAdd(bn_grad + q * C + c, sw[q]);
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
     }
   }
   block_sum_lead<NW, 4>(dgam, red4);
-  if (threadIdx.x == 0 && dgamma != nullptr) {
+  if (threadIdx.x == 0 && dgamma != nullptr && !(probe & 4)) {
     float* p = dgamma + (int64_t)(blockIdx.x % dg_shards) * dg_stride;
 #pragma unroll
     for (int q = 0; q < 4; ++q) atomicAdd(p + q, dgam[q]);
@@ -1326,11 +1326,14 @@ extern "C" int bmnas_node_mix_ln_bwd(const float* g, const float* pre, const flo
   if (!bmnas_node_mix_ln_bwd_ok(b, C, L)) return BMNAS_E_LIMIT;
   const int cl4 = C * L / 4;
   hipStream_t st = (hipStream_t)stream;
+  // BMNAS_MIXLN_PROBE: timing diagnostics only (1: no BatchNorm atomics, 2: half of the first phase,
+  // 4: no dgamma atomics — results incomplete)
+  static const int probe = []() { const char* e = getenv("BMNAS_MIXLN_PROBE"); return e ? atoi(e) : 0; }();
 #define NMLB(V1, V2)                                                                                         \
   hipLaunchKernelGGL((node_mix_ln_bwd_k<V1, V2, 512>), dim3(2 * b), dim3(512), 0, st, g, pre, ln_w, stats,   \
                      g_in, dresid, accumulate_resid, x, y, p1, U, chan, gamma, dgamma, dgamma_shards,        \
                      dgamma_shard_stride, dx, dy, accumulate_mask, dV, bn_grad, b, C, L, to_cfg(drop_glu),   \
-                     to_cfg(drop_fc))
+                     to_cfg(drop_fc), probe)
   if (cl4 <= 512) NMLB(1, 1);
   else if (cl4 <= 1024) NMLB(2, 1);
   else NMLB(4, 2);
