@@ -3,6 +3,7 @@
 // thread), two block reductions (mean, then centred second moment), one coalesced write.
 // Algorithmic bytes fwd: (n_src [+1 resid] + n_src) * T (+ 2*D*4 params), T = b*C*L*4.
 #include "common.hpp"
+#include <cstdlib>
 #include "../../include/bmnas_hip.h"
 #include "arch_body.hpp"
 
@@ -429,8 +430,17 @@ int fill_prob(LnAffineProb& P, const float* g, const float* gscale, const float*
   return 0;
 }
 
+// samples per workgroup of the LayerNorm affine reductions: 16 up to 256 samples (smaller chunks = more
+// atomics: measured slower, 6.5 vs 4.6 us at b = 128), then b / 16 — every chunk ends in one atomic per
+// element, and at b = 1024 sixteen-sample chunks meant 1.5 M atomics per pass (BMNAS_LN_CHUNK: tuning hook)
+inline int ln_affine_chunk(int b) {
+  static const int forced = []() { const char* e = getenv("BMNAS_LN_CHUNK"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return forced;
+  return b <= 256 ? 16 : (b + 15) / 16;
+}
+
 int launch_ln_affine(LnAffineBatch& B, hipStream_t st) {
-  B.chunk = 16;      // (smaller chunks = more atomics: measured slower, 6.5 vs 4.6 us)
+  B.chunk = ln_affine_chunk(B.b);
   int maxd4 = 0;
   for (int i = 0; i < B.n; ++i) maxd4 = B.p[i].d4 > maxd4 ? B.p[i].d4 : maxd4;
   dim3 grid((maxd4 + 63) / 64, (B.b + B.chunk - 1) / B.chunk, B.n);
@@ -509,7 +519,7 @@ extern "C" int bmnas_backward_epilogue(int n_prob, const float* const* g, const 
   if (total < 0) return total;
   B.n = n_prob;
   B.b = b;
-  B.chunk = 16;
+  B.chunk = ln_affine_chunk(B.b);
   int maxd4 = 0;
   for (int i = 0; i < B.n; ++i) maxd4 = B.p[i].d4 > maxd4 ? B.p[i].d4 : maxd4;
   dim3 grid((maxd4 + 63) / 64, (B.b + B.chunk - 1) / B.chunk, B.n + 1 + n_sums);
