@@ -439,6 +439,13 @@ __global__ __launch_bounds__(256) void conv_ksplit_multi_k(ConvArgs a) {
   conv_ksplit_body<TRANS, 1, 1, 12, true>(a, blockIdx.x, blockIdx.y, lds);
 }
 
+// BatchNorm input gradient  dU = scale * (dV - kb - (U - mean) * kw)  (kb = sum dV / N, kw = rstd * sum dV u_hat / N)
+// as  dU = alpha * dV + beta * U + gamma:  the pipelined data-gradient tiles and the weight-gradient tiles
+// apply it to every operand element they stage, two FMAs instead of five operations each.
+__device__ __forceinline__ float4 bn_fold_coef(float scale, float kb, float mean, float kw) {
+  return make_float4(scale, -scale * kw, scale * (kw * mean - kb), 0.f);
+}
+
 // ---- pipelined LDS tile kernel (forward) -----------------------------------------------------------
 // Counters (profiles/r01_pmc_gemm.txt) show the split-K kernel spending 45 % of a wave's life in one
 // burst of operand fetches (83 MB through L2 for 6 MB of unique data: every 16x16 / 32x32 tile
@@ -678,8 +685,8 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     boffg[i] = (int64_t)kr * a.ldw + 4 * j4;
     bsl[i] = ABUF + kr * JP + 4 * c4;
   }
-  // BatchNorm-backward fold: per-channel (scale, kb, mean, rstd * kw) of all K channels in LDS
-  // behind the two operand buffers
+  // BatchNorm-backward fold: per-channel (alpha, beta, gamma) of all K channels in LDS behind the two
+  // operand buffers — dU = alpha * dV + beta * U + gamma (bn_fold_coef): two FMAs per element
   const bool fold_bn = a.bn_U != nullptr;
   float4* coef = reinterpret_cast<float4*>(smem + 2 * BUF);
   int chl[NA];                                                  // channel of ra[i] inside a chunk
@@ -707,10 +714,10 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
         if (fold_bn) {
           const float4 cf = coef[c * KC + chl[i]];
           if (a.bn_train) {
-            v.x = cf.x * (v.x - cf.y - (ru[i].x - cf.z) * cf.w);
-            v.y = cf.x * (v.y - cf.y - (ru[i].y - cf.z) * cf.w);
-            v.z = cf.x * (v.z - cf.y - (ru[i].z - cf.z) * cf.w);
-            v.w = cf.x * (v.w - cf.y - (ru[i].w - cf.z) * cf.w);
+            v.x = fmaf(cf.x, v.x, fmaf(cf.y, ru[i].x, cf.z));
+            v.y = fmaf(cf.x, v.y, fmaf(cf.y, ru[i].y, cf.z));
+            v.z = fmaf(cf.x, v.z, fmaf(cf.y, ru[i].z, cf.z));
+            v.w = fmaf(cf.x, v.w, fmaf(cf.y, ru[i].w, cf.z));
           } else {
             v = f4_scale(v, cf.x);
           }
@@ -736,7 +743,7 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
       const float sc = a.bn_chan[2 * K + m];
       float4 cf = make_float4(sc, 0.f, 0.f, 0.f);
       if (a.bn_train)
-        cf = make_float4(sc, a.bn_grad[K + m] * invN, a.bn_chan[m], a.bn_chan[K + m] * (a.bn_grad[m] * invN));
+        cf = bn_fold_coef(sc, a.bn_grad[K + m] * invN, a.bn_chan[m], a.bn_chan[K + m] * (a.bn_grad[m] * invN));
       coef[m] = cf;
     }
     __syncthreads();
@@ -1136,17 +1143,17 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
       const int mt = m0 + 16 * tm;
       const int m = (mt < a.M ? mt : a.M - 16) + lo;
       const float sc = a.bn_chan[2 * a.M + m];
-      cf[tm] = a.bn_train ? make_float4(sc, a.bn_grad[a.M + m] * invN, a.bn_chan[m],
-                                        a.bn_chan[a.M + m] * (a.bn_grad[m] * invN))
+      cf[tm] = a.bn_train ? bn_fold_coef(sc, a.bn_grad[a.M + m] * invN, a.bn_chan[m],
+                                         a.bn_chan[a.M + m] * (a.bn_grad[m] * invN))
                           : make_float4(sc, 0.f, 0.f, 0.f);
     }
   }
   auto bn_fold = [&](float4 v, const float4 u, const float4 c) __attribute__((always_inline)) -> float4 {
     if (!a.bn_train) return f4_scale(v, c.x);
-    v.x = c.x * (v.x - c.y - (u.x - c.z) * c.w);
-    v.y = c.x * (v.y - c.y - (u.y - c.z) * c.w);
-    v.z = c.x * (v.z - c.y - (u.z - c.z) * c.w);
-    v.w = c.x * (v.w - c.y - (u.w - c.z) * c.w);
+    v.x = fmaf(c.x, v.x, fmaf(c.y, u.x, c.z));
+    v.y = fmaf(c.x, v.y, fmaf(c.y, u.y, c.z));
+    v.z = fmaf(c.x, v.z, fmaf(c.y, u.z, c.z));
+    v.w = fmaf(c.x, v.w, fmaf(c.y, u.w, c.z));
     return v;
   };
 
