@@ -131,6 +131,27 @@ __device__ __forceinline__ void block_sum_lead(float (&v)[N], float* red) {
   }
 }
 
+// Picking one of a few kernel-argument pointers by a run-time (per-lane) index:  never `args.p[q]` — that
+// is a MEMORY load of the pointer from the kernarg segment plus an s_waitcnt vmcnt(0) in front of the load
+// it feeds (one more memory round trip, and every earlier load of the wave is waited for).  A chain of
+// selects over the compile-time-indexed pointers keeps them in SGPRs; the empty asm keeps LLVM from folding
+// select(load, load) back into load(select(address, address)).
+template <typename T>
+__device__ __forceinline__ T* sgpr_ptr(T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+template <typename T, int N>
+__device__ __forceinline__ T* pick_ptr(T* const (&arr)[N], int q) {
+  T* p = sgpr_ptr(arr[0]);
+#pragma unroll
+  for (int qq = 1; qq < N; ++qq) {
+    T* c = sgpr_ptr(arr[qq]);
+    p = (q == qq) ? c : p;
+  }
+  return p;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

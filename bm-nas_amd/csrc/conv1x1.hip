@@ -148,7 +148,10 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
     const int i0 = blk * 16;
     const int q = i0 / a.Ci;                              // wave-uniform
     const int ci = i0 - q * a.Ci + 4 * h;
-    const float* src = a.act.p[q];
+    // a select chain, not a.act.p[q]: indexing the kernel-argument array with a run-time q is a MEMORY load
+    // of the pointer (global_load_dwordx2 + s_waitcnt vmcnt(0)) per block — every block's operand loads
+    // then wait for the previous block's, one round trip per block instead of one per wave
+    const float* src = pick_ptr(a.act.p, q);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const float* pp = src + abase[tn] + (int64_t)ci * a.L;
@@ -231,7 +234,9 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
     const float bj = (a.bias != nullptr) ? a.bias[jj] : 0.f;
     const int q = jj / a.Cj;
     const int cj = jj - q * a.Cj;
-    float* d = a.dst.p[q];
+    float* d = a.dst.p[0];
+#pragma unroll
+    for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const float4 o = make_float4(acc[tn][tj][0] + bj, acc[tn][tj][1] + bj, acc[tn][tj][2] + bj,
@@ -257,6 +262,14 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
 // latency at batch 128.
 template <int TN, int TJ>
 constexpr size_t conv_ksplit_lds();
+
+// Phase probes INSIDE the split-K body (BMNAS_CONV_PROBE bits 1 = no MFMA, 2 = no loads, 4 = no stores,
+// 8 = no barrier) exist only in builds with -DBMNAS_BODY_PROBES=1: left in as runtime branches they sit
+// between the operand loads, and hipcc then ends each block's loads with a branch and a wait.
+#ifndef BMNAS_BODY_PROBES
+#define BMNAS_BODY_PROBES 0
+#endif
+#define KS_PROBE(a, bit) (BMNAS_BODY_PROBES && ((a).probe & (bit)))
 
 // MULTI: contractions longer than the 4 * KPW blocks a workgroup holds in registers at once (the K = 2048
 // reshape layers) run as several rounds of [all loads, then all MFMAs] into the same accumulators.
@@ -304,20 +317,23 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
     // inside the round loop, where hipcc would turn it into a branch + s_waitcnt per block
     const int q = MULTI ? 0 : i0 / a.Ci;
     const int ci = i0 - q * a.Ci + 4 * h;
-    const float* src = a.act.p[q];
+    // a select chain, not a.act.p[q]: indexing the kernel-argument array with a run-time q is a MEMORY load
+    // of the pointer (global_load_dwordx2 + s_waitcnt vmcnt(0)) per block — every block's operand loads
+    // then wait for the previous block's, one round trip per block instead of one per wave
+    const float* src = pick_ptr(a.act.p, q);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const float* pp = src + abase[tn] + (int64_t)ci * a.L;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float t = (!MULTI && (a.probe & 2)) ? (float)lane : pp[(int64_t)r * a.L];
+        const float t = (!MULTI && KS_PROBE(a, 2)) ? (float)lane : pp[(int64_t)r * a.L];
         av[kb][tn][r] = vb ? t : 0.f;                    // blocks past the end contribute zero
         if (fold_bn && a.bn_train) uv[kb][tn][r] = a.bn_U[abase[tn] + (int64_t)(ci + r) * a.L];
       }
     }
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
-      if (!MULTI && (a.probe & 2)) {
+      if (!MULTI && KS_PROBE(a, 2)) {
         bv[kb][tj][0] = bv[kb][tj][1] = bv[kb][tj][2] = bv[kb][tj][3] = (float)lo;
       } else if (TRANS) {
         const float* pp = a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h;
@@ -365,7 +381,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
   // keep every load above this line: without the fence hipcc sinks the loads next to their
   // MFMAs to save registers, which re-serialises load -> wait -> multiply per block
   __builtin_amdgcn_sched_barrier(0);
-  if (!MULTI && (a.probe & 1)) {
+  if (!MULTI && KS_PROBE(a, 1)) {
 #pragma unroll
     for (int kb = 0; kb < KPW; ++kb)
 #pragma unroll
@@ -393,7 +409,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj)
       part[wave][tn * TJ + tj][lane] = make_float4(acc[tn][tj][0], acc[tn][tj][1], acc[tn][tj][2], acc[tn][tj][3]);
-  if (!(a.probe & 8)) __syncthreads();
+  if (!KS_PROBE(a, 8)) __syncthreads();
 
   // wave w finishes the tiles t = w, w + 4, ...:  o[r] = OUT[n = 16*g + 4h + r][j]
   const int l0 = (4 * h) & (a.L - 1);
@@ -413,7 +429,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
     for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
     const int so = g * a.spw + ((4 * h) >> a.Lb);
     const bool vo = so < a.b;
-    if (vo && d != nullptr && (!(a.probe & 4) || o.x == 12345.f)) {
+    if (vo && d != nullptr && (!KS_PROBE(a, 4) || o.x == 12345.f)) {
       float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
       st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
     }
