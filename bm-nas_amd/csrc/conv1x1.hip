@@ -1107,7 +1107,12 @@ struct ConvWArgs {
 // operands are float4 along l (next group's loads issued before this group's 16 MFMAs), the
 // eight partial tiles meet in LDS and leave with coalesced stores (single split) or
 // well-shaped fp32 atomics (128-B runs along k).
-template <int NW>
+// FOLD: the BatchNorm input gradient is applied to the dU operand (ConvWArgs::bn_U != nullptr).  A template
+// parameter, not a run-time test: with `if (a.bn_U)` / `if (a.bn_train)` inside the loop hipcc joined the
+// branches with s_waitcnt vmcnt(0) — and with the fold written where the operands are LOADED it had to wait
+// for the loads it had just issued before the previous group's MFMAs: every group paid a full memory round
+// trip (the two-set pipeline existed in the source only).
+template <int NW, bool FOLD>
 __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, const int by, const int bz,
                                             char* lds) {
   float (*tile)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(lds);                          // [NW][1056]
@@ -1149,56 +1154,59 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
   float bsum[2] = {0.f, 0.f};
 
   // BatchNorm-backward fold (see ConvArgs): this lane's two dU rows are two fixed channels, their
-  // (scale, kb, mean, rstd * kw) live in registers for the whole walk over the batch
-  const bool fold_bn = a.bn_U != nullptr;
+  // (alpha, beta, gamma) of dU = alpha * dV + beta * U + gamma live in registers for the whole walk over
+  // the batch (eval mode: alpha = scale, beta = gamma = 0)
   float4 cf[2] = {z4, z4};
-  if (fold_bn) {
+  if (FOLD) {
     const float invN = 1.f / (float)(a.b * a.L);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int mt = m0 + 16 * tm;
       const int m = (mt < a.M ? mt : a.M - 16) + lo;
       const float sc = a.bn_chan[2 * a.M + m];
-      cf[tm] = a.bn_train ? bn_fold_coef(sc, a.bn_grad[a.M + m] * invN, a.bn_chan[m],
-                                         a.bn_chan[a.M + m] * (a.bn_grad[m] * invN))
-                          : make_float4(sc, 0.f, 0.f, 0.f);
+      cf[tm] = make_float4(sc, 0.f, 0.f, 0.f);
+      if (a.bn_train)                                                     // (outside the loop; bn_grad is null in eval)
+        cf[tm] = bn_fold_coef(sc, a.bn_grad[a.M + m] * invN, a.bn_chan[m],
+                              a.bn_chan[a.M + m] * (a.bn_grad[m] * invN));
     }
   }
-  auto bn_fold = [&](float4 v, const float4 u, const float4 c) __attribute__((always_inline)) -> float4 {
-    if (!a.bn_train) return f4_scale(v, c.x);
-    v.x = fmaf(c.x, v.x, fmaf(c.y, u.x, c.z));
-    v.y = fmaf(c.x, v.y, fmaf(c.y, u.y, c.z));
-    v.z = fmaf(c.x, v.z, fmaf(c.y, u.z, c.z));
-    v.w = fmaf(c.x, v.w, fmaf(c.y, u.w, c.z));
-    return v;
-  };
 
   // loads are unconditional from clamped addresses; what must not contribute to the sum over
   // n (padded samples, groups past the split) is zeroed in the dU operand by a select
-  float4 a0[2], b0[2], a1[2], b1[2];           // two statically named operand sets
-  auto load_ops = [&](float4 (&A)[2], float4 (&B)[2], int g) __attribute__((always_inline)) {
+  struct Ops {
+    float4 A[2], U[2], B[2];
+    bool vs;
+  };
+  auto load_raw = [&](Ops& o, int g) __attribute__((always_inline)) {
     const int gc = g < gend ? g : gend - 1;
     const int s = gc * a.spw + sh;
     const int sc = s < a.b ? s : a.b - 1;
-    const bool vs = (g < gend) && (s < a.b);
+    o.vs = (g < gend) && (s < a.b);
     const int64_t uo = (int64_t)sc * a.M * a.L + l0;
     const int64_t xb = (int64_t)sc * a.C_src * a.L + l0;
-    float4 u0 = ld4(a.dU + uo + aoff0), u1 = ld4(a.dU + uo + aoff1);
-    if (fold_bn) {
-      float4 r0 = z4, r1 = z4;
-      if (a.bn_train) {
-        r0 = ld4(a.bn_U + uo + aoff0);
-        r1 = ld4(a.bn_U + uo + aoff1);
-      }
-      u0 = bn_fold(u0, r0, cf[0]);
-      u1 = bn_fold(u1, r1, cf[1]);
+    o.A[0] = ld4(a.dU + uo + aoff0);
+    o.A[1] = ld4(a.dU + uo + aoff1);
+    if (FOLD) {
+      o.U[0] = ld4(a.bn_U + uo + aoff0);
+      o.U[1] = ld4(a.bn_U + uo + aoff1);
     }
-    A[0] = vs ? u0 : z4;
-    A[1] = vs ? u1 : z4;
-    B[0] = ld4(bsrc0 + xb + boff0);
-    B[1] = ld4(bsrc1 + xb + boff1);
+    o.B[0] = ld4(bsrc0 + xb + boff0);
+    o.B[1] = ld4(bsrc1 + xb + boff1);
   };
-  auto mma_ops = [&](const float4 (&A)[2], const float4 (&B)[2]) __attribute__((always_inline)) {
+  // the fold is applied HERE, when the set is consumed: by then the other set's loads are in flight
+  auto mma_ops = [&](Ops& o) __attribute__((always_inline)) {
+    float4 A[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      float4 v = o.A[tm];
+      if (FOLD) {
+        v.x = fmaf(cf[tm].x, v.x, fmaf(cf[tm].y, o.U[tm].x, cf[tm].z));
+        v.y = fmaf(cf[tm].x, v.y, fmaf(cf[tm].y, o.U[tm].y, cf[tm].z));
+        v.z = fmaf(cf[tm].x, v.z, fmaf(cf[tm].y, o.U[tm].z, cf[tm].z));
+        v.w = fmaf(cf[tm].x, v.w, fmaf(cf[tm].y, o.U[tm].w, cf[tm].z));
+      }
+      A[tm] = o.vs ? v : z4;
+    }
     if (want_bias) {
       bsum[0] += f4_hsum(A[0]);
       bsum[1] += f4_hsum(A[1]);
@@ -1207,27 +1215,30 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int tk = 0; tk < 2; ++tk) {
-        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].x, B[tk].x, acc[tm][tk], 0, 0, 0);
-        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].y, B[tk].y, acc[tm][tk], 0, 0, 0);
-        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].z, B[tk].z, acc[tm][tk], 0, 0, 0);
-        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].w, B[tk].w, acc[tm][tk], 0, 0, 0);
+        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].x, o.B[tk].x, acc[tm][tk], 0, 0, 0);
+        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].y, o.B[tk].y, acc[tm][tk], 0, 0, 0);
+        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].z, o.B[tk].z, acc[tm][tk], 0, 0, 0);
+        acc[tm][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tm].w, o.B[tk].w, acc[tm][tk], 0, 0, 0);
       }
   };
   // two-set software pipeline, straight-line steady state (groups past the split are clamped +
-  // zeroed by load_ops, so running one extra masked group is harmless).  Measured: 12.5 us vs
-  // 15.9 us for issuing all of a wave's loads up front; a three-set ring with the BatchNorm fold
-  // moved to the point of use: no gain (13.6 vs 13.9 us alone, 24.4 vs 24.0 us merged).  NB: that
-  // variant with `break`s out of the ring loop was MISCOMPILED by hipcc 7.2 (wrong accumulators on
-  // the exit paths) — keep exits out of MFMA pipeline loops, predicate the tail instead.
+  // zeroed, so running one extra masked group is harmless).  NB: a variant with `break`s out of a
+  // ring loop was MISCOMPILED by hipcc 7.2 (wrong accumulators on the exit paths) — keep exits out of
+  // MFMA pipeline loops, predicate the tail instead.
+  Ops s0, s1;
   int g = gbeg + wave;
-  load_ops(a0, b0, g);
+  load_raw(s0, g);
   for (; g + NW < gend; g += 2 * NW) {
-    load_ops(a1, b1, g + NW);
-    mma_ops(a0, b0);
-    load_ops(a0, b0, g + 2 * NW);
-    mma_ops(a1, b1);
+    load_raw(s1, g + NW);
+    __builtin_amdgcn_sched_barrier(0);       // the loads stay IN FRONT of the other set's MFMAs (hipcc sinks them)
+    mma_ops(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_raw(s0, g + 2 * NW);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_ops(s1);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  if (g < gend) mma_ops(a0, b0);
+  if (g < gend) mma_ops(s0);
 
   // acc[tm][tk][r] = dW[m0 + 16tm + 4h + r][k0 + 16tk + lo]
 #pragma unroll
@@ -1279,7 +1290,8 @@ constexpr size_t conv_w_lds() { return (size_t)NW * (32 * 33 + 32) * sizeof(floa
 
 __global__ __launch_bounds__(512) void conv_w_k(ConvWArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[conv_w_lds<8>()];
-  conv_w_body<8>(a, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+  if (a.bn_U != nullptr) conv_w_body<8, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+  else conv_w_body<8, false>(a, blockIdx.x, blockIdx.y, blockIdx.z, lds);
 }
 
 // The whole backward of a NodeMixedOp's contractions in ONE grid (search mode): attention
@@ -1304,7 +1316,8 @@ __global__ __launch_bounds__(256) void conv_bwd_all_k(ConvArgs a, SdpaBwdArgs s,
     // short data-gradient tiles, which then fill the gaps
     const int t = blk - s.groups;
     const int bz = t / (wx * wy), r = t - bz * wx * wy;
-    conv_w_body<4>(w, r % wx, r / wx, bz, merged_smem);
+    if (w.bn_U != nullptr) conv_w_body<4, true>(w, r % wx, r / wx, bz, merged_smem);
+    else conv_w_body<4, false>(w, r % wx, r / wx, bz, merged_smem);
   } else {
     const int t = blk - s.groups - n_w;
     conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx, merged_smem);
@@ -1321,7 +1334,8 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_k(ConvArgs a, ConvWArgs w, 
   const int blk = blockIdx.x;
   if (blk < n_w) {
     const int bz = blk / (wx * wy), r = blk - bz * wx * wy;
-    conv_w_body<4>(w, r % wx, r / wx, bz, merged_smem);
+    if (w.bn_U != nullptr) conv_w_body<4, true>(w, r % wx, r / wx, bz, merged_smem);
+    else conv_w_body<4, false>(w, r % wx, r / wx, bz, merged_smem);
   } else {
     const int t = blk - n_w;
     conv_ksplit_body<false, 1, 1, KPW>(a, t % gx, t / gx, merged_smem);
@@ -1359,7 +1373,8 @@ __global__ __launch_bounds__(256) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdAr
       bx = r % wx;
       by = r / wx;
     }
-    conv_w_body<4>(w, bx, by, bz, merged_smem);
+    if (w.bn_U != nullptr) conv_w_body<4, true>(w, bx, by, bz, merged_smem);
+    else conv_w_body<4, false>(w, bx, by, bz, merged_smem);
   } else {
     const int t = blk - s.groups - n_w;
     conv_pipe_bwd_body<KC, NG>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
