@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void conv_pipe_fwd_k(ConvArgs a, int gx) {
 constexpr int kPipeBN = 32, kPipeBJ = 64;
 
 // NG = n-groups per tile: 2 (32 x 64 tile, two j-tiles per wave) or 1 (16 x 64, one per wave)
-template <int KC, int NG>
+template <int KC, int NG, bool FOLD>
 __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int bx, const int by,
                                                    float* __restrict__ smem) {
   constexpr int JP = kPipeBJ + 4;
@@ -702,8 +702,9 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     bsl[i] = ABUF + kr * JP + 4 * c4;
   }
   // BatchNorm-backward fold: per-channel (alpha, beta, gamma) of all K channels in LDS behind the two
-  // operand buffers — dU = alpha * dV + beta * U + gamma (bn_fold_coef): two FMAs per element
-  const bool fold_bn = a.bn_U != nullptr;
+  // operand buffers — dU = alpha * dV + beta * U + gamma (bn_fold_coef): two FMAs per element.  FOLD is a
+  // template parameter (eval mode: alpha = scale, beta = gamma = 0, U still fetched): no run-time branches
+  // inside the chunk loop, where hipcc joins them with s_waitcnt vmcnt(0).
   float4* coef = reinterpret_cast<float4*>(smem + 2 * BUF);
   int chl[NA];                                                  // channel of ra[i] inside a chunk
 #pragma unroll
@@ -712,37 +713,38 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     const int qq = q < A4 ? q : A4 - 1;
     chl[i] = ((qq - (qq / cl4) * cl4) * 4) >> a.Lb;
   }
-  float4 ra[NA], ru[NA], rb[NB];
-  auto fetch = [&](int c) __attribute__((always_inline)) {
+  // ONE chunk of global loads in flight.  Two (register sets by chunk parity, measured again in round 2 with
+  // the branch-free loop): 196 VGPRs, data-gradient tiles alone +5 us, merged launch +1.5 us.
+  struct Regs {
+    float4 ra[NA], ru[NA], rb[NB];
+  };
+  auto fetch = [&](Regs& R, int c) __attribute__((always_inline)) {
+    c = c < nchunk ? c : nchunk - 1;                           // past the end: a harmless repeat, no branch
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
-      if (fold_bn && a.bn_train) ru[i] = ld4(a.bn_U + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
+      R.ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
+      if (FOLD) R.ru[i] = ld4(a.bn_U + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = ld4(a.W + boffg[i] + (int64_t)(c * KC) * a.ldw);
+    for (int i = 0; i < NB; ++i) R.rb[i] = ld4(a.W + boffg[i] + (int64_t)(c * KC) * a.ldw);
   };
-  auto stash = [&](float* buf, int c) __attribute__((always_inline)) {
+  auto stash = [&](float* buf, const Regs& R, int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      if (t + 256 * i < A4) {
-        float4 v = ra[i];
-        if (fold_bn) {
+      if (256 * (i + 1) <= A4 || t + 256 * i < A4) {          // whole rounds: no predicate
+        float4 v = R.ra[i];
+        if (FOLD) {
           const float4 cf = coef[c * KC + chl[i]];
-          if (a.bn_train) {
-            v.x = fmaf(cf.x, v.x, fmaf(cf.y, ru[i].x, cf.z));
-            v.y = fmaf(cf.x, v.y, fmaf(cf.y, ru[i].y, cf.z));
-            v.z = fmaf(cf.x, v.z, fmaf(cf.y, ru[i].z, cf.z));
-            v.w = fmaf(cf.x, v.w, fmaf(cf.y, ru[i].w, cf.z));
-          } else {
-            v = f4_scale(v, cf.x);
-          }
+          v.x = fmaf(cf.x, v.x, fmaf(cf.y, R.ru[i].x, cf.z));
+          v.y = fmaf(cf.x, v.y, fmaf(cf.y, R.ru[i].y, cf.z));
+          v.z = fmaf(cf.x, v.z, fmaf(cf.y, R.ru[i].z, cf.z));
+          v.w = fmaf(cf.x, v.w, fmaf(cf.y, R.ru[i].w, cf.z));
         }
         st4(buf + asl[i], v);
       }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      if (t + 256 * i < B4) st4(buf + bsl[i], rb[i]);
+      if (256 * (i + 1) <= B4 || t + 256 * i < B4) st4(buf + bsl[i], R.rb[i]);
   };
   const int gl = (NG == 2) ? (wave & 1) : 0, jl0 = (NG == 2) ? 2 * (wave >> 1) : wave;
   const int aoff = (gl * a.spw + (lo >> a.Lb)) * KC * (a.L + 4) + (lo & (a.L - 1));
@@ -752,26 +754,10 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
   f32x4 acc[WJ];
 #pragma unroll
   for (int tj = 0; tj < WJ; ++tj) acc[tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  fetch(0);
-  if (fold_bn) {
-    const float invN = 1.f / (float)(a.b * a.L);
-    for (int m = t; m < K; m += 256) {
-      const float sc = a.bn_chan[2 * K + m];
-      float4 cf = make_float4(sc, 0.f, 0.f, 0.f);
-      if (a.bn_train)
-        cf = bn_fold_coef(sc, a.bn_grad[K + m] * invN, a.bn_chan[m], a.bn_chan[K + m] * (a.bn_grad[m] * invN));
-      coef[m] = cf;
-    }
-    __syncthreads();
-  }
-  stash(smem, 0);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const float* cur = smem + (c & 1) * BUF;
-    if (c + 1 < nchunk) fetch(c + 1);
-    // all LDS operand reads of the chunk first, then its MFMAs back to back: with one wave per
-    // SIMD nothing else hides the LDS latency, so it is paid once per chunk instead of per k-block
-    // (the fences keep hipcc from re-interleaving them and from hoisting the barrier above the MFMAs)
+  // all LDS operand reads of a chunk first, then its MFMAs back to back: with one wave per SIMD nothing
+  // else hides the LDS latency, so it is paid once per chunk instead of per k-block (the fences keep hipcc
+  // from re-interleaving them and from hoisting the barrier above the MFMAs)
+  auto compute = [&](const float* cur) __attribute__((always_inline)) {
     constexpr int NKB = KC / 16;
     float av[NKB][4], bv[NKB][WJ][4];
 #pragma unroll
@@ -793,8 +779,28 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
         for (int r = 0; r < 4; ++r)
           acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][r], bv[kb][tj][r], acc[tj], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+  };
+  Regs R;
+  fetch(R, 0);
+  if (FOLD) {
+    const float invN = 1.f / (float)(a.b * a.L);
+    for (int m = t; m < K; m += 256) {
+      const float sc = a.bn_chan[2 * K + m];
+      float4 cf = make_float4(sc, 0.f, 0.f, 0.f);
+      if (a.bn_train)
+        cf = bn_fold_coef(sc, a.bn_grad[K + m] * invN, a.bn_chan[m], a.bn_chan[K + m] * (a.bn_grad[m] * invN));
+      coef[m] = cf;
+    }
+    __syncthreads();
+  }
+  stash(smem, R, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    fetch(R, c + 1);                                           // in flight during this chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    compute(smem + (c & 1) * BUF);
     if (c + 1 < nchunk) {
-      stash(smem + ((c + 1) & 1) * BUF, c + 1);
+      stash(smem + ((c + 1) & 1) * BUF, R, c + 1);            // the other buffer: nobody reads it now
       __syncthreads();
     }
   }
@@ -821,7 +827,8 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
 template <int KC, int NG>
 __global__ __launch_bounds__(256) void conv_pipe_bwd_k(ConvArgs a, int gx) {
   extern __shared__ __attribute__((aligned(16))) float pipe_smem[];
-  conv_pipe_bwd_body<KC, NG>(a, blockIdx.x % gx, blockIdx.x / gx, pipe_smem);
+  if (a.bn_U != nullptr) conv_pipe_bwd_body<KC, NG, true>(a, blockIdx.x % gx, blockIdx.x / gx, pipe_smem);
+  else conv_pipe_bwd_body<KC, NG, false>(a, blockIdx.x % gx, blockIdx.x / gx, pipe_smem);
 }
 
 template <int KC, int NG>
@@ -1377,7 +1384,8 @@ __global__ __launch_bounds__(256) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdAr
     else conv_w_body<4, false>(w, bx, by, bz, merged_smem);
   } else {
     const int t = blk - s.groups - n_w;
-    conv_pipe_bwd_body<KC, NG>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
+    if (a.bn_U != nullptr) conv_pipe_bwd_body<KC, NG, true>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
+    else conv_pipe_bwd_body<KC, NG, false>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
   }
 }
 
