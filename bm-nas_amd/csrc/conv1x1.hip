@@ -549,6 +549,14 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
 #pragma unroll
     for (int tj = 0; tj < 3; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the epilogue's bias values go out with the first operand loads: fetched where they are used, each
+  // output tile ended in load -> s_waitcnt vmcnt(0) -> store, three dependent round trips per wave
+  float bjv[3];
+#pragma unroll
+  for (int tj = 0; tj < 3; ++tj) {
+    const int jt = j0 + 16 * (jl0 + tj);
+    bjv[tj] = (a.bias != nullptr) ? a.bias[(jt < a.J ? jt : a.J - 16) + lo] : 0.f;
+  }
   fetch(0);
   stash(smem);
   __syncthreads();
@@ -599,7 +607,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
       const int g = bx * NG + gl0 + tn, jt = j0 + 16 * (jl0 + tj);
       if (g >= a.n_groups || jt >= a.J) continue;              // wave-uniform
       const int jj = jt + lo;
-      const float bj = (a.bias != nullptr) ? a.bias[jj] : 0.f;
+      const float bj = bjv[tj];
       const float4 o = make_float4(acc[tn][tj][0] + bj, acc[tn][tj][1] + bj, acc[tn][tj][2] + bj,
                                    acc[tn][tj][3] + bj);
       const int so = g * a.spw + ((4 * h) >> a.Lb);
