@@ -45,26 +45,35 @@ __device__ __forceinline__ void bn_fin_fill(const BnFin& f, float* __restrict__ 
   const bool wr = writer && !(f.on & 2);                      // (bit 1: timing experiments only)
   const bool upd = wr && f.training && f.running_mean != nullptr;
   for (int m0 = 4 * (int)threadIdx.x; m0 < M; m0 += 4 * BS) {   // one trip for M <= 4 * BS
+    // EVERY load unconditional, from an always-valid address where its operand is absent (eval mode has no
+    // sums, the conv may have no bias, training may not track running statistics): a load under `if` is a
+    // branch, and hipcc copies the loaded registers at the join behind s_waitcnt — which put a full drain
+    // between the sums and the affine parameters: two dependent round trips at the start of every consumer
+    const bool tr = f.training != 0;
+    const bool has_cb = tr && f.conv_bias != nullptr, need_run = upd || !tr;
+    const int mv = m0 + 8 <= M ? m0 : (M >= 8 ? M - 8 : 0);    // (dummy reads stay inside bn_w)
+    const float4* st = tr ? reinterpret_cast<const float4*>(f.stat + 2 * m0)
+                          : reinterpret_cast<const float4*>(f.bn_w + mv);
+    const int64_t sstr = tr ? (int64_t)(M / 2) : 0;
     float4 v[kMaxShards][2];
-    if (f.training) {
-      const float4* st = reinterpret_cast<const float4*>(f.stat + 2 * m0);
 #pragma unroll
-      for (int k = 0; k < kMaxShards; ++k) {                   // clamped shard index: no predicated loads
-        const float4* p = st + (int64_t)(k < f.shards ? k : 0) * (M / 2);
-        v[k][0] = p[0];                                        // (sum, sumsq) of channels m0, m0 + 1
-        v[k][1] = p[1];                                        //              of channels m0 + 2, m0 + 3
-      }
+    for (int k = 0; k < kMaxShards; ++k) {                     // clamped shard index: no predicated loads
+      const float4* p = st + (int64_t)(k < f.shards ? k : 0) * sstr;
+      v[k][0] = p[0];                                          // (sum, sumsq) of channels m0, m0 + 1
+      v[k][1] = p[1];                                          //              of channels m0 + 2, m0 + 3
     }
     const float4 w4 = ld4(f.bn_w + m0), b4 = ld4(f.bn_b + m0);
-    float4 cb4 = make_float4(0.f, 0.f, 0.f, 0.f), rm4 = cb4, rv4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (f.training && f.conv_bias != nullptr) cb4 = ld4(f.conv_bias + m0);
-    if (upd || !f.training) {
-      rm4 = ld4(f.running_mean + m0);
-      rv4 = ld4(f.running_var + m0);
-    }
+    float4 cb4 = ld4((has_cb ? f.conv_bias : f.bn_w) + m0);
+    float4 rm4 = ld4((need_run ? f.running_mean : f.bn_w) + m0);
+    float4 rv4 = ld4((need_run ? f.running_var : f.bn_w) + m0);
     long long nb = 0;
     const bool bump = wr && f.training && f.nbt != nullptr && m0 < f.n_nbt;
     if (bump) nb = f.nbt[m0];                                  // (n_nbt <= 4: the counters of thread 0)
+    if (!has_cb) cb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!need_run) {
+      rm4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      rv4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
     if (f.training) {
 #pragma unroll

@@ -185,24 +185,25 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
   // finalisation (its own memory round trip + a barrier), then the arithmetic: the two latencies
   // overlap instead of adding up
   float4 ua[VPT], ug[VPT], uf[VPT], xv[VPT], yv[VPT], pv[VPT], rv[VPT];
+  // (clamped addresses, not `if (r < cl4)` around the loads: the predicated form compiled to branches whose
+  // join copied every loaded register — behind s_waitcnt vmcnt(4..0) — BEFORE the BatchNorm finalisation's own
+  // loads were issued: two dependent round trips instead of the one this ordering is for)
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    const int r = threadIdx.x + k * BS;
-    v[k] = lw[k] = lb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ua[k] = ug[k] = uf[k] = xv[k] = yv[k] = pv[k] = rv[k] = v[k];
-    if (r < cl4) {
-      lw[k] = ld4(ln_w + (int64_t)r * 4);
-      lb[k] = ld4(ln_b + (int64_t)r * 4);
-      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
-      const int64_t ub = ((int64_t)smp * M) * L + (int64_t)r * 4;
-      ua[k] = ld4(U + ub);
-      ug[k] = ld4(U + ub + (int64_t)C * L);
-      uf[k] = ld4(U + ub + (int64_t)2 * C * L);
-      xv[k] = ld4(x + e);
-      yv[k] = ld4(y + e);
-      pv[k] = ld4(p1 + e);
-      rv[k] = ld4(resid + e);
-    }
+    const int r0 = threadIdx.x + k * BS;
+    const int r = r0 < cl4 ? r0 : cl4 - 1;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lw[k] = ld4(ln_w + (int64_t)r * 4);
+    lb[k] = ld4(ln_b + (int64_t)r * 4);
+    const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+    const int64_t ub = ((int64_t)smp * M) * L + (int64_t)r * 4;
+    ua[k] = ld4(U + ub);
+    ug[k] = ld4(U + ub + (int64_t)C * L);
+    uf[k] = ld4(U + ub + (int64_t)2 * C * L);
+    xv[k] = ld4(x + e);
+    yv[k] = ld4(y + e);
+    pv[k] = ld4(p1 + e);
+    rv[k] = ld4(resid + e);
   }
   bn_fin_fill<BS>(fin, chan, M, b * L, sc, sh, blockIdx.x == 0);
   float sum = 0.f;
@@ -460,8 +461,8 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
     ua[k] = ug[k] = uf[k] = xv[k] = yv[k] = pv[k] = oldr[k] = oldx[k] = oldy[k] = zero;
 #pragma unroll
     for (int q = 0; q < 3; ++q) csc[k][q] = csh[k][q] = cmu[k][q] = crs[k][q] = 0.f;
-    if (idx < h4) {
-      const int r = half * h4 + idx;
+    {                                                    // clamped addresses, no predicate around the loads
+      const int r = half * h4 + (idx < h4 ? idx : h4 - 1);
       const int c = r / l4n;
       const int64_t e = ((int64_t)smp * cl4 + r) * 4;
       const int64_t ub = ((int64_t)smp * M) * L + (int64_t)r * 4;
@@ -492,15 +493,16 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
   for (int k = 0; k < VPT1; ++k) {
     const int idx = threadIdx.x + k * BS;
     xh[k] = dxh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < cl4 && !((probe & 2) && idx >= h4)) {
-      int r = half * h4 + idx;
+    {
+      const bool on = idx < cl4 && !((probe & 2) && idx >= h4);
+      int r = half * h4 + (idx < cl4 ? idx : cl4 - 1);
       r = r >= cl4 ? r - cl4 : r;
       const int64_t e = ((int64_t)smp * cl4 + r) * 4;
       const float4 pr = ld4(pre + e), w = ld4(ln_w + (int64_t)r * 4), g = ld4(gy + e);
       xh[k] = make_float4((pr.x - mean) * rstd, (pr.y - mean) * rstd, (pr.z - mean) * rstd, (pr.w - mean) * rstd);
       dxh[k] = f4_mul(g, w);
-      s12[0] += f4_hsum(dxh[k]);
-      s12[1] += f4_dot(dxh[k], xh[k]);
+      s12[0] += on ? f4_hsum(dxh[k]) : 0.f;
+      s12[1] += on ? f4_dot(dxh[k], xh[k]) : 0.f;
     }
   }
   block_sum_n<NW, 2>(s12, red2);
