@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   float* sc = fin_lds;
   float* sh = fin_lds + M;
+  const DropRt rglu = drop_begin(dglu), rfc = drop_begin(dfc);
   bn_fin_fill<256>(fin, chan, M, b * L, sc, sh, blockIdx.x == 0);
   const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
   const int64_t total = (int64_t)b * cl4;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
     const float4 va = affine4(ld4(U + ub), sc[c], sh[c]);
     const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), sc[C + c], sh[C + c]);
     const float4 vf = affine4(ld4(U + ub + (int64_t)2 * C * L), sc[2 * C + c], sh[2 * C + c]);
-    const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
+    const float4 m2 = drop_mult4(rglu, (uint64_t)e), m3 = drop_mult4(rfc, (uint64_t)e);
     const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e);
     float4 o;
     o.x = g0 * (xv.x + yv.x) + g1 * pv.x + g2 * (va.x * sigmoidf(vg.x) * m2.x) + g3 * (fmaxf(vf.x, 0.f) * m3.x);
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
   float* sc = fin_lds;
   float* sh = fin_lds + M;
   const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
+  const DropRt rglu = drop_begin(dglu), rfc = drop_begin(dfc);
   float4 v[VPT], lw[VPT], lb[VPT];
   // every global load of the sample first (raw conv outputs included), THEN the BatchNorm
   // finalisation (its own memory round trip + a barrier), then the arithmetic: the two latencies
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
       const float4 va = affine4(ua[k], sc[c], sh[c]);
       const float4 vg = affine4(ug[k], sc[C + c], sh[C + c]);
       const float4 vf = affine4(uf[k], sc[2 * C + c], sh[2 * C + c]);
-      const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
+      const float4 m2 = drop_mult4(rglu, (uint64_t)e), m3 = drop_mult4(rfc, (uint64_t)e);
       float4 o;
       o.x = g0 * (xv[k].x + yv[k].x) + g1 * pv[k].x + g2 * (va.x * sigmoidf(vg.x) * m2.x) + g3 * (fmaxf(vf.x, 0.f) * m3.x);
       o.y = g0 * (xv[k].y + yv[k].y) + g1 * pv[k].y + g2 * (va.y * sigmoidf(vg.y) * m2.y) + g3 * (fmaxf(vf.y, 0.f) * m3.y);
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
   const bool active = r < cl4;
   const int c = active ? r / l4n : 0;
   const float g0 = gamma[0], g2 = gamma[2], g3 = gamma[3];
+  const DropRt rglu = drop_begin(dglu), rfc = drop_begin(dfc);
   float sc[3], sh[3], mu[3], rs[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
         gv = ld4(g + e);
       }
       const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e);
-      const float4 m2 = drop_mult4(dglu, (uint64_t)e), m3 = drop_mult4(dfc, (uint64_t)e);
+      const float4 m2 = drop_mult4(rglu, (uint64_t)e), m3 = drop_mult4(rfc, (uint64_t)e);
       const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
       const float uaq[4] = {ua.x, ua.y, ua.z, ua.w}, ugq[4] = {ug.x, ug.y, ug.z, ug.w},
                   ufq[4] = {uf.x, uf.y, uf.z, uf.w};
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
   __shared__ float red4[NW * 4];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C, h4 = cl4 / 2;
   const int smp = blockIdx.x >> 1, half = blockIdx.x & 1;
-  const bool same = (x == y);
+  const DropRt rglu = drop_begin(dglu), rfc = drop_begin(dfc);
   // second-phase operands first: they do not depend on the sums
   float4 ua[VPT2], ug[VPT2], uf[VPT2], xv[VPT2], yv[VPT2], pv[VPT2], oldr[VPT2], oldx[VPT2], oldy[VPT2];
   float csc[VPT2][3], csh[VPT2][3], cmu[VPT2][3], crs[VPT2][3];
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
       ug[k] = ld4(U + ub + (int64_t)C * L);
       uf[k] = ld4(U + ub + (int64_t)2 * C * L);
       xv[k] = ld4(x + e);
-      yv[k] = same ? xv[k] : ld4(y + e);
+      yv[k] = ld4(y + e);                                 // (x == y: an L1 hit — `same ? xv : load` was a wait + copy)
       pv[k] = ld4(p1 + e);
       if (acc_resid) oldr[k] = ld4(dresid + e);
       if (dx != nullptr && (acc_mask & 1u)) oldx[k] = ld4(dx + e);
@@ -489,21 +492,25 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
   // first phase: the whole sample's sum(gy w) and sum(gy w xhat)
   float4 xh[VPT1], dxh[VPT1];
   float s12[2] = {0.f, 0.f};
+  // (all loads of the phase, then its arithmetic: interleaved per k, the first k's use of `mean` drained every
+  // load in flight before the second k's loads were issued)
 #pragma unroll
   for (int k = 0; k < VPT1; ++k) {
     const int idx = threadIdx.x + k * BS;
-    xh[k] = dxh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-      const bool on = idx < cl4 && !((probe & 2) && idx >= h4);
-      int r = half * h4 + (idx < cl4 ? idx : cl4 - 1);
-      r = r >= cl4 ? r - cl4 : r;
-      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
-      const float4 pr = ld4(pre + e), w = ld4(ln_w + (int64_t)r * 4), g = ld4(gy + e);
-      xh[k] = make_float4((pr.x - mean) * rstd, (pr.y - mean) * rstd, (pr.z - mean) * rstd, (pr.w - mean) * rstd);
-      dxh[k] = f4_mul(g, w);
-      s12[0] += on ? f4_hsum(dxh[k]) : 0.f;
-      s12[1] += on ? f4_dot(dxh[k], xh[k]) : 0.f;
-    }
+    int r = half * h4 + (idx < cl4 ? idx : cl4 - 1);
+    r = r >= cl4 ? r - cl4 : r;
+    const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+    xh[k] = ld4(pre + e);
+    dxh[k] = f4_mul(ld4(gy + e), ld4(ln_w + (int64_t)r * 4));
+  }
+#pragma unroll
+  for (int k = 0; k < VPT1; ++k) {
+    const int idx = threadIdx.x + k * BS;
+    const bool on = idx < cl4 && !((probe & 2) && idx >= h4);
+    const float4 pr = xh[k];
+    xh[k] = make_float4((pr.x - mean) * rstd, (pr.y - mean) * rstd, (pr.z - mean) * rstd, (pr.w - mean) * rstd);
+    s12[0] += on ? f4_hsum(dxh[k]) : 0.f;
+    s12[1] += on ? f4_dot(dxh[k], xh[k]) : 0.f;
   }
   block_sum_n<NW, 2>(s12, red2);
   const float inv_d = 1.f / (float)(cl4 * 4);
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
       gv.w = rstd * (dxh[k].w - m1 - xh[k].w * m2);
       if (gbuf != nullptr) st4(gbuf + e, gv);
       if (dresid != nullptr) st4(dresid + e, f4_add(gv, oldr[k]));
-      const float4 m2d = drop_mult4(dglu, (uint64_t)e), m3d = drop_mult4(dfc, (uint64_t)e);
+      const float4 m2d = drop_mult4(rglu, (uint64_t)e), m3d = drop_mult4(rfc, (uint64_t)e);
       const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
       const float uaq[4] = {ua[k].x, ua[k].y, ua[k].z, ua[k].w}, ugq[4] = {ug[k].x, ug[k].y, ug[k].z, ug[k].w},
                   ufq[4] = {uf[k].x, uf[k].y, uf[k].z, uf[k].w};
@@ -587,6 +594,7 @@ __global__ __launch_bounds__(256) void bn_glu_fwd_k(const float* __restrict__ U,
                                                     const float* __restrict__ chan,
                                                     float* __restrict__ out, int b, int C, int L,
                                                     DropCfg d) {
+  const DropRt dr = drop_begin(d);
   const int cl4 = C * L / 4, l4n = L / 4, M = 2 * C;
   const int64_t total = (int64_t)b * cl4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(256) void bn_glu_fwd_k(const float* __restrict__ U,
     const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
     const float4 va = affine4(ld4(U + ub), chan[2 * M + c], chan[3 * M + c]);
     const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), chan[2 * M + C + c], chan[3 * M + C + c]);
-    const float4 m = drop_mult4(d, (uint64_t)(i * 4));
+    const float4 m = drop_mult4(dr, (uint64_t)(i * 4));
     st4(out + i * 4, make_float4(va.x * sigmoidf(vg.x) * m.x, va.y * sigmoidf(vg.y) * m.y,
                                   va.z * sigmoidf(vg.z) * m.z, va.w * sigmoidf(vg.w) * m.w));
   }
@@ -607,6 +615,7 @@ __global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
                                                     const float* __restrict__ chan,
                                                     float* __restrict__ dV, float* bn_grad, int b,
                                                     int C, int L, int chunk, DropCfg d) {
+  const DropRt dr = drop_begin(d);
   __shared__ float csum[3][4][64];
   const int cl4 = C * L / 4, l4n = L / 4, M = 2 * C;
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
       const int64_t e = ((int64_t)s * cl4 + r) * 4;
       const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
       const float4 ua = ld4(U + ub), ug = ld4(U + ub + (int64_t)C * L), gv = ld4(g + e);
-      const float4 m = drop_mult4(d, (uint64_t)e);
+      const float4 m = drop_mult4(dr, (uint64_t)e);
       const float uaq[4] = {ua.x, ua.y, ua.z, ua.w}, ugq[4] = {ug.x, ug.y, ug.z, ug.w},
                   gq[4] = {gv.x, gv.y, gv.z, gv.w}, mq[4] = {m.x, m.y, m.z, m.w};
       float da[4], dg[4];
@@ -675,6 +684,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_k(const float* __restrict__ U
                                                      float* __restrict__ chan, BnFin fin,
                                                      float* __restrict__ out, int b, int M, int L,
                                                      DropCfg d) {
+  const DropRt dr = drop_begin(d);
   extern __shared__ float fin_lds[];
   float* sc = fin_lds;
   float* sh = fin_lds + M;
@@ -685,7 +695,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_k(const float* __restrict__ U
     const int r = (int)(i % ml4);
     const int c = r / l4n;
     const float4 v = affine4(ld4(U + i * 4), sc[c], sh[c]);
-    const float4 m = drop_mult4(d, (uint64_t)(i * 4));
+    const float4 m = drop_mult4(dr, (uint64_t)(i * 4));
     st4(out + i * 4, make_float4(fmaxf(v.x, 0.f) * m.x, fmaxf(v.y, 0.f) * m.y,
                                   fmaxf(v.z, 0.f) * m.z, fmaxf(v.w, 0.f) * m.w));
   }
@@ -696,6 +706,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g
                                                      const float* __restrict__ chan,
                                                      float* __restrict__ dV, float* bn_grad, int b,
                                                      int M, int L, int chunk, DropCfg d) {
+  const DropRt dr = drop_begin(d);
   __shared__ float csum[3][2][64];
   const int ml4 = M * L / 4, l4n = L / 4;
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -711,7 +722,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g
     for (int s = s_beg + sl; s < s_end; s += 4) {
       const int64_t e = ((int64_t)s * ml4 + r) * 4;
       const float4 u = ld4(U + e), gv = ld4(g + e);
-      const float4 m = drop_mult4(d, (uint64_t)e);
+      const float4 m = drop_mult4(dr, (uint64_t)e);
       const float uq[4] = {u.x, u.y, u.z, u.w}, gq[4] = {gv.x, gv.y, gv.z, gv.w},
                   mq[4] = {m.x, m.y, m.z, m.w};
       float dv[4];
@@ -750,6 +761,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
     const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* __restrict__ o_out,
     float* __restrict__ out, float* __restrict__ stats, int b, int C, int L, DropCfg d,
     float* __restrict__ osum) {
+  const DropRt dr = drop_begin(d);
   __shared__ float red[8];
   __shared__ float red6[8 * 6];
   extern __shared__ float fin_lds[];
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
       const int c = r / l4n;
       const int64_t e = ((int64_t)smp * cl4 + r) * 4;
       const float4 a = affine4(v[k], sc[c], sh[c]);
-      const float4 m = drop_mult4(d, (uint64_t)e);
+      const float4 m = drop_mult4(dr, (uint64_t)e);
       const float4 o = make_float4(fmaxf(a.x, 0.f) * m.x, fmaxf(a.y, 0.f) * m.y, fmaxf(a.z, 0.f) * m.z,
                                    fmaxf(a.w, 0.f) * m.w);
       st4(o_out + e, o);
@@ -842,6 +854,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
     const float* __restrict__ ln_w, const float* __restrict__ stats, const float* __restrict__ U,
     const float* __restrict__ chan, float* __restrict__ dV, float* bn_grad, float* dresid, int acc_resid,
     int b, int C, int L, DropCfg d) {
+  const DropRt dr = drop_begin(d);
   __shared__ float red[8];
   const int cl4 = C * L / 4, l4n = L / 4;
   const int smp = blockIdx.x;
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
       dx.w = rstd * (dxh[k].w - m1 - xh[k].w * m2);
       if (dresid != nullptr) st4(dresid + e, f4_add(dx, old[k]));
       const float mu = chan[c], rs = chan[C + c], scv = chan[2 * C + c], shv = chan[3 * C + c];
-      const float4 m = drop_mult4(d, (uint64_t)e);
+      const float4 m = drop_mult4(dr, (uint64_t)e);
       const float uq[4] = {u[k].x, u[k].y, u[k].z, u[k].w}, gq[4] = {dx.x, dx.y, dx.z, dx.w},
                   mq[4] = {m.x, m.y, m.z, m.w};
       float dv[4];

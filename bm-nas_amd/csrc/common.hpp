@@ -42,6 +42,28 @@ __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
   return make_uint4(c0, c1, c2, c3);
 }
 
+// The same with the device step counter already read: kernels call drop_begin() FIRST, so that the counter's
+// load goes out with their operand loads.  Read inside drop_mult4 (hipGraph replays: step != nullptr) it was a
+// load -> s_waitcnt vmcnt(0) in the middle of the arithmetic, once per dropout site — dependent round trips
+// on the critical path of every kernel with a dropout.
+struct DropRt {
+  uint32_t thr;
+  float scale;
+  uint64_t seed;
+  uint64_t off;
+};
+__device__ __forceinline__ DropRt drop_begin(const DropCfg& d) {
+  DropRt r{d.thr, d.scale, d.seed, d.offset};
+  if (d.thr != 0u && d.step != nullptr) r.off += d.step[0];
+  return r;
+}
+__device__ __forceinline__ float4 drop_mult4(const DropRt& d, uint64_t e) {
+  if (d.thr == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);
+  uint4 r = philox4x32_10(d.off + (e >> 2), d.seed);
+  return make_float4(r.x >= d.thr ? d.scale : 0.f, r.y >= d.thr ? d.scale : 0.f,
+                     r.z >= d.thr ? d.scale : 0.f, r.w >= d.thr ? d.scale : 0.f);
+}
+
 // mask*scale multipliers for the float4 starting at flat element index e (e % 4 == 0)
 __device__ __forceinline__ float4 drop_mult4(const DropCfg& d, uint64_t e) {
   if (d.thr == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);

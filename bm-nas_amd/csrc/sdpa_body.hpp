@@ -118,6 +118,7 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
                                               const float* __restrict__ ln_b, float* __restrict__ out,
                                               float* __restrict__ xhat, float* __restrict__ stats,
                                               const SdpaGeom& G, const DropCfg& drop, char* lds) {
+  const DropRt drop_rt = drop_begin(drop);          // the step counter's load goes out first
   // LDS comes from the caller (kSdpaFwdLds bytes, 16-byte aligned) so that a launch that merges
   // this body with others pays max(), not sum(), of their footprints
   float4* ldsS = reinterpret_cast<float4*>(lds);                 // [4 * 64]
@@ -156,7 +157,7 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
       o = __builtin_amdgcn_mfma_f32_16x16x4f32(p[2], yv[k].z, o, 0, 0, 0);
       o = __builtin_amdgcn_mfma_f32_16x16x4f32(p[3], yv[k].w, o, 0, 0, 0);
       const int64_t e = ((int64_t)sh * G.C + ch * 16 + lo) * G.L + l0;
-      const float4 m = v_h ? drop_mult4(drop, (uint64_t)e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 m = v_h ? drop_mult4(drop_rt, (uint64_t)e) : make_float4(0.f, 0.f, 0.f, 0.f);
       od[k] = make_float4(o[0] * m.x, o[1] * m.y, o[2] * m.z, o[3] * m.w);
       sum += f4_hsum(od[k]);
     }
@@ -199,6 +200,7 @@ __device__ __forceinline__ void sdpa_bwd_body(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ ln_w,
     const float* __restrict__ xhat, const float* __restrict__ stats, float* dx, float* dy,
     uint32_t acc_mask, const SdpaGeom& G, const DropCfg& drop, char* lds) {
+  const DropRt drop_rt = drop_begin(drop);          // the step counter's load goes out first
   // LDS from the caller: sdpa_bwd_lds(C) bytes, 16-byte aligned (see sdpa_fwd_body)
   float4* ldsS = reinterpret_cast<float4*>(lds);                                  // [4 * 64]
   float (*tP)[16 * 17] = reinterpret_cast<float (*)[16 * 17]>(lds + 4096);        // [4][272]
@@ -263,7 +265,7 @@ __device__ __forceinline__ void sdpa_bwd_body(
     const int ch = wave + 4 * k;
     if (ch < nch) {
       const int64_t e = ((int64_t)sh * G.C + ch * 16 + lo) * G.L + l0;
-      const float4 m = v_h ? drop_mult4(drop, (uint64_t)e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 m = v_h ? drop_mult4(drop_rt, (uint64_t)e) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 d = make_float4(rstd * (dv[k].x - m1 - xh[k].x * m2) * m.x,
                                    rstd * (dv[k].y - m1 - xh[k].y * m2) * m.y,
                                    rstd * (dv[k].z - m1 - xh[k].z * m2) * m.z,
