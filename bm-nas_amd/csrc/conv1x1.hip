@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void conv_pipe_fwd_k(ConvArgs a, int gx) {
 constexpr int kPipeBN = 32, kPipeBJ = 64;
 
 // NG = n-groups per tile: 2 (32 x 64 tile, two j-tiles per wave) or 1 (16 x 64, one per wave)
-template <int KC, int NG, bool FOLD>
+template <int KC, int NG, bool FOLD, bool LA2 = false>
 __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int bx, const int by,
                                                    float* __restrict__ smem) {
   constexpr int JP = kPipeBJ + 4;
@@ -721,8 +721,6 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     const int qq = q < A4 ? q : A4 - 1;
     chl[i] = ((qq - (qq / cl4) * cl4) * 4) >> a.Lb;
   }
-  // ONE chunk of global loads in flight.  Two (register sets by chunk parity, measured again in round 2 with
-  // the branch-free loop): 196 VGPRs, data-gradient tiles alone +5 us, merged launch +1.5 us.
   struct Regs {
     float4 ra[NA], ru[NA], rb[NB];
   };
@@ -803,13 +801,38 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
   }
   stash(smem, R, 0);
   __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    fetch(R, c + 1);                                           // in flight during this chunk's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-    compute(smem + (c & 1) * BUF);
-    if (c + 1 < nchunk) {
-      stash(smem + ((c + 1) & 1) * BUF, R, c + 1);            // the other buffer: nobody reads it now
+  if (LA2 && (nchunk & 1) == 0 && nchunk >= 4) {
+    // TWO chunks of global loads in flight (register sets by chunk parity).  The steady-state loop has no
+    // conditional fetch or stash: a stash that may be skipped leaves its set's loads pending on one path, and
+    // hipcc then waits for them at the loop head on EVERY path (that, not the idea, is what made the first
+    // two-chunk experiments slower); the last two chunks run after the loop.
+    Regs Q;
+    fetch(Q, 1);
+    for (int c = 0; c + 2 < nchunk; c += 2) {
+      fetch(R, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(smem);
+      stash(smem + BUF, Q, c + 1);                             // the other buffer: nobody reads it now
       __syncthreads();
+      fetch(Q, c + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(smem + BUF);
+      stash(smem, R, c + 2);
+      __syncthreads();
+    }
+    compute(smem);
+    stash(smem + BUF, Q, nchunk - 1);
+    __syncthreads();
+    compute(smem + BUF);
+  } else {
+    for (int c = 0; c < nchunk; ++c) {
+      fetch(R, c + 1);                                         // in flight during this chunk's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      compute(smem + (c & 1) * BUF);
+      if (c + 1 < nchunk) {
+        stash(smem + ((c + 1) & 1) * BUF, R, c + 1);          // the other buffer: nobody reads it now
+        __syncthreads();
+      }
     }
   }
   const int l0 = (4 * h) & (a.L - 1);
@@ -1357,8 +1380,15 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_k(ConvArgs a, ConvWArgs w, 
   }
 }
 
+#ifndef BMNAS_PIPE_LA2
+#define BMNAS_PIPE_LA2 1
+#endif
+constexpr bool kLa2 = BMNAS_PIPE_LA2 != 0;
+
+// (second __launch_bounds__ argument: at least 3 waves per SIMD, i.e. <= 168 VGPRs — the grid is ~750
+// workgroups and all of them must be resident at once)
 template <int KC, int KCH, int NG>
-__global__ __launch_bounds__(256) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
+__global__ __launch_bounds__(256, 3) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
                                                            int n_w, int wx, int wy) {
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   const int blk = blockIdx.x;
@@ -1392,7 +1422,7 @@ __global__ __launch_bounds__(256) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdAr
     else conv_w_body<4, false>(w, bx, by, bz, merged_smem);
   } else {
     const int t = blk - s.groups - n_w;
-    if (a.bn_U != nullptr) conv_pipe_bwd_body<KC, NG, true>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
+    if (a.bn_U != nullptr) conv_pipe_bwd_body<KC, NG, true, kLa2>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
     else conv_pipe_bwd_body<KC, NG, false>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
   }
 }
