@@ -467,7 +467,7 @@ def roofline_report(a, c, step, ms_per_step, log):
     if top is not None:
         top = dict(top)
         top['measured'] = (source + f'; mean over {len(replays)} replays of End - Start per dispatch; '
-                           'the same figures as profiles/r02_kernel_stats_graph.csv')
+                           'cross-check: profiles/r02_kernel_stats_<config>_b<batch>.csv (rocprofv3 --kernel-trace --stats of the same command)')
         out['roofline'] = top
     return out
 
