@@ -402,6 +402,8 @@ MIX_PREV_MAX = 5
 FUSE_PROLOGUE_PAIR = os.environ.get('BMNAS_FUSE_PROLOGUE_PAIR', '1') != '0'
 # node_multiplier == 1, <= 128 samples: the node's LayerNorm backward inside the mix-backward launch
 FUSE_LN_BWD = os.environ.get('BMNAS_FUSE_LN_BWD', '1') != '0'
+# small batches, node_multiplier != 1: the next cell step's K1 pair sum inside the node's tail launch
+FUSE_NEXT_PAIR = os.environ.get('BMNAS_FUSE_NEXT_PAIR', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
 FUSE_HEAD = os.environ.get('BMNAS_FUSE_HEAD', '1') != '0'
 
@@ -521,7 +523,7 @@ FUSE_PAIR = True   # search mode: cell-level mixed sum + the node's first inner 
 
 
 def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=None, stats=None,
-                  want_sums=False):
+                  want_sums=False, next_pair=None):
     """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
     device tensors.  NP: parameter pack of the NodeCell.  z0: the first inner mixed sum when the
     caller already formed it (bmnas_mixsum_pair_fwd)."""
@@ -533,6 +535,7 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
     sv.zs, sv.mixed, sv.offsets = [], [], []
     offset = 0
     sv.fused_tail = nm == 1 and FUSE_TAIL
+    sv.next_pair_done = False
     sv.stats = _empty(x, b * 2)
     # per-sample (sum, sum of squares) of the node output, for the head's K7 LayerNorm (head.hip)
     sv.osum = _empty(x, b * 2) if want_sums else None
@@ -571,8 +574,9 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
         sv.fused_bn_tail = FUSE_BN_TAIL and b <= BN_TAIL_MAX_B and C <= 1024
         if sv.fused_bn_tail:             # BatchNorm + ReLU + dropout + residual + LayerNorm: one launch
             out = torch.empty_like(x)
+            sv.next_pair_done = next_pair is not None
             lib.bn_relu_ln_fwd(V, chan, x, NP.ln_w, NP.ln_b, o, out, sv.stats, b, C, L, sv.d_out,
-                               sv.oconv.fin, sv.osum)
+                               sv.oconv.fin, sv.osum, next_pair)
             sv.o = o
             return out, sv
         lib.bn_relu_fwd(V, chan, o, b, C, L, sv.d_out, sv.oconv.fin)
@@ -671,8 +675,12 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
     states = list(xs)
     sv.sifs, sv.nodes, sv.offsets = [], [], []
     offset = 0
+    pending_pair = None                          # (sif, z0) of step i formed by step i - 1's tail launch
     for i in range(S):
-        if FUSE_PAIR and len(states) <= 15:
+        if pending_pair is not None:
+            sif, z0 = pending_pair
+            pending_pair = None
+        elif FUSE_PAIR and len(states) <= 15:
             sif, z0 = torch.empty_like(xs[0]), torch.empty_like(xs[0])
             if i == 0 and prologue is not None:
                 prologue(states, sif, z0)        # the cell prologue rides in this launch (bmnas_cell_prologue_pair)
@@ -680,9 +688,18 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
                 lib.mixsum_pair_fwd(states, alpha_w[offset:, 1], 2, beta_ws[i][:, 1], 2, sif, z0)
         else:
             sif, z0 = mixsum_fwd(states, alpha_w[offset:, 1]), None
+        # small batches: step i + 1's pair sum (its inputs = today's states + this node's output) rides in the
+        # launch that ends this node (bmnas_bn_relu_ln_fwd_pair)
+        next_pair = None
+        if (FUSE_NEXT_PAIR and FUSE_PAIR and FUSE_BN_TAIL and i + 1 < S and nm != 1 and len(states) + 1 <= 15
+                and lib.bn_relu_ln_fwd_pair_ok(b, C, L, len(states))):
+            nsif, nz0 = torch.empty_like(xs[0]), torch.empty_like(xs[0])
+            next_pair = (list(states), alpha_w[offset + len(states):, 1], 2, beta_ws[i + 1][:, 1], 2, nsif, nz0)
         out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm, z0,
                                  None if weffs is None else weffs[i * ns:(i + 1) * ns], stats,
-                                 want_sums=head is not None)
+                                 want_sums=head is not None, next_pair=next_pair)
+        if next_pair is not None and nsv.next_pair_done:
+            pending_pair = (next_pair[5], next_pair[6])
         nsv.paired = z0 is not None
         sv.sifs.append(sif)
         sv.nodes.append(nsv)

@@ -116,6 +116,9 @@ SIGNATURES = {
     'bmnas_bn_relu_fwd': ([_P, _P, BnFin, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_ln_fwd': ([_P, _P, BnFin, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P, _P], _I),
+    'bmnas_bn_relu_ln_fwd_pair_ok': ([_I, _I, _I, _I], _I),
+    'bmnas_bn_relu_ln_fwd_pair': ([_P, _P, BnFin, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P, _PP, _I, _P, _I,
+                                   _P, _I, _P, _P, _P], _I),
     'bmnas_bn_relu_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_bwd_apply': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_linear_fwd': ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
@@ -545,10 +548,23 @@ def bn_relu_bwd(g, U, chan, dV, bn_grad, b, M, L, drop):
                                     _stream()), 'bn_relu_bwd')
 
 
-def bn_relu_ln_fwd(U, chan, resid, ln_w, ln_b, o, out, stats, b, Cc, L, drop, fin=NO_FIN, out_sums=None):
-    _check(load().bmnas_bn_relu_ln_fwd(_ptr(U), _ptr(chan), fin, _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(o),
-                                       _ptr(out), _ptr(stats), b, Cc, L, drop, _ptr(out_sums), _stream()),
-           'bn_relu_ln_fwd')
+def bn_relu_ln_fwd_pair_ok(b, Cc, L, n_prev):
+    return bool(load().bmnas_bn_relu_ln_fwd_pair_ok(b, Cc, L, n_prev))
+
+
+def bn_relu_ln_fwd(U, chan, resid, ln_w, ln_b, o, out, stats, b, Cc, L, drop, fin=NO_FIN, out_sums=None, nxt=None):
+    """nxt = (xs, w, w_stride, w2, w2_stride, h, z): the next cell step's K1 pair sum in the same launch
+    (bmnas_bn_relu_ln_fwd_pair; its last input is the `out` of this call)."""
+    if nxt is None:
+        _check(load().bmnas_bn_relu_ln_fwd(_ptr(U), _ptr(chan), fin, _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(o),
+                                           _ptr(out), _ptr(stats), b, Cc, L, drop, _ptr(out_sums), _stream()),
+               'bn_relu_ln_fwd')
+        return
+    xs, w, ws, w2, w2s, h, z = nxt
+    _check(load().bmnas_bn_relu_ln_fwd_pair(_ptr(U), _ptr(chan), fin, _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(o),
+                                            _ptr(out), _ptr(stats), b, Cc, L, drop, _ptr(out_sums), _ptrs(xs),
+                                            len(xs), w.data_ptr(), ws, w2.data_ptr(), w2s, _ptr(h), _ptr(z),
+                                            _stream()), 'bn_relu_ln_fwd_pair')
 
 
 def bn_relu_ln_bwd(g, o, resid, ln_w, stats, U, chan, dV, bn_grad, dresid, acc_resid, b, Cc, L, drop):

@@ -755,12 +755,26 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g
 // One workgroup per sample (the LayerNorm's two reductions stay in registers); the BatchNorm is
 // finalised by every workgroup at its start (bn_fin.hpp).  o is written out as well: the batched
 // LayerNorm-affine gradient of the backward epilogue reads the LayerNorm input from it.
-template <int VPT, int BS>
+// NP > 0 (small batches): the NEXT cell step's K1 pair sum rides along (FusionCell.forward, reference
+// models/search/darts/model_search.py:58 + node_search.py:54 at t = 0): its inputs are NP earlier states plus
+// the node output this workgroup has just normalised — per-sample, elementwise, and all of its loads go out
+// with the kernel's first loads:   h = sum_{j < NP} w_j xs[j] + w_NP out,   z = (w2_0 + w2_1) h.
+// One launch (~4.8 us at 6-8 samples per GPU) less per cell step after the first.
+struct PairNextF {
+  PtrsIn xs;
+  const float* w;          // softmaxed edge weights, element j at w[j * ws]
+  const float* w2;
+  float* h;
+  float* z;
+  int ws, w2s;
+};
+
+template <int VPT, int BS, int NP = 0>
 __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
     const float* __restrict__ U, float* __restrict__ chan, BnFin fin, const float* __restrict__ resid,
     const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* __restrict__ o_out,
     float* __restrict__ out, float* __restrict__ stats, int b, int C, int L, DropCfg d,
-    float* __restrict__ osum) {
+    float* __restrict__ osum, PairNextF P) {
   const DropRt dr = drop_begin(d);
   __shared__ float red[8];
   __shared__ float red6[8 * 6];
@@ -770,17 +784,27 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
   float* sc = fin_lds;
   float* sh = fin_lds + C;
   float4 v[VPT], lw[VPT], lb[VPT], rv[VPT];
+  float4 pn[VPT][NP > 0 ? NP : 1];
+  float pw[NP + 1];
+  float ps2 = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {                     // every global load first, then the finalisation
-    const int r = threadIdx.x + k * BS;
-    v[k] = lw[k] = lb[k] = rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < cl4) {
-      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
-      lw[k] = ld4(ln_w + (int64_t)r * 4);
-      lb[k] = ld4(ln_b + (int64_t)r * 4);
-      v[k] = ld4(U + e);
-      rv[k] = ld4(resid + e);
+    const int r0 = threadIdx.x + k * BS;
+    const int r = r0 < cl4 ? r0 : cl4 - 1;            // clamped, not predicated (see node_mix_ln_fwd_k)
+    const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+    lw[k] = ld4(ln_w + (int64_t)r * 4);
+    lb[k] = ld4(ln_b + (int64_t)r * 4);
+    v[k] = ld4(U + e);
+    rv[k] = ld4(resid + e);
+    if (NP > 0) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) pn[k][j] = ld4(P.xs.p[j] + e);
     }
+  }
+  if (NP > 0) {
+#pragma unroll
+    for (int j = 0; j <= NP; ++j) pw[j] = P.w[j * P.ws];
+    ps2 = P.w2[0] + P.w2[P.w2s];
   }
   bn_fin_fill<BS>(fin, chan, C, b * L, sc, sh, blockIdx.x == 0);
   float sum = 0.f;
@@ -838,9 +862,27 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
     const int r = threadIdx.x + k * BS;
     if (r < cl4) {
       const float4 w = lw[k], bb = lb[k];
-      st4(out + ((int64_t)smp * cl4 + r) * 4,
-          make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
-                      (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w));
+      const float4 y = make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
+                                   (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w);
+      const int64_t e = ((int64_t)smp * cl4 + r) * 4;
+      st4(out + e, y);
+      if (NP > 0) {
+        // the arithmetic of mixsum_pair_fwd_k, in its order: inputs 0 .. NP-1, then this output
+        float4 acc = f4_scale(pn[k][0], pw[0]);
+#pragma unroll
+        for (int j = 1; j < NP; ++j) {
+          acc.x = fmaf(pw[j], pn[k][j].x, acc.x);
+          acc.y = fmaf(pw[j], pn[k][j].y, acc.y);
+          acc.z = fmaf(pw[j], pn[k][j].z, acc.z);
+          acc.w = fmaf(pw[j], pn[k][j].w, acc.w);
+        }
+        acc.x = fmaf(pw[NP], y.x, acc.x);
+        acc.y = fmaf(pw[NP], y.y, acc.y);
+        acc.z = fmaf(pw[NP], y.z, acc.z);
+        acc.w = fmaf(pw[NP], y.w, acc.w);
+        st4(P.h + e, acc);
+        st4(P.z + e, f4_scale(acc, ps2));
+      }
     }
   }
 }
@@ -1415,11 +1457,44 @@ extern "C" int bmnas_bn_relu_bwd(const float* g, const float* U, const float* ch
   return 0;
 }
 
+extern "C" int bmnas_bn_relu_ln_fwd_pair(const float* U, float* chan, bmnas_bn_fin_t fin, const float* resid,
+                                         const float* ln_w, const float* ln_b, float* o, float* out,
+                                         float* stats, int b, int C, int L, bmnas_dropout_t drop,
+                                         float* out_sums, const float* const* xs, int n_prev, const float* w,
+                                         int w_stride, const float* w2, int w2_stride, float* h, float* z,
+                                         void* stream);
+
 extern "C" int bmnas_bn_relu_ln_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, const float* resid,
                                     const float* ln_w, const float* ln_b, float* o, float* out, float* stats,
                                     int b, int C, int L, bmnas_dropout_t drop, float* out_sums,
                                     void* stream) {
+  return bmnas_bn_relu_ln_fwd_pair(U, chan, fin, resid, ln_w, ln_b, o, out, stats, b, C, L, drop, out_sums,
+                                   nullptr, 0, nullptr, 1, nullptr, 1, nullptr, nullptr, stream);
+}
+
+extern "C" int bmnas_bn_relu_ln_fwd_pair_ok(int b, int C, int L, int n_prev) {
+  return b >= 1 && b <= 128 && n_prev >= 1 && n_prev <= BMNAS_MAX_PTRS - 1 && C * L / 4 <= 256;
+}
+
+extern "C" int bmnas_bn_relu_ln_fwd_pair(const float* U, float* chan, bmnas_bn_fin_t fin, const float* resid,
+                                         const float* ln_w, const float* ln_b, float* o, float* out,
+                                         float* stats, int b, int C, int L, bmnas_dropout_t drop,
+                                         float* out_sums, const float* const* xs, int n_prev, const float* w,
+                                         int w_stride, const float* w2, int w2_stride, float* h, float* z,
+                                         void* stream) {
   if (!U || !chan || !resid || !ln_w || !ln_b || !o || !out || !stats || b < 0 || C < 1) return BMNAS_E_ARG;
+  PairNextF P{};
+  if (n_prev > 0) {
+    if (!xs || !w || !w2 || !h || !z || w_stride < 1 || w2_stride < 1) return BMNAS_E_ARG;
+    if (!bmnas_bn_relu_ln_fwd_pair_ok(b > 0 ? b : 1, C, L, n_prev)) return BMNAS_E_LIMIT;
+    for (int j = 0; j < n_prev; ++j) {
+      if (!xs[j]) return BMNAS_E_ARG;
+      P.xs.p[j] = xs[j];
+    }
+    P.w = w; P.w2 = w2; P.h = h; P.z = z; P.ws = w_stride; P.w2s = w2_stride;
+  } else if (n_prev < 0) {
+    return BMNAS_E_ARG;
+  }
   if (L % 4 || L > 16 || C % 4) return BMNAS_E_SHAPE;
   BnFin f;
   if (int e = to_fin(fin, &f)) return e;
@@ -1431,14 +1506,28 @@ extern "C" int bmnas_bn_relu_ln_fwd(const float* U, float* chan, bmnas_bn_fin_t 
   const int need = (C * L / 4 + bs - 1) / bs;
   if (C > 4 * bs) return BMNAS_E_LIMIT;                 // bn_fin_fill: one trip
   hipStream_t st = (hipStream_t)stream;
+  if (n_prev > 0) {                                      // (host-checked: one float4 per lane, 256 lanes)
+#define BRP(N)                                                                                          \
+  case N:                                                                                               \
+    hipLaunchKernelGGL((bn_relu_ln_fwd_k<1, 256, N>), dim3(b), dim3(256), fin_lds, st, U, chan, f, resid, \
+                       ln_w, ln_b, o, out, stats, b, C, L, to_cfg(drop), out_sums, P);                  \
+    break;
+    switch (n_prev) {
+      BRP(1) BRP(2) BRP(3) BRP(4) BRP(5) BRP(6) BRP(7) BRP(8) BRP(9) BRP(10) BRP(11) BRP(12) BRP(13) BRP(14) BRP(15)
+      default: return BMNAS_E_LIMIT;
+    }
+#undef BRP
+    BMNAS_CHECK_LAUNCH();
+    return 0;
+  }
 #define BRL(V)                                                                                          \
   do {                                                                                                  \
     if (wide)                                                                                           \
       hipLaunchKernelGGL((bn_relu_ln_fwd_k<V, 512>), dim3(b), dim3(512), fin_lds, st, U, chan, f, resid, \
-                         ln_w, ln_b, o, out, stats, b, C, L, to_cfg(drop), out_sums);                   \
+                         ln_w, ln_b, o, out, stats, b, C, L, to_cfg(drop), out_sums, P);                \
     else                                                                                                \
       hipLaunchKernelGGL((bn_relu_ln_fwd_k<V, 256>), dim3(b), dim3(256), fin_lds, st, U, chan, f, resid, \
-                         ln_w, ln_b, o, out, stats, b, C, L, to_cfg(drop), out_sums);                   \
+                         ln_w, ln_b, o, out, stats, b, C, L, to_cfg(drop), out_sums, P);                \
   } while (0)
   if (need <= 1) BRL(1);
   else if (need <= 2) BRL(2);

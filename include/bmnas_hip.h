@@ -360,6 +360,19 @@ int bmnas_bn_relu_bwd(const float* g, const float* U, const float* chan, float* 
 int bmnas_bn_relu_ln_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, const float* resid,
                          const float* ln_w, const float* ln_b, float* o, float* out, float* stats, int b,
                          int C, int L, bmnas_dropout_t drop, float* out_sums, void* stream);
+/* bmnas_bn_relu_ln_fwd with the NEXT cell step's K1 pair sum in the same launch (small batches:
+ * bmnas_bn_relu_ln_fwd_pair_ok — b <= 128, C*L <= 1024, n_prev <= 15; BMNAS_E_LIMIT otherwise).  FusionCell.forward,
+ * reference model_search.py:58 (+ node_search.py:54 at t = 0): the next step's inputs are n_prev earlier
+ * states xs[j] (b, C, L) and the node output `out` this launch produces:
+ *   h = sum_{j < n_prev} w[j*w_stride] xs[j] + w[n_prev*w_stride] out,   z = (w2[0] + w2[w2_stride]) h
+ * (w, w2: SOFTMAXED weights, as bmnas_mixsum_pair_fwd takes them; same arithmetic order).  n_prev == 0: exactly
+ * bmnas_bn_relu_ln_fwd. */
+int bmnas_bn_relu_ln_fwd_pair_ok(int b, int C, int L, int n_prev);
+int bmnas_bn_relu_ln_fwd_pair(const float* U, float* chan, bmnas_bn_fin_t fin, const float* resid,
+                              const float* ln_w, const float* ln_b, float* o, float* out, float* stats, int b,
+                              int C, int L, bmnas_dropout_t drop, float* out_sums, const float* const* xs,
+                              int n_prev, const float* w, int w_stride, const float* w2, int w2_stride, float* h,
+                              float* z, void* stream);
 int bmnas_bn_relu_ln_bwd(const float* g, const float* o, const float* resid, const float* ln_w,
                          const float* stats, const float* U, const float* chan, float* dV, float* bn_grad,
                          float* dresid, int accumulate_resid, int b, int C, int L, bmnas_dropout_t drop,

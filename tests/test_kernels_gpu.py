@@ -392,6 +392,48 @@ def test_node_mix_next_sum_matches_separate_launches(b, C, L, n_prev, have_g, al
         assert_close_scaled(k, got[k], want[k].cpu(), rel=1e-5)
 
 
+@pytest.mark.parametrize('b,C,L,n_prev,drop', [(8, 128, 8, 8, True), (6, 128, 8, 9, False), (64, 128, 8, 4, True),
+                                               (3, 16, 4, 1, False), (128, 64, 16, 15, True), (5, 32, 16, 2, False)])
+def test_bn_relu_ln_fwd_with_next_pair_sum(b, C, L, n_prev, drop):
+    """bmnas_bn_relu_ln_fwd_pair (NodeCell tail + the next cell step's K1 pair sum, model_search.py:58 +
+    node_search.py:54) against the two launches it replaces: bmnas_bn_relu_ln_fwd + bmnas_mixsum_pair_fwd —
+    identical node outputs and, same arithmetic order, identical sums."""
+    from bmnas import lib
+    assert lib.bn_relu_ln_fwd_pair_ok(b, C, L, n_prev)
+    assert not lib.bn_relu_ln_fwd_pair_ok(129, C, L, n_prev) and not lib.bn_relu_ln_fwd_pair_ok(b, 512, 16, n_prev)
+    g = _gen(6100 + b + C + n_prev)
+    d = dev()
+    U, x = _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d)
+    ln_w, ln_b = (_rand(g, C, L) * 0.3 + 1.0).to(d), (_rand(g, C, L) * 0.2).to(d)
+    Ud = U.double()
+    mean = Ud.mean(dim=(0, 2))
+    rstd = 1.0 / torch.sqrt(Ud.var(dim=(0, 2), unbiased=False) + 1e-5)
+    bn_w, bn_b = (_rand(g, C) * 0.3 + 1.0).to(d).double(), (_rand(g, C) * 0.2).to(d).double()
+    scale = rstd * bn_w
+    chan = torch.cat([mean, rstd, scale, bn_b - mean * scale]).float()
+    prev = [_rand(g, b, C, L).to(d) for _ in range(n_prev)]
+    w = torch.softmax(_rand(g, n_prev + 1, 2), -1).to(d)
+    w2 = torch.softmax(_rand(g, 3, 2), -1).to(d)
+    dcfg = lib.make_dropout(0.15, 77, 0) if drop else lib.NO_DROP
+
+    def run(fused):
+        o, out = torch.empty_like(x), torch.empty_like(x)
+        stats, osum = torch.empty(b, 2, device=d), torch.empty(b, 2, device=d)
+        h, z = torch.empty_like(x), torch.empty_like(x)
+        if fused:
+            lib.bn_relu_ln_fwd(U, chan, x, ln_w, ln_b, o, out, stats, b, C, L, dcfg, lib.NO_FIN, osum,
+                               (prev, w[:, 1], 2, w2[:, 1], 2, h, z))
+        else:
+            lib.bn_relu_ln_fwd(U, chan, x, ln_w, ln_b, o, out, stats, b, C, L, dcfg, lib.NO_FIN, osum)
+            lib.mixsum_pair_fwd(prev + [out], w[:, 1], 2, w2[:, 1], 2, h, z)
+        torch.cuda.synchronize()
+        return dict(o=o, out=out, stats=stats, osum=osum, h=h, z=z)
+
+    want, got = run(False), run(True)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
 @pytest.mark.parametrize('b,C,L,racc,xacc,drop,same', [(128, 192, 16, 0, 0, True, True), (8, 128, 8, 1, 1, False, True),
                                                          (5, 32, 16, 0, 1, True, True), (3, 16, 4, 1, 0, False, False),
                                                          (100, 256, 16, 0, 0, True, True), (7, 512, 16, 1, 1, True, False),
