@@ -588,7 +588,7 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
     return out, sv
 
 
-def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, defer_first=False):
+def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, defer_first=False, pre_pair=None):
     """g: grad of the node output.  x_slot / y_slot: GradSlots of the two inputs (the same
     object in search mode).  dbeta_w / dgamma_w: zero-initialised (k_in,2)/(ns,4) buffers
     receiving the gradients w.r.t. the SOFTMAXED weights.  NG: gradient pack.
@@ -605,8 +605,20 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
         dV = _empty(x, b, C, L)
         if sv.fused_bn_tail:
             racc = x_slot.acc_bit()
+            pre = None
+            if pre_pair is not None:
+                # the next cell step's K1 pair backward runs first in this launch and completes g
+                pbufs, pmask = _write_group(pre_pair['slots'])
+                g_slot = pre_pair['g_slot']
+                g_full = g_slot.buf()
+                g_slot.written = True
+                pre = (pre_pair['xs'], pbufs, pmask, pre_pair['out'], pre_pair['w'], 2, pre_pair['w2'], 2,
+                       pre_pair['h'], pre_pair['gh'], pre_pair['gz'], pre_pair['gz2'], pre_pair['dw'],
+                       pre_pair['dw2'], pre_pair['shards'], pre_pair['stride'], g_full)
             lib.bn_relu_ln_bwd(g, sv.o, x, NP.ln_w, sv.stats, sv.oconv.U, sv.oconv.chan, dV, NG.bn_grad,
-                               x_slot.buf(), racc, b, C, L, sv.d_out)
+                               x_slot.buf(), racc, b, C, L, sv.d_out, pre)
+            if pre is not None:
+                g = pre[-1]
         else:
             d_o = GradSlot(x)
             bufs, mask = _write_group([d_o])
@@ -750,18 +762,30 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
                        b, C, L, True, getattr(CG, 'scrub', None))
         _ln_affine(deferred, g, None, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, CG.dln_w, CG.dln_b,
                    b, C, L, True, False)
+    pending = None                 # the K1 pair backward of step i + 1, to run inside node i's first launch
     for i in reversed(range(S)):
         gn = slots[N + i].get()
-        if gn is None:
+        if gn is None and pending is None:
             continue
         sif_slot = GradSlot(x0)
         nsv = sv.nodes[i]
+        pre_pair, pending = pending, None
         gz = node_cell_bwd(nsv, gn, sif_slot, sif_slot, dbeta_ws[i], dgamma_ws[i], CG.nodes[i], deferred,
-                           defer_first=nsv.paired)
+                           defer_first=nsv.paired, pre_pair=pre_pair)
         off = sv.offsets[i]
         n_in = N + i
         if gz is not None:
             gz, gz2 = gz
+            prev = sv.nodes[i - 1] if i >= 1 else None
+            if (FUSE_NEXT_PAIR and prev is not None and prev.nm != 1 and getattr(prev, 'fused_bn_tail', False)
+                    and lib.bn_relu_ln_fwd_pair_ok(b, C, L, n_in - 1)):
+                # small batches: this backward rides at the start of the previous node's tail launch
+                # (bmnas_bn_relu_ln_bwd_pair), whose input gradient it completes
+                pending = dict(xs=sv.states[:n_in - 1], slots=slots[:n_in - 1], g_slot=slots[n_in - 1],
+                               out=sv.states[n_in - 1], w=sv.alpha_w[off:, 1], w2=nsv.beta_w[:, 1],
+                               h=sv.sifs[i], gh=sif_slot.get(), gz=gz, gz2=gz2, dw=dalpha_w[off:, 1],
+                               dw2=dbeta_ws[i][:, 1], shards=CG.shards, stride=CG.shard_stride)
+                continue
             bufs, mask = _write_group(slots[:n_in])
             lib.mixsum_pair_bwd(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
                                 sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1],

@@ -119,6 +119,8 @@ SIGNATURES = {
     'bmnas_bn_relu_ln_fwd_pair_ok': ([_I, _I, _I, _I], _I),
     'bmnas_bn_relu_ln_fwd_pair': ([_P, _P, BnFin, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P, _PP, _I, _P, _I,
                                    _P, _I, _P, _P, _P], _I),
+    'bmnas_bn_relu_ln_bwd_pair': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, Dropout, _PP, _PP, _I,
+                                   _U32, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P], _I),
     'bmnas_bn_relu_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_bwd_apply': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_linear_fwd': ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
@@ -567,10 +569,22 @@ def bn_relu_ln_fwd(U, chan, resid, ln_w, ln_b, o, out, stats, b, Cc, L, drop, fi
                                             _stream()), 'bn_relu_ln_fwd_pair')
 
 
-def bn_relu_ln_bwd(g, o, resid, ln_w, stats, U, chan, dV, bn_grad, dresid, acc_resid, b, Cc, L, drop):
-    _check(load().bmnas_bn_relu_ln_bwd(_ptr(g), _ptr(o), _ptr(resid), _ptr(ln_w), _ptr(stats), _ptr(U),
-                                       _ptr(chan), _ptr(dV), _ptr(bn_grad), _ptr(dresid), int(acc_resid), b, Cc,
-                                       L, drop, _stream()), 'bn_relu_ln_bwd')
+def bn_relu_ln_bwd(g, o, resid, ln_w, stats, U, chan, dV, bn_grad, dresid, acc_resid, b, Cc, L, drop, pre=None):
+    """pre = (xs, dxs, acc_mask, out, w, w_stride, w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards,
+    dw_shard_stride, g_full): the backward of the next cell step's K1 pair sum first, in the same launch
+    (bmnas_bn_relu_ln_bwd_pair; g may then be None)."""
+    if pre is None:
+        _check(load().bmnas_bn_relu_ln_bwd(_ptr(g), _ptr(o), _ptr(resid), _ptr(ln_w), _ptr(stats), _ptr(U),
+                                           _ptr(chan), _ptr(dV), _ptr(bn_grad), _ptr(dresid), int(acc_resid), b,
+                                           Cc, L, drop, _stream()), 'bn_relu_ln_bwd')
+        return
+    xs, dxs, acc, out, w, ws, w2, w2s, h, gh, gz, gz2, dw, dw2, shards, stride, g_full = pre
+    _check(load().bmnas_bn_relu_ln_bwd_pair(_ptr(g), _ptr(o), _ptr(resid), _ptr(ln_w), _ptr(stats), _ptr(U),
+                                            _ptr(chan), _ptr(dV), _ptr(bn_grad), _ptr(dresid), int(acc_resid), b, Cc,
+                                            L, drop, _ptrs(xs), _ptrs(dxs), len(xs), acc, _ptr(out),
+                                            w.data_ptr(), ws, w2.data_ptr(), w2s, _ptr(h), _ptr(gh), _ptr(gz),
+                                            _ptr(gz2), dw.data_ptr(), dw2.data_ptr(), shards, stride,
+                                            _ptr(g_full), _stream()), 'bn_relu_ln_bwd_pair')
 
 
 def bn_bwd_apply(dV, U, chan, bn_grad, b, M, L, training):

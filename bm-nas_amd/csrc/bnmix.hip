@@ -890,19 +890,48 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
 // Backward of the same tail: LayerNorm input gradient dx (added to / written as the residual's
 // gradient), then through dropout and ReLU to dV (the gradient w.r.t. the BatchNorm output) plus the
 // BatchNorm reductions bn_grad = (sum dV * u_hat | sum dV) — one atomic pair per channel per sample.
-template <int VPT, int BS>
+// NP > 0 (one float4 per lane, small batches): the backward of the NEXT cell step's K1 pair sum runs first, in
+// the same launch (bmnas_mixsum_pair_bwd, model_search.py:58 backwards).  That sum's last input is THIS node's
+// output, so its backward is what completes the gradient the LayerNorm backward below starts from:
+//   G = gh + (w2_0 + w2_1) (gz + gz2);   dxs[j] (=|+=) w_j G, dw_j += <G, xs[j]>  (j < NP);
+//   gy = g + w_NP G  (g: what other consumers accumulated, nullable; gy is also written to g_full for the
+//   deferred LayerNorm-affine reduction),  dw_NP += <G, out>,  dw2_0, dw2_1 += <gz + gz2, h>.
+// Destinations must not alias each other (cell-level states never do).
+struct PairPrevB {
+  PtrsIn xs;
+  PtrsOut dxs;
+  const float* out;       // this node's forward output
+  const float* w;
+  const float* w2;
+  const float* h;
+  const float* gh;        // nullable
+  const float* gz;
+  const float* gz2;       // nullable
+  float* dw;
+  float* dw2;
+  float* g_full;
+  int64_t dw_stride;
+  int ws, w2s, dw_shards;
+  uint32_t acc;
+};
+
+template <int VPT, int BS, int NP = 0>
 __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
     const float* __restrict__ g, const float* __restrict__ o, const float* __restrict__ resid,
     const float* __restrict__ ln_w, const float* __restrict__ stats, const float* __restrict__ U,
     const float* __restrict__ chan, float* __restrict__ dV, float* bn_grad, float* dresid, int acc_resid,
-    int b, int C, int L, DropCfg d) {
+    int b, int C, int L, DropCfg d, PairPrevB P) {
   const DropRt dr = drop_begin(d);
   __shared__ float red[8];
+  __shared__ float redp[(BS / 64) * (NP + 2)];
   const int cl4 = C * L / 4, l4n = L / 4;
   const int smp = blockIdx.x;
   const float mean = stats[2 * smp], rstd = stats[2 * smp + 1];
   float4 xh[VPT], dxh[VPT], u[VPT], old[VPT];
   float s1 = 0.f, s2 = 0.f;
+  float part[NP + 2];
+#pragma unroll
+  for (int j = 0; j < NP + 2; ++j) part[j] = 0.f;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int r = threadIdx.x + k * BS;
@@ -911,13 +940,53 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
       const int64_t e = ((int64_t)smp * cl4 + r) * 4;
       const float4 x = f4_add(ld4(o + e), ld4(resid + e));
       const float4 w = ld4(ln_w + (int64_t)r * 4);
-      const float4 gy = ld4(g + e);
+      float4 gy = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (NP == 0 || g != nullptr) gy = ld4(g + e);
       u[k] = ld4(U + e);
       if (acc_resid) old[k] = ld4(dresid + e);
+      if (NP > 0) {
+        // every load of the pair backward with the loads above, arithmetic after
+        const float4 za = ld4(P.gz + e), h4 = ld4(P.h + e), ov = ld4(P.out + e);
+        float4 zb = make_float4(0.f, 0.f, 0.f, 0.f), gh4 = zb;
+        if (P.gz2 != nullptr) zb = ld4(P.gz2 + e);
+        if (P.gh != nullptr) gh4 = ld4(P.gh + e);
+        float4 xv[NP > 0 ? NP : 1], od[NP > 0 ? NP : 1];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          xv[j] = ld4(P.xs.p[j] + e);
+          od[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (P.dxs.p[j] != nullptr && (P.acc & (1u << j))) od[j] = ld4(P.dxs.p[j] + e);
+        }
+        const float sw2 = P.w2[0] + P.w2[P.w2s];
+        const float4 z4 = f4_add(za, zb);
+        const float4 G = f4_add(f4_scale(z4, sw2), gh4);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          part[j] += f4_dot(G, xv[j]);
+          if (P.dxs.p[j] != nullptr) st4(P.dxs.p[j] + e, f4_add(f4_scale(G, P.w[j * P.ws]), od[j]));
+        }
+        part[NP] += f4_dot(G, ov);
+        part[NP + 1] += f4_dot(z4, h4);
+        gy = f4_add(gy, f4_scale(G, P.w[NP * P.ws]));
+        st4(P.g_full + e, gy);
+      }
       xh[k] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
       dxh[k] = f4_mul(gy, w);
       s1 += f4_hsum(dxh[k]);
       s2 += f4_dot(dxh[k], xh[k]);
+    }
+  }
+  if (NP > 0) {
+    // dw / dw2: one sharded atomic per weight per workgroup, as bmnas_mixsum_pair_bwd
+    block_sum_n<BS / 64, NP + 2>(part, redp);
+    if ((int)threadIdx.x <= NP + 2) {
+      const int t = threadIdx.x;
+      float val = part[NP + 1];                               // (selects: no run-time index into registers)
+#pragma unroll
+      for (int j = 0; j <= NP; ++j) val = (t == j) ? part[j] : val;
+      const int64_t sh = (int64_t)(blockIdx.x % P.dw_shards) * P.dw_stride;
+      if (t <= NP) atomicAdd(P.dw + sh + t * P.ws, val);
+      else atomicAdd(P.dw2 + sh + (t - NP - 1) * P.w2s, val);
     }
   }
   const float inv_d = 1.f / (float)(cl4 * 4);
@@ -1540,12 +1609,51 @@ extern "C" int bmnas_bn_relu_ln_fwd_pair(const float* U, float* chan, bmnas_bn_f
   return 0;
 }
 
+extern "C" int bmnas_bn_relu_ln_bwd_pair(
+    const float* g, const float* o, const float* resid, const float* ln_w, const float* stats, const float* U,
+    const float* chan, float* dV, float* bn_grad, float* dresid, int accumulate_resid, int b, int C, int L,
+    bmnas_dropout_t drop, const float* const* xs, float* const* dxs, int n_prev, uint32_t accumulate_mask,
+    const float* out, const float* w, int w_stride, const float* w2, int w2_stride, const float* h,
+    const float* gh, const float* gz, const float* gz2, float* dw, float* dw2, int dw_shards,
+    int64_t dw_shard_stride, float* g_full, void* stream);
+
 extern "C" int bmnas_bn_relu_ln_bwd(const float* g, const float* o, const float* resid, const float* ln_w,
                                     const float* stats, const float* U, const float* chan, float* dV,
                                     float* bn_grad, float* dresid, int accumulate_resid, int b, int C,
                                     int L, bmnas_dropout_t drop, void* stream) {
-  if (!g || !o || !resid || !ln_w || !stats || !U || !chan || !dV || !bn_grad || b < 0 || C < 1)
+  return bmnas_bn_relu_ln_bwd_pair(g, o, resid, ln_w, stats, U, chan, dV, bn_grad, dresid, accumulate_resid, b, C,
+                                   L, drop, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, nullptr, 1, nullptr,
+                                   nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, nullptr, stream);
+}
+
+extern "C" int bmnas_bn_relu_ln_bwd_pair(
+    const float* g, const float* o, const float* resid, const float* ln_w, const float* stats, const float* U,
+    const float* chan, float* dV, float* bn_grad, float* dresid, int accumulate_resid, int b, int C, int L,
+    bmnas_dropout_t drop, const float* const* xs, float* const* dxs, int n_prev, uint32_t accumulate_mask,
+    const float* out, const float* w, int w_stride, const float* w2, int w2_stride, const float* h,
+    const float* gh, const float* gz, const float* gz2, float* dw, float* dw2, int dw_shards,
+    int64_t dw_shard_stride, float* g_full, void* stream) {
+  if ((n_prev == 0 && !g) || !o || !resid || !ln_w || !stats || !U || !chan || !dV || !bn_grad || b < 0 || C < 1)
     return BMNAS_E_ARG;
+  PairPrevB P{};
+  if (n_prev > 0) {
+    if (!xs || !dxs || !out || !w || !w2 || !h || !gz || !dw || !dw2 || !g_full || w_stride < 1 || w2_stride < 1 ||
+        dw_shards < 1)
+      return BMNAS_E_ARG;
+    if (!bmnas_bn_relu_ln_fwd_pair_ok(b > 0 ? b : 1, C, L, n_prev)) return BMNAS_E_LIMIT;
+    for (int j = 0; j < n_prev; ++j) {
+      if (!xs[j]) return BMNAS_E_ARG;
+      P.xs.p[j] = xs[j];
+      P.dxs.p[j] = dxs[j];
+      for (int k = 0; k < j; ++k)
+        if (dxs[j] != nullptr && dxs[j] == dxs[k]) return BMNAS_E_ARG;     // old values are fetched up front
+    }
+    P.out = out; P.w = w; P.w2 = w2; P.h = h; P.gh = gh; P.gz = gz; P.gz2 = gz2; P.dw = dw; P.dw2 = dw2;
+    P.g_full = g_full; P.dw_stride = dw_shard_stride; P.ws = w_stride; P.w2s = w2_stride;
+    P.dw_shards = dw_shards; P.acc = accumulate_mask;
+  } else if (n_prev < 0) {
+    return BMNAS_E_ARG;
+  }
   if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
   if (accumulate_resid && !dresid) return BMNAS_E_ARG;
   if (b == 0) return 0;
@@ -1553,14 +1661,28 @@ extern "C" int bmnas_bn_relu_ln_bwd(const float* g, const float* o, const float*
   const int bs = wide ? 512 : 256;
   const int need = (C * L / 4 + bs - 1) / bs;
   hipStream_t st = (hipStream_t)stream;
+  if (n_prev > 0) {                                      // (host-checked: one float4 per lane, 256 lanes)
+#define BRP(N)                                                                                          \
+  case N:                                                                                               \
+    hipLaunchKernelGGL((bn_relu_ln_bwd_k<1, 256, N>), dim3(b), dim3(256), 0, st, g, o, resid, ln_w, stats, \
+                       U, chan, dV, bn_grad, dresid, accumulate_resid, b, C, L, to_cfg(drop), P);       \
+    break;
+    switch (n_prev) {
+      BRP(1) BRP(2) BRP(3) BRP(4) BRP(5) BRP(6) BRP(7) BRP(8) BRP(9) BRP(10) BRP(11) BRP(12) BRP(13) BRP(14) BRP(15)
+      default: return BMNAS_E_LIMIT;
+    }
+#undef BRP
+    BMNAS_CHECK_LAUNCH();
+    return 0;
+  }
 #define BRL(V)                                                                                          \
   do {                                                                                                  \
     if (wide)                                                                                           \
       hipLaunchKernelGGL((bn_relu_ln_bwd_k<V, 512>), dim3(b), dim3(512), 0, st, g, o, resid, ln_w, stats, \
-                         U, chan, dV, bn_grad, dresid, accumulate_resid, b, C, L, to_cfg(drop));        \
+                         U, chan, dV, bn_grad, dresid, accumulate_resid, b, C, L, to_cfg(drop), P);     \
     else                                                                                                \
       hipLaunchKernelGGL((bn_relu_ln_bwd_k<V, 256>), dim3(b), dim3(256), 0, st, g, o, resid, ln_w, stats, \
-                         U, chan, dV, bn_grad, dresid, accumulate_resid, b, C, L, to_cfg(drop));        \
+                         U, chan, dV, bn_grad, dresid, accumulate_resid, b, C, L, to_cfg(drop), P);     \
   } while (0)
   if (need <= 1) BRL(1);
   else if (need <= 2) BRL(2);

@@ -377,6 +377,22 @@ int bmnas_bn_relu_ln_bwd(const float* g, const float* o, const float* resid, con
                          const float* stats, const float* U, const float* chan, float* dV, float* bn_grad,
                          float* dresid, int accumulate_resid, int b, int C, int L, bmnas_dropout_t drop,
                          void* stream);
+/* bmnas_bn_relu_ln_bwd with the backward of the NEXT cell step's K1 pair sum first, in the same launch (the
+ * counterpart of bmnas_bn_relu_ln_fwd_pair; same limits).  That sum's inputs are xs[0 .. n_prev-1] and this
+ * node's forward output `out`:  G = gh + (w2[0] + w2[w2_stride]) (gz + gz2)  (gh, gz2 nullable);
+ *   dxs[j] (=|+= by bit j of accumulate_mask; nullable; pairwise distinct) w[j*w_stride] G,
+ *   dw[shard + j*w_stride] += <G, xs[j]> (j < n_prev), dw[shard + n_prev*w_stride] += <G, out>,
+ *   dw2[shard], dw2[shard + w2_stride] += <gz + gz2, h>   (shards as in bmnas_mixsum_pair_bwd);
+ * the node-output gradient the LayerNorm backward starts from is  g + w[n_prev*w_stride] G  (g nullable: what
+ * other consumers accumulated), also written to g_full (b, C, L).  Replaces bmnas_mixsum_pair_bwd +
+ * bmnas_bn_relu_ln_bwd (reference model_search.py:58 and node_search.py:64-69, backwards). */
+int bmnas_bn_relu_ln_bwd_pair(const float* g, const float* o, const float* resid, const float* ln_w,
+                              const float* stats, const float* U, const float* chan, float* dV, float* bn_grad,
+                              float* dresid, int accumulate_resid, int b, int C, int L, bmnas_dropout_t drop,
+                              const float* const* xs, float* const* dxs, int n_prev, uint32_t accumulate_mask,
+                              const float* out, const float* w, int w_stride, const float* w2, int w2_stride,
+                              const float* h, const float* gh, const float* gz, const float* gz2, float* dw,
+                              float* dw2, int dw_shards, int64_t dw_shard_stride, float* g_full, void* stream);
 
 /* Backward, phase B: BatchNorm input gradient, in place on dV (b, M, L):
  *   training: dU = scale*(dV - bn_grad[M+m]/N - u_hat*bn_grad[m]/N), N = b*L;  eval: dU = scale*dV. */

@@ -21,7 +21,7 @@ def test_header_declares_the_hot_path_entry_points():
     for must in ('bmnas_mixsum_fwd', 'bmnas_mixsum_bwd', 'bmnas_sdpa_ln_fwd', 'bmnas_sdpa_ln_bwd',
                  'bmnas_conv1x1_fwd', 'bmnas_conv1x1_bwd_data', 'bmnas_conv1x1_bwd_weight',
                  'bmnas_cat_ln_fwd', 'bmnas_cat_ln_bwd', 'bmnas_node_mix_fwd', 'bmnas_node_mix_bwd',
-                 'bmnas_node_mix_ln_bwd', 'bmnas_bn_relu_ln_fwd_pair',
+                 'bmnas_node_mix_ln_bwd', 'bmnas_bn_relu_ln_fwd_pair', 'bmnas_bn_relu_ln_bwd_pair',
                  'bmnas_bn_finalize', 'bmnas_arch_softmax_multi', 'bmnas_version'):
         assert must in syms
 

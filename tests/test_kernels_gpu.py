@@ -434,6 +434,70 @@ def test_bn_relu_ln_fwd_with_next_pair_sum(b, C, L, n_prev, drop):
         assert torch.equal(got[k], want[k]), k
 
 
+@pytest.mark.parametrize('b,C,L,n_prev,have_g,have_gh,have_gz2,acc,drop',
+                         [(8, 128, 8, 8, True, True, True, 0b10110101, True), (6, 128, 8, 9, False, False, False, 0, False),
+                          (64, 128, 8, 4, True, False, True, 0b1111, True), (3, 16, 4, 1, False, True, False, 1, False),
+                          (128, 64, 16, 14, True, True, False, 0x2aaa, True), (5, 32, 16, 2, True, True, True, 0, False)])
+def test_bn_relu_ln_bwd_with_next_pair_backward(b, C, L, n_prev, have_g, have_gh, have_gz2, acc, drop):
+    """bmnas_bn_relu_ln_bwd_pair (the next cell step's K1 pair backward + the NodeCell tail backward in one
+    launch; model_search.py:58 and node_search.py:64-69 backwards) against bmnas_mixsum_pair_bwd +
+    bmnas_bn_relu_ln_bwd, which the oracle tests pin: destinations (overwriting / accumulating / absent), the
+    completed node-output gradient, arch-weight gradients over shards, dV, BatchNorm reductions, residual."""
+    from bmnas import lib
+    g = _gen(8200 + b + C + n_prev)
+    d = dev()
+    U, x, o = _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d)
+    ln_w = (_rand(g, C, L) * 0.3 + 1.0).to(d)
+    Ud = U.double()
+    mean = Ud.mean(dim=(0, 2))
+    rstd = 1.0 / torch.sqrt(Ud.var(dim=(0, 2), unbiased=False) + 1e-5)
+    bn_w, bn_b = (_rand(g, C) * 0.3 + 1.0).to(d).double(), (_rand(g, C) * 0.2).to(d).double()
+    scale = rstd * bn_w
+    chan = torch.cat([mean, rstd, scale, bn_b - mean * scale]).float()
+    pre = (o + x).double()
+    stats = torch.stack([pre.mean(dim=(1, 2)), 1.0 / torch.sqrt(pre.var(dim=(1, 2), unbiased=False) + 1e-5)],
+                        dim=1).float().contiguous()
+    prev = [_rand(g, b, C, L).to(d) for _ in range(n_prev)]
+    out_fwd = _rand(g, b, C, L).to(d)                       # the node's forward output (the sum's last input)
+    h = _rand(g, b, C, L).to(d)
+    w = torch.softmax(_rand(g, n_prev + 1, 2), -1).to(d)
+    w2 = torch.softmax(_rand(g, 3, 2), -1).to(d)
+    gz, gz2, gh = _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d), _rand(g, b, C, L).to(d)
+    g_part = _rand(g, b, C, L).to(d)
+    old = [_rand(g, b, C, L).to(d) for _ in range(n_prev)]
+    old_res = _rand(g, b, C, L).to(d)
+    skip = {1} if n_prev > 2 else set()                     # one destination absent
+    dcfg = lib.make_dropout(0.15, 99, 0) if drop else lib.NO_DROP
+    shards, stride = 4, 64
+
+    def run(fused):
+        dst = [None if j in skip else old[j].clone() for j in range(n_prev)]
+        dw = torch.zeros(shards * stride, device=d)
+        dw2 = torch.zeros(shards * stride, device=d)
+        dV, bn_grad, dres = torch.empty_like(x), torch.zeros(2 * C, device=d), old_res.clone()
+        gfull = g_part.clone() if have_g else torch.empty_like(x)
+        if fused:
+            lib.bn_relu_ln_bwd(gfull if have_g else None, o, x, ln_w, stats, U, chan, dV, bn_grad, dres, 1, b, C, L,
+                               dcfg, (prev, dst, acc, out_fwd, w[:, 1], 2, w2[:, 1], 2, h, gh if have_gh else None,
+                                      gz, gz2 if have_gz2 else None, dw, dw2, shards, stride, gfull))
+        else:
+            lib.mixsum_pair_bwd(prev + [out_fwd], dst + [gfull], w[:, 1], 2, w2[:, 1], 2, h,
+                                gh if have_gh else None, gz, dw, dw2, acc | ((1 << n_prev) if have_g else 0),
+                                shards, stride, gz2 if have_gz2 else None)
+            lib.bn_relu_ln_bwd(gfull, o, x, ln_w, stats, U, chan, dV, bn_grad, dres, 1, b, C, L, dcfg)
+        torch.cuda.synchronize()
+        res = dict(g_full=gfull, dV=dV, bn_grad=bn_grad, dresid=dres,
+                   dw=dw.view(shards, stride).sum(0)[:2 * (n_prev + 1)], dw2=dw2.view(shards, stride).sum(0)[:4])
+        for j, t in enumerate(dst):
+            if t is not None:
+                res[f'dx{j}'] = t
+        return res
+
+    want, got = run(False), run(True)
+    for k in want:
+        assert_close_scaled(k, got[k], want[k].cpu(), rel=2e-5)
+
+
 @pytest.mark.parametrize('b,C,L,racc,xacc,drop,same', [(128, 192, 16, 0, 0, True, True), (8, 128, 8, 1, 1, False, True),
                                                          (5, 32, 16, 0, 1, True, True), (3, 16, 4, 1, 0, False, False),
                                                          (100, 256, 16, 0, 0, True, True), (7, 512, 16, 1, 1, True, False),
