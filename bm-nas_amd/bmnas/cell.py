@@ -277,7 +277,7 @@ def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, du
     return U, chan, sv
 
 
-def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
+def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None, mix=None):
     """dV (gradient w.r.t. the BN output, with bn_grad already reduced) -> in place dU;
     then data gradient into src_slots and weight/bias gradient (+=) into dW / dbias."""
     b, L = sv.U.shape[0], sv.U.shape[2]
@@ -307,8 +307,9 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None):
     bufs, mask = _write_group(slots)
     if pair:
         lib.conv1x1_bwd_all(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, sv.srcs, dW,
-                            dW.shape[1], dbias, sv.dup, (sv.U, sv.chan, bn_grad, sv.training))
+                            dW.shape[1], dbias, sv.dup, (sv.U, sv.chan, bn_grad, sv.training), mix)
         return
+    assert mix is None, 'mix epilogue: only with the one-launch out_conv backward'
     if attn is not None and dW is not None and FUSE_BWD_ALL:
         # data gradient, weight gradient and the attention backward share one grid
         lib.conv1x1_bwd_all_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, sv.srcs, dW,
@@ -404,6 +405,9 @@ FUSE_PROLOGUE_PAIR = os.environ.get('BMNAS_FUSE_PROLOGUE_PAIR', '1') != '0'
 FUSE_LN_BWD = os.environ.get('BMNAS_FUSE_LN_BWD', '1') != '0'
 # small batches, node_multiplier != 1: the next cell step's K1 pair sum inside the node's tail launch
 FUSE_NEXT_PAIR = os.environ.get('BMNAS_FUSE_NEXT_PAIR', '1') != '0'
+# small grids, node_multiplier != 1: the last inner step's mix backward as the epilogue of the out_conv
+# data-gradient tiles (needs the one-launch out_conv backward, FUSE_BWD_PAIR)
+FUSE_MIX_EPILOGUE = os.environ.get('BMNAS_FUSE_MIX_EPILOGUE', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
 FUSE_HEAD = os.environ.get('BMNAS_FUSE_HEAD', '1') != '0'
 
@@ -458,7 +462,7 @@ def _attn_affine_bwd(sv, g, G, deferred=None):
 
 
 def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=0, deferred=None, nxt=None,
-                   ln=None):
+                   ln=None, pre_done=None):
     """g: grad of the mixed output (None with nxt: nothing accumulated yet).  nxt: see lib.node_mix_bwd.
     dgamma_row (4 floats, +=), x_slot / y_slot: GradSlots (y_slot None when x is y).  G: gradient pack (stack_dW, stack_dbias, stack_bn_grad,
     dln_w, dln_b), all += .
@@ -468,10 +472,23 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
     x, y = sv.x, sv.y
     b, C, L = x.shape
     M = 3 * C
-    dV = _empty(x, b, M, L)
+    dV = _empty(x, b, M, L) if pre_done is None else pre_done[0]
     bn_grad = G.stack_bn_grad            # [dW_bn (3C) | dB_bn (3C)], zero-initialised by caller
     with _Fork(x.device) as fork:
-        if sv.same:
+        if sv.same and pre_done is not None:
+            # the mix backward already ran as the epilogue of the out_conv data-gradient tiles
+            # (bmnas_conv1x1_bwd_all_mix): dV, bn_grad, dgamma and x_slot are done; the contractions remain
+            dxb = pre_done[1]
+            if sv.merged and x_slot.extra is None:
+                x_slot.extra = torch.empty_like(x)
+                conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias, fork,
+                            attn=(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, x_slot.extra, None,
+                                  0, C, sv.d_attn))
+            else:
+                conv_bn_bwd(sv.conv, dV, bn_grad, [x_slot], G.stack_dW, G.stack_dbias, fork)
+                lib.sdpa_ln_bwd(g, sv.gamma[1:2], x, y, sv.P.ln_w, sv.xhat1, sv.stats1, dxb, None, 1, b, C, L,
+                                sv.d_attn)
+        elif sv.same:
             if ln is not None:
                 gy, pre, ln_w, stats, r_slot, g_slot = ln
                 g = g_slot.buf()
@@ -601,6 +618,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
     tail = list(range(2 + ns - nm, 2 + ns))
     resid = None if sv.fused_tail else x                 # fused: sv.o already holds o + x
     ln_job = None
+    mix_done = None
     if nm != 1:
         dV = _empty(x, b, C, L)
         if sv.fused_bn_tail:
@@ -626,8 +644,22 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
             lib.cat_ln_bwd(g, [sv.o], x, NP.ln_w, NP.ln_b, sv.stats, bufs, x_slot.buf(),
                            mask | (racc << 31), None, None, b, C, L, False)
             lib.bn_relu_bwd(d_o.buf(), sv.oconv.U, sv.oconv.chan, dV, NG.bn_grad, b, C, L, sv.d_out)
+        mix = None
+        mlast = sv.mixed[ns - 1]
+        last_slot = slots[2 + ns - 1]
+        if (FUSE_MIX_EPILOGUE and FUSE_BWD_PAIR and mlast.same and last_slot.get() is None
+                and len({id(slots[j]) for j in tail}) == nm and sv.oconv.fold == 0
+                and lib.conv1x1_bwd_all_mix_ok(b, L, C, nm, C)):
+            # the last inner step's mix backward rides in the out_conv data-gradient tiles of its channels
+            mz_slot = GradSlot(x)
+            mdV = _empty(x, b, 3 * C, L)
+            mG = NG.mixed[ns - 1]
+            mix = (nm - 1, mlast.conv.U, mlast.conv.chan, mlast.x, mlast.p1, mlast.gamma, dgamma_w[ns - 1],
+                   NG.shards, NG.shard_stride, mz_slot.buf(), mz_slot.acc_bit(), mdV, mG.stack_bn_grad,
+                   mlast.d_glu, mlast.d_fc)
+            mix_done = (mdV, mz_slot)
         conv_bn_bwd(sv.oconv, dV, NG.bn_grad, [slots[j] for j in tail],
-                    NG.out_conv_dW.view(C, nm * C), NG.out_conv_db)
+                    NG.out_conv_dW.view(C, nm * C), NG.out_conv_db, mix=mix)
     elif (FUSE_LN_BWD and sv.fused_tail and sv.mixed[ns - 1].same and slots[tail[0]].get() is None
           and lib.node_mix_ln_bwd_ok(b, C, L)):
         # the LayerNorm backward rides in the last inner step's mix-backward launch
@@ -645,7 +677,12 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
         gs = None if ln is not None else slots[2 + t].get()
         if gs is None and pending is None and ln is None:
             continue                                    # this inner state feeds nothing
-        z_slot = GradSlot(x)
+        pre_done = None
+        if mix_done is not None and t == ns - 1:
+            z_slot = mix_done[1]
+            pre_done = (mix_done[0], z_slot.buf())
+        else:
+            z_slot = GradSlot(x)
         nxt = None
         if pending is not None:
             gz, gz2, off_n, n_in = pending              # states[:n_in - 1] + this step's output states[n_in - 1]
@@ -656,7 +693,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
                    NG.shard_stride, sv.states[n_in - 1], gz, gz2, g_out)
             pending = None
         node_mixed_bwd(sv.mixed[t], gs, dgamma_w[t], z_slot, None, NG.mixed[t], NG.shards, NG.shard_stride,
-                       deferred, nxt, ln)
+                       deferred, nxt, ln, pre_done)
         if t == 0 and defer_first:
             return z_slot.buf(), z_slot.extra
         off = sv.offsets[t]

@@ -44,6 +44,15 @@ class Dropout(C.Structure):
 NO_DROP = Dropout(0, 1.0, 0, 0, None)
 
 
+class MixEp(C.Structure):
+    """bmnas_mix_ep_t"""
+    _fields_ = [('U', C.c_void_p), ('chan', C.c_void_p), ('x', C.c_void_p), ('p1', C.c_void_p),
+                ('gamma', C.c_void_p), ('dgamma', C.c_void_p), ('dgamma_shards', C.c_int),
+                ('dgamma_shard_stride', C.c_int64), ('dx', C.c_void_p), ('accumulate_dx', C.c_int),
+                ('dV', C.c_void_p), ('bn_grad', C.c_void_p), ('q', C.c_int), ('drop_glu', Dropout),
+                ('drop_fc', Dropout)]
+
+
 class BnFin(C.Structure):
     """bmnas_bn_fin_t"""
     _fields_ = [('stat', C.c_void_p), ('conv_bias', C.c_void_p), ('bn_w', C.c_void_p), ('bn_b', C.c_void_p),
@@ -94,6 +103,9 @@ SIGNATURES = {
                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P, _P, _P, _I, _P], _I),
     'bmnas_conv1x1_bwd_all': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _PP, _P, _I, _P, _I,
                                _P, _P, _P, _I, _P], _I),
+    'bmnas_conv1x1_bwd_all_mix_ok': ([_I, _I, _I, _I, _I], _I),
+    'bmnas_conv1x1_bwd_all_mix': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _PP, _P, _I, _P, _I,
+                                   _P, _P, _P, _I, C.POINTER(MixEp), _P], _I),
     'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_probe_read': ([_P, _I64, _I, _I, _P, _P], _I),
@@ -430,15 +442,32 @@ def conv1x1_bwd_all_sdpa(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, wsrc
                                              int(btrain), _stream()), 'conv1x1_bwd_all_sdpa')
 
 
+def conv1x1_bwd_all_mix_ok(b, L, M, n_src, C_src):
+    return bool(load().bmnas_conv1x1_bwd_all_mix_ok(b, L, M, n_src, C_src))
+
+
 def conv1x1_bwd_all(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, wsrcs, dW, ldw_grad, dbias, dup_cols,
-                    bn=None):
+                    bn=None, mix=None):
     """bn_bwd_apply (bn = (U, chan, bn_grad, training)) + data gradient + weight gradient of a conv
-    without an attention branch; one launch at small grids."""
+    without an attention branch; one launch at small grids.
+    mix = (q, U, chan, x, p1, gamma, dgamma, dg_shards, dg_stride, dx, acc_dx, dV, bn_grad, dglu, dfc): the
+    NodeMixedOp backward behind source q as the epilogue of its data-gradient tiles (bmnas_conv1x1_bwd_all_mix)."""
     bU, bchan, bgrad, btrain = (None, None, None, 0) if bn is None else bn
-    _check(load().bmnas_conv1x1_bwd_all(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs), C_src,
-                                        acc_mask, b, L, M, _ptrs(wsrcs), dW.data_ptr(), ldw_grad,
-                                        None if dbias is None else dbias.data_ptr(), dup_cols, _ptr(bU),
-                                        _ptr(bchan), _ptr(bgrad), int(btrain), _stream()), 'conv1x1_bwd_all')
+    if mix is None:
+        _check(load().bmnas_conv1x1_bwd_all(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs), C_src,
+                                            acc_mask, b, L, M, _ptrs(wsrcs), dW.data_ptr(), ldw_grad,
+                                            None if dbias is None else dbias.data_ptr(), dup_cols, _ptr(bU),
+                                            _ptr(bchan), _ptr(bgrad), int(btrain), _stream()), 'conv1x1_bwd_all')
+        return
+    q, mU, mchan, mx, mp1, mgamma, mdgamma, mshards, mstride, mdx, macc, mdV, mbn, dglu, dfc = mix
+    ep = MixEp(_ptr(mU), _ptr(mchan), _ptr(mx), _ptr(mp1), mgamma.data_ptr(),
+               None if mdgamma is None else mdgamma.data_ptr(), mshards, mstride, _ptr(mdx), int(macc), _ptr(mdV),
+               _ptr(mbn), q, dglu, dfc)
+    _check(load().bmnas_conv1x1_bwd_all_mix(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs), C_src,
+                                            acc_mask, b, L, M, _ptrs(wsrcs), dW.data_ptr(), ldw_grad,
+                                            None if dbias is None else dbias.data_ptr(), dup_cols, _ptr(bU),
+                                            _ptr(bchan), _ptr(bgrad), int(btrain), C.byref(ep), _stream()),
+           'conv1x1_bwd_all_mix')
 
 
 def conv1x1_bwd_weight(dU, srcs, C_src, dW, ldw, dbias, dup_cols, b, L, M):

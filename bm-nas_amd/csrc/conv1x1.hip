@@ -260,6 +260,107 @@ __global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
 // waits once, runs its MFMAs back to back, and the four partial tiles are summed through
 // LDS.  Splitting K four ways also quadruples the number of waves, which is what hides the
 // latency at batch 128.
+// ---- K2 backward as the epilogue of a data-gradient tile (small grids) -------------------------------------
+// NodeCell's out_conv reads cat(states[-node_multiplier:]) (node_search.py:59-61); the last of those states is the
+// output of the last inner step's NodeMixedOp and feeds nothing else, so the out_conv data gradient for its
+// channels IS the complete gradient of that mixed output.  The tile that has just formed it applies the whole
+// NodeMixedOp backward of bmnas_node_mix_bwd to its 16 (sample, l) x 16 channel elements (x is y: search mode)
+// instead of a launch of its own reading it back: the gamma-weighted gradients of the four primitives'
+// BatchNorm outputs (dV), the BatchNorm reductions, dgamma and the gradient of the op's input.
+struct MixEp {
+  const float* U;          // (b, 3C, L) stacked conv output of the mixed op
+  const float* chan;       // its mean | rstd | scale | shift (M = 3C)
+  const float* x;          // its input (b, C, L)
+  const float* p1;         // attention branch output
+  const float* gamma;      // 4 softmaxed weights
+  float* dgamma;           // += over dgamma_shards copies
+  float* dx;               // gradient of the input: (=|+=) 2 g0 g
+  float* dV;               // (b, 3C, L)
+  float* bn_grad;          // (6C) +=
+  int64_t dg_stride;
+  int dg_shards, acc_dx, q, on;
+  DropCfg dglu, dfc;
+};
+
+__device__ __forceinline__ float sigmoid_ep(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// lane = (channel cj = .. + lo, four consecutive l of sample `so`); gv = gradient of the mixed output there
+// (zero for padded samples: vo false).  All 64 lanes of the wave call it (shuffles).
+__device__ __forceinline__ void mix_ep_tile(const MixEp& m, const float4 gv, const int so, const int cj,
+                                            const int l0, const bool vo, const int C, const int L,
+                                            const int shard) {
+  const int M = 3 * C;
+  const int sc_ = vo ? so : 0;
+  const int64_t e = ((int64_t)sc_ * C + cj) * L + l0;
+  const int64_t ub = ((int64_t)sc_ * M + cj) * L + l0;
+  const float4 ua = ld4(m.U + ub), ug = ld4(m.U + ub + (int64_t)C * L), uf = ld4(m.U + ub + (int64_t)2 * C * L);
+  const float4 xv = ld4(m.x + e), pv = ld4(m.p1 + e);
+  float4 oldx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m.acc_dx) oldx = ld4(m.dx + e);
+  float mu[3], rs[3], sc[3], sh[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    mu[k] = m.chan[k * C + cj];
+    rs[k] = m.chan[M + k * C + cj];
+    sc[k] = m.chan[2 * M + k * C + cj];
+    sh[k] = m.chan[3 * M + k * C + cj];
+  }
+  const float g0 = m.gamma[0], g2 = m.gamma[2], g3 = m.gamma[3];
+  const DropRt rglu = drop_begin(m.dglu), rfc = drop_begin(m.dfc);
+  const float4 m2 = drop_mult4(rglu, (uint64_t)e), m3 = drop_mult4(rfc, (uint64_t)e);
+  const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+  const float uaq[4] = {ua.x, ua.y, ua.z, ua.w}, ugq[4] = {ug.x, ug.y, ug.z, ug.w}, ufq[4] = {uf.x, uf.y, uf.z, uf.w};
+  const float xq[4] = {2.f * xv.x, 2.f * xv.y, 2.f * xv.z, 2.f * xv.w};       // x + y, x is y
+  const float pq[4] = {pv.x, pv.y, pv.z, pv.w};
+  const float m2q[4] = {m2.x, m2.y, m2.z, m2.w}, m3q[4] = {m3.x, m3.y, m3.z, m3.w};
+  float da[4], dg[4], df[4], dgam[4] = {0.f, 0.f, 0.f, 0.f}, sw[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {                                // the arithmetic of node_mix_bwd_k, term for term
+    const float va = fmaf(uaq[t], sc[0], sh[0]), vg = fmaf(ugq[t], sc[1], sh[1]), vf = fmaf(ufq[t], sc[2], sh[2]);
+    const float sg = sigmoid_ep(vg);
+    dgam[0] += gq[t] * xq[t];
+    dgam[1] += gq[t] * pq[t];
+    dgam[2] += gq[t] * (va * sg * m2q[t]);
+    dgam[3] += gq[t] * (fmaxf(vf, 0.f) * m3q[t]);
+    const float gm2 = g2 * gq[t] * m2q[t];
+    da[t] = gm2 * sg;
+    dg[t] = gm2 * va * sg * (1.f - sg);
+    df[t] = (vf > 0.f) ? g3 * gq[t] * m3q[t] : 0.f;
+    sw[0] += da[t] * (uaq[t] - mu[0]) * rs[0];
+    sw[1] += dg[t] * (ugq[t] - mu[1]) * rs[1];
+    sw[2] += df[t] * (ufq[t] - mu[2]) * rs[2];
+    sb[0] += da[t]; sb[1] += dg[t]; sb[2] += df[t];
+  }
+  if (vo) {
+    st4(m.dV + ub, make_float4(da[0], da[1], da[2], da[3]));
+    st4(m.dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
+    st4(m.dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
+    st4(m.dx + e, f4_add(f4_scale(gv, 2.f * g0), oldx));      // dy == NULL: both halves into dx
+  }
+  // BatchNorm reductions over the tile's 16 columns: the four lanes h of a channel (xor 16 / 32), then one
+  // atomic pair per channel and primitive; dgamma over the wave, one atomic each into this tile's shard
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    sw[k] += __shfl_xor(sw[k], 16, 64); sw[k] += __shfl_xor(sw[k], 32, 64);
+    sb[k] += __shfl_xor(sb[k], 16, 64); sb[k] += __shfl_xor(sb[k], 32, 64);
+  }
+  const int lane = threadIdx.x & 63;
+  if ((lane >> 4) == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      atomicAdd(m.bn_grad + k * C + cj, sw[k]);
+      atomicAdd(m.bn_grad + M + k * C + cj, sb[k]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dgam[q] = wave_sum(dgam[q]);
+  if (lane == 0 && m.dgamma != nullptr) {
+    float* p = m.dgamma + (int64_t)(shard % m.dg_shards) * m.dg_stride;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(p + q, dgam[q]);
+  }
+}
+
 template <int TN, int TJ>
 constexpr size_t conv_ksplit_lds();
 
@@ -273,8 +374,9 @@ constexpr size_t conv_ksplit_lds();
 
 // MULTI: contractions longer than the 4 * KPW blocks a workgroup holds in registers at once (the K = 2048
 // reshape layers) run as several rounds of [all loads, then all MFMAs] into the same accumulators.
-template <bool TRANS, int TN, int TJ, int KPW, bool MULTI = false>
-__device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx, const int by, char* lds) {
+template <bool TRANS, int TN, int TJ, int KPW, bool MULTI = false, bool MIXEP = false>
+__device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx, const int by, char* lds,
+                                                 const MixEp* mix = nullptr) {
   // caller-provided LDS (conv_ksplit_lds<TN, TJ>() bytes): merged launches pay max(), not sum()
   float4 (*part)[TN * TJ][64] = reinterpret_cast<float4 (*)[TN * TJ][64]>(lds);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -429,10 +531,15 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
     for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
     const int so = g * a.spw + ((4 * h) >> a.Lb);
     const bool vo = so < a.b;
+    float4 ov = o;
     if (vo && d != nullptr && (!KS_PROBE(a, 4) || o.x == 12345.f)) {
       float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
-      st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
+      if (a.acc_mask & (1u << q)) ov = f4_add(o, ld4(pp));
+      st4(pp, ov);
     }
+    if (MIXEP && q == mix->q)                                  // wave-uniform: a 16-channel tile lies in one source
+      mix_ep_tile(*mix, vo ? ov : make_float4(0.f, 0.f, 0.f, 0.f), so, cj, l0, vo, a.Cj, a.L,
+                  by * (int)gridDim.x + bx);
     bn_tile_stats(a, o, bj, vo, g, jj, h);
   }
 }
@@ -1367,7 +1474,7 @@ __global__ __launch_bounds__(256) void conv_bwd_all_k(ConvArgs a, SdpaBwdArgs s,
 // BatchNorm input gradient is applied while the operands are staged (ConvArgs::bn_U).
 template <int KPW>
 __global__ __launch_bounds__(256) void conv_bwd_pair_k(ConvArgs a, ConvWArgs w, int gx, int n_w, int wx,
-                                                       int wy) {
+                                                       int wy, MixEp mix) {
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   const int blk = blockIdx.x;
   if (blk < n_w) {
@@ -1376,7 +1483,8 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_k(ConvArgs a, ConvWArgs w, 
     else conv_w_body<4, false>(w, r % wx, r / wx, bz, merged_smem);
   } else {
     const int t = blk - n_w;
-    conv_ksplit_body<false, 1, 1, KPW>(a, t % gx, t / gx, merged_smem);
+    if (mix.on) conv_ksplit_body<false, 1, 1, KPW, false, true>(a, t % gx, t / gx, merged_smem, &mix);
+    else conv_ksplit_body<false, 1, 1, KPW>(a, t % gx, t / gx, merged_smem);
   }
 }
 
@@ -1957,13 +2065,57 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   return 0;
 }
 
+namespace {
+// the grid rule of bmnas_conv1x1_bwd_all's one-launch form (the only one that can carry the mix epilogue)
+inline bool bwd_all_merged(int b, int L, int M, int J) {
+  int Lb, spw, ng;
+  if (check_shape(b, L, &Lb, &spw, &ng)) return false;
+  const long jt = J / 16;
+  const int kpw = (M / 16 + 3) / 4;
+  const bool pipe = conv_pipe_mode() && M % 48 == 0 && (((long)ng + 1) / 2) * ((J + kPipeBJ - 1) / kPipeBJ) >= 96;
+  return !pipe && (((long)ng + 1) / 2) * ((jt + 1) / 2) < 1024 && kpw <= 4 && kpw * 4 * 3 + 4 <= 232;
+}
+}  // namespace
+
+extern "C" int bmnas_conv1x1_bwd_all_mix_ok(int b, int L, int M, int n_src, int C_src) {
+  return b >= 1 && n_src >= 1 && C_src % 16 == 0 && M % 16 == 0 && bwd_all_merged(b, L, M, n_src * C_src);
+}
+
+extern "C" int bmnas_conv1x1_bwd_all_mix(const float* dU, const float* W, int ldw, int fold_cols,
+                                         float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
+                                         int b, int L, int M, const float* const* wsrcs, float* dW,
+                                         int ldw_grad, float* dbias, int dup_cols, const float* bn_U,
+                                         const float* bn_chan, const float* bn_grad, int bn_training,
+                                         const bmnas_mix_ep_t* mix, void* stream);
+
 extern "C" int bmnas_conv1x1_bwd_all(const float* dU, const float* W, int ldw, int fold_cols,
                                      float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
                                      int b, int L, int M, const float* const* wsrcs, float* dW,
                                      int ldw_grad, float* dbias, int dup_cols, const float* bn_U,
                                      const float* bn_chan, const float* bn_grad, int bn_training,
                                      void* stream) {
+  return bmnas_conv1x1_bwd_all_mix(dU, W, ldw, fold_cols, dsrcs, n_src, C_src, accumulate_mask, b, L, M, wsrcs, dW,
+                                   ldw_grad, dbias, dup_cols, bn_U, bn_chan, bn_grad, bn_training, nullptr, stream);
+}
+
+extern "C" int bmnas_conv1x1_bwd_all_mix(const float* dU, const float* W, int ldw, int fold_cols,
+                                         float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
+                                         int b, int L, int M, const float* const* wsrcs, float* dW,
+                                         int ldw_grad, float* dbias, int dup_cols, const float* bn_U,
+                                         const float* bn_chan, const float* bn_grad, int bn_training,
+                                         const bmnas_mix_ep_t* mix, void* stream) {
   if (bn_U != nullptr && (!bn_chan || (bn_training && !bn_grad))) return BMNAS_E_ARG;
+  MixEp me{};
+  if (mix != nullptr) {
+    if (!mix->U || !mix->chan || !mix->x || !mix->p1 || !mix->gamma || !mix->dx || !mix->dV || !mix->bn_grad ||
+        mix->q < 0 || mix->q >= n_src || mix->dgamma_shards < 1 || !dsrcs || !dsrcs[mix->q] || fold_cols != 0)
+      return BMNAS_E_ARG;
+    if (!bmnas_conv1x1_bwd_all_mix_ok(b > 0 ? b : 1, L, M, n_src, C_src)) return BMNAS_E_LIMIT;
+    me.U = mix->U; me.chan = mix->chan; me.x = mix->x; me.p1 = mix->p1; me.gamma = mix->gamma;
+    me.dgamma = mix->dgamma; me.dx = mix->dx; me.dV = mix->dV; me.bn_grad = mix->bn_grad;
+    me.dg_stride = mix->dgamma_shard_stride; me.dg_shards = mix->dgamma_shards; me.acc_dx = mix->accumulate_dx;
+    me.q = mix->q; me.on = 1; me.dglu = to_cfg(mix->drop_glu); me.dfc = to_cfg(mix->drop_fc);
+  }
   if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
   if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
   if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
@@ -1991,6 +2143,7 @@ extern "C" int bmnas_conv1x1_bwd_all(const float* dU, const float* W, int ldw, i
                       kpw * 4 * 3 + 4 <= 232;
   bool want_data = false;
   for (int q = 0; q < n_src; ++q) want_data = want_data || dsrcs[q] != nullptr;
+  if (mix != nullptr && !(merged && want_data)) return BMNAS_E_LIMIT;     // (host-checked by the caller: _mix_ok)
   if (!merged || !want_data) {
     // separate launches.  The pipelined data-gradient kernel and the weight-gradient kernel both apply the
     // BatchNorm input gradient while staging their operands, so only the other data-gradient families
@@ -2036,7 +2189,7 @@ extern "C" int bmnas_conv1x1_bwd_all(const float* dU, const float* W, int ldw, i
 #define BP_CASE(K)                                                                                     \
   case K:                                                                                              \
     hipLaunchKernelGGL((conv_bwd_pair_k<K>), grid, dim3(256), lds, st, a, w, gx, n_w, (int)wgrid.x,    \
-                       (int)wgrid.y);                                                                  \
+                       (int)wgrid.y, me);                                                              \
     break;
   switch (kpw) { BP_CASE(1) BP_CASE(2) BP_CASE(3) BP_CASE(4) default: return BMNAS_E_LIMIT; }
 #undef BP_CASE

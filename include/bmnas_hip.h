@@ -220,6 +220,36 @@ int bmnas_conv1x1_bwd_all(const float* dU, const float* W, int ldw, int fold_col
                           const float* const* wsrcs, float* dW, int ldw_grad, float* dbias,
                           int dup_cols, const float* bn_U, const float* bn_chan, const float* bn_grad,
                           int bn_training, void* stream);
+/* bmnas_conv1x1_bwd_all with the backward of the NodeMixedOp behind one of its sources as the epilogue of that
+ * source's data-gradient tiles (small grids only: bmnas_conv1x1_bwd_all_mix_ok; BMNAS_E_LIMIT otherwise).
+ * NodeCell's out_conv reads cat(states[-node_multiplier:]) (reference node_search.py:59-61); source `q` is the
+ * output of the last inner step's NodeMixedOp (node_operations.py:118-120, x is y) and feeds nothing else, so its
+ * data gradient — still written to dsrcs[q], the attention backward reads it — is the complete gradient g of
+ * that output: the tile applies bmnas_node_mix_bwd(g, x, x, p1, U, chan, gamma, ...) to its elements (dx (=|+=)
+ * 2 gamma[0] g, dV, bn_grad, dgamma shards as there).  One launch (~5.6 us at 6-8 samples per GPU) less per
+ * cell step. */
+typedef struct {
+  const float* U;
+  const float* chan;
+  const float* x;
+  const float* p1;
+  const float* gamma;
+  float* dgamma;
+  int dgamma_shards;
+  int64_t dgamma_shard_stride;
+  float* dx;
+  int accumulate_dx;
+  float* dV;
+  float* bn_grad;
+  int q;
+  bmnas_dropout_t drop_glu, drop_fc;
+} bmnas_mix_ep_t;
+int bmnas_conv1x1_bwd_all_mix_ok(int b, int L, int M, int n_src, int C_src);
+int bmnas_conv1x1_bwd_all_mix(const float* dU, const float* W, int ldw, int fold_cols, float* const* dsrcs,
+                              int n_src, int C_src, uint32_t accumulate_mask, int b, int L, int M,
+                              const float* const* wsrcs, float* dW, int ldw_grad, float* dbias, int dup_cols,
+                              const float* bn_U, const float* bn_chan, const float* bn_grad, int bn_training,
+                              const bmnas_mix_ep_t* mix, void* stream);
 /* dW[m*ldw + k] += sum_{s,l} dU[s,m,l] * cat(srcs)[s,k,l];  dbias[m] += sum_{s,l} dU[s,m,l]
  * (atomic adds: caller zeroes; dbias may be NULL).  If dup_cols > 0 the same value is also
  * added at column k + dup_cols (folded x-is-y weights, see bmnas_fold_weight). */

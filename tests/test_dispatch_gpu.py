@@ -148,3 +148,55 @@ def test_every_family_is_reachable(monkeypatch):
     calls = lib.conv_family_calls()
     dead = [k for k, v in calls.items() if v == 0]
     assert not dead, (dead, calls)
+
+
+_ANY_TOGGLE = [k for k in os.environ if k.startswith('BMNAS_') and k not in ('BMNAS_DEFAULT',)]
+
+
+@pytest.mark.skipif(bool(_ANY_TOGGLE), reason=f'launch counts describe the default switches ({_ANY_TOGGLE})')
+@pytest.mark.parametrize('name,batch', [('ntu', 8), ('ego', 6)])
+def test_small_batch_launch_merges_are_taken(name, batch, monkeypatch):
+    """At 6-8 samples per GPU (BASELINE configs 4 / 5) the step is its launch count: the merges of round 2 must
+    actually be dispatched there — the next cell step's K1 pair sum / its backward inside the NodeCell tail
+    launches (bmnas_bn_relu_ln_fwd_pair / _bwd_pair) and the last inner step's mix backward inside the out_conv
+    data-gradient tiles (bmnas_conv1x1_bwd_all_mix).  Counted at the Python boundary, with the merges on and off;
+    parity of both forms is what the network tests check."""
+    import torch
+    from bmnas import lib, cell as K
+    from gpu_util import build_search_net
+    from oracle import fusion_oracle as fo, synth
+    cfg = fo.CONFIGS[name]
+    net = build_search_net(cfg, 5, 'train')
+    xs = [x.cuda().requires_grad_(True) for x in synth.make_inputs(cfg, batch, 5)]
+    counted = ('node_mix_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'bn_relu_ln_fwd', 'bn_relu_ln_bwd',
+               'conv1x1_bwd_all')
+    calls = {}
+
+    def wrap(fn_name):
+        fn = getattr(lib, fn_name)
+
+        def w(*a, **k):
+            calls[fn_name] = calls.get(fn_name, 0) + 1
+            return fn(*a, **k)
+        return w
+    for n in counted:
+        monkeypatch.setattr(lib, n, wrap(n))
+
+    def step():
+        calls.clear()
+        for p in list(net.parameters()) + list(net.arch_parameters()) + xs:
+            p.grad = None
+        net(xs).square().mean().backward()
+        torch.cuda.synchronize()
+        return dict(calls)
+    S, ns = cfg.S, cfg.ns
+    on = step()
+    assert on.get('mixsum_pair_fwd', 0) == 0                 # first in the prologue launch, the rest in the tails
+    assert on['mixsum_pair_bwd'] == 1                        # only the first cell step's (no node before it)
+    assert on['node_mix_bwd'] == S * (ns - 1)                # the last inner step's rides in conv1x1_bwd_all
+    assert on['bn_relu_ln_fwd'] == S and on['bn_relu_ln_bwd'] == S and on['conv1x1_bwd_all'] == S
+    monkeypatch.setattr(K, 'FUSE_NEXT_PAIR', False)
+    monkeypatch.setattr(K, 'FUSE_MIX_EPILOGUE', False)
+    off = step()
+    assert off['mixsum_pair_fwd'] == S - 1 and off['mixsum_pair_bwd'] == S
+    assert off['node_mix_bwd'] == S * ns
