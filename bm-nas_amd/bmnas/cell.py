@@ -72,6 +72,7 @@ class _DropState:
         self.offset = 0
         self.device_counter = None       # int64 cuda tensor while capturing / replaying
         self.pending_advance = None      # (counter, span) to hand to the first cell prologue of a capture
+        self.record = None               # a list: every live site is appended as (descriptor, numel), in call order
 
     def make(self, p, numel, training):
         if not training or p <= 0.0:
@@ -80,7 +81,19 @@ class _DropState:
         d = lib.make_dropout(p, torch.initial_seed(), self.offset,
                              None if ctr is None else ctr.data_ptr())
         self.offset += (numel + 3) // 4
+        if self.record is not None and d.thr != 0:
+            self.record.append((d, numel))
         return d
+
+    def take_advance(self):
+        """The captured step's counter advance, for the cell prologue launch to carry — but only while NO
+        dropout site has been issued yet: a site in front of the prologue (the reshape layers' dropout) reads
+        the counter before the advance in its forward and after it in its backward, i.e. would regenerate a
+        mask the forward never applied.  Such a step keeps the add at the end of the graph instead."""
+        if self.pending_advance is None or self.offset != 0:
+            return None
+        adv, self.pending_advance = self.pending_advance, None
+        return adv
 
 
 DROP = _DropState()

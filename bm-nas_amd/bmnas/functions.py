@@ -367,7 +367,7 @@ class FusedCellFn(Function):
             weffs = [torch.empty((3 * C_, C_), device=dev, dtype=torch.float32) for _ in mixed]
             # under capture the first prologue of the step also advances the dropout step counter
             # (bmnas.graph.GraphedStep), saving the separate add launch at the end of every replay
-            adv, K.DROP.pending_advance = K.DROP.pending_advance, None
+            adv = K.DROP.take_advance()
             stackW = [m.stack_W for m in mixed]
             if (K.FUSE_PROLOGUE_PAIR and K.FUSE_PAIR and alpha_is_logits and N <= 15
                     and logits[0].shape[1] == 2 and logits[1].shape[1] == 2 and logits[1].shape[0] >= 2):

@@ -52,8 +52,10 @@ class GraphedStep:
             with torch.cuda.graph(self.graph):
                 out = fn()
                 self.span = K.DROP.offset
-                consumed = K.DROP.pending_advance is None
-                if self.span > 0 and not consumed:
+                # True: a cell prologue advanced the counter in front of every dropout site of the step (they
+                # all read the advanced value); False: the sites read the old value and this add ends the graph
+                self.advanced_first = K.DROP.pending_advance is None
+                if self.span > 0 and not self.advanced_first:
                     self.counter.add_(self.span)      # next replay draws new dropout masks
             self.span_dev.fill_(self.span)
             # keep the static storage, not the Python autograd graph that produced it (a retained
@@ -68,6 +70,11 @@ class GraphedStep:
     def replay(self):
         self.graph.replay()
         return self.outputs
+
+    def site_step_value(self):
+        """The value of the step counter that the dropout sites of the LAST replay read (synchronises)."""
+        now = int(self.counter.item())
+        return now if self.advanced_first else now - self.span
 
 
 class GraphedTrainStep:

@@ -79,6 +79,7 @@ _U32 = C.c_uint32
 
 SIGNATURES = {
     'bmnas_version': ([], _I),
+    'bmnas_dropout_mask': ([Dropout, _I64, _P, _P], _I),
     'bmnas_mixsum_fwd': ([_PP, _I, _P, _I, _P, _I64, _P], _I),
     'bmnas_mixsum_bwd': ([_PP, _PP, _I, _P, _I, _P, _P, _P, _I, _I64, _U32, _I64, _P], _I),
     'bmnas_mixsum_pair_fwd': ([_PP, _I, _P, _I, _P, _I, _P, _P, _I64, _P], _I),
@@ -228,6 +229,19 @@ def make_dropout(p, seed, offset, step_ptr=None):
         return NO_DROP
     return Dropout(min(thr, 0xFFFFFFFF), 1.0 / (1.0 - p), seed & 0xFFFFFFFFFFFFFFFF,
                    offset & 0xFFFFFFFFFFFFFFFF, step_ptr)
+
+
+def dropout_mask(drop, numel, device, step_value=None):
+    """The multipliers (0 or 1/(1-p)) the kernels apply at the dropout site `drop` to the `numel` elements of
+    its output, as a flat fp32 tensor (bmnas_dropout_mask).  step_value: use this value of the device step
+    counter instead of reading it (a site of a captured step, asked about after later replays)."""
+    out = torch.empty(numel, device=device, dtype=torch.float32)
+    if drop.thr == 0:
+        return out.fill_(1.0)
+    if step_value is not None:
+        drop = Dropout(drop.thr, drop.scale, drop.seed, (drop.offset + int(step_value)) & 0xFFFFFFFFFFFFFFFF, None)
+    _check(load().bmnas_dropout_mask(drop, numel, out.data_ptr(), _stream()), 'dropout_mask')
+    return out
 
 
 # ------------------------------------------------------------------------- wrappers

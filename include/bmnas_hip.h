@@ -54,6 +54,14 @@ typedef struct {
 
 int bmnas_version(void);
 
+/* The multipliers of ONE dropout site as a tensor: out[e] = (element e kept ? drop.scale : 0) for
+ * e in [0, n_elem) — exactly what every kernel that takes `drop` applies to flat element e of that site's
+ * (b, C, L) output (nn.Dropout at node_operations.py:38, :55, :105, node_search.py:64, aux_models.py:114).
+ * Audit entry point: lets a CPU checker re-run a dropout-ON step under the SAME masks (torch's generator
+ * cannot be reproduced bit for bit; this Philox stream can be exported).  With drop.step != NULL the device
+ * counter is read when the launch executes, like in the kernels.  Nothing on the hypernet path calls it. */
+int bmnas_dropout_mask(bmnas_dropout_t drop, int64_t n_elem, float* out, void* stream);
+
 /* ---- K1: architecture-weighted mixed-edge sum ---------------------------------------
  * out[e] = sum_j w[j*w_stride] * xs[j][e]   over n_elem elements.
  * Replaces sum(FusionMixedOp_j(h_j, weights[offset+j])) at model_search.py:58 and

@@ -139,8 +139,46 @@ def is_buffer(key: str) -> bool:
 
 
 # ------------------------------------------------------------------ primitive ops
+_INJECTED = None      # iterator over multiplier tensors while `injected_masks` is active
+
+
+class injected_masks:
+    """with injected_masks(masks): every LIVE dropout site (train mode, p > 0) multiplies its input by the next
+    tensor of `masks` instead of drawing from torch's generator.  A mask holds the site's multipliers — 0 for a
+    dropped element, 1/(1-p) for a kept one — which is all nn.Dropout does (x * Bernoulli(1-p) / (1-p),
+    node_operations.py:38, :55, :105; node_search.py:64).  Sites are visited in the reference's execution
+    order: per inner step ScaledDotAttn, LinearGLU, ConcatFC (node_operations.py:119 evaluates `_ops` in list
+    order), then the node's out_conv dropout, cell step by cell step.  `.used` counts the masks consumed."""
+
+    def __init__(self, masks):
+        self.masks = list(masks)
+        self.used = 0
+
+    def __enter__(self):
+        global _INJECTED
+        assert _INJECTED is None, 'injected_masks does not nest'
+        _INJECTED = self
+        return self
+
+    def __exit__(self, *exc):
+        global _INJECTED
+        _INJECTED = None
+        return False
+
+    def next(self, x):
+        if self.used >= len(self.masks):
+            raise IndexError(f'dropout site {self.used}: no mask left ({len(self.masks)} injected)')
+        m = self.masks[self.used]
+        self.used += 1
+        if m.numel() != x.numel():
+            raise ValueError(f'dropout site {self.used - 1}: mask of {m.numel()} elements for a tensor {tuple(x.shape)}')
+        return m.reshape(x.shape).to(x.dtype)
+
+
 def _dropout(x, p, training):
     # nn.Dropout: identity in eval; in train mode Bernoulli(1-p) mask scaled by 1/(1-p).
+    if _INJECTED is not None and training and p > 0.0:
+        return x * _INJECTED.next(x)
     return F.dropout(x, p=p, training=training)
 
 
@@ -322,6 +360,37 @@ def fusion_cell(inputs: Sequence[torch.Tensor], arch: Sequence[torch.Tensor], p,
 def hypernet_logits(inputs, arch, p, cls_w, cls_b, cfg, training, attn_drop=ATTN_DROP, primitives=None):
     """fusion_net + central_classifier (mmimdb_darts_searchable.py:113-114)."""
     return F.linear(fusion_cell(inputs, arch, p, cfg, training, attn_drop, primitives), cls_w, cls_b)
+
+
+# ---------------------------------------------------------------- reshape layers (row f1)
+def reshape_pool(x, L, kind):
+    """The pooling in front of the reshape conv.  kind 'mmimdb': ReshapeInputLayer_MMIMDB.forward
+    (aux_models.py:101-108): (b, C_in[, H, W]) -> unsqueeze twice -> view(b, C_in, d2, -1) ->
+    AdaptiveMaxPool2d((sqrt L, sqrt L)) -> (b, C_in, L).  kind 'video': ReshapeInputLayer.forward
+    (aux_models.py:62-70): view(b, C_in, T, -1) -> AdaptiveMaxPool2d((L, 1)) -> (b, C_in, L) ->
+    F.interpolate(out, L) (nearest; an identity once the pool already returns L positions)."""
+    if kind == 'mmimdb':
+        side = int(math.sqrt(L * 1.0))
+        assert side * side == L
+        out = x.unsqueeze(-1).unsqueeze(-1)
+        out = out.view(out.size(0), out.size(1), out.size(2), -1)
+        out = F.adaptive_max_pool2d(out, (side, side))
+        return out.view(out.size(0), out.size(1), -1)
+    out = x.unsqueeze(-1)
+    out = out.view(out.size(0), out.size(1), out.size(2), -1)
+    out = F.adaptive_max_pool2d(out, (L, 1))
+    out = out.view(out.size(0), out.size(1), -1)
+    return F.interpolate(out, L)
+
+
+def reshape_layer(x, p, prefix, L, kind, training, drpt):
+    """ReshapeInputLayer{,_MMIMDB}.forward (aux_models.py:62-76, 101-115): pool -> Conv1d(C_in, C, 1) ->
+    BatchNorm1d(C) -> ReLU -> Dropout(drpt)."""
+    out = reshape_pool(x, L, kind)
+    out = _conv_bn(out, p[prefix + '.conv.weight'], p[prefix + '.conv.bias'], p[prefix + '.bn.weight'],
+                   p[prefix + '.bn.bias'], p[prefix + '.bn.running_mean'], p[prefix + '.bn.running_var'], training)
+    _bump_nbt(p, prefix + '.bn.num_batches_tracked', training)
+    return _dropout(F.relu(out), drpt, training)
 
 
 def loss_fn(kind: str):

@@ -81,3 +81,12 @@ def make_labels(kind, batch, num_outputs, seed):
     if kind == 'bce':
         return torch.from_numpy((rng.uniform(size=(batch, num_outputs)) < 0.2).astype(np.float32))
     return torch.from_numpy(rng.integers(0, num_outputs, size=(batch,)).astype(np.int64))
+
+
+def make_drop_mask(seed, site, shape, p):
+    """Multipliers of dropout site number `site` of a step (0 for a dropped element, 1/(1-p) for a kept one):
+    what nn.Dropout(p) applies in train mode, with the Bernoulli(1-p) draw coming from this module's
+    counter-keyed generator instead of torch's stream (round-3 'train_drop' fixtures)."""
+    rng = _rng(seed + 5000003 + 7919 * site)
+    keep = rng.uniform(size=tuple(shape)) >= p
+    return torch.from_numpy(keep.astype(np.float32) * np.float32(1.0 / (1.0 - p)))

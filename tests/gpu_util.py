@@ -102,17 +102,50 @@ def assert_summary_scaled(name, got, want, rel=2e-4):
         (name, 'head', head, want[2:])
 
 
-def assert_close_either(name, got, want_a, want_b, rel=1e-4):
-    """Pass if `got` matches want_a OR want_b (per tensor).  Used where two legitimate evaluations
-    of the reference math exist — the fp32 op sequence and the same in float64 — and a ReLU /
-    dropout-free mask decision on a pre-activation within round-off of zero may fall either way:
-    such a flip moves whole gradient tensors by ~1e-2 of their scale (measured: the two CPU
-    evaluations differ from each other by that much at batch 128-250), which is not an error of
-    either side."""
-    try:
-        assert_close_scaled(name, got, want_a, rel)
-    except AssertionError as first:
+def assert_close_of_scale(name, got, want, rel=1e-4, floor=1e-6):
+    """|got - want| <= rel * max|want| for every element: "within 1e-4 of scale", the bound BASELINE.json's
+    north_star states for logits (no per-element relative term on top)."""
+    got = np.asarray(got.detach().cpu().numpy() if torch.is_tensor(got) else got, dtype=np.float64)
+    want = np.asarray(want.detach().cpu().numpy() if torch.is_tensor(want) else want, dtype=np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    if want.size == 0:
+        return
+    tol = scale_tol(want, rel, floor)
+    err = np.abs(got - want)
+    if not np.isfinite(got).all() or not (err <= tol).all():
+        i = int(np.argmax(err))
+        raise AssertionError(f'{name}: max|err|={np.nanmax(err):.3e} > {rel:g} of scale {np.abs(want).max():.3e} at '
+                             f'flat {i}: got {got.reshape(-1)[i]!r} want {want.reshape(-1)[i]!r}')
+
+
+class EitherLog:
+    """Per-tensor comparison against the fp32 oracle, with the float64 evaluation of the same oracle as a
+    second legitimate answer (a ReLU decision on a pre-activation within round-off of zero may fall either way and
+    moves whole gradient tensors by ~1e-2 of their scale: DESIGN.md section 4, tools/diag_ntu250.py).  Unlike a
+    bare "either" it RECORDS which evaluation matched and fails when more than `max_rescued` tensors needed the
+    second one — a real regression in one branch cannot hide behind the rescue."""
+
+    def __init__(self, max_rescued):
+        self.max_rescued = max_rescued
+        self.first, self.rescued = [], []
+
+    def check(self, name, got, want_a, want_b, rel=1e-4, of_scale=False):
+        """want_b: the second evaluation, or a callable that produces it (only computed when needed)."""
+        close = assert_close_of_scale if of_scale else assert_close_scaled
         try:
-            assert_close_scaled(name, got, want_b, rel)
-        except AssertionError as second:
-            raise AssertionError(f'{first}\n   and against the second evaluation: {second}') from None
+            close(name, got, want_a, rel)
+            self.first.append(name)
+            return 'fp32'
+        except AssertionError as first:
+            try:
+                close(name, got, want_b() if callable(want_b) else want_b, rel)
+            except AssertionError as second:
+                raise AssertionError(f'{first}\n   and against the float64 evaluation: {second}') from None
+            self.rescued.append(name)
+            return 'fp64'
+
+    def finish(self):
+        if len(self.rescued) > self.max_rescued:
+            raise AssertionError(f'{len(self.rescued)} tensors matched only the float64 evaluation (allowed: '
+                                 f'{self.max_rescued}): {self.rescued}')
+        return self.rescued

@@ -217,9 +217,10 @@ def test_node_mixed_op(b, C, L, same, training):
                 assert_close_scaled(k, v.float(), po[prefix[:-len('_ops')] + k].float())
 
 
-def test_dropout_mask_is_consistent_between_forward_and_backward():
-    """Philox dropout: keep fraction ~ 1-p, kept values scaled by 1/(1-p), and the backward
-    regenerates exactly the forward's mask."""
+def test_dropout_keep_fraction_and_fresh_masks():
+    """Philox dropout statistics only: zero fraction ~ dead-ReLU + p of the rest, a new mask on every call,
+    identity in eval mode.  (That kept values are scaled by 1/(1-p) and that the backward regenerates exactly
+    the forward's mask is checked against the oracle under exported masks in tests/test_dropout_gpu.py.)"""
     from models.search.darts.node_operations import ConcatFC
     cfg = fo.make_cfg(N=2, C=64, L=16, drpt=0.25)
     torch.manual_seed(0)

@@ -8,11 +8,13 @@ import torch
 
 from oracle import fusion_oracle as fo
 from oracle import synth
-from gpu_util import (Args, assert_close_either, assert_close_scaled, assert_summary_scaled, build_found_net, build_search_net, dev,
+from gpu_util import (Args, EitherLog, assert_close_scaled, assert_summary_scaled, build_found_net, build_search_net, dev,
                       set_mode)
 from util import case_id, cfg_of, golden_files, load_npz, summarize
 
 pytestmark = pytest.mark.gpu
+
+RESCUE_MAX = 6     # tensors per real-config case that may match only the float64 oracle evaluation (EitherLog)
 
 
 def _run_search_case(meta, head=None):
@@ -57,7 +59,9 @@ def _run_search_case(meta, head=None):
 
 
 @pytest.mark.parametrize('head', [None, 'fused', 'deferred'])
-@pytest.mark.parametrize('path', golden_files('hypernet_*.npz'), ids=case_id)
+# ('train_drop' fixtures were drawn under torch-side seeded masks: they pin the ORACLE's dropout sites,
+# tests/test_oracle_golden.py; the HIP path with dropout on is checked in tests/test_dropout_gpu.py)
+@pytest.mark.parametrize('path', [p for p in golden_files('hypernet_*.npz') if 'train_drop' not in p], ids=case_id)
 def test_search_hypernet_matches_reference_golden(path, head):
     meta, z = load_npz(path)
     if head is not None and meta['cfg']['M'] > meta['cfg']['S']:
@@ -107,7 +111,7 @@ def test_search_hypernet_matches_reference_golden(path, head):
                                                       ('ego', 7, 83, 'ce'),
                                                       # BASELINE.json per-GPU sizes (configs 2-5)
                                                       ('mmimdb', 128, 23, 'bce'), ('ntu', 8, 60, 'ce'),
-                                                      ('ntu', 64, 60, 'ce'), ('ego', 6, 83, 'ce'),
+                                                      ('ntu', 64, 60, 'ce'), ('ego', 6, 83, 'ce'), ('ego', 48, 83, 'ce'),
                                                       # ragged production batches: the merged / pipelined
                                                       # launches see partial tiles
                                                       ('mmimdb', 100, 23, 'bce'), ('mmimdb', 250, 23, 'bce'),
@@ -139,20 +143,26 @@ def test_search_hypernet_matches_oracle_real_configs(name, batch, nout, loss_kin
     dlogits, dloss, dgrads = fo.search_step([f64(x) for x in synth.make_inputs(cfg, batch, seed)], labels,
                                             [f64(a) for a in arch], p64, f64(cw), f64(cb), cfg, loss_kind,
                                             training=True, attn_drop=0.0)
-    assert_close_scaled('logits', logits, ologits)
-    assert_close_scaled('loss', loss, oloss)
+    # which evaluation each tensor matched is recorded; at most RESCUE_MAX tensors may need the float64 one
+    # (measured on MI355X: 0-2 per case, always downstream of one flipped ReLU), logits at 1e-4 OF SCALE
+    log = EitherLog(RESCUE_MAX)
+    log.check('logits', logits, ologits, dlogits, rel=1e-4, of_scale=True)
+    log.check('loss', loss, oloss, dloss, rel=1e-4, of_scale=True)
     for k, v in net.named_parameters():
         if k.endswith('conv.bias'):
             assert float(v.grad.abs().max()) < 1e-4, k
         else:
-            assert_close_either('grad:' + k, v.grad, ograds[k], dgrads[k], rel=2e-4)
+            log.check('grad:' + k, v.grad, ograds[k], dgrads[k], rel=2e-4)
     for i, a in enumerate(net.arch_parameters()):
-        assert_close_either(f'grad:arch.{i}', a.grad, ograds[f'arch.{i}'], dgrads[f'arch.{i}'], rel=2e-4)
+        log.check(f'grad:arch.{i}', a.grad, ograds[f'arch.{i}'], dgrads[f'arch.{i}'], rel=2e-4)
     for i, x in enumerate(xs):
-        assert_close_either(f'grad:input.{i}', x.grad, ograds[f'input.{i}'], dgrads[f'input.{i}'], rel=2e-4)
+        log.check(f'grad:input.{i}', x.grad, ograds[f'input.{i}'], dgrads[f'input.{i}'], rel=2e-4)
     for k in ('weight', 'bias'):
         kk = 'central_classifier.' + k
-        assert_close_either('grad:' + kk, getattr(cls, k).grad, ograds[kk], dgrads[kk], rel=2e-4)
+        log.check('grad:' + kk, getattr(cls, k).grad, ograds[kk], dgrads[kk], rel=2e-4)
+    rescued = log.finish()
+    if rescued:
+        print(f'[{name} b{batch} head={head}] matched the float64 evaluation only: {rescued}')
     for k, v in net.state_dict().items():
         if fo.is_buffer(k):
             assert_close_scaled('buf:' + k, v.float(), p[k].float())

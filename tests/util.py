@@ -36,7 +36,17 @@ def mode_flags(mode):
     every dropout an identity; 'eval' = eval mode."""
     if mode == 'eval':
         return False, None, fo.ATTN_DROP
+    if mode == 'train_drop':             # round 3: every dropout live, masks injected (golden_masks)
+        return True, None, fo.ATTN_DROP
     return True, 0.0, 0.0
+
+
+def golden_masks(meta):
+    """The dropout multipliers of a 'train_drop' fixture's live sites, in execution order, regenerated from
+    the seeds the generator used (tests/golden/make_golden_r03.py: site k of the step ->
+    synth.make_drop_mask(seed, k, shape, p); sites with p = 1e-12 are identities and are skipped)."""
+    return [synth.make_drop_mask(meta['seed'], k, s['shape'], s['p'])
+            for k, s in enumerate(meta['sites']) if s['p'] > 1e-6]
 
 
 def summarize(t, nsample=8):
