@@ -159,6 +159,7 @@ SIGNATURES = {
     'bmnas_comm_init_rank': ([C.POINTER(C.c_void_p), _I, _I, _P], _I),
     'bmnas_comm_destroy': ([_P], _I),
     'bmnas_allreduce_f32': ([_P, _I64, _I, _P, _P], _I),
+    'bmnas_comm_info': ([_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], _I),
     'bmnas_cell_prologue': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P, _P,
                              _P, _I64, _P], _I),
     'bmnas_cell_prologue_pair': ([_PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _PP, _PP, _I, _I, _I, _P,
@@ -385,6 +386,13 @@ def comm_init_rank(world, rank, uid):
 
 def comm_destroy(comm):
     _check(load().bmnas_comm_destroy(comm), 'comm_destroy')
+
+
+def comm_info(comm):
+    """-> dict(ranks, rank, hip_device, rccl_version) as the communicator reports them (ncclCommCount, ...)."""
+    v = [C.c_int(-1) for _ in range(4)]
+    _check(load().bmnas_comm_info(comm, *[C.byref(x) for x in v]), 'comm_info')
+    return dict(ranks=v[0].value, rank=v[1].value, hip_device=v[2].value, rccl_version=v[3].value)
 
 
 def allreduce_f32(buf, comm, average=False):

@@ -27,6 +27,9 @@ struct Rccl {
   int (*CommDestroy)(NcclComm) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   int (*GetVersion)(int*) = nullptr;
+  int (*CommCount)(NcclComm, int*) = nullptr;
+  int (*CommUserRank)(NcclComm, int*) = nullptr;
+  int (*CommCuDevice)(NcclComm, int*) = nullptr;
   bool ok = false;
 };
 
@@ -51,6 +54,9 @@ Rccl& rccl() {
     r.CommDestroy = (int (*)(NcclComm))dlsym(r.handle, "ncclCommDestroy");
     r.AllReduce = (int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t))dlsym(r.handle, "ncclAllReduce");
     r.GetVersion = (int (*)(int*))dlsym(r.handle, "ncclGetVersion");
+    r.CommCount = (int (*)(NcclComm, int*))dlsym(r.handle, "ncclCommCount");
+    r.CommUserRank = (int (*)(NcclComm, int*))dlsym(r.handle, "ncclCommUserRank");
+    r.CommCuDevice = (int (*)(NcclComm, int*))dlsym(r.handle, "ncclCommCuDevice");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
   });
   return r;
@@ -92,6 +98,20 @@ extern "C" int bmnas_comm_destroy(void* comm) {
   Rccl& r = rccl();
   if (!r.ok) return kErrNoRccl;
   return nccl_rc(r.CommDestroy((NcclComm)comm));
+}
+
+// What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion):
+// evidence, printed in bench.py's N > 1 line, that RCCL really spans the ranks the launcher started.
+extern "C" int bmnas_comm_info(void* comm, int* n_ranks, int* user_rank, int* hip_device, int* rccl_version) {
+  if (!comm) return BMNAS_E_ARG;
+  Rccl& r = rccl();
+  if (!r.ok) return kErrNoRccl;
+  int v = -1, rc = 0;
+  if (n_ranks) { v = -1; if (r.CommCount) rc = r.CommCount((NcclComm)comm, &v); if (rc) return nccl_rc(rc); *n_ranks = v; }
+  if (user_rank) { v = -1; if (r.CommUserRank) rc = r.CommUserRank((NcclComm)comm, &v); if (rc) return nccl_rc(rc); *user_rank = v; }
+  if (hip_device) { v = -1; if (r.CommCuDevice) rc = r.CommCuDevice((NcclComm)comm, &v); if (rc) return nccl_rc(rc); *hip_device = v; }
+  if (rccl_version) { v = -1; if (r.GetVersion) rc = r.GetVersion(&v); if (rc) return nccl_rc(rc); *rccl_version = v; }
+  return 0;
 }
 
 extern "C" int bmnas_allreduce_f32(float* buf, int64_t count, int average, void* comm, void* stream) {

@@ -577,6 +577,11 @@ int bmnas_comm_get_unique_id(void* id_out);
 int bmnas_comm_init_rank(void** comm_out, int world, int rank, const void* id);
 int bmnas_comm_destroy(void* comm);
 int bmnas_allreduce_f32(float* buf, int64_t count, int average, void* comm, void* stream);
+/* What the communicator itself reports — ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion —
+ * each pointer nullable; -1 where librccl lacks the query.  bench.py prints them in its N > 1 line as
+ * evidence that the collective spans the ranks the launcher started (the reference has no counterpart:
+ * nn.DataParallel lives in one process). */
+int bmnas_comm_info(void* comm, int* n_ranks, int* user_rank, int* hip_device, int* rccl_version);
 
 /* ---- diagnostics: read-width calibration for rocprofv3's FETCH_SIZE (tools/calibrate_fetch.sh) ----
  * Reads p[0 .. n_floats) exactly once with `width` bytes per lane per load (4, 8, 16), or (width 64) as

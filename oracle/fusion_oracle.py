@@ -182,6 +182,58 @@ def _dropout(x, p, training):
     return F.dropout(x, p=p, training=training)
 
 
+_RELU_POLICY = None     # a relu_decisions instance while one is active
+
+
+class relu_decisions:
+    """with relu_decisions(near=d, flips=F) as rd: ... — bookkeeping of the ReLU branch decisions of one oracle
+    evaluation (F.relu at node_operations.py:54, node_search.py:63, model_search.py:65, aux_models.py:73, :112,
+    operations.py:34).  A ReLU input within floating-point round-off of zero may legitimately fall on either
+    side: two correct fp32 evaluations of the same math (different summation orders) can disagree on it, and
+    ONE such element moves whole gradient tensors by ~1e-2 of their scale (it removes or adds one sample's term
+    of a batch reduction).  `near`: every element with |input| < near is recorded as (site, flat index, value)
+    in `.ambiguous` (sites numbered in execution order).  `flips`: a set of (site, flat index) that take the
+    OPPOSITE branch in this evaluation (output x * [x <= 0] there), so a checker can ask whether a result
+    equals the reference math under SOME assignment of the ambiguous decisions."""
+
+    def __init__(self, near=0.0, flips=()):
+        self.near = near
+        self.flips = {}
+        for site, idx in flips:
+            self.flips.setdefault(site, []).append(idx)
+        self.ambiguous = []
+        self.site = 0
+
+    def __enter__(self):
+        global _RELU_POLICY
+        assert _RELU_POLICY is None, 'relu_decisions does not nest'
+        _RELU_POLICY = self
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_POLICY
+        _RELU_POLICY = None
+        return False
+
+    def apply(self, x):
+        site = self.site
+        self.site += 1
+        flat = x.detach().reshape(-1)
+        if self.near > 0:
+            for i in torch.nonzero(flat.abs() < self.near).reshape(-1).tolist():
+                self.ambiguous.append((site, i, float(flat[i])))
+        if site not in self.flips:
+            return F.relu(x)
+        keep = (flat > 0)
+        for i in self.flips[site]:
+            keep[i] = not bool(keep[i])
+        return x * keep.reshape(x.shape).to(x.dtype)
+
+
+def _relu(x):
+    return F.relu(x) if _RELU_POLICY is None else _RELU_POLICY.apply(x)
+
+
 def mixed_edge(x, w):
     """FusionMixedOp.forward (operations.py:104-105) with PRIMITIVES ['none','skip']:
     sum(w_p * op_p(x)) = 0 + w[0]*Zero(x) + w[1]*Identity(x); Zero is x.mul(0.)
@@ -202,7 +254,7 @@ def op_fc(x, p, prefix, kind, training, drpt):
     Linear(C, C) over the channel dim (transpose, linear, transpose) -> ReLU | Mish
     (x * tanh(softplus(x)), operations.py:44-46) -> BatchNorm1d(C) -> Dropout(drpt)."""
     out = F.linear(x.transpose(1, 2), p[prefix + '.linear.weight'], p[prefix + '.linear.bias']).transpose(1, 2)
-    out = F.relu(out) if kind == 'fc_relu' else out * torch.tanh(F.softplus(out))
+    out = _relu(out) if kind == 'fc_relu' else out * torch.tanh(F.softplus(out))
     out = F.batch_norm(out, p[prefix + '.bn.running_mean'], p[prefix + '.bn.running_var'],
                        p[prefix + '.bn.weight'], p[prefix + '.bn.bias'], training, BN_MOMENTUM, EPS)
     _bump_nbt(p, prefix + '.bn.num_batches_tracked', training)
@@ -270,7 +322,7 @@ def op_concat_fc(x, y, p, prefix, training, drpt):
     out = _conv_bn(cat, p[prefix + '.conv.weight'], p[prefix + '.conv.bias'],
                    p[prefix + '.bn.weight'], p[prefix + '.bn.bias'],
                    p[prefix + '.bn.running_mean'], p[prefix + '.bn.running_var'], training)
-    out = F.relu(out)
+    out = _relu(out)
     return _dropout(out, drpt, training)
 
 
@@ -320,7 +372,7 @@ def node_cell(x, y, beta_w, gamma_w, p, prefix, cfg, training, attn_drop=ATTN_DR
                        p[prefix + '.bn.weight'], p[prefix + '.bn.bias'],
                        p[prefix + '.bn.running_mean'], p[prefix + '.bn.running_var'], training)
         _bump_nbt(p, prefix + '.bn.num_batches_tracked', training)
-        out = F.relu(out)
+        out = _relu(out)
         out = _dropout(out, cfg.drpt, training)
     out = out + x      # reference does the in-place ``out += x`` (node_search.py:67)
     ln_w, ln_b = p[prefix + '.ln.weight'], p[prefix + '.ln.bias']
@@ -353,7 +405,7 @@ def fusion_cell(inputs: Sequence[torch.Tensor], arch: Sequence[torch.Tensor], p,
     out = torch.cat(states[-cfg.M:], dim=1)
     ln_w, ln_b = p['cell.ln.weight'], p['cell.ln.bias']
     out = F.layer_norm(out, tuple(ln_w.shape), ln_w, ln_b, EPS)
-    out = F.relu(out)
+    out = _relu(out)
     return out.view(out.size(0), -1)
 
 
@@ -390,7 +442,7 @@ def reshape_layer(x, p, prefix, L, kind, training, drpt):
     out = _conv_bn(out, p[prefix + '.conv.weight'], p[prefix + '.conv.bias'], p[prefix + '.bn.weight'],
                    p[prefix + '.bn.bias'], p[prefix + '.bn.running_mean'], p[prefix + '.bn.running_var'], training)
     _bump_nbt(p, prefix + '.bn.num_batches_tracked', training)
-    return _dropout(F.relu(out), drpt, training)
+    return _dropout(_relu(out), drpt, training)
 
 
 def loss_fn(kind: str):
@@ -514,7 +566,7 @@ def found_node_cell(x, y, sg, p, prefix, cfg, training, attn_drop=ATTN_DROP):
                        p[prefix + '.bn.weight'], p[prefix + '.bn.bias'],
                        p[prefix + '.bn.running_mean'], p[prefix + '.bn.running_var'], training)
         _bump_nbt(p, prefix + '.bn.num_batches_tracked', training)
-        out = F.relu(out)
+        out = _relu(out)
         out = _dropout(out, cfg.drpt, training)
     out = out + x
     ln_w, ln_b = p[prefix + '.ln.weight'], p[prefix + '.ln.bias']
@@ -533,7 +585,7 @@ def found_cell(inputs, genotype, p, cfg, training, attn_drop=ATTN_DROP):
     M = len(genotype.concat)
     out = torch.cat(states[-M:], dim=1)
     ln_w, ln_b = p['cell.ln.weight'], p['cell.ln.bias']
-    out = F.relu(F.layer_norm(out, tuple(ln_w.shape), ln_w, ln_b, EPS))
+    out = _relu(F.layer_norm(out, tuple(ln_w.shape), ln_w, ln_b, EPS))
     return out.view(out.size(0), -1)
 
 

@@ -118,34 +118,114 @@ def assert_close_of_scale(name, got, want, rel=1e-4, floor=1e-6):
                              f'flat {i}: got {got.reshape(-1)[i]!r} want {want.reshape(-1)[i]!r}')
 
 
-class EitherLog:
-    """Per-tensor comparison against the fp32 oracle, with the float64 evaluation of the same oracle as a
-    second legitimate answer (a ReLU decision on a pre-activation within round-off of zero may fall either way and
-    moves whole gradient tensors by ~1e-2 of their scale: DESIGN.md section 4, tools/diag_ntu250.py).  Unlike a
-    bare "either" it RECORDS which evaluation matched and fails when more than `max_rescued` tensors needed the
-    second one — a real regression in one branch cannot hide behind the rescue."""
+def _np64(t):
+    return np.asarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float64)
 
-    def __init__(self, max_rescued):
-        self.max_rescued = max_rescued
-        self.first, self.rescued = [], []
 
-    def check(self, name, got, want_a, want_b, rel=1e-4, of_scale=False):
-        """want_b: the second evaluation, or a callable that produces it (only computed when needed)."""
-        close = assert_close_of_scale if of_scale else assert_close_scaled
-        try:
-            close(name, got, want_a, rel)
-            self.first.append(name)
-            return 'fp32'
-        except AssertionError as first:
+def match_step(got, specs, evaluate, label='', near=2e-5, max_ambiguous=96):
+    """Does the HIP result of a whole step equal the reference math?  `got`: name -> tensor; `specs`: name ->
+    (rel, of_scale) tolerance; `evaluate(double, flips, near)` -> (name -> expected tensor, ambiguous ReLU inputs)
+    runs the CPU oracle (oracle.fusion_oracle.relu_decisions).
+
+    Every tensor must match ONE evaluation of the oracle at full tolerance:
+      1. the fp32 op sequence (the reference's own arithmetic), or
+      2. the same in float64, or
+      3. float64 with an explicit set of ReLU decisions flipped, all of them on inputs within `near` of zero.
+    (3) exists because a ReLU input within round-off of zero falls on either side depending on the summation
+    order, and one such element moves whole gradient tensors by ~1e-2 of their scale (a sample's term enters or
+    leaves a batch reduction): at 250 samples the two CPU evaluations already disagree with EACH OTHER that way
+    (DESIGN.md section 4).  The flipped set is not guessed: every ambiguous element's effect on the result is
+    measured by one oracle evaluation, the residual (got - float64) is decomposed over those effect vectors by
+    least squares, and the decomposition is then VERIFIED by an exact evaluation under that assignment.
+    Returns (and prints, when it is not plain fp32) which evaluation matched."""
+    def failures(want):
+        out = []
+        for k, g in got.items():
+            rel, of_scale = specs[k]
             try:
-                close(name, got, want_b() if callable(want_b) else want_b, rel)
-            except AssertionError as second:
-                raise AssertionError(f'{first}\n   and against the float64 evaluation: {second}') from None
-            self.rescued.append(name)
-            return 'fp64'
+                (assert_close_of_scale if of_scale else assert_close_scaled)(k, g, want[k], rel)
+            except AssertionError as e:
+                out.append(str(e))
+        return out
 
-    def finish(self):
-        if len(self.rescued) > self.max_rescued:
-            raise AssertionError(f'{len(self.rescued)} tensors matched only the float64 evaluation (allowed: '
-                                 f'{self.max_rescued}): {self.rescued}')
-        return self.rescued
+    want32, _ = evaluate(False, (), 0.0)
+    f32 = failures(want32)
+    if not f32:
+        return 'fp32'
+    want64, amb = evaluate(True, (), near)
+    f64 = failures(want64)
+    if not f64:
+        print(f'[{label}] matches the float64 evaluation ({len(f32)} tensors differ from the fp32 one: {f32[0][:120]})')
+        return 'fp64'
+    if not amb or len(amb) > max_ambiguous:
+        raise AssertionError(f'[{label}] {len(f64)} tensors match neither evaluation and {len(amb)} ReLU inputs are within '
+                             f'{near:g} of zero:\n  fp32: ' + '\n  fp32: '.join(f32[:4]) + '\n  fp64: ' + '\n  fp64: '.join(f64[:4]))
+    # residual and per-element effect vectors over the (small) parameter / arch tensors, each in units of its scale
+    keys = [k for k in got if got[k].numel() <= (1 << 20)]
+    scale = {k: max(float(np.abs(_np64(want64[k])).max()), 1e-30) for k in keys}
+    vec = lambda d: np.concatenate([(_np64(d[k]).reshape(-1)) / scale[k] for k in keys])
+    base = vec(want64)
+    resid = vec(got) - base
+    cols = []
+    for site, idx, val in amb:
+        w, _ = evaluate(True, [(site, idx)], 0.0)
+        cols.append(vec(w) - base)
+    coef = np.linalg.lstsq(np.stack(cols, 1), resid, rcond=None)[0]
+    flips = [(s_, i_) for (s_, i_, _), c in zip(amb, coef) if c > 0.5]
+    wantf, _ = evaluate(True, flips, 0.0)
+    ff = failures(wantf)
+    desc = ', '.join(f'site {s_} elem {i_} (input {v:+.1e}, weight {c:.2f})' for (s_, i_, v), c in zip(amb, coef) if c > 0.5)
+    if ff:
+        raise AssertionError(f'[{label}] no assignment of the {len(amb)} ambiguous ReLU decisions reproduces the result '
+                             f'(tried flipping: {desc or "none"}; weights {np.round(coef, 2).tolist()}):\n  ' + '\n  '.join(ff[:4])
+                             + '\n  against plain float64: ' + f64[0])
+    print(f'[{label}] matches float64 with {len(flips)} of {len(amb)} ambiguous ReLU decisions on the other side: {desc}')
+    return f'fp64+{len(flips)}flips'
+
+
+def compare_search_step(cfg, batch, nout, loss_kind, net, cls, input_grads, logits, loss, masks=None, seed=31,
+                        label='', attn_drop=None):
+    """Every tensor of one search step (logits, loss, every weight / arch / input gradient) against the oracle,
+    through match_step; BatchNorm running statistics against the fp32 oracle.  masks: the dropout multipliers of
+    the step's live sites in issue order (None: dropout is an identity, attn_drop must then be 0)."""
+    import contextlib
+    from oracle import fusion_oracle as fo
+
+    def evaluate(double, flips, near):
+        f = (lambda t: t.double() if t.is_floating_point() else t) if double else (lambda t: t)
+        p = {k: f(v) for k, v in synth.make_params(cfg, seed).items()}
+        cw, cb = synth.make_classifier(cfg, nout, seed)
+        inj = fo.injected_masks(masks) if masks is not None else contextlib.nullcontext()
+        with inj, fo.relu_decisions(near, flips) as rd:
+            lg, ls, grads = fo.search_step([f(x) for x in synth.make_inputs(cfg, batch, seed)],
+                                           synth.make_labels(loss_kind, batch, nout, seed),
+                                           [f(a) for a in synth.make_arch(cfg, seed)], p, f(cw), f(cb), cfg, loss_kind,
+                                           training=True, **({} if attn_drop is None else {'attn_drop': attn_drop}))
+        if masks is not None:
+            assert inj.used == len(masks)
+        want = {'logits': lg, 'loss': ls}
+        for k, v in grads.items():
+            want['grad:' + k] = v
+        want['_params'] = p
+        return want, rd.ambiguous
+
+    got, specs = {'logits': logits, 'loss': loss}, {'logits': (1e-4, True), 'loss': (1e-4, True)}
+    for k, v in net.named_parameters():
+        if k.endswith('conv.bias'):
+            assert float(v.grad.abs().max()) < 1e-4, k       # mathematically zero (BN removes the mean)
+        else:
+            got['grad:' + k] = v.grad
+    for i, a in enumerate(net.arch_parameters()):
+        got[f'grad:arch.{i}'] = a.grad
+    for i, g in enumerate(input_grads):
+        got[f'grad:input.{i}'] = g
+    for k in ('weight', 'bias'):
+        got['grad:central_classifier.' + k] = getattr(cls, k).grad
+    for k in got:
+        specs.setdefault(k, (2e-4, False))
+    how = match_step(got, specs, evaluate, label)
+    p32 = evaluate(False, (), 0.0)[0]['_params']
+    for k, v in net.state_dict().items():
+        if fo.is_buffer(k):
+            assert_close_scaled('buf:' + k, v.float(), p32[k].float())
+    return how

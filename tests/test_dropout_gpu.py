@@ -17,8 +17,8 @@ import torch
 
 from oracle import fusion_oracle as fo
 from oracle import philox, synth
-from gpu_util import (Args, EitherLog, assert_close_of_scale, assert_close_scaled, build_found_net, build_search_net,
-                      dev)
+from gpu_util import (Args, assert_close_of_scale, assert_close_scaled, build_found_net, build_search_net,
+                      compare_search_step, dev)
 from util import golden_files, load_npz
 
 pytestmark = pytest.mark.gpu
@@ -316,52 +316,11 @@ def _forward(net, cls, xs, crit, y, head):
         return logits, crit(logits, y)
 
 
-def _oracle_step(cfg, batch, nout, loss_kind, masks, seed=31, double=False):
-    f = (lambda t: t.double() if t.is_floating_point() else t) if double else (lambda t: t)
-    p = {k: f(v) for k, v in synth.make_params(cfg, seed).items()}
-    cw, cb = synth.make_classifier(cfg, nout, seed)
-    with fo.injected_masks(masks) as inj:
-        logits, loss, grads = fo.search_step([f(x) for x in synth.make_inputs(cfg, batch, seed)],
-                                             synth.make_labels(loss_kind, batch, nout, seed),
-                                             [f(a) for a in synth.make_arch(cfg, seed)], p, f(cw), f(cb), cfg,
-                                             loss_kind, training=True)
-    assert inj.used == len(masks)
-    return logits, loss, grads, p
-
-
-def _compare_step(cfg, batch, nout, loss_kind, masks, net, cls, grads_in, logits, loss, max_rescued):
-    """Every tensor of the step against the oracle under `masks`.  A tensor that misses the fp32 evaluation may
-    match the float64 one instead (ReLU decisions on pre-activations within round-off of zero, DESIGN.md section
-    4) — at most `max_rescued` of them, reported in the failure message."""
-    ologits, oloss, ograds, p = _oracle_step(cfg, batch, nout, loss_kind, masks)
-    dl = None
-
-    def f64():
-        nonlocal dl
-        if dl is None:
-            dl = _oracle_step(cfg, batch, nout, loss_kind, masks, double=True)
-        return dl
-
-    log = EitherLog(max_rescued)
-    log.check('logits', logits, ologits, lambda: f64()[0], rel=1e-4, of_scale=True)
-    log.check('loss', loss, oloss, lambda: f64()[1], rel=1e-4, of_scale=True)
-    named = dict(net.named_parameters())
-    for k, v in named.items():
-        if k.endswith('conv.bias'):
-            assert float(v.grad.abs().max()) < 1e-4, k
-        else:
-            log.check('grad:' + k, v.grad, ograds[k], lambda k=k: f64()[2][k], rel=2e-4)
-    for i, a in enumerate(net.arch_parameters()):
-        log.check(f'grad:arch.{i}', a.grad, ograds[f'arch.{i}'], lambda i=i: f64()[2][f'arch.{i}'], rel=2e-4)
-    for i, g in enumerate(grads_in):
-        log.check(f'grad:input.{i}', g, ograds[f'input.{i}'], lambda i=i: f64()[2][f'input.{i}'], rel=2e-4)
-    for k in ('weight', 'bias'):
-        kk = 'central_classifier.' + k
-        log.check('grad:' + kk, getattr(cls, k).grad, ograds[kk], lambda kk=kk: f64()[2][kk], rel=2e-4)
-    for k, v in net.state_dict().items():
-        if fo.is_buffer(k):
-            assert_close_scaled('buf:' + k, v.float(), p[k].float())
-    log.finish()
+def _compare_step(cfg, batch, nout, loss_kind, masks, net, cls, grads_in, logits, loss, label=''):
+    """Every tensor of the step against the oracle under `masks` (gpu_util.compare_search_step: the whole step
+    must match one evaluation of the reference math — fp32, float64, or float64 with a verified set of ReLU
+    decisions on inputs within round-off of zero taken the other way)."""
+    return compare_search_step(cfg, batch, nout, loss_kind, net, cls, grads_in, logits, loss, masks=masks, label=label)
 
 
 REAL = [('mmimdb', 128, 23, 'bce', None), ('ntu', 8, 60, 'ce', None), ('ego', 6, 83, 'ce', None),
@@ -382,7 +341,7 @@ def test_search_step_with_live_dropout_matches_oracle(name, batch, nout, loss_ki
     per_node = cfg.ns * (1 + (2 if cfg.drpt > 0 else 0)) + (1 if cfg.nm != 1 and cfg.drpt > 0 else 0)
     assert len(rec) == cfg.S * per_node
     _compare_step(cfg, batch, nout, loss_kind, site_masks(rec), net, cls, [x.grad for x in xs], logits, loss,
-                  max_rescued=3)
+                  f'{name} b{batch} head={head}')
 
 
 @pytest.mark.parametrize('name,batch,nout,loss_kind,drpt', REAL[:4])
@@ -419,7 +378,7 @@ def test_search_step_with_live_dropout_under_graph_replay(name, batch, nout, los
         for p, gr in zip(params, grads):
             p.grad = gr
         _compare_step(cfg, batch, nout, loss_kind, masks, net, cls, [x.grad for x in xs], logits, loss,
-                      max_rescued=3)
+                      f'{name} b{batch} replay {replay}')
     assert not torch.equal(seen[0][0], seen[2][0]) and not torch.equal(seen[0][0], seen[1][0])
 
 
