@@ -106,23 +106,34 @@ def synth_batch(c, batch, device, seed, tier='F', cname='mmimdb'):
     return xs, y
 
 
+class _K1Units(float):
+    """algorithmic bytes of a K1 launch that also remember the n_in of its cell-level sum (roofline 'k1' object)"""
+    n_in = None
+
+
+def _k1(units, n_in):
+    u = _K1Units(units)
+    u.n_in = n_in
+    return u
+
+
 def algo_table(C, L):
     """wrapper name -> (bound, algorithmic units of one launch); SURVEY.md section 8(d)."""
     T = lambda t: t.numel() * 4
     return {
-        'mixsum_fwd': lambda xs, w, ws, out, *_: ('hbm', (len(xs) + 1) * T(out)),
+        'mixsum_fwd': lambda xs, w, ws, out, *_: ('hbm', _k1((len(xs) + 1) * T(out), len(xs))),
         # reads: g (+ g2) + the n_in inputs + the destinations that accumulate; writes: the destinations
         'mixsum_bwd': lambda xs, dxs, w, ws, g, dw, acc, sh=1, st=0, g2=None:
-            ('hbm', (1 + (g2 is not None) + len(xs) + bin(acc).count('1')
-                     + sum(d is not None for d in dxs)) * T(g)),
-        'mixsum_pair_fwd': lambda xs, w, ws, w2, ws2, out, *_: ('hbm', (len(xs) + 2) * T(out)),
+            ('hbm', _k1((1 + (g2 is not None) + len(xs) + bin(acc).count('1')
+                         + sum(d is not None for d in dxs)) * T(g), len(xs))),
+        'mixsum_pair_fwd': lambda xs, w, ws, w2, ws2, out, *_: ('hbm', _k1((len(xs) + 2) * T(out), len(xs))),
         # the first pair sum with the cell prologue's jobs in the same launch: K1's bytes + the folds
         'cell_prologue_pair': lambda al, ol, Ws, We, M, Cc, step, scrub, xs, a, bt, h, z:
-            ('hbm', (len(xs) + 2) * T(h) + sum(T(w) + T(e) for w, e in zip(Ws, We))
-             + (0 if scrub is None else T(scrub))),
+            ('hbm', _k1((len(xs) + 2) * T(h) + sum(T(w) + T(e) for w, e in zip(Ws, We))
+                        + (0 if scrub is None else T(scrub)), len(xs))),
         'mixsum_pair_bwd': lambda xs, dxs, w, ws, w2, ws2, h, gh, gz, dw, dw2, acc, sh=1, st=0, gz2=None:
-            ('hbm', (2 + (gh is not None) + (gz2 is not None) + len(xs) + bin(acc).count('1')
-                     + sum(d is not None for d in dxs)) * T(gz)),
+            ('hbm', _k1((2 + (gh is not None) + (gz2 is not None) + len(xs) + bin(acc).count('1')
+                         + sum(d is not None for d in dxs)) * T(gz), len(xs))),
         'cat_ln_fwd': lambda srcs, resid, w, b_, out, *_:
             ('hbm', (len(srcs) + (1 if resid is not None else 0)) * T(srcs[0]) + T(out) + 2 * T(w)),
         'cat_ln_bwd': lambda g, srcs, resid, w, *_:
@@ -167,8 +178,9 @@ def algo_table(C, L):
         'bn_relu_ln_fwd': lambda U, ch, resid, w, *_: ('hbm', 4 * T(U) + 2 * T(w)),
         'bn_relu_ln_bwd': lambda g, o, resid, w, st, U, *_: ('hbm', 6 * T(U) + T(w)),
         'fold_weight': lambda W, We, *_: ('hbm', T(W) + T(We)),
-        # K7 + classifier: three accumulator sets (logits, A, B) forward; dfeat + dW backward
-        'head_fwd': lambda srcs, sums, lw, lb, W, bias, hb, st, b, Cc, L_, O: ('mfma', 6.0 * b * O * len(srcs) * Cc * L_),
+        # K7 + classifier: the ALGORITHMIC classifier product 2 b M C L out; the kernel executes
+        # three accumulator sets (logits, A, B), i.e. 3x that, which is its own business
+        'head_fwd': lambda srcs, sums, lw, lb, W, bias, hb, st, b, Cc, L_, O: ('mfma', 2.0 * b * O * len(srcs) * Cc * L_),
         'head_bwd': lambda srcs, sums, ds, m, lw, lb, W, hb, st, mode, g, gs, lab, loss, part, b, Cc, L_, O, *_:
             ('mfma', 4.0 * b * O * len(srcs) * Cc * L_),
         'linear_fwd': lambda feat, W, bias, out, b, O, Kd: ('mfma', 2.0 * b * O * Kd),
@@ -463,6 +475,28 @@ def roofline_report(a, c, step, ms_per_step, log):
                               'replay_span_us': round(span, 2), 'headline_us_per_step': round(ms_per_step * 1e3, 2),
                               'profiled_child_us_per_step': None if child_ms is None else round(child_ms * 1e3, 2),
                               'wrappers_without_kernel': unmatched}}
+    # K1 (the >= 40 % HBM target of north_star) under SURVEY.md 8(d)'s LITERAL byte counts — forward (n_in + 1) T,
+    # backward (2 n_in + 1) T per cell-level sum, whatever else the launch carries (the pair kernels also form /
+    # differentiate the node's first inner sum, the first one also the cell prologue: not counted here)
+    T_bytes = a.batch * c['C'] * c['L'] * 4
+    k1 = {'formula': 'SURVEY.md 8(d): fwd (n_in+1)*T, bwd (2*n_in+1)*T per cell-level mixed sum; T = b*C*L*4',
+          'T_bytes': T_bytes, 'peak_GBs': HBM_PEAK_GBS, 'launches': []}
+    tot = {'fwd': [0.0, 0.0], 'bwd': [0.0, 0.0]}
+    for i, n in enumerate(names):
+        u = units[i]
+        n_in = None if u is None else getattr(u[2], 'n_in', None)
+        if n_in is None or n_in <= 3:                  # cell-level sums only (the inner sums have 2-4 inputs)
+            continue
+        d = 'bwd' if 'bwd' in u[0] else 'fwd'
+        by = ((2 * n_in + 1) if d == 'bwd' else (n_in + 1)) * T_bytes
+        k1['launches'].append({'kernel': n, 'dir': d, 'n_in': n_in, 'bytes': by, 'avg_us': round(dur[i], 2),
+                               'frac': round(by / (dur[i] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+        tot[d][0] += by
+        tot[d][1] += dur[i]
+    for d in ('fwd', 'bwd'):
+        if tot[d][1] > 0:
+            k1[d + '_frac'] = round(tot[d][0] / (tot[d][1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    out['k1'] = k1
     top = next((r for r in rows if r['frac'] is not None), None)
     if top is not None:
         top = dict(top)
@@ -520,6 +554,227 @@ def roofline_from_events(a, c, step, ms_per_step, log, algo):
     return out
 
 
+class DPStep:
+    """The benchmarked step in its data-parallel shapes.  Every gradient that is averaged across ranks (weights +
+    alpha/beta/gamma) lives in ONE flat fp32 bucket; the captured step writes into it, so the per-step
+    communication is RCCL all-reduce(avg) on that bucket and nothing else (no flatten / unflatten / scale
+    kernels).  The bucket is laid out with the LAST cell step's conv / BatchNorm gradients first: they are final
+    half-way through the backward, and the 'overlap' shape reduces them on a forked stream while the first
+    step's backward runs (bmnas.cell.NODE_DONE_HOOK)."""
+
+    def __init__(self, model, c, crit, xs, y, params, arch, device, comm, loss_scale, bucket=True):
+        self.model, self.c, self.crit, self.xs, self.y = model, c, crit, xs, y
+        self.device, self.comm, self.loss_scale = device, comm, loss_scale
+        self.shared = params + arch
+        self.leaves = self.shared + xs
+        self.last_node = model.fusion_net.cell._step_nodes[c['S'] - 1].node_cell
+        early = [p_ for n_, p_ in self.last_node.named_parameters() if '.ln.' not in n_ and not n_.startswith('ln.')]
+        self.early_ids = {id(p_) for p_ in early}
+        order = early + [t for t in self.shared if id(t) not in self.early_ids]
+        self.flat, self.view_of, self.n_early = None, {}, 0
+        if bucket:
+            self.flat = torch.zeros(sum(t.numel() for t in order), device=device)
+            off = 0
+            for t in order:
+                self.view_of[id(t)] = self.flat[off:off + t.numel()].view(t.shape)
+                off += t.numel()
+                if id(t) in self.early_ids:
+                    self.n_early = off
+        self.flat_views = [self.view_of[id(t)] for t in self.shared] if bucket else []
+        self.side = torch.cuda.Stream(device) if comm is not None else None
+
+    def _node_done(self, i, NG):
+        if i != self.c['S'] - 1:
+            return
+        gs = self.last_node.grads_in_param_order(NG)
+        pairs = [(self.view_of[id(p_)], g_) for p_, g_ in zip(self.last_node.param_list(), gs)
+                 if id(p_) in self.early_ids]
+        self.side.wait_stream(torch.cuda.current_stream())   # fork (a capture turns it into a graph branch)
+        with torch.cuda.stream(self.side):
+            torch._foreach_copy_([v for v, _ in pairs], [g_ for _, g_ in pairs])
+            self.comm.all_reduce(self.flat[:self.n_early], average=True)
+
+    def make_step(self, shape):
+        """shape: 'single' (no bucket), 'host' (gradients into the bucket; the all-reduce is issued by the host
+        after the replay), 'graph' (the all-reduce is the last launch of the captured step), 'overlap' (two
+        all-reduces inside the captured step, the first on a forked stream as soon as its gradients are final)."""
+        from bmnas import cell as K
+        from bmnas import nn as bnn
+        from bmnas.functions import unit_grad
+        model, crit, xs, y, leaves, shared = self.model, self.crit, self.xs, self.y, self.leaves, self.shared
+
+        def fn():
+            # gradients are taken with autograd.grad (no AccumulateGrad nodes, whose streams are pinned at
+            # creation and do not follow the capture stream) and then attached as .grad — the tensors are
+            # static, replays refresh them in place
+            K.NODE_DONE_HOOK = self._node_done if shape == 'overlap' else None
+            try:
+                with bnn.fused_criterion():
+                    loss = crit(model(xs), y)
+                if shape != 'single' and self.loss_scale != 1.0:
+                    grads = torch.autograd.grad(loss * self.loss_scale, leaves, allow_unused=True)
+                else:
+                    grads = torch.autograd.grad(loss, leaves, grad_outputs=unit_grad(self.device), allow_unused=True)
+            finally:
+                K.NODE_DONE_HOOK = None
+            if shape == 'single':
+                for t, g in zip(leaves, grads):
+                    t.grad = g
+                return loss
+            late = [(v, g) for t, v, g in zip(shared, self.flat_views, grads)
+                    if not (shape == 'overlap' and id(t) in self.early_ids)]
+            torch._foreach_copy_([v for v, _ in late], [g for _, g in late])
+            if shape == 'graph':
+                self.comm.all_reduce(self.flat, average=True)            # a launch on the capture stream
+            elif shape == 'overlap':
+                self.comm.all_reduce(self.flat[self.n_early:], average=True)
+                torch.cuda.current_stream().wait_stream(self.side)       # join
+            for t, v in zip(shared, self.flat_views):
+                t.grad = v
+            for t, g in zip(xs, grads[len(shared):]):
+                t.grad = g
+            return loss
+        return fn
+
+
+def dp_shapes_selfcheck(cname, batch):
+    """tests/test_optim_gpu.py: the bucket after a 'graph'-shape step and after an 'overlap'-shape step (each
+    captured and replayed once) on the same model and batch, dropout off, world-size-1 communicator.
+    -> {parameter name: (plain, overlapped)}"""
+    from bmnas import dist as bdist
+    from bmnas import nn as bnn
+    from bmnas.graph import GraphedStep
+    c = dict(CONFIGS[cname], drpt=0.0)
+    device = torch.device('cuda', torch.cuda.current_device())
+    torch.manual_seed(2)
+    model = HyperNet(c, 'F', cname).to(device).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
+    xs, y = synth_batch(c, batch, device, 0, 'F', cname)
+    params, arch = list(model.parameters()), list(model.arch_parameters())
+    dp = DPStep(model, c, crit, xs, y, params, arch, device, bdist.NativeComm.get(), 1.0)
+    names = [n for n, _ in model.named_parameters()] + [f'arch.{i}' for i in range(len(arch))]
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    out = {}
+    for shape in ('graph', 'overlap'):
+        g = GraphedStep(dp.make_step(shape), warmup=1)
+        model.load_state_dict(state)
+        dp.flat.fill_(float('nan'))
+        g.replay()
+        torch.cuda.synchronize()
+        for n, v in zip(names, dp.flat_views):
+            out.setdefault(n, []).append(v.detach().clone())
+    return {k: tuple(v) for k, v in out.items()}
+
+
+def headline(a, c, world, shapes, best, eager_ms, rccl, note=None):
+    """The JSON line.  shapes: shape name -> list of timed-region durations (s), each region = --steps steps
+    bracketed by barrier + synchronize, max over ranks; the headline is the MEDIAN region of the best shape."""
+    dt = statistics.median(shapes[best])
+    step_desc = {'single': 'fwd+bwd, one hipGraph replay',
+                 'eager': 'fwd+bwd issued from Python, then flatten + RCCL all-reduce + copy back',
+                 'host': 'fwd+bwd as one hipGraph replay writing every w- and arch-gradient into one flat bucket, '
+                         'then ONE host-issued RCCL all-reduce(avg) of the bucket',
+                 'graph': 'fwd+bwd + ONE RCCL all-reduce(avg) of the flat gradient bucket, all inside one hipGraph '
+                          'replay (bmnas_allreduce_f32 through the C ABI)',
+                 'overlap': 'fwd+bwd + RCCL all-reduce(avg) of the flat gradient bucket in two parts inside one '
+                            'hipGraph replay: the last cell step\'s conv / BatchNorm gradients on a forked stream '
+                            'while the first step\'s backward runs, the rest at the end'}[best]
+    result = {
+        'metric': ('search-steps/sec (fwd+bwd of fusion hypernet) on MM-IMDB synthetic'
+                   if a.config == 'mmimdb' else
+                   f'search-steps/sec (fwd+bwd of fusion hypernet) on {a.config} synthetic')
+                  + (' [tier R: reshape layers + hypernet]' if a.tier == 'R' else ''),
+        'value': round(world * a.steps / dt, 3),
+        'unit': 'steps/s',
+        'n_gpus': world,
+        'steps': a.steps,
+        'warmup': a.warmup,
+        'ms_per_step': round(dt / a.steps * 1e3, 4),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'{a.config} fusion search, batch {a.batch} per GPU x {world} GPU(s), '
+                               f'N{c["N"]} C{c["C"]} L{c["L"]} steps{c["S"]} node_steps{c["ns"]} '
+                               f'node_multiplier{c["nm"]}, train mode, dropout {c["drpt"]}/0.1(attn)',
+                   'inputs': ('(b, C, L) features' if a.tier == 'F' else
+                              f'pooled backbone features (b, C_in, L), C_in = {C_INS[a.config]}, through the reshape layers'),
+                   'global_batch': a.batch * world, 'per_gpu_batch': a.batch,
+                   'parallelism': f'dp{world}', 'mode': a.mode, 'step': step_desc},
+        'samples_per_s': round(world * a.steps * a.batch / dt, 1),
+        'timed_regions': {'n': len(shapes[best]), 'steps_each': a.steps, 'headline': 'median',
+                          'ms_per_step': [round(t / a.steps * 1e3, 4) for t in shapes[best]]},
+    }
+    if len(shapes) > 1:
+        result['step_shapes'] = {k: {'ms_per_step_median': round(statistics.median(v) / a.steps * 1e3, 4),
+                                     'ms_per_step': [round(t / a.steps * 1e3, 4) for t in v]}
+                                 for k, v in shapes.items()}
+        result['step_shapes']['headline'] = best
+    if rccl is not None:
+        result['rccl'] = rccl
+    if note:
+        result['note'] = note
+    if eager_ms is not None:
+        result['eager_ms_per_step'] = round(eager_ms, 4)
+    return result
+
+
+def dp_report(bdist, comm, comm_err, flat, n_early, device, world, rank, host_reduce, log):
+    """The N > 1 line's evidence that the collective really spans the ranks: what the process group and the
+    C-ABI communicator report, every rank's device (all-gathered), and the bucket's all-reduce timed alone."""
+    import torch.distributed as tdist
+    props = torch.cuda.get_device_properties(device)
+    me = {'rank': rank, 'device': str(device), 'name': props.name,
+          'pci': ':'.join(f'{getattr(props, k, -1):02x}' if isinstance(getattr(props, k, None), int) else '?'
+                          for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')),
+          'uuid': str(getattr(props, 'uuid', ''))}
+    if comm is not None:
+        me['comm'] = comm.info
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        tdist.all_gather_object(ranks, me)
+    out = {'ranks': world, 'backend': tdist.get_backend() if world > 1 else 'none (single process)',
+           'comm_ranks': None if comm is None else comm.info['ranks'],
+           'rccl_version': None if comm is None else comm.info['rccl_version'],
+           'devices': ranks, 'distinct_devices': len({(r['pci'], r['uuid']) for r in ranks}),
+           'allreduce_bytes': int(flat.numel() * 4), 'allreduce_early_bytes': int(n_early * 4)}
+    if comm_err:
+        out['native_comm_error'] = comm_err
+
+    def timed(fn, n=30):
+        for _ in range(5):
+            fn()
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / n * 1e3], device=device, dtype=torch.float64)
+        if world > 1:
+            bdist.all_reduce(t, tdist.ReduceOp.MAX)
+        return round(float(t.item()), 2)
+
+    us = {}
+    if host_reduce is not None:
+        us['torch_distributed'] = timed(host_reduce)
+    if comm is not None:
+        us['c_abi'] = timed(lambda: comm.all_reduce(flat, average=True))
+        us['c_abi_early_part'] = timed(lambda: comm.all_reduce(flat[:n_early], average=True))
+    out['allreduce_us'] = us
+    log(f'rccl: {world} ranks, {out["distinct_devices"]} distinct devices, bucket {out["allreduce_bytes"]} B, '
+        f'all-reduce alone {us} us')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -534,6 +789,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-full-step', action='store_true')
+    ap.add_argument('--regions', type=int, default=5,
+                    help='timed regions of --steps steps each; the headline is their median (each region is the '
+                         'contract\'s measurement: barrier + synchronize on both sides, max over ranks)')
+    ap.add_argument('--dp-selftest', action='store_true',
+                    help='one GPU: build a world-size-1 RCCL communicator and run the N > 1 step shapes (bucket, '
+                         'in-graph all-reduce, forked-stream overlap) through it')
     a = ap.parse_args()
 
     from bmnas import dist as bdist
@@ -569,55 +830,63 @@ def main():
         return loss
 
     # N > 1: every gradient that is averaged across ranks (weights + alpha/beta/gamma) lives in ONE
-    # flat fp32 bucket; the captured step writes into it and scales the loss by 1/world, so the
-    # per-step communication is a single RCCL all-reduce(sum) on that bucket and nothing else
-    # (no flatten / unflatten / scale kernels on the host path).
+    # flat fp32 bucket; the captured step writes into it, so the per-step communication is RCCL
+    # all-reduce(avg) on that bucket and nothing else (no flatten / unflatten / scale kernels).  The bucket is
+    # laid out with the LAST cell step's conv / BatchNorm gradients first: they are final half-way through the
+    # backward (the 'overlap' shape reduces them on a forked stream while the first step's backward runs).
     shared = params + arch
-    flat = torch.zeros(sum(t.numel() for t in shared), device=device) if world > 1 else None
-    flat_views = []
-    if world > 1:
-        off = 0
-        for t in shared:
-            flat_views.append(flat[off:off + t.numel()].view(t.shape))
-            off += t.numel()
-    # RCCL can average in the collective (ReduceOp.AVG): the captured step is then exactly the
+    # RCCL can average in the collective (ReduceOp.AVG / ncclAvg): the captured step is then exactly the
     # single-GPU one; without it (gloo test harness) the loss is pre-scaled and the bucket summed
     use_avg = world > 1 and bdist.avg_supported(device)
-    # opt-in (BMNAS_NATIVE_RCCL=1): RCCL through the C ABI, captured INSIDE the step's hipGraph
-    native = world > 1 and bdist.native_rccl_enabled() and a.mode == 'graph'
-    comm = bdist.NativeComm.get() if native else None
-    use_avg = use_avg or native
     loss_scale = 1.0 if (world == 1 or use_avg) else 1.0 / world
-
-    def step_for_capture():
-        # same work as step(); gradients are taken with autograd.grad (no AccumulateGrad nodes,
-        # whose streams are pinned at creation and do not follow the capture stream) and then
-        # attached as .grad — the tensors are static, replays refresh them in place
-        with bnn.fused_criterion():
-            loss = crit(model(xs), y)
-        if world > 1:
-            if loss_scale != 1.0:
-                grads = torch.autograd.grad(loss * loss_scale, leaves, allow_unused=True)
-            else:
-                grads = torch.autograd.grad(loss, leaves, grad_outputs=unit_grad(device), allow_unused=True)
-            torch._foreach_copy_(flat_views, list(grads[:len(shared)]))
-            if native:
-                comm.all_reduce(flat, average=True)          # a launch on the capture stream
-            for t, v in zip(shared, flat_views):
-                t.grad = v
-            for t, g in zip(xs, grads[len(shared):]):
-                t.grad = g
-        else:
-            grads = torch.autograd.grad(loss, leaves, grad_outputs=unit_grad(device), allow_unused=True)
-            for t, g in zip(leaves, grads):
-                t.grad = g
-        return loss
+    # RCCL through the C ABI (bmnas_allreduce_f32): a plain launch on the current stream, so it can be captured
+    # INSIDE the step's hipGraph.  Tried whenever the process group is RCCL; every rank must succeed.
+    comm, comm_err = None, None
+    want_native = a.mode == 'graph' and ((world > 1 and torch.distributed.get_backend() == 'nccl') or a.dp_selftest)
+    if want_native:
+        try:
+            comm = bdist.NativeComm.get()
+        except Exception as e:                       # noqa: BLE001
+            comm_err = f'{type(e).__name__}: {e}'[:200]
+        if not bdist.all_ranks_agree(comm is not None, device):
+            comm = None
+    dp = DPStep(model, c, crit, xs, y, params, arch, device, comm, loss_scale, bucket=world > 1 or a.dp_selftest)
+    flat, n_early, make_step = dp.flat, dp.n_early, dp.make_step
 
     if world > 1:
         bdist.broadcast_state(model, arch)
         red_all = bdist.FlatGradAllReducer(shared)          # eager mode: flatten -> all-reduce -> copy back
 
+    def host_reduce():
+        bdist.all_reduce(flat, torch.distributed.ReduceOp.AVG if use_avg else torch.distributed.ReduceOp.SUM)
+
+    def measure(run, regions):
+        """W untimed warm-up steps, then `regions` timed regions of EXACTLY a.steps steps, each bracketed by a
+        barrier + synchronize on both sides, MAX over ranks per region -> list of region times (s)."""
+        for _ in range(a.warmup):
+            run()
+        out = []
+        for _ in range(regions):
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                run()
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], device=device, dtype=torch.float64)
+                bdist.all_reduce(t, torch.distributed.ReduceOp.MAX)
+                dt = float(t.item())
+            out.append(dt)
+        return out
+
     eager_ms = None
+    shapes = {}
+    from bmnas.graph import GraphedStep
     if a.mode == 'graph':
         # short eager measurement for reference, then capture
         for _ in range(3):
@@ -628,9 +897,8 @@ def main():
             step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t0) / 10 * 1e3
-        from bmnas.graph import GraphedStep
         log(f'eager {eager_ms:.3f} ms/step; capturing hipGraph')
-        graphed = GraphedStep(step_for_capture)
+        graphed = GraphedStep(make_step('single' if world == 1 else 'host'))
         log('captured')
         run_local = graphed.replay
     else:
@@ -638,61 +906,57 @@ def main():
 
     def run():
         run_local()
-        if world > 1 and not native:
+        if world > 1:
             if a.mode == 'graph':
-                bdist.all_reduce(flat, torch.distributed.ReduceOp.AVG if use_avg
-                                 else torch.distributed.ReduceOp.SUM)
+                host_reduce()
             else:
                 red_all()
 
-    for _ in range(a.warmup):
-        run()
-    log('warm-up done')
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        bdist.all_reduce(t, torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    times = measure(run, a.regions)
+    log('timed regions (ms/step): ' + ', '.join(f'{t / a.steps * 1e3:.4f}' for t in times))
+    first = 'single' if world == 1 else ('host' if a.mode == 'graph' else 'eager')
+    shapes[first] = times
+    best = first
 
-    result = {
-        'metric': ('search-steps/sec (fwd+bwd of fusion hypernet) on MM-IMDB synthetic'
-                   if a.config == 'mmimdb' else
-                   f'search-steps/sec (fwd+bwd of fusion hypernet) on {a.config} synthetic')
-                  + (' [tier R: reshape layers + hypernet]' if a.tier == 'R' else ''),
-        'value': round(world * a.steps / dt, 3),
-        'unit': 'steps/s',
-        'n_gpus': world,
-        'steps': a.steps,
-        'warmup': a.warmup,
-        'ms_per_step': round(dt / a.steps * 1e3, 4),
-        'higher_is_better': True,
-        'scaling': 'weak',
-        'vs_baseline': None,
-        'dtype': 'f32',
-        'data': 'synthetic',
-        'config': {'workload': f'{a.config} fusion search, batch {a.batch} per GPU x {world} GPU(s), '
-                               f'N{c["N"]} C{c["C"]} L{c["L"]} steps{c["S"]} node_steps{c["ns"]} '
-                               f'node_multiplier{c["nm"]}, train mode, dropout {c["drpt"]}/0.1(attn)',
-                   'inputs': ('(b, C, L) features' if a.tier == 'F' else
-                              f'pooled backbone features (b, C_in, L), C_in = {C_INS[a.config]}, through the reshape layers'),
-                   'global_batch': a.batch * world, 'per_gpu_batch': a.batch,
-                   'parallelism': f'dp{world}', 'mode': a.mode,
-                   'step': 'fwd+bwd (+ flat RCCL all-reduce of w- and arch-grads when n_gpus > 1'
-                           + (', captured in the hipGraph via the C ABI)' if native else ')')},
-        'samples_per_s': round(world * a.steps * a.batch / dt, 1),
-    }
-    if eager_ms is not None:
-        result['eager_ms_per_step'] = round(eager_ms, 4)
+    rccl = None
+    guard = None
+    if world > 1 or a.dp_selftest:
+        rccl = dp_report(bdist, comm, comm_err, flat, n_early, device, world, rank, host_reduce if world > 1 else None, log)
+    if comm is not None and a.mode == 'graph':
+        # the in-graph shapes are measured AFTER a complete, valid measurement exists: should a captured RCCL
+        # launch wedge on some node, the watchdog prints the line with what has been measured and ends the run
+        pending = {'line': None}
 
+        def bail():
+            if rank == 0 and pending['line'] is not None:
+                print(json.dumps(pending['line']), flush=True)
+            os._exit(0)
+
+        import threading
+        guard = threading.Timer(float(os.environ.get('BMNAS_BENCH_WATCHDOG_S', '240')), bail)
+        guard.daemon = True
+        pending['line'] = headline(a, c, world, shapes, best, eager_ms, rccl, note='in-graph RCCL shapes did not finish '
+                                   '(watchdog): host-issued all-reduce only')
+        guard.start()
+        for shape in ('graph', 'overlap'):
+            try:
+                g2 = GraphedStep(make_step(shape), warmup=1)
+                ok = True
+            except Exception as e:                   # noqa: BLE001
+                ok = False
+                rccl[f'{shape}_error'] = f'{type(e).__name__}: {e}'[:200]
+            if not bdist.all_ranks_agree(ok, device):
+                continue
+            shapes[shape] = measure(g2.replay, a.regions)
+            log(f'{shape}: ' + ', '.join(f'{t / a.steps * 1e3:.4f}' for t in shapes[shape]) + ' ms/step')
+            if statistics.median(shapes[shape]) < statistics.median(shapes[best]):
+                best = shape
+        if world > 1:
+            torch.distributed.barrier()
+        guard.cancel()
+
+    result = headline(a, c, world, shapes, best, eager_ms, rccl)
+    dt = statistics.median(shapes[best])
     log(f'timed region done: {dt / a.steps * 1e3:.4f} ms/step')
     if not a.no_full_step:
         # secondary figure: never allowed to take the headline line down with it

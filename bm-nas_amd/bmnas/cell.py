@@ -153,7 +153,13 @@ class HeadState(Pack):
 
     def resolve(self, g):
         """-> (mode, dlogits, gscale, labels) for bmnas_head_bwd given the incoming gradient g."""
-        if self.deferred is not None and g.data_ptr() == self.marker.data_ptr():
+        if self.deferred is not None:
+            if g.data_ptr() != self.marker.data_ptr():
+                # autograd summed the (uninitialised) marker with another gradient of the logits: a second
+                # loss term on them inside bmnas.nn.fused_criterion().  There is no dlogits tensor to add to.
+                raise lib.BmnasError('fused criterion: the logits received a gradient besides the deferred '
+                                     'criterion\'s (an auxiliary loss on the logits?); evaluate the losses outside '
+                                     'bmnas.nn.fused_criterion() or combine them into one criterion call')
             kind, labels = self.deferred
             return (1 if kind == 'bce' else 2), None, self.gscale, labels
         return 0, (g if g.is_contiguous() else g.contiguous()), None, None
@@ -783,6 +789,14 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
     return out, sv
 
 
+# Data-parallel overlap (bench.py's 'overlap' shape): a callable (i, NG) invoked right after the launches of
+# step node i's backward have been issued.  From that point the node's conv / BatchNorm gradients in NG
+# (stack_dW, stack_dbias, stack_bn_grad, out_conv_dW / _db, bn_grad) are final — its LayerNorm-affine gradients
+# are not (the epilogue launch sums them) — so an all-reduce of them can run on a forked stream while the
+# remaining nodes' backward continues.
+NODE_DONE_HOOK = None
+
+
 def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, epilogue=None):
     """Returns the list of input gradients (None where not needed).  d*_w: zero-initialised
     buffers for the gradients w.r.t. the softmaxed arch weights.  CG: gradient pack."""
@@ -822,6 +836,8 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
         pre_pair, pending = pending, None
         gz = node_cell_bwd(nsv, gn, sif_slot, sif_slot, dbeta_ws[i], dgamma_ws[i], CG.nodes[i], deferred,
                            defer_first=nsv.paired, pre_pair=pre_pair)
+        if NODE_DONE_HOOK is not None:
+            NODE_DONE_HOOK(i, CG.nodes[i])
         off = sv.offsets[i]
         n_in = N + i
         if gz is not None:

@@ -89,6 +89,12 @@ class NativeComm:
         if self.world > 1:
             dist.broadcast_object_list(uid, src=0, group=group)
         self.comm = lib.comm_init_rank(self.world, self.rank, uid[0])
+        # the first collective on a communicator sets up its channels (host-side handshakes between ranks):
+        # do it here, where every rank is known to be present, not inside somebody's stream capture
+        warm = torch.ones(1, device='cuda')
+        lib.allreduce_f32(warm, self.comm, True)
+        torch.cuda.current_stream().synchronize()
+        self.info = lib.comm_info(self.comm)
 
     @classmethod
     def get(cls, group=None):
@@ -144,18 +150,47 @@ def shard(t, rank, world, dim=0):
 
 class FlatGradAllReducer:
     """Averages the .grad of a fixed tensor list across ranks with ONE all-reduce on a flat
-    fp32 bucket (4.2 / 6.3 / 9.3 MB of weights, or the 42 / 70 / 94-float arch vector)."""
+    fp32 bucket (4.2 / 6.3 / 9.3 MB of weights, or the 42 / 70 / 94-float arch vector).
+
+    Whatever path a rank is on — a captured step that produced its gradients straight in the bucket, or an
+    eager step whose .grad tensors are copied in — the step's communication is the SAME call, `reduce_bucket()`:
+    same communicator, same reduction, same scaling (`plan()`, decided once, collectively).  A rank that could
+    not capture its step and a rank replaying its graph therefore still pair up."""
 
     def __init__(self, tensors, group=None):
         self.tensors = [t for t in tensors]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._plan = None
+        self.flat = None
+        self.reduced = False
+
+    def plan(self):
+        """How the bucket is averaged: 'native' — RCCL through the C ABI, ncclAvg (BMNAS_NATIVE_RCCL=1; a plain
+        launch on the current stream, capturable); 'avg' — torch.distributed with ReduceOp.AVG (RCCL);
+        'presum' — the bucket holds gradients pre-scaled by 1/world and is summed (gloo has no AVG).
+        Probing AVG support is a 1-element collective: every rank calls plan() at its first step."""
+        if self._plan is None:
+            dev = self.tensors[0].device
+            if self.world <= 1:
+                self._plan = 'single'
+            elif native_rccl_enabled() and dev.type == 'cuda' and dist.get_backend(self.group) == 'nccl':
+                self._plan = 'native'
+                NativeComm.get(self.group)                  # collective init, here rather than inside a capture
+            else:
+                self._plan = 'avg' if avg_supported(dev, self.group) else 'presum'
+        return self._plan
+
+    @property
+    def loss_scale(self):
+        """What a step that writes its gradients straight into the bucket multiplies its loss by."""
+        return 1.0 / self.world if self.plan() == 'presum' else 1.0
 
     # -- persistent bucket: gradients are PRODUCED in the flat buffer (GraphedTrainStep writes them
-    # there inside the captured step, pre-scaled by 1/world), so a step's communication is one
-    # all-reduce(sum) and nothing else: no flatten, no scale, no copy back
+    # there inside the captured step), so a step's communication is one all-reduce and nothing else:
+    # no flatten, no scale, no copy back
     def ensure_bucket(self):
-        if getattr(self, 'flat', None) is None:
+        if self.flat is None:
             dev = self.tensors[0].device
             self.flat = torch.zeros(sum(t.numel() for t in self.tensors), device=dev, dtype=torch.float32)
             self.views, off = [], 0
@@ -164,21 +199,26 @@ class FlatGradAllReducer:
                 off += t.numel()
         return self.views
 
-    def all_reduce_bucket(self, average=False):
-        """average=False: the bucket holds gradients pre-scaled by 1/world (sum them);
-        average=True: unscaled gradients, reduced with ReduceOp.AVG (see avg_supported)."""
-        if self.world > 1:
-            if native_rccl_enabled() and self.flat.is_cuda and dist.get_backend(self.group) == 'nccl':
-                NativeComm.get(self.group).all_reduce(self.flat, average)      # capturable launch
-            else:
-                all_reduce(self.flat, dist.ReduceOp.AVG if average else dist.ReduceOp.SUM, self.group)
+    def reduce_bucket(self):
+        """The ONE collective of a step.  The bucket holds this rank's gradients (pre-scaled by `loss_scale`)."""
+        plan = self.plan()
+        if plan == 'native':
+            NativeComm.get(self.group).all_reduce(self.flat, average=True)
+        elif plan == 'avg':
+            all_reduce(self.flat, dist.ReduceOp.AVG, self.group)
+        elif plan == 'presum':
+            all_reduce(self.flat, dist.ReduceOp.SUM, self.group)
+
+    def all_reduce_bucket(self):
+        """After a step that wrote its gradients into the bucket: reduce, and tell the optimizer pre-hook."""
+        self.reduce_bucket()
         self.reduced = True                      # the optimizer pre-hook must not average again
 
     def __call__(self):
         """Eager path (optimizer.step pre-hook): average .grad across ranks.  The collective always
-        spans the WHOLE tensor list (missing gradients travel as zeros) so that a rank on the eager
-        path and a rank replaying its captured step issue the same all-reduce."""
-        if getattr(self, 'reduced', False):
+        spans the WHOLE tensor list (missing gradients travel as zeros) and goes through reduce_bucket(),
+        so that a rank on the eager path and a rank replaying its captured step issue the same all-reduce."""
+        if self.reduced:
             self.reduced = False
             return
         if self.world <= 1:
@@ -189,10 +229,21 @@ class FlatGradAllReducer:
             self.flat.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        all_reduce(self.flat, dist.ReduceOp.SUM, self.group)
-        self.flat.mul_(1.0 / self.world)
+        if self.plan() == 'presum':
+            self.flat.mul_(1.0 / self.world)
+        self.reduce_bucket()
         if have:
             torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
+
+
+def all_ranks_agree(ok, device, group=None):
+    """True iff `ok` is true on EVERY rank (a MIN all-reduce of one flag): used where ranks decide locally
+    whether they can take a path whose collectives differ (capturing a step)."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return bool(ok)
+    t = torch.tensor([1.0 if ok else 0.0], device=device)
+    all_reduce(t, dist.ReduceOp.MIN, group)
+    return bool(t.item() > 0.5)
 
 
 def attach(optimizer, tensors=None, group=None):

@@ -170,6 +170,10 @@ class _ZeroPool:
 
     def take(self, n, device):
         n = self._round(n)
+        cap = device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        if self.chunk is not None and getattr(self, 'captured', cap) != cap:
+            self.chunk, self.in_backward = None, False      # allocated inside / outside a capture that is over
+        self.captured = cap
         if not self.in_backward:
             self.in_backward = True
             FWD_STAT_POOL.close()
@@ -210,6 +214,10 @@ class _FwdStatPool:
         """-> zero-filled view of STAT_SHARDS * M * 2 floats (the interface conv_bn_fwd expects of `stats`)."""
         n = (K.STAT_SHARDS * M * 2 + 3) // 4 * 4
         dev = self.device
+        cap = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        if self.open and getattr(self, 'captured', cap) != cap:
+            self.open, self.chunk = False, None             # the pass that opened the chunk belonged to a capture
+        self.captured = cap
         if not self.open:
             self.open, self.off, self.total = True, 0, 0
             self.chunk = torch.zeros(self.last_total, device=dev, dtype=torch.float32) if self.last_total else None
@@ -222,6 +230,14 @@ class _FwdStatPool:
 
 
 FWD_STAT_POOL = _FwdStatPool()
+
+
+def reset_pools():
+    """Forget every buffer the two pools hold.  Called when a hipGraph capture aborts: slices handed out inside
+    the dead capture point at memory of a released capture pool whose zero-fill node never ran — the next
+    eager forward must not be given the rest of that chunk as 'zero-filled' BatchNorm sums."""
+    ZERO_POOL.pending, ZERO_POOL.chunk, ZERO_POOL.off, ZERO_POOL.in_backward = 0, None, 0, False
+    FWD_STAT_POOL.open, FWD_STAT_POOL.chunk, FWD_STAT_POOL.off, FWD_STAT_POOL.total = False, None, 0, 0
 # BMNAS_FUSE_BN_FINALIZE=0: bn_finalize launches, as in round 1
 FUSE_STANDALONE_BN = K.FUSE_BN_FINALIZE
 
@@ -498,6 +514,9 @@ class DeferredLossFn(Function):
 
     @staticmethod
     def forward(ctx, z, target, head, kind):
+        if head.deferred is not None:
+            raise lib.BmnasError('fused criterion: a second criterion on the same logits (the head evaluates ONE '
+                                 'criterion in its backward launch); call it outside bmnas.nn.fused_criterion()')
         head.deferred = (kind, target if target.is_contiguous() else target.contiguous())
         head.gscale = None
         ctx.head = head

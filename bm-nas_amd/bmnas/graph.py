@@ -9,7 +9,6 @@ the kernels add a DEVICE counter to their Philox offsets and the graph advances 
 import torch
 
 from . import cell as K
-from .dist import avg_supported
 from .functions import unit_grad
 
 
@@ -63,6 +62,10 @@ class GraphedStep:
             det = lambda o: o.detach() if torch.is_tensor(o) else o
             self.outputs = type(out)(det(o) for o in out) if isinstance(out, (tuple, list)) else det(out)
             del out
+        except BaseException:
+            from . import functions
+            functions.reset_pools()                   # see reset_pools: nothing of a dead capture may be handed out
+            raise
         finally:
             K.DROP.offset, K.DROP.device_counter = saved
             K.DROP.pending_advance = None
@@ -134,18 +137,14 @@ class GraphedTrainStep:
         self.inputs = [x.detach().clone().requires_grad_(x.requires_grad) for x in inputs]
         self.labels = labels.detach().clone()
         # RCCL through the C ABI (bmnas.dist.NativeComm, opt-in BMNAS_NATIVE_RCCL=1) is a plain launch
-        # on the capture stream: the all-reduce and the Adam step then live INSIDE the graph
-        from .dist import NativeComm, native_rccl_enabled
-        import torch.distributed as tdist
-        self.native = (reducer is not None and native_rccl_enabled() and self.labels.is_cuda
-                       and tdist.get_backend(reducer.group) == 'nccl')
+        # on the capture stream: the all-reduce and the Adam step then live INSIDE the graph.
+        # reducer.plan() is decided once, collectively, and is the same for captured and eager steps.
+        self.native = reducer is not None and reducer.plan() == 'native'
         self.in_graph_step = reducer is None or self.native
         views = reducer.ensure_bucket() if reducer is not None else None
-        # with ReduceOp.AVG (RCCL) the captured step is the single-GPU one: unscaled loss, constant
-        # unit gradient; otherwise the loss is pre-scaled by 1/world and the bucket is summed
-        self.average = reducer is not None and (self.native or avg_supported(self.labels.device, reducer.group))
-        scale = 1.0 / reducer.world if (reducer is not None and not self.average) else 1.0
-        comm = NativeComm.get(reducer.group) if self.native else None
+        # with an averaging collective (RCCL) the captured step is the single-GPU one: unscaled loss, constant
+        # unit gradient; otherwise (gloo) the loss is pre-scaled by 1/world and the bucket is summed
+        scale = reducer.loss_scale if reducer is not None else 1.0
         armed = [False]
 
         from . import nn as bnn
@@ -172,7 +171,10 @@ class GraphedTrainStep:
                 for t, g in zip(self.targets, grads):
                     t.grad = g
             if self.native:
-                comm.all_reduce(reducer.flat, average=True)     # captured: a launch on this stream
+                # only in the capture: a warm-up pass that raised on one rank must not leave the others waiting
+                # inside a real collective (the communicator's channels were set up at its creation)
+                if torch.cuda.is_current_stream_capturing():
+                    reducer.reduce_bucket()                     # captured: a launch on this stream
                 reducer.reduced = True                          # the step pre-hook must not reduce again
             if self.in_graph_step and armed[0]:
                 optimizer.step()
@@ -225,14 +227,25 @@ class GraphedTrainStep:
         if not (isinstance(inputs, (list, tuple)) and all(torch.is_tensor(x) for x in inputs)
                 and torch.is_tensor(labels)):
             return False
+        from .dist import all_ranks_agree
         try:
-            return GraphedTrainStep(model, criterion, optimizer, inputs, labels)
+            step = GraphedTrainStep(model, criterion, optimizer, inputs, labels)
         except Exception as e:                       # noqa: BLE001 — capture errors are of many types
             torch.cuda.synchronize()
+            from . import functions
+            functions.reset_pools()                  # buffers handed out inside the dead capture are gone
             if logger is not None:
                 logger.info('hipGraph capture of the step failed ({}: {}); staying eager'.format(
                     type(e).__name__, e))
-            return False
+            step = False
+        # data parallel: every rank replays, or none does (capture success is decided per rank; the eager
+        # reducer issues the same collective as a replaying rank, but the step's structure — where Adam
+        # runs, which buffers hold the gradients — should not differ between replicas either)
+        if not all_ranks_agree(bool(step), labels.device):
+            if step and logger is not None:
+                logger.info('another rank could not capture its step: staying eager on every rank')
+            step = False
+        return step
 
     @staticmethod
     def enabled(args):
@@ -270,6 +283,6 @@ class GraphedTrainStep:
             # the optimizer must read the bucket views the graph has just written
             for t, g in zip(self.targets, self.static_grads):
                 t.grad = g
-            self.reducer.all_reduce_bucket(self.average)
+            self.reducer.all_reduce_bucket()
             opt.step()
         return loss, logits

@@ -231,7 +231,11 @@ def test_head_state_resolves_deferred_and_given_gradients():
     assert h.resolve(g)[0] == 0 and h.resolve(g)[1] is g
     labels = torch.zeros(4, 3)
     h.deferred = ('bce', labels)
-    assert h.resolve(g)[0] == 0                       # a real dlogits tensor: the plain mode
+    # a criterion was deferred into the head's backward launch, yet another gradient reached the logits
+    # (autograd summed it with the marker into a new tensor): there is no dlogits to add it to — refuse loudly
+    from bmnas.lib import BmnasError
+    with pytest.raises(BmnasError, match='besides the deferred'):
+        h.resolve(g)
     mode, gt, gs, lab = h.resolve(h.marker)
     assert (mode, gt, gs) == (1, None, None) and lab is labels
     h.deferred = ('ce', labels)

@@ -192,6 +192,10 @@ def test_native_rccl_allreduce_single_rank_and_under_graph_capture():
         lib.allreduce_f32(x, comm, average=True)
         torch.cuda.synchronize()
         assert torch.equal(x, want)
+        # what the communicator reports about itself (bmnas_comm_info: the N > 1 bench line prints it)
+        info = lib.comm_info(comm)
+        assert info['ranks'] == 1 and info['rank'] == 0 and info['hip_device'] == torch.cuda.current_device()
+        assert info['rccl_version'] > 20000
         # captured: y = 2 * x ; all-reduce(y) ; z = y + 1  replayed on fresh data
         y = torch.empty_like(x)
         z = torch.empty_like(x)
@@ -213,3 +217,46 @@ def test_native_rccl_allreduce_single_rank_and_under_graph_capture():
             assert torch.equal(z, torch.full_like(z, 2.0 * k + 1.0))
     finally:
         lib.comm_destroy(comm)
+
+
+def test_bench_dp_step_shapes_on_one_gpu(tmp_path):
+    """bench.py --dp-selftest: the N > 1 step shapes — gradients produced in the flat bucket (last cell step's
+    conv / BatchNorm gradients first), the in-graph RCCL all-reduce, and the forked-stream early all-reduce
+    joined before the step ends — captured and replayed through a world-size-1 communicator (one GPU is all a
+    test box has).  The line must carry the rccl evidence object and the per-shape timings."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from bmnas import lib
+    if not lib.comm_available():
+        pytest.skip('librccl not loadable in this process')
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    r = subprocess.run([sys.executable, bench, '--dp-selftest', '--steps', '5', '--warmup', '2', '--regions', '3',
+                        '--no-full-step', '--no-roofline', '--no-cpu-baseline'], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert set(d['step_shapes']) >= {'single', 'graph', 'overlap', 'headline'}, d['step_shapes']
+    assert d['rccl']['comm_ranks'] == 1 and d['rccl']['distinct_devices'] == 1
+    assert d['rccl']['allreduce_bytes'] > d['rccl']['allreduce_early_bytes'] > 0
+    assert d['timed_regions']['n'] == 3 and len(d['timed_regions']['ms_per_step']) == 3
+    assert abs(d['value'] - 5 / (d['ms_per_step'] * 5e-3)) / d['value'] < 1e-3
+
+
+def test_overlapped_bucket_reduction_gives_the_same_gradients():
+    """The 'overlap' step shape against the plain one, same model, same batch, dropout off: every gradient in
+    the bucket the same up to the run-to-run order of the fp32 atomics that accumulate them (1e-5 of scale; world
+    size 1: the two all-reduces are identities, so a real difference would come from the fork / join — a part
+    copied before its gradients were final, or a view the final copy overwrote — and be O(1))."""
+    import os
+    import sys
+    from bmnas import lib
+    if not lib.comm_available():
+        pytest.skip('librccl not loadable in this process')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as B
+    for cname, batch in (('mmimdb', 32), ('ntu', 8)):
+        got = B.dp_shapes_selfcheck(cname, batch)
+        for k, (plain, over) in got.items():
+            assert torch.equal(plain, over), (cname, k, float((plain - over).abs().max()))
