@@ -307,14 +307,14 @@ KERNELS_OF = {
     'ln_affine_bwd': ('ln_affine_bwd_k',), 'ln_affine_bwd_multi': ('ln_affine_bwd_multi_k', 'ln_affine_bwd_k'),
     'backward_epilogue': ('backward_epilogue_k',),
     'sdpa_ln_fwd': ('sdpa_ln_fwd_k',), 'sdpa_ln_bwd': ('sdpa_ln_bwd_k',),
-    'conv1x1_fwd': ('conv_pipe_fwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_nj_k', 'conv_fwd_k'),
-    'conv1x1_bwd_data': ('conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_nj_k', 'conv_bwd_k'),
+    'conv1x1_fwd': ('conv_pipe_fwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_fwd_k'),
+    'conv1x1_bwd_data': ('conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_bwd_k'),
     'conv1x1_bwd_weight': ('conv_w_k',),
     'conv1x1_fwd_sdpa': ('conv_pipe_fwd_sdpa_k', 'conv_fwd_sdpa_k'),
     'conv1x1_bwd_data_sdpa': ('conv_pipe_bwd_sdpa_k', 'conv_bwd_sdpa_k'),
     'conv1x1_bwd_all_sdpa': ('conv_bwd_all_pipe_k', 'conv_bwd_all_k'),
     # (large grids run as bn_bwd_apply + data + weight launches: the units go to the data-gradient kernel)
-    'conv1x1_bwd_all': ('conv_bwd_pair_k', 'conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_nj_k', 'conv_bwd_k'),
+    'conv1x1_bwd_all': ('conv_bwd_pair_k', 'conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_bwd_k'),
     'node_mix_fwd': ('node_mix_fwd_k',), 'node_mix_ln_fwd': ('node_mix_ln_fwd_k',),
     'node_mix_bwd': ('node_mix_bwd_k',), 'node_mix_ln_bwd': ('node_mix_ln_bwd_k',),
     'bn_relu_fwd': ('bn_relu_fwd_k',), 'bn_relu_bwd': ('bn_relu_bwd_k',),

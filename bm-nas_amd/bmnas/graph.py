@@ -268,9 +268,19 @@ class GraphedTrainStep:
 
     def __call__(self, inputs, labels):
         with torch.no_grad():
+            # the batch into the graph's static tensors: ONE multi-tensor copy launch for the modalities that
+            # are already on the device (seven separate copy launches cost ~23 us of a 190 us step), plain
+            # copies for anything else (host tensors: the copy IS the H2D transfer)
+            same = [(d, s_) for d, s_ in zip(self.inputs, inputs)
+                    if s_.device == d.device and s_.dtype == d.dtype and s_.data_ptr() != d.data_ptr()]
+            batched = {id(d) for d, _ in same} if len(same) > 1 else set()
+            if batched:
+                torch._foreach_copy_([d for d, _ in same], [s_ for _, s_ in same])
             for dst, src in zip(self.inputs, inputs):
-                dst.copy_(src, non_blocking=True)
-            self.labels.copy_(labels, non_blocking=True)
+                if id(dst) not in batched and src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            if labels.data_ptr() != self.labels.data_ptr():
+                self.labels.copy_(labels, non_blocking=True)
         opt = self.optimizer
         if self.in_graph_step:
             opt.activate(self.plan)          # an eager step in between must not leak into the replay

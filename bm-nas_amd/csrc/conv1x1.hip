@@ -96,161 +96,6 @@ __device__ __forceinline__ void bn_tile_stats(const ConvArgs& a, const float4 o,
   }
 }
 
-// OUT[n][j] = sum_i ACT[i][n] * MAT(i, j);  TRANS: MAT(i,j) = W[j*ldw + i] (forward conv),
-// else MAT(i,j) = W[i*ldw + j] (data gradient).  A wave owns TN x TJ MFMA tiles
-// (16*TN columns n, 16*TJ columns j); a workgroup is 4 waves laid out WN x (4/WN).
-// The contraction runs in groups of KB blocks of 16 channels: all operand loads of group
-// g+1 are issued (into a second register set) before the MFMAs of group g, so at 1-2
-// waves per SIMD the L2 latency hides behind 16*KB*TN*TJ/4... MFMAs instead of being paid
-// per block.  No LDS, no barriers.
-template <bool TRANS, int TN, int TJ, int WN>
-__global__ __launch_bounds__(256) void conv_nj_k(ConvArgs a) {
-  constexpr int KB = 4;
-  constexpr int WJ = 4 / WN;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lo = lane & 15, h = lane >> 4;
-  const int wn = wave % WN, wj = wave / WN;
-  const int g0 = (blockIdx.x * WN + wn) * TN;            // first n-group of this wave
-  const int j0 = (blockIdx.y * WJ + wj) * (16 * TJ);
-  if (g0 >= a.n_groups || j0 >= a.J) return;             // wave-uniform; no barriers below
-
-  // Operand addresses are CLAMPED into range instead of predicating the loads (predicated
-  // loads compile to a branch per load and wreck the schedule): padded samples / tiles past
-  // the edge read a valid neighbour, their results are simply never stored.
-  int64_t abase[TN];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    int g = g0 + tn;
-    g = g < a.n_groups ? g : a.n_groups - 1;
-    int s = g * a.spw + (lo >> a.Lb);
-    s = s < a.b ? s : a.b - 1;
-    abase[tn] = ((int64_t)s * a.Ci) * a.L + (lo & (a.L - 1));
-  }
-  bool vj[TJ];
-  int jcl[TJ];
-#pragma unroll
-  for (int tj = 0; tj < TJ; ++tj) {
-    vj[tj] = (j0 + 16 * tj) < a.J;                       // J % 16 == 0
-    jcl[tj] = (vj[tj] ? j0 + 16 * tj : a.J - 16) + lo;
-  }
-
-  f32x4 acc[TN][TJ];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nblk = a.I / 16;
-  const int ngrp = nblk / KB;                             // full groups; the tail runs unpipelined
-  float av[2][KB][TN][4], bv[2][KB][TJ][4];
-
-  auto load_block = [&](float (&A)[TN][4], float (&B)[TJ][4], int blk) {
-    const int i0 = blk * 16;
-    const int q = i0 / a.Ci;                              // wave-uniform
-    const int ci = i0 - q * a.Ci + 4 * h;
-    // a select chain, not a.act.p[q]: indexing the kernel-argument array with a run-time q is a MEMORY load
-    // of the pointer (global_load_dwordx2 + s_waitcnt vmcnt(0)) per block — every block's operand loads
-    // then wait for the previous block's, one round trip per block instead of one per wave
-    const float* src = pick_ptr(a.act.p, q);
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const float* pp = src + abase[tn] + (int64_t)ci * a.L;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) A[tn][r] = pp[(int64_t)r * a.L];
-    }
-#pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) {
-      if (TRANS) {
-        const float* pp = a.W + (int64_t)jcl[tj] * a.ldw + i0 + 4 * h;
-        float4 w4 = ld4(pp);
-        if (a.fold > 0) w4 = f4_add(w4, ld4(pp + a.fold));
-        B[tj][0] = w4.x; B[tj][1] = w4.y; B[tj][2] = w4.z; B[tj][3] = w4.w;
-      } else {
-        const float* pp = a.W + (int64_t)(i0 + 4 * h) * a.ldw + jcl[tj];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          B[tj][r] = pp[(int64_t)r * a.ldw] + (a.fold > 0 ? pp[(int64_t)r * a.ldw + a.fold] : 0.f);
-      }
-    }
-  };
-  auto mma_block = [&](const float (&A)[TN][4], const float (&B)[TJ][4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int tj = 0; tj < TJ; ++tj)
-          acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tn][r], B[tj][r], acc[tn][tj], 0, 0, 0);
-  };
-  auto load_group = [&](float (&A)[KB][TN][4], float (&B)[KB][TJ][4], int grp) {
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) load_block(A[kb], B[kb], grp * KB + kb);
-  };
-  auto mma_group = [&](const float (&A)[KB][TN][4], const float (&B)[KB][TJ][4]) {
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) mma_block(A[kb], B[kb]);
-  };
-
-  if (ngrp > 0) {
-    // software pipeline over two statically named register sets.  The steady-state body is
-    // straight-line (no conditionals), so hipcc's waits before each MFMA group are COUNTED
-    // vmcnt(N) that leave the next group's loads in flight (a branch join would force
-    // vmcnt(0) and serialise load -> compute).
-    load_group(av[0], bv[0], 0);
-    int grp = 0;
-    for (; grp + 2 < ngrp; grp += 2) {
-      load_group(av[1], bv[1], grp + 1);
-      mma_group(av[0], bv[0]);
-      load_group(av[0], bv[0], grp + 2);
-      mma_group(av[1], bv[1]);
-    }
-    if (grp + 1 < ngrp) {
-      load_group(av[1], bv[1], grp + 1);
-      mma_group(av[0], bv[0]);
-      mma_group(av[1], bv[1]);
-    } else {
-      mma_group(av[0], bv[0]);
-    }
-  }
-  for (int blk = ngrp * KB; blk < nblk; ++blk) {          // < KB leftover blocks
-    load_block(av[0][0], bv[0][0], blk);
-    mma_block(av[0][0], bv[0][0]);
-  }
-
-  // epilogue.  acc[tn][tj][r] = OUT[n = 16*(g0+tn) + 4h + r][j = j0 + 16*tj + lo]
-  bool vo[TN];
-  int so[TN];
-  const int l0 = (4 * h) & (a.L - 1);
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int g = g0 + tn;
-    so[tn] = g * a.spw + ((4 * h) >> a.Lb);
-    vo[tn] = (g < a.n_groups) && (so[tn] < a.b);
-  }
-#pragma unroll
-  for (int tj = 0; tj < TJ; ++tj) {
-    if (!vj[tj]) continue;
-    const int jj = j0 + 16 * tj + lo;
-    const float bj = (a.bias != nullptr) ? a.bias[jj] : 0.f;
-    const int q = jj / a.Cj;
-    const int cj = jj - q * a.Cj;
-    float* d = a.dst.p[0];
-#pragma unroll
-    for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const float4 o = make_float4(acc[tn][tj][0] + bj, acc[tn][tj][1] + bj, acc[tn][tj][2] + bj,
-                                   acc[tn][tj][3] + bj);
-      if (vo[tn] && d != nullptr) {
-        float* pp = d + ((int64_t)so[tn] * a.Cj + cj) * a.L + l0;
-        st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
-      }
-      // per-channel batch statistics over this tile's (<= 16) valid columns (n-group g0 + tn)
-      if (g0 + tn < a.n_groups) bn_tile_stats(a, o, bj, vo[tn], g0 + tn, jj, h);      // wave-uniform guard
-    }
-  }
-}
-
 // ---- split-K variant: ONE memory round trip per wave ------------------------------------------
 // At these sizes (0.1-0.5 GFLOP per GEMM, every operand L2-resident) the kernels are bound
 // by exposed load latency, not by MFMA or bandwidth: a wave that alternates "load a slice /
@@ -1548,7 +1393,7 @@ __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W
 
 // Which GEMM family a call was dispatched to (diagnostics for tests/test_dispatch_gpu.py: host-side
 // counters, never read by a kernel).  Order = bmnas_conv_family_name().
-enum ConvFamily { F_NJ, F_KSPLIT, F_PIPE_FWD, F_PIPE_BWD, F_LDS, F_FWD_SDPA_PIPE, F_FWD_SDPA_KSPLIT,
+enum ConvFamily { F_KSPLIT, F_PIPE_FWD, F_PIPE_BWD, F_LDS, F_FWD_SDPA_PIPE, F_FWD_SDPA_KSPLIT,
                   F_BWD_SDPA_KSPLIT, F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_BWD_PAIR, F_COUNT };
 long g_family_calls[F_COUNT] = {0};
 #define BMNAS_COUNT(f) (++g_family_calls[f])
@@ -1680,7 +1525,7 @@ inline bool launch_pipe_fwd(const ConvArgs& a, hipStream_t st) {
 }
 
 template <bool TRANS>
-void launch_nj(const ConvArgs& a, hipStream_t st) {
+void launch_gemm(const ConvArgs& a, hipStream_t st) {
   const long jt = a.J / 16, ng = a.n_groups;
   if (TRANS && launch_pipe_fwd(a, st)) return;
   if (!TRANS && conv_pipe_mode() && a.I == a.Ci && a.fold == 0 && a.I % 48 == 0 && a.J % 16 == 0 && a.ldw % 4 == 0) {
@@ -1704,8 +1549,11 @@ void launch_nj(const ConvArgs& a, hipStream_t st) {
     if (wgs(2, 2) >= 1024 && launch_ksplit<TRANS, 2, 2>(a, st)) return;
     if (launch_ksplit<TRANS, 1, 1>(a, st)) return;
   }
-  if (a.I >= 64 && ng * jt >= 256) {
-    // production sizes: LDS-staged kernel; biggest tile that still yields >= ~400 workgroups
+  {
+    // generic fallback: whole-K LDS-staged tiles.  No shape of the reference's configurations lands here (the
+    // pipelined tile kernels take the large grids, the split-K kernels the small ones); what does: channel
+    // counts that are not a multiple of 32 at large grids, a fused cat of two sources with K > 768 at small
+    // ones.  Biggest tile that still yields >= ~400 workgroups.
     const long wg64 = ((ng + 3) / 4) * ((jt + 3) / 4), wg3264 = ((ng + 1) / 2) * ((jt + 3) / 4);
     BMNAS_COUNT(F_LDS);
     if (wg64 >= 400) {
@@ -1718,20 +1566,6 @@ void launch_nj(const ConvArgs& a, hipStream_t st) {
       hipLaunchKernelGGL((conv_lds_k<TRANS, 32, 32>), dim3((unsigned)((ng + 1) / 2), (unsigned)((jt + 1) / 2)),
                          dim3(256), 0, st, a);
     }
-    return;
-  }
-  BMNAS_COUNT(F_NJ);
-  const long waves22 = ((ng + 1) / 2) * ((jt + 1) / 2);
-  const long waves12 = ng * ((jt + 1) / 2);
-  if (waves22 >= 2048) {
-    dim3 grid((unsigned)((ng + 3) / 4), (unsigned)((jt + 3) / 4));            // WG = 2x2 waves of 2x2 tiles
-    hipLaunchKernelGGL((conv_nj_k<TRANS, 2, 2, 2>), grid, dim3(256), 0, st, a);
-  } else if (waves12 >= 2048) {
-    dim3 grid((unsigned)((ng + 1) / 2), (unsigned)((jt + 3) / 4));            // WG = 2x2 waves of 1x2 tiles
-    hipLaunchKernelGGL((conv_nj_k<TRANS, 1, 2, 2>), grid, dim3(256), 0, st, a);
-  } else {
-    dim3 grid((unsigned)ng, (unsigned)((jt + 3) / 4));                        // WG = 1x4 waves of 1x1 tiles
-    hipLaunchKernelGGL((conv_nj_k<TRANS, 1, 1, 1>), grid, dim3(256), 0, st, a);
   }
 }
 }  // namespace
@@ -1756,7 +1590,7 @@ extern "C" int bmnas_conv1x1_fwd(const float* const* srcs, int n_src, int C_src,
   a.part = stat_shards ? nullptr : part; a.stat = stat_shards ? part : nullptr; a.stat_shards = stat_shards;
   a.Ci = C_src; a.I = n_src * C_src; a.Cj = M; a.J = M;
   a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = conv_probe(); a.fold = fold_cols;
-  launch_nj<true>(a, (hipStream_t)stream);
+  launch_gemm<true>(a, (hipStream_t)stream);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
@@ -1776,7 +1610,7 @@ extern "C" int bmnas_conv1x1_bwd_data(const float* dU, const float* W, int ldw, 
   a.W = W; a.bias = nullptr; a.part = nullptr; a.ldw = ldw;
   a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
   a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = conv_probe(); a.fold = fold_cols;
-  launch_nj<false>(a, (hipStream_t)stream);
+  launch_gemm<false>(a, (hipStream_t)stream);
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
@@ -1844,7 +1678,7 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
   if (!done && ((ng + 1) / 2) * ((jt + 1) / 2) >= 1024) done = launch_ksplit_sdpa_fwd<2, 2>(a, s, st);
   if (!done) done = launch_ksplit_sdpa_fwd<1, 1>(a, s, st);
   if (!done) {
-    launch_nj<true>(a, st);
+    launch_gemm<true>(a, st);
     BMNAS_CHECK_LAUNCH();
     return bmnas_sdpa_ln_fwd(x, y, ln_w, ln_b, out, xhat, stats, b, C, L, drop, stream);
   }
@@ -1886,7 +1720,7 @@ extern "C" int bmnas_conv1x1_bwd_data_sdpa(const float* dU, const float* W, int 
   if (((ng + 1) / 2) * ((jt + 1) / 2) >= 1024) done = launch_ksplit_sdpa_bwd<2, 2>(a, s, st);
   if (!done) done = launch_ksplit_sdpa_bwd<1, 1>(a, s, st);
   if (!done) {
-    launch_nj<false>(a, st);
+    launch_gemm<false>(a, st);
     BMNAS_CHECK_LAUNCH();
     return bmnas_sdpa_ln_bwd(g, gscale, x, y, ln_w, xhat, stats, dx, dy, sdpa_accumulate_mask, b, C, L,
                              drop, stream);
@@ -2206,7 +2040,7 @@ extern "C" int bmnas_conv_family_calls(long* out, int n, int reset) {
 }
 
 extern "C" const char* bmnas_conv_family_name(int i) {
-  static const char* names[F_COUNT] = {"nj", "ksplit", "pipe_fwd", "pipe_bwd", "lds", "fwd_sdpa_pipe",
+  static const char* names[F_COUNT] = {"ksplit", "pipe_fwd", "pipe_bwd", "lds", "fwd_sdpa_pipe",
                                        "fwd_sdpa_ksplit", "bwd_sdpa_ksplit", "bwd_all_pipe", "bwd_all_ksplit",
                                        "conv_w", "bwd_pair"};
   return (i >= 0 && i < F_COUNT) ? names[i] : nullptr;

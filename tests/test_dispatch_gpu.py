@@ -9,10 +9,9 @@ fp32 torch contraction in the same test, so no family runs unverified:
     ksplit                  split-K, one memory round trip (small grids, K <= 768) or several register rounds
                             in one launch (longer K at <= 512 workgroups: the C_in = 1024 / 2048 reshape layers
                             at <= 64 samples per GPU)
-    lds                     whole-K LDS tiles: generic large-grid fallback (channel counts that the pipelined
-                            kernels do not take, e.g. not a multiple of 32) — no reference shape needs it
-    nj                      direct kernel: generic small-grid fallback (e.g. a fused torch.cat of two sources
-                            with K > 1792) — no reference shape needs it
+    lds                     whole-K LDS tiles: the ONE generic fallback (channel counts that the pipelined kernels
+                            do not take at large grids, a fused torch.cat of two sources with K > 768 at small
+                            ones) — no reference shape needs it (round 3 removed the second fallback, conv_nj_k)
     fwd_sdpa_pipe / _ksplit conv + attention in one launch (search NodeMixedOp, large / small batch)
     bwd_all_pipe / _ksplit  data-gradient + weight-gradient + attention backward in one launch
     bwd_sdpa_ksplit         data-gradient + attention backward (BMNAS_FUSE_BWD_ALL=0 path)
@@ -81,7 +80,7 @@ CASES = [
     ('reshape MM-IMDB C_in 512 b128', 128, 512, 192, 16, {'pipe_fwd', 'pipe_bwd'}),
     ('out_conv NTU b8', 8, 256, 128, 8, {'ksplit'}),
     ('reshape NTU C_in 2048 b64', 64, 2048, 128, 8, {'ksplit'}),        # multi-round split-K (10.7 us; lds: 51 us)
-    ('reshape NTU C_in 2048 b6', 6, 2048, 128, 8, {'ksplit'}),          # (10.7 us; nj: 23 us)
+    ('reshape NTU C_in 2048 b6', 6, 2048, 128, 8, {'ksplit'}),
     ('reshape NTU C_in 2048 b256', 256, 2048, 128, 8, {'pipe_fwd'}),
     # generic fallbacks for shapes outside the reference's configurations:
     ('channels not a multiple of 32, large grid: C_in 2064 b512', 512, 2064, 128, 8, {'lds'}),
@@ -117,14 +116,14 @@ def test_merged_launch_families(name, batch, expect):
     assert expect <= got, (name, batch, got)
 
 
-def test_cat_of_two_sources_with_long_contraction_takes_the_direct_kernel():
-    """nj: the generic direct kernel — here a two-source (fused torch.cat) K = 2048 contraction at a tiny
-    grid, which the multi-round split-K kernel (single source) does not cover."""
+def test_cat_of_two_sources_with_long_contraction_takes_the_generic_kernel():
+    """lds, the generic fallback, also at a tiny grid: a two-source (fused torch.cat) K = 2048 contraction,
+    which the multi-round split-K kernel (single source) does not cover."""
     from bmnas import lib
     lib.conv_family_calls(reset=True)
     _conv_case(6, 2048, 128, 8, n_src=2)
     got = {k for k, v in lib.conv_family_calls().items() if v > 0}
-    assert 'nj' in got, got
+    assert 'lds' in got, got
 
 
 def test_every_family_is_reachable(monkeypatch):

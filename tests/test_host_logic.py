@@ -288,3 +288,77 @@ def test_forward_stat_pool_sizes_a_pass_by_the_previous_one():
     assert c.numel() == n(64) and float(c.abs().sum()) == 0.0
     pool.close()
     assert pool.last_total == n(16) + n(32) + n(64)
+
+
+def test_searcher_facades_build_loaders_and_hand_over(monkeypatch):
+    """models/darts_searchable.py (reference :25-90): MMIMDB_Searcher / NTUSearcher / Ego_Searcher build the
+    datasets' DataLoaders and call the per-dataset train_darts_model.  The datasets and models.utils are out of
+    scope (reference checkout): stubs stand in; what is checked is the wiring — splits, batch size, shuffling,
+    the arguments handed to train_darts_model — and the per-rank loaders under WORLD_SIZE > 1."""
+    import sys
+    import types
+    from torch.utils.data import Dataset
+    from torch.utils.data.distributed import DistributedSampler
+
+    class DS(Dataset):
+        def __init__(self, *a, **k):
+            self.stage = k.get('stage')
+
+        def __len__(self):
+            return 10
+
+        def __getitem__(self, i):
+            return i
+
+    tv = types.ModuleType('torchvision')
+    tvt = types.ModuleType('torchvision.transforms')
+    tvt.Compose = lambda ts: ts
+    tv.transforms = tvt
+    ds = types.ModuleType('datasets')
+    mm = types.ModuleType('datasets.mmimdb')
+    mm.ToTensor, mm.MM_IMDB = (lambda: 'tt'), DS
+    nt = types.ModuleType('datasets.ntu')
+    nt.NormalizeLen = nt.ToTensor = nt.AugCrop = lambda: 't'
+    nt.NTU = DS
+    eg = types.ModuleType('datasets.ego')
+    eg.get_train_loader = lambda opt, args: ('train', opt)
+    eg.get_dev_loader = lambda opt, args: ('dev', opt)
+    eg.get_test_loader = lambda opt, args: ('test', opt)
+    mu = types.ModuleType('models.utils')
+    mu.parse_opts = lambda args: 'OPT'
+    for name, mod in (('torchvision', tv), ('torchvision.transforms', tvt), ('datasets', ds),
+                      ('datasets.mmimdb', mm), ('datasets.ntu', nt), ('datasets.ego', eg), ('models.utils', mu)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    import models.darts_searchable as S
+    import models.search.ego_darts_searchable as ego
+    import models.search.mmimdb_darts_searchable as mmimdb
+    import models.search.ntu_darts_searchable as ntu
+    calls = []
+    monkeypatch.setattr(mmimdb, 'train_darts_model', lambda *a: calls.append(('mmimdb', a)) or 'r1')
+    monkeypatch.setattr(ntu, 'train_darts_model', lambda *a: calls.append(('ntu', a)) or 'r2')
+    monkeypatch.setattr(ego, 'train_darts_model', lambda *a: calls.append(('ego', a)) or 'r3')
+
+    class A:
+        datadir, batchsize, num_workers = '/nowhere', 4, 0
+
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    s = S.MMIMDB_Searcher(A(), 'dev0', 'log')
+    assert set(s.dataloaders) == {'train', 'dev', 'test'} and s.dataloaders['train'].batch_size == 4
+    assert s.dataloaders['dev'].dataset.stage == 'dev'
+    assert s.search() == 'r1' and calls[-1][0] == 'mmimdb' and calls[-1][1][0] is s.dataloaders
+    n = S.NTUSearcher(A(), 'dev0', 'log')
+    assert n.dataloaders['train'].dataset.stage == 'train_exp' and n.search() == 'r2'
+    assert calls[-1][1][1:] == (n.args, 'dev0', 'log')
+    e = S.Ego_Searcher(A(), 'dev0', 'log')
+    assert e.opt == 'OPT' and e.dataloaders['dev'] == ('dev', 'OPT') and e.search() == 'r3'
+    assert calls[-1][1][2] == 'OPT'                       # ego's train_darts_model(dataloaders, args, opt, device, logger)
+    # data parallel launch: per-rank loaders with a DistributedSampler and batchsize // world
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    import torch.distributed as dist
+    monkeypatch.setattr(dist, 'is_available', lambda: True)
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_world_size', lambda group=None: 2)
+    monkeypatch.setattr(dist, 'get_rank', lambda group=None: 1)
+    s2 = S.MMIMDB_Searcher(A(), 'dev0', 'log')
+    ld = s2.dataloaders['train']
+    assert isinstance(ld.sampler, DistributedSampler) and ld.batch_size == 2 and len(list(ld.sampler)) == 5

@@ -258,5 +258,9 @@ def test_overlapped_bucket_reduction_gives_the_same_gradients():
     import bench as B
     for cname, batch in (('mmimdb', 32), ('ntu', 8)):
         got = B.dp_shapes_selfcheck(cname, batch)
+        from gpu_util import assert_close_scaled
         for k, (plain, over) in got.items():
-            assert torch.equal(plain, over), (cname, k, float((plain - over).abs().max()))
+            # (fp32 atomics accumulate these in a run-dependent order: 1e-5 of scale, not bit equality; a part
+            # copied before its gradients were final, or overwritten by the final copy, would be off by O(1))
+            assert torch.isfinite(over).all(), (cname, k)
+            assert_close_scaled(f'{cname}:{k}', over, plain, rel=1e-5, floor=1e-9)
