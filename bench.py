@@ -86,7 +86,8 @@ class HyperNet(torch.nn.Module):
 
     def forward(self, xs):
         if self.tier == 'R':
-            xs = [layer._tail(x) for layer, x in zip(self.reshape_layers, xs)]
+            import models.auxiliary.aux_models as aux
+            xs = aux.reshape_tails(list(self.reshape_layers), xs)
         # = central_classifier(fusion_net(xs)), what Searchable_*.forward does (HyperNetBase.fuse)
         return self.fusion_net.forward_classified(xs, self.central_classifier)
 

@@ -299,6 +299,87 @@ class ConvBnActFn(Function):
                 *dsrcs)
 
 
+class ReshapeGroupFn(Function):
+    """The N reshape layers in front of the fusion cell (ReshapeInputLayer{,_MMIMDB}.forward after the pooling,
+    aux_models.py:71-74 / 111-114: Conv1d(C_in_i, C, 1) -> BatchNorm1d(C) -> ReLU -> Dropout(drpt) on each of the
+    N pooled modality features) as FOUR launches for the whole group instead of five per layer: grouped GEMM
+    (+ BatchNorm batch sums), grouped BN-finalise + ReLU + dropout; grouped activation / BatchNorm-reduction
+    backward, grouped weight- and data-gradient GEMMs with the BatchNorm input gradient folded in.
+    Same kernels bodies, same arithmetic and same dropout sites (layer 0 first) as N ConvBnActFn calls."""
+
+    @staticmethod
+    def forward(ctx, n, p, training, buffers, *tensors):
+        xs = [_c(_f32(t)) for t in tensors[:n]]
+        _require_gpu(xs[0], 'reshape layers')
+        prm = [tensors[n + 4 * i:n + 4 * i + 4] for i in range(n)]          # conv.weight, conv.bias, bn.weight, bn.bias
+        b, L = xs[0].shape[0], xs[0].shape[2]
+        M = prm[0][0].shape[0]
+        dev = xs[0].device
+        Ws = [_c(w).view(M, -1) for w, _, _, _ in prm]
+        cbs = [_c(cb) for _, cb, _, _ in prm]
+        Us = [torch.empty((b, M, L), device=dev, dtype=torch.float32) for _ in range(n)]
+        chans = [torch.empty(4 * M, device=dev, dtype=torch.float32) for _ in range(n)]
+        stats, shards = None, 0
+        if training and b * L < 2:
+            raise ValueError(f'Expected more than 1 value per channel when training, got input size {[b, M, L]}')
+        # ONE zero-filled buffer for everything the group accumulates with atomics — the forward's BatchNorm
+        # batch sums and (when a backward will follow) bn_grad | dW | dbias of every layer — cleared by ONE
+        # launch, which under hipGraph capture also advances the dropout step counter: it is the first launch
+        # of the step, in front of every dropout site (bmnas.cell._DropState.take_advance)
+        per = K.STAT_SHARDS * M * 2 if training else 0
+        want_bwd = any(ctx.needs_input_grad)              # (all False when autograd is not recording)
+        sizes = [2 * M + M * W.shape[1] + M for W in Ws] if want_bwd else []
+        offs = [n * per]
+        for sz in sizes:
+            offs.append(offs[-1] + (sz + 3) // 4 * 4)
+        adv = K.DROP.take_advance() if (training and p > 0.0) else None
+        pool = torch.empty(offs[-1], device=dev, dtype=torch.float32) if offs[-1] else None
+        if pool is not None or adv is not None:
+            lib.cell_prologue([], [], [], [], 4, 4, adv, pool)
+        if training:
+            shards = K.STAT_SHARDS
+            stats = [pool[i * per:(i + 1) * per] for i in range(n)]
+        ctx.zero = (pool, offs, sizes) if want_bwd else None
+        lib.conv1x1_fwd_group(xs, Ws, cbs, Us, stats, shards, b, L, M)
+        outs = [torch.empty((b, M, L), device=dev, dtype=torch.float32) for _ in range(n)]
+        drops = [K.DROP.make(p, outs[i].numel(), training) for i in range(n)]
+        fins = [lib.make_bn_fin(None if stats is None else stats[i], shards, cbs[i], _c(prm[i][2]), _c(prm[i][3]),
+                                buffers[i][0], buffers[i][1], buffers[i][2], training) for i in range(n)]
+        lib.bn_relu_fwd_group(Us, chans, outs, fins, drops, b, M, L)
+        ctx.n, ctx.xs, ctx.Ws, ctx.Us, ctx.chans, ctx.drops, ctx.training = n, xs, Ws, Us, chans, drops, training
+        ctx.wshapes = [tuple(w.shape) for w, _, _, _ in prm]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, xs, Ws, Us = ctx.n, ctx.xs, ctx.Ws, ctx.Us
+        b, M, L = Us[0].shape
+        dev = Us[0].device
+        gs = [torch.zeros_like(Us[i]) if g is None else _c(g) for i, g in enumerate(gs)]
+        # bn_grad | dW | dbias of every layer: the buffer the forward's first launch cleared (a second backward
+        # over the same graph gets a fresh one)
+        if ctx.zero is not None:
+            zero, offs, sizes = ctx.zero
+            ctx.zero = None
+        else:
+            sizes = [2 * M + M * W.shape[1] + M for W in Ws]
+            offs = [0]
+            for sz in sizes:
+                offs.append(offs[-1] + (sz + 3) // 4 * 4)
+            zero = torch.zeros(offs[-1], device=dev, dtype=torch.float32)
+        bn_grads = [zero[offs[i]:offs[i] + 2 * M] for i in range(n)]
+        dWs = [zero[offs[i] + 2 * M:offs[i] + 2 * M + M * Ws[i].shape[1]].view(M, Ws[i].shape[1]) for i in range(n)]
+        dbs = [zero[offs[i] + 2 * M + M * Ws[i].shape[1]:offs[i] + sizes[i]] for i in range(n)]
+        dVs = [torch.empty_like(U) for U in Us]
+        lib.bn_relu_bwd_group(gs, Us, ctx.chans, dVs, bn_grads, ctx.drops, b, M, L)
+        dxs = [torch.empty_like(x) if ctx.needs_input_grad[4 + i] else None for i, x in enumerate(xs)]
+        lib.conv1x1_bwd_group(dVs, Ws, xs, dxs, dWs, dbs, Us, ctx.chans, bn_grads, ctx.training, b, L, M)
+        grads = []
+        for i in range(n):
+            grads += [dWs[i].view(ctx.wshapes[i]), dbs[i], bn_grads[i][:M], bn_grads[i][M:]]
+        return (None, None, None, None, *dxs, *grads)
+
+
 # ---------------------------------------------------------------- search NodeMixedOp
 class NodeMixedFn(Function):
     """NodeMixedOp.forward(x, y, weights) (node_operations.py:118-120) as one fused

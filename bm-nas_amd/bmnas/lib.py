@@ -62,6 +62,33 @@ class BnFin(C.Structure):
 
 NO_FIN = BnFin()
 
+MAX_GROUP = 8
+
+
+class ConvFwdProb(C.Structure):
+    """bmnas_conv_fwd_prob_t"""
+    _fields_ = [('src', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p), ('U', C.c_void_p),
+                ('stat', C.c_void_p), ('C_in', C.c_int), ('ldw', C.c_int)]
+
+
+class BnReluFwdProb(C.Structure):
+    """bmnas_bn_relu_fwd_prob_t"""
+    _fields_ = [('U', C.c_void_p), ('chan', C.c_void_p), ('out', C.c_void_p), ('fin', BnFin), ('drop', Dropout)]
+
+
+class BnReluBwdProb(C.Structure):
+    """bmnas_bn_relu_bwd_prob_t"""
+    _fields_ = [('g', C.c_void_p), ('U', C.c_void_p), ('chan', C.c_void_p), ('dV', C.c_void_p),
+                ('bn_grad', C.c_void_p), ('drop', Dropout)]
+
+
+class ConvBwdProb(C.Structure):
+    """bmnas_conv_bwd_prob_t"""
+    _fields_ = [('dV', C.c_void_p), ('W', C.c_void_p), ('src', C.c_void_p), ('dsrc', C.c_void_p),
+                ('dW', C.c_void_p), ('dbias', C.c_void_p), ('bn_U', C.c_void_p), ('bn_chan', C.c_void_p),
+                ('bn_grad', C.c_void_p), ('C_in', C.c_int), ('ldw', C.c_int), ('ldw_grad', C.c_int),
+                ('accumulate', C.c_int)]
+
 
 def make_bn_fin(stat, shards, conv_bias, bn_w, bn_b, rm, rv, nbt, training):
     """Descriptor for in-kernel BatchNorm finalisation (bmnas_bn_fin_t): the consumer of a conv output
@@ -128,6 +155,11 @@ SIGNATURES = {
     'bmnas_bn_glu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_fwd': ([_P, _P, BnFin, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_conv1x1_group_ok': ([_I, C.POINTER(C.c_int), _I, _I, _I], _I),
+    'bmnas_conv1x1_fwd_group': ([C.POINTER(ConvFwdProb), _I, _I, _I, _I, _I, _P], _I),
+    'bmnas_bn_relu_fwd_group': ([C.POINTER(BnReluFwdProb), _I, _I, _I, _I, _P], _I),
+    'bmnas_bn_relu_bwd_group': ([C.POINTER(BnReluBwdProb), _I, _I, _I, _I, _P], _I),
+    'bmnas_conv1x1_bwd_group': ([C.POINTER(ConvBwdProb), _I, _I, _I, _I, _I, _P], _I),
     'bmnas_bn_relu_ln_fwd': ([_P, _P, BnFin, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P, _P], _I),
     'bmnas_bn_relu_ln_fwd_pair_ok': ([_I, _I, _I, _I], _I),
     'bmnas_bn_relu_ln_fwd_pair': ([_P, _P, BnFin, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P, _PP, _I, _P, _I,
@@ -363,6 +395,56 @@ def head_bwd(srcs, sums, dsrcs, acc_mask, ln_w, ln_b, W, hb, stats, mode, g, gsc
                                  None if labels is None else labels.data_ptr(), _ptr(loss), _ptr(part),
                                  b, Cc, L, O, _ptr(scrub),
                                  0 if scrub is None else scrub.numel(), _stream()), 'head_bwd')
+
+
+def conv1x1_group_ok(c_ins, b, L, M):
+    """Whether the N convs (C_in_i -> M on (b, C_in_i, L)) can go through the grouped entry points."""
+    if not 1 <= len(c_ins) <= MAX_GROUP:
+        return False
+    arr = (C.c_int * len(c_ins))(*[int(c) for c in c_ins])
+    return bool(load().bmnas_conv1x1_group_ok(len(c_ins), arr, b, L, M))
+
+
+def conv1x1_fwd_group(srcs, Ws, biases, Us, stats, stat_shards, b, L, M):
+    """U_i = W_i x_i + bias_i for every layer of the group in ONE launch; stats[i]: zero-filled BatchNorm sums
+    (stat_shards copies) or None with stat_shards 0."""
+    n = len(srcs)
+    probs = (ConvFwdProb * n)()
+    for i in range(n):
+        W = Ws[i]
+        probs[i] = ConvFwdProb(_ptr(srcs[i]), _ptr(W), _ptr(biases[i]), _ptr(Us[i]),
+                               None if stats is None or stats[i] is None else _ptr(stats[i]), srcs[i].shape[1],
+                               W.shape[1])
+    _check(load().bmnas_conv1x1_fwd_group(probs, n, stat_shards, b, L, M, _stream()), 'conv1x1_fwd_group')
+
+
+def bn_relu_fwd_group(Us, chans, outs, fins, drops, b, M, L):
+    n = len(Us)
+    probs = (BnReluFwdProb * n)()
+    for i in range(n):
+        probs[i] = BnReluFwdProb(_ptr(Us[i]), _ptr(chans[i]), _ptr(outs[i]), fins[i], drops[i])
+    _check(load().bmnas_bn_relu_fwd_group(probs, n, b, M, L, _stream()), 'bn_relu_fwd_group')
+
+
+def bn_relu_bwd_group(gs, Us, chans, dVs, bn_grads, drops, b, M, L):
+    n = len(gs)
+    probs = (BnReluBwdProb * n)()
+    for i in range(n):
+        probs[i] = BnReluBwdProb(_ptr(gs[i]), _ptr(Us[i]), _ptr(chans[i]), _ptr(dVs[i]), _ptr(bn_grads[i]), drops[i])
+    _check(load().bmnas_bn_relu_bwd_group(probs, n, b, M, L, _stream()), 'bn_relu_bwd_group')
+
+
+def conv1x1_bwd_group(dVs, Ws, srcs, dsrcs, dWs, dbiases, bn_Us, bn_chans, bn_grads, training, b, L, M):
+    """Weight / bias gradients (+=) and, where dsrcs[i] is not None, the input gradient of every layer of the
+    group in ONE launch, the BatchNorm input gradient applied on the fly (dVs = gradients w.r.t. the BatchNorm
+    outputs, bn_grads already reduced)."""
+    n = len(dVs)
+    probs = (ConvBwdProb * n)()
+    for i in range(n):
+        probs[i] = ConvBwdProb(_ptr(dVs[i]), _ptr(Ws[i]), _ptr(srcs[i]), _ptr(dsrcs[i]), _ptr(dWs[i]),
+                               _ptr(dbiases[i]), _ptr(bn_Us[i]), _ptr(bn_chans[i]), _ptr(bn_grads[i]),
+                               srcs[i].shape[1], Ws[i].shape[1], dWs[i].shape[1], 0)
+    _check(load().bmnas_conv1x1_bwd_group(probs, n, int(training), b, L, M, _stream()), 'conv1x1_bwd_group')
 
 
 def comm_available():

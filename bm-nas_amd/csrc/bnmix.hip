@@ -8,6 +8,7 @@
 #include "../../include/bmnas_hip.h"
 #include "arch_body.hpp"
 #include "bn_fin.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -680,18 +681,16 @@ __global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
   }
 }
 
-__global__ __launch_bounds__(256) void bn_relu_fwd_k(const float* __restrict__ U,
-                                                     float* __restrict__ chan, BnFin fin,
-                                                     float* __restrict__ out, int b, int M, int L,
-                                                     DropCfg d) {
+__device__ __forceinline__ void bn_relu_fwd_body(const float* __restrict__ U, float* __restrict__ chan,
+                                                 const BnFin& fin, float* __restrict__ out, int b, int M, int L,
+                                                 const DropCfg& d, const int bx, const int nbx, float* fin_lds) {
   const DropRt dr = drop_begin(d);
-  extern __shared__ float fin_lds[];
   float* sc = fin_lds;
   float* sh = fin_lds + M;
-  bn_fin_fill<256>(fin, chan, M, b * L, sc, sh, blockIdx.x == 0);
+  bn_fin_fill<256>(fin, chan, M, b * L, sc, sh, bx == 0);
   const int ml4 = M * L / 4, l4n = L / 4;
   const int64_t total = (int64_t)b * ml4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nbx * 256) {
     const int r = (int)(i % ml4);
     const int c = r / l4n;
     const float4 v = affine4(ld4(U + i * 4), sc[c], sh[c]);
@@ -701,21 +700,53 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_k(const float* __restrict__ U
   }
 }
 
-__global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g,
-                                                     const float* __restrict__ U,
-                                                     const float* __restrict__ chan,
-                                                     float* __restrict__ dV, float* bn_grad, int b,
-                                                     int M, int L, int chunk, DropCfg d) {
+__global__ __launch_bounds__(256) void bn_relu_fwd_k(const float* __restrict__ U,
+                                                     float* __restrict__ chan, BnFin fin,
+                                                     float* __restrict__ out, int b, int M, int L,
+                                                     DropCfg d) {
+  extern __shared__ float fin_lds[];
+  bn_relu_fwd_body(U, chan, fin, out, b, M, L, d, blockIdx.x, gridDim.x, fin_lds);
+}
+
+// The same for up to kBnGroup convs of one shape in ONE launch (the N reshape layers in front of the fusion
+// cell, aux_models.py:71-74 / 111-114): blockIdx.y = problem.
+constexpr int kBnGroup = 8;
+struct BnReluFwdGroup {
+  const float* U[kBnGroup];
+  float* chan[kBnGroup];
+  float* out[kBnGroup];
+  BnFin fin[kBnGroup];
+  DropCfg drop[kBnGroup];
+};
+__global__ __launch_bounds__(256) void bn_relu_fwd_group_k(BnReluFwdGroup G, int b, int M, int L) {
+  extern __shared__ float fin_lds[];
+  // (chains over the compile-time-indexed elements, not G.x[p]: a run-time index sends the by-value argument
+  // struct through scratch)
+  const int p = blockIdx.y;
+  BnFin fin = G.fin[0];
+  DropCfg d = G.drop[0];
+  const float* U = G.U[0];
+  float* chan = G.chan[0];
+  float* out = G.out[0];
+#pragma unroll
+  for (int q = 1; q < kBnGroup; ++q)
+    if (p == q) { fin = G.fin[q]; d = G.drop[q]; U = G.U[q]; chan = G.chan[q]; out = G.out[q]; }
+  bn_relu_fwd_body(U, chan, fin, out, b, M, L, d, blockIdx.x, gridDim.x, fin_lds);
+}
+
+__device__ __forceinline__ void bn_relu_bwd_body(const float* __restrict__ g, const float* __restrict__ U,
+                                                 const float* __restrict__ chan, float* __restrict__ dV,
+                                                 float* bn_grad, int b, int M, int L, int chunk, const DropCfg& d,
+                                                 const int bx, const int by, float (*csum)[2][64]) {
   const DropRt dr = drop_begin(d);
-  __shared__ float csum[3][2][64];
   const int ml4 = M * L / 4, l4n = L / 4;
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int r = blockIdx.x * 64 + col;
+  const int r = bx * 64 + col;
   const bool active = r < ml4;
   const int c = active ? r / l4n : 0;
   const float mu = chan[c], rs = chan[M + c], sc = chan[2 * M + c], sh = chan[3 * M + c];
   float sw = 0.f, sb = 0.f;
-  const int s_beg = blockIdx.y * chunk;
+  const int s_beg = by * chunk;
   int s_end = s_beg + chunk;
   if (s_end > b) s_end = b;
   if (active) {
@@ -748,6 +779,39 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g
     atomicAdd(bn_grad + c, w);
     atomicAdd(bn_grad + M + c, bb);
   }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_k(const float* __restrict__ g,
+                                                     const float* __restrict__ U,
+                                                     const float* __restrict__ chan,
+                                                     float* __restrict__ dV, float* bn_grad, int b,
+                                                     int M, int L, int chunk, DropCfg d) {
+  __shared__ float csum[3][2][64];
+  bn_relu_bwd_body(g, U, chan, dV, bn_grad, b, M, L, chunk, d, blockIdx.x, blockIdx.y, csum);
+}
+
+// ... and its backward for the whole group: blockIdx.z = problem
+struct BnReluBwdGroup {
+  const float* g[kBnGroup];
+  const float* U[kBnGroup];
+  const float* chan[kBnGroup];
+  float* dV[kBnGroup];
+  float* bn_grad[kBnGroup];
+  DropCfg drop[kBnGroup];
+};
+__global__ __launch_bounds__(256) void bn_relu_bwd_group_k(BnReluBwdGroup G, int b, int M, int L, int chunk) {
+  __shared__ float csum[3][2][64];
+  const int p = blockIdx.z;
+  DropCfg d = G.drop[0];
+  const float* g = G.g[0];
+  const float* U = G.U[0];
+  const float* chan = G.chan[0];
+  float* dV = G.dV[0];
+  float* bn_grad = G.bn_grad[0];
+#pragma unroll
+  for (int q = 1; q < kBnGroup; ++q)
+    if (p == q) { d = G.drop[q]; g = G.g[q]; U = G.U[q]; chan = G.chan[q]; dV = G.dV[q]; bn_grad = G.bn_grad[q]; }
+  bn_relu_bwd_body(g, U, chan, dV, bn_grad, b, M, L, chunk, d, blockIdx.x, blockIdx.y, csum);
 }
 
 // NodeCell's tail with node_multiplier != 1 (node_search.py:64-69) as ONE launch per direction:
@@ -1526,6 +1590,52 @@ extern "C" int bmnas_bn_relu_bwd(const float* g, const float* U, const float* ch
   return 0;
 }
 
+extern "C" int bmnas_bn_relu_fwd_group(const bmnas_bn_relu_fwd_prob_t* probs, int n, int b, int M, int L,
+                                       void* stream) {
+  if (!probs || n < 1 || b < 0 || M < 1) return BMNAS_E_ARG;
+  if (n > kBnGroup) return BMNAS_E_LIMIT;
+  if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (M > 4096 || M % 4) return BMNAS_E_LIMIT;
+  BnReluFwdGroup G{};
+  for (int p = 0; p < n; ++p) {
+    if (!probs[p].U || !probs[p].chan || !probs[p].out) return BMNAS_E_ARG;
+    if (int e = to_fin(probs[p].fin, &G.fin[p])) return e;
+    if (G.fin[p].on && G.fin[p].training && b * L < 2) return BMNAS_E_ARG;
+    G.U[p] = probs[p].U; G.chan[p] = probs[p].chan; G.out[p] = probs[p].out; G.drop[p] = to_cfg(probs[p].drop);
+  }
+  if (b == 0) return 0;
+  const int64_t total = (int64_t)b * M * L / 4;
+  // every workgroup starts by finalising the BatchNorm statistics (bn_fin_fill): ~3 workgroups per CU over
+  // the whole group, each walking several float4 rounds, not one workgroup per 256 float4
+  int gx = stream_grid(total);
+  const int cap = std::max(1, 768 / n);
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(bn_relu_fwd_group_k, dim3(gx, n), dim3(256), (size_t)2 * M * sizeof(float), (hipStream_t)stream,
+                     G, b, M, L);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_bn_relu_bwd_group(const bmnas_bn_relu_bwd_prob_t* probs, int n, int b, int M, int L,
+                                       void* stream) {
+  if (!probs || n < 1 || b < 0 || M < 1) return BMNAS_E_ARG;
+  if (n > kBnGroup) return BMNAS_E_LIMIT;
+  if (!(L == 4 || L == 8 || L == 16)) return BMNAS_E_SHAPE;
+  BnReluBwdGroup G{};
+  for (int p = 0; p < n; ++p) {
+    if (!probs[p].g || !probs[p].U || !probs[p].chan || !probs[p].dV || !probs[p].bn_grad) return BMNAS_E_ARG;
+    G.g[p] = probs[p].g; G.U[p] = probs[p].U; G.chan[p] = probs[p].chan; G.dV[p] = probs[p].dV;
+    G.bn_grad[p] = probs[p].bn_grad; G.drop[p] = to_cfg(probs[p].drop);
+  }
+  if (b == 0) return 0;
+  const int ml4 = M * L / 4;
+  const int chunk = pick_chunk(b, ml4 * n);
+  dim3 grid((ml4 + 63) / 64, (b + chunk - 1) / chunk, n);
+  hipLaunchKernelGGL(bn_relu_bwd_group_k, grid, dim3(256), 0, (hipStream_t)stream, G, b, M, L, chunk);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int bmnas_bn_relu_ln_fwd_pair(const float* U, float* chan, bmnas_bn_fin_t fin, const float* resid,
                                          const float* ln_w, const float* ln_b, float* o, float* out,
                                          float* stats, int b, int C, int L, bmnas_dropout_t drop,
@@ -1799,6 +1909,9 @@ extern "C" int bmnas_cell_prologue(const float* const* a, float* const* out, con
                             scrub_n))
     return e;
   if (L.blocks == 0) return 0;
+  // a large zero-fill (the reshape group's accumulation buffers: ~2 MB) wants more than the few softmax / fold
+  // workgroups: one per 4 KB, at most two per CU
+  if (scrub_n > 0) L.blocks = std::max(L.blocks, (int)std::min<int64_t>(512, (scrub_n / 4 + 255) / 256));
   hipLaunchKernelGGL(cell_prologue_k, dim3(L.blocks), dim3(256), 0, (hipStream_t)stream, L.P, L.F,
                      (unsigned long long*)step_counter, (const unsigned long long*)step_span, scrub,
                      scrub_n / 4);

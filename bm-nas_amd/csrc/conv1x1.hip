@@ -1380,6 +1380,123 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBw
   }
 }
 
+// ---- grouped launches: the N reshape layers in front of the fusion cell ------------------------------------
+// (ReshapeInputLayer / _MMIMDB, aux_models.py:51-76, 87-115: N independent Conv1d(C_in_i -> C, k = 1) + BatchNorm
+// on N modality tensors of one (b, L).)  One launch per layer left 6-8 short launches in a row, each on a fraction
+// of the chip (MM-IMDB b = 128: 6 x 11.7 us forward, 10 x 9 us backward); here every layer's tiles share ONE
+// grid.  Block ranges per problem; the bodies are the single-conv ones: pipelined LDS tiles where a layer has
+// enough of them, the multi-round split-K body otherwise (any K, 16 x 16 tiles).
+constexpr int kGroupMax = 8;
+struct ConvFwdGroup {
+  ConvArgs a[kGroupMax];
+  int start[kGroupMax + 1];      // first block of problem p (start[n] = grid size)
+  int gx[kGroupMax];
+  int kind[kGroupMax];           // 0: conv_pipe_fwd_body<32, 2>; 1: conv_ksplit_body<true, 1, 1, 12, MULTI>
+  int n;
+};
+
+// problem of this block: the last p with start[p] <= blockIdx.x (wave-uniform by construction; readfirstlane
+// says so to the compiler)
+__device__ __forceinline__ int group_problem(const int (&start)[kGroupMax + 1], int n) {
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < kGroupMax; ++q) p += (q < n && (int)blockIdx.x >= start[q]) ? 1 : 0;
+  return __builtin_amdgcn_readfirstlane(p);
+}
+// arr[p] of a kernel-argument array WITHOUT indexing it at run time: a run-time index makes clang copy the whole
+// by-value argument struct to scratch and read it back with vector loads (the pointers then sit in VGPRs, which
+// the SGPR pointer selects of the bodies refuse); a chain over the compile-time-indexed elements keeps every
+// field a scalar load
+template <typename T, int N>
+__device__ __forceinline__ T pick_uniform(const T (&arr)[N], int p) {
+  T v = arr[0];
+#pragma unroll
+  for (int q = 1; q < N; ++q)
+    if (p == q) v = arr[q];
+  return v;
+}
+// ... and tell the compiler that what came out is wave-uniform (it is: p is): every field back into SGPRs
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uni(T* ptr) {
+  const uint64_t u = reinterpret_cast<uint64_t>(ptr);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ ConvArgs uni(ConvArgs a) {
+#pragma unroll
+  for (int q = 0; q < kConvPtrs; ++q) {
+    a.act.p[q] = uni(a.act.p[q]);
+    a.dst.p[q] = uni(a.dst.p[q]);
+  }
+  a.W = uni(a.W); a.bias = uni(a.bias); a.part = uni(a.part); a.stat = uni(a.stat);
+  a.stat_shards = uni(a.stat_shards);
+  a.bn_U = uni(a.bn_U); a.bn_chan = uni(a.bn_chan); a.bn_grad = uni(a.bn_grad); a.bn_train = uni(a.bn_train);
+  a.ldw = uni(a.ldw); a.Ci = uni(a.Ci); a.Cj = uni(a.Cj); a.I = uni(a.I); a.J = uni(a.J);
+  a.b = uni(a.b); a.L = uni(a.L); a.Lb = uni(a.Lb); a.spw = uni(a.spw); a.n_groups = uni(a.n_groups);
+  a.n_part = uni(a.n_part); a.acc_mask = (uint32_t)uni((int)a.acc_mask); a.fold = uni(a.fold); a.probe = uni(a.probe);
+  return a;
+}
+__device__ __forceinline__ ConvWArgs uni(ConvWArgs a) {
+  a.bn_U = uni(a.bn_U); a.bn_chan = uni(a.bn_chan); a.bn_grad = uni(a.bn_grad); a.bn_train = uni(a.bn_train);
+  a.dU = uni(a.dU);
+#pragma unroll
+  for (int q = 0; q < kConvPtrs; ++q) a.src.p[q] = uni(a.src.p[q]);
+  a.dW = uni(a.dW); a.dbias = uni(a.dbias);
+  a.ldw = uni(a.ldw); a.C_src = uni(a.C_src); a.M = uni(a.M); a.K = uni(a.K); a.dup_cols = uni(a.dup_cols);
+  a.b = uni(a.b); a.L = uni(a.L); a.Lb = uni(a.Lb); a.spw = uni(a.spw); a.n_groups = uni(a.n_groups);
+  a.groups_per_split = uni(a.groups_per_split); a.use_atomic = uni(a.use_atomic);
+  return a;
+}
+
+__global__ __launch_bounds__(256) void conv_fwd_group_k(ConvFwdGroup G) {
+  extern __shared__ __attribute__((aligned(16))) char group_smem[];
+  const int p = group_problem(G.start, G.n);
+  const ConvArgs a = uni(pick_uniform(G.a, p));
+  const int t = blockIdx.x - uni(pick_uniform(G.start, p)), gx = uni(pick_uniform(G.gx, p));
+  if (uni(pick_uniform(G.kind, p)) == 0) conv_pipe_fwd_body<32, 2>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+  else conv_ksplit_body<true, 1, 1, 12, true>(a, t % gx, t / gx, group_smem);
+}
+
+// backward of the group: every layer's weight-gradient tiles (first: they walk many n-groups each), then every
+// layer's data-gradient tiles, the BatchNorm input gradient applied while the operands are staged (bn_U).
+struct ConvBwdGroup {
+  ConvArgs a[kGroupMax];
+  ConvWArgs w[kGroupMax];
+  int wstart[kGroupMax + 1];     // weight-gradient blocks of problem p
+  int dstart[kGroupMax + 1];     // data-gradient blocks (after all weight-gradient blocks); empty: no input gradient
+  int wx[kGroupMax], wy[kGroupMax];
+  int gx[kGroupMax];
+  int kind[kGroupMax];           // 0: conv_pipe_bwd_body<48, 2>; 3 / 6: conv_ksplit_body<false, 1, 1, KPW>
+  int n, n_w;
+};
+
+__global__ __launch_bounds__(256, 3) void conv_bwd_group_k(ConvBwdGroup G) {
+  extern __shared__ __attribute__((aligned(16))) char group_smem[];
+  const int n_w = G.n_w;
+  if ((int)blockIdx.x < n_w) {
+    const int p = group_problem(G.wstart, G.n);
+    const ConvWArgs w = uni(pick_uniform(G.w, p));
+    const int t = blockIdx.x - uni(pick_uniform(G.wstart, p)), wx = uni(pick_uniform(G.wx, p)), wy = uni(pick_uniform(G.wy, p));
+    const int bz = t / (wx * wy), r = t - bz * wx * wy;
+    if (w.bn_U != nullptr) conv_w_body<4, true>(w, r % wx, r / wx, bz, group_smem);
+    else conv_w_body<4, false>(w, r % wx, r / wx, bz, group_smem);
+  } else {
+    const int p = group_problem(G.dstart, G.n);
+    const ConvArgs a = uni(pick_uniform(G.a, p));
+    const int t = blockIdx.x - uni(pick_uniform(G.dstart, p)), gx = uni(pick_uniform(G.gx, p)), kind = uni(pick_uniform(G.kind, p));
+    if (kind == 0) {
+      if (a.bn_U != nullptr) conv_pipe_bwd_body<48, 2, true, kLa2>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+      else conv_pipe_bwd_body<48, 2, false>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+    } else if (kind == 3) {
+      conv_ksplit_body<false, 1, 1, 3>(a, t % gx, t / gx, group_smem);
+    } else {
+      conv_ksplit_body<false, 1, 1, 6>(a, t % gx, t / gx, group_smem);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W,
                                                      float* __restrict__ Weff, int M, int C) {
   const int c4n = C / 4;
@@ -1394,7 +1511,7 @@ __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W
 // Which GEMM family a call was dispatched to (diagnostics for tests/test_dispatch_gpu.py: host-side
 // counters, never read by a kernel).  Order = bmnas_conv_family_name().
 enum ConvFamily { F_KSPLIT, F_PIPE_FWD, F_PIPE_BWD, F_LDS, F_FWD_SDPA_PIPE, F_FWD_SDPA_KSPLIT,
-                  F_BWD_SDPA_KSPLIT, F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_BWD_PAIR, F_COUNT };
+                  F_BWD_SDPA_KSPLIT, F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_BWD_PAIR, F_FWD_GROUP, F_BWD_GROUP, F_COUNT };
 long g_family_calls[F_COUNT] = {0};
 #define BMNAS_COUNT(f) (++g_family_calls[f])
 
@@ -2031,6 +2148,130 @@ extern "C" int bmnas_conv1x1_bwd_all_mix(const float* dU, const float* W, int ld
   return 0;
 }
 
+extern "C" int bmnas_conv1x1_group_ok(int n, const int* C_in, int b, int L, int M) {
+  if (n < 1 || n > kGroupMax || !C_in || b < 1 || M < 16 || M % 16 || M > 384) return 0;
+  int Lb, spw, ng;
+  if (check_shape(b, L, &Lb, &spw, &ng)) return 0;
+  for (int p = 0; p < n; ++p)
+    if (C_in[p] < 16 || C_in[p] % 16) return 0;
+  return 1;
+}
+
+extern "C" int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n, int stat_shards, int b, int L,
+                                       int M, void* stream) {
+  if (!probs || n < 1 || b < 0 || M < 1 || stat_shards < 0) return BMNAS_E_ARG;
+  if (n > kGroupMax) return BMNAS_E_LIMIT;
+  if (M % 16) return BMNAS_E_SHAPE;
+  ConvFwdGroup G{};
+  G.n = n;
+  size_t lds = conv_ksplit_lds<1, 1>();
+  int blocks = 0;
+  // longest contraction first: its tiles run longest
+  int order[kGroupMax];
+  for (int p = 0; p < n; ++p) order[p] = p;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && probs[order[j]].C_in > probs[order[j - 1]].C_in; --j) std::swap(order[j], order[j - 1]);
+  for (int q = 0; q < n; ++q) {
+    const bmnas_conv_fwd_prob_t& P = probs[order[q]];
+    if (!P.src || !P.W || !P.U || P.C_in < 16) return BMNAS_E_ARG;
+    if (P.C_in % 16 || P.ldw % 4 || P.ldw < P.C_in) return BMNAS_E_SHAPE;
+    ConvArgs& a = G.a[q];
+    if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
+    a.act.p[0] = P.src; a.dst.p[0] = P.U; a.W = P.W; a.bias = P.bias; a.ldw = P.ldw;
+    a.part = nullptr; a.stat = stat_shards ? P.stat : nullptr; a.stat_shards = stat_shards;
+    if (stat_shards && !P.stat) return BMNAS_E_ARG;
+    a.Ci = P.C_in; a.I = P.C_in; a.Cj = M; a.J = M; a.b = b; a.L = L; a.n_part = a.n_groups;
+    const int pgx = (a.n_groups + 1) / 2, pgy = (M + kPipeJ - 1) / kPipeJ;
+    G.start[q] = blocks;
+    if (P.C_in % 32 == 0 && pgx * pgy >= 48) {
+      G.kind[q] = 0; G.gx[q] = pgx;
+      blocks += pgx * pgy;
+      lds = std::max(lds, conv_pipe_lds<32, 2>(L));
+    } else {
+      G.kind[q] = 1; G.gx[q] = a.n_groups;
+      blocks += a.n_groups * (M / 16);
+    }
+  }
+  G.start[n] = blocks;
+  if (b == 0) return 0;
+  BMNAS_COUNT(F_FWD_GROUP);
+  hipLaunchKernelGGL(conv_fwd_group_k, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, G);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_conv1x1_bwd_group(const bmnas_conv_bwd_prob_t* probs, int n, int bn_training, int b, int L,
+                                       int M, void* stream) {
+  if (!probs || n < 1 || b < 0 || M < 1) return BMNAS_E_ARG;
+  if (n > kGroupMax) return BMNAS_E_LIMIT;
+  if (M % 16 || M > 384) return BMNAS_E_SHAPE;
+  ConvBwdGroup G{};
+  G.n = n;
+  size_t lds = conv_w_lds<4>();
+  int order[kGroupMax];
+  for (int p = 0; p < n; ++p) order[p] = p;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && probs[order[j]].C_in > probs[order[j - 1]].C_in; --j) std::swap(order[j], order[j - 1]);
+  int blocks = 0;
+  for (int q = 0; q < n; ++q) {                      // weight-gradient tiles
+    const bmnas_conv_bwd_prob_t& P = probs[order[q]];
+    if (!P.dV || !P.W || !P.src || !P.dW || P.C_in < 16) return BMNAS_E_ARG;
+    if (P.bn_U != nullptr && (!P.bn_chan || (bn_training && !P.bn_grad))) return BMNAS_E_ARG;
+    if (P.C_in % 16 || P.ldw % 4 || P.ldw < P.C_in) return BMNAS_E_SHAPE;
+    ConvWArgs& w = G.w[q];
+    dim3 wgrid;
+    const float* srcs[1] = {P.src};
+    if (int e = fill_w_args(w, P.dV, srcs, 1, P.C_in, P.dW, P.ldw_grad, P.dbias, 0, b, L, M, 4, &wgrid)) return e;
+    {
+      // fill_w_args sizes the batch splits for a conv that has the chip to itself; here n layers share the
+      // grid: as many splits as bring the GROUP to ~3 weight-gradient workgroups per CU (every split is another
+      // round of fp32 atomics on dW)
+      long tiles_all = 0;
+      for (int r = 0; r < n; ++r) tiles_all += (long)((M + 31) / 32) * ((probs[r].C_in + 31) / 32);
+      int splits = (int)std::max<long>(1, (768 + tiles_all - 1) / tiles_all);
+      const int max_splits = (w.n_groups + 7) / 8;
+      splits = std::min(splits, std::max(1, max_splits));
+      w.groups_per_split = (w.n_groups + splits - 1) / splits;
+      splits = (w.n_groups + w.groups_per_split - 1) / w.groups_per_split;
+      w.use_atomic = splits > 1;
+      wgrid.z = (unsigned)splits;
+    }
+    w.bn_U = P.bn_U; w.bn_chan = P.bn_chan; w.bn_grad = P.bn_grad; w.bn_train = bn_training;
+    G.wstart[q] = blocks; G.wx[q] = (int)wgrid.x; G.wy[q] = (int)wgrid.y;
+    blocks += (int)(wgrid.x * wgrid.y * wgrid.z);
+  }
+  G.wstart[n] = blocks;
+  G.n_w = blocks;
+  for (int q = 0; q < n; ++q) {                      // data-gradient tiles
+    const bmnas_conv_bwd_prob_t& P = probs[order[q]];
+    ConvArgs& a = G.a[q];
+    if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
+    G.dstart[q] = blocks;
+    if (P.dsrc == nullptr) continue;
+    a.act.p[0] = P.dV; a.dst.p[0] = P.dsrc; a.W = P.W; a.ldw = P.ldw;
+    a.Ci = M; a.I = M; a.Cj = P.C_in; a.J = P.C_in; a.b = b; a.L = L; a.acc_mask = P.accumulate ? 1u : 0u;
+    a.bn_U = P.bn_U; a.bn_chan = P.bn_chan; a.bn_grad = P.bn_grad; a.bn_train = bn_training;
+    const int pgx = (a.n_groups + 1) / 2, pgy = (a.J + kPipeBJ - 1) / kPipeBJ;
+    const size_t coef = a.bn_U ? (size_t)a.I * sizeof(float4) : 0;
+    if (M % 48 == 0 && pgx * pgy >= 48) {
+      G.kind[q] = 0; G.gx[q] = pgx;
+      blocks += pgx * pgy;
+      lds = std::max(lds, conv_pipe_bwd_lds<48, 2>(L) + coef);
+    } else {
+      G.kind[q] = (M / 16 + 3) / 4 <= 3 ? 3 : 6;
+      G.gx[q] = a.n_groups;
+      blocks += a.n_groups * (a.J / 16);
+      lds = std::max(lds, conv_ksplit_lds<1, 1>() + coef);
+    }
+  }
+  G.dstart[n] = blocks;
+  if (b == 0) return 0;
+  BMNAS_COUNT(F_BWD_GROUP);
+  hipLaunchKernelGGL(conv_bwd_group_k, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, G);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int bmnas_conv_family_calls(long* out, int n, int reset) {
   if (!out && n > 0) return BMNAS_E_ARG;
   for (int i = 0; i < n && i < F_COUNT; ++i) out[i] = g_family_calls[i];
@@ -2042,7 +2283,7 @@ extern "C" int bmnas_conv_family_calls(long* out, int n, int reset) {
 extern "C" const char* bmnas_conv_family_name(int i) {
   static const char* names[F_COUNT] = {"ksplit", "pipe_fwd", "pipe_bwd", "lds", "fwd_sdpa_pipe",
                                        "fwd_sdpa_ksplit", "bwd_sdpa_ksplit", "bwd_all_pipe", "bwd_all_ksplit",
-                                       "conv_w", "bwd_pair"};
+                                       "conv_w", "bwd_pair", "fwd_group", "bwd_group"};
   return (i >= 0 && i < F_COUNT) ? names[i] : nullptr;
 }
 

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from bmnas.functions import ConvBnActFn
+from bmnas.functions import ConvBnActFn, ReshapeGroupFn
 
 
 class Identity(nn.Module):
@@ -59,12 +59,14 @@ class ReshapeInputLayer(_ReshapeBase):
         super().__init__(C_in, C, L, args)
         self.pool = nn.AdaptiveMaxPool2d((L, 1))
 
-    def forward(self, x):
+    def pooled(self, x):
         out = x.unsqueeze(-1)
         out = out.view(out.size(0), out.size(1), out.size(2), -1)
         out = self.pool(out).view(out.size(0), out.size(1), -1)
-        out = F.interpolate(out, self.L)
-        return self._tail(out)
+        return F.interpolate(out, self.L)
+
+    def forward(self, x):
+        return self._tail(self.pooled(x))
 
 
 class ReshapeInputLayer_MMIMDB(_ReshapeBase):
@@ -76,8 +78,53 @@ class ReshapeInputLayer_MMIMDB(_ReshapeBase):
         assert side * side == L
         self.pool = nn.AdaptiveMaxPool2d((side, side))
 
-    def forward(self, x):
+    def pooled(self, x):
         out = x.unsqueeze(-1).unsqueeze(-1)
         out = out.view(out.size(0), out.size(1), out.size(2), -1)
-        out = self.pool(out).view(out.size(0), out.size(1), -1)
-        return self._tail(out)
+        return self.pool(out).view(out.size(0), out.size(1), -1)
+
+    def forward(self, x):
+        return self._tail(self.pooled(x))
+
+
+def reshape_tails(layers, pooled):
+    """[layer._tail(f) for layer, f in zip(layers, pooled)] — the conv -> bn -> relu -> dropout stacks of the
+    reshape layers on their pooled inputs (b, C_in_i, L) — with every eligible layer of the list in ONE grouped
+    set of launches (bmnas.functions.ReshapeGroupFn: 4 launches for the group instead of 5 per layer).  Layers the
+    group cannot take (placeholders of a found net, CPU tensors, channel counts off the kernels' grid) run on their
+    own, exactly as before."""
+    from bmnas import lib
+    outs = [None] * len(layers)
+    idx = [i for i, (layer, f) in enumerate(zip(layers, pooled))
+           if isinstance(layer, _ReshapeBase) and torch.is_tensor(f) and f.is_cuda and f.dim() == 3
+           and f.dtype == torch.float32]
+    grp = []
+    if len(idx) >= 2:
+        l0 = layers[idx[0]]
+        same = [i for i in idx if layers[i].C == l0.C and layers[i].L == l0.L and layers[i].training == l0.training
+                and layers[i].dropout.p == l0.dropout.p and pooled[i].shape[0] == pooled[idx[0]].shape[0]
+                and pooled[i].shape[2] == l0.L and layers[i].conv.in_channels == pooled[i].shape[1]]
+        same = same[:lib.MAX_GROUP]
+        if len(same) >= 2 and lib.conv1x1_group_ok([layers[i].conv.in_channels for i in same],
+                                                   pooled[same[0]].shape[0], l0.L, l0.C):
+            grp = same
+    if grp:
+        ls = [layers[i] for i in grp]
+        buffers = [(m.bn.running_mean, m.bn.running_var, m.bn.num_batches_tracked) for m in ls]
+        params = []
+        for m in ls:
+            params += [m.conv.weight, m.conv.bias, m.bn.weight, m.bn.bias]
+        res = ReshapeGroupFn.apply(len(grp), ls[0].dropout.p, ls[0].training, buffers, *[pooled[i] for i in grp],
+                                   *params)
+        for i, r in zip(grp, res):
+            outs[i] = r
+    for i, (layer, f) in enumerate(zip(layers, pooled)):
+        if outs[i] is None:
+            outs[i] = layer._tail(f) if isinstance(layer, _ReshapeBase) else layer(f)
+    return outs
+
+
+def reshape_all(layers, features):
+    """[layer(f) for layer, f in zip(layers, features)] with the conv stacks grouped (reshape_tails)."""
+    pooled = [layer.pooled(f) if isinstance(layer, _ReshapeBase) else f for layer, f in zip(layers, features)]
+    return reshape_tails(layers, pooled)

@@ -74,7 +74,10 @@ class HyperNetBase(nn.Module):
         return layers
 
     def reshape_input_features(self, input_features):
-        return [layer(f) for layer, f in zip(self.reshape_layers, input_features)]
+        # = [layer(f) for layer, f in zip(self.reshape_layers, input_features)], the conv stacks of all
+        # modalities in one grouped set of launches (models.auxiliary.aux_models.reshape_all)
+        import models.auxiliary.aux_models as aux
+        return aux.reshape_all(list(self.reshape_layers), list(input_features))
 
     def fuse(self, raw_features):
         feats = self.reshape_input_features(list(raw_features))

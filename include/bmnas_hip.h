@@ -387,6 +387,64 @@ int bmnas_bn_relu_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, float* ou
 int bmnas_bn_relu_bwd(const float* g, const float* U, const float* chan, float* dV, float* bn_grad,
                       int b, int M, int L, bmnas_dropout_t drop, void* stream);
 
+/* ---- the N reshape layers in front of the fusion cell as ONE launch per stage ----------
+ * ReshapeInputLayer / ReshapeInputLayer_MMIMDB (aux_models.py:51-76, 87-115; built per modality at
+ * mmimdb_darts_searchable.py:84-90, ntu_darts_searchable.py:102-108, ego_darts_searchable.py:102-108) are N
+ * independent  Conv1d(C_in_i -> C, k = 1) -> BatchNorm1d(C) -> ReLU -> Dropout  stacks on N pooled feature
+ * tensors (b, C_in_i, L) of one batch: the same four kernels N times over.  These entry points take all N
+ * problems (n <= BMNAS_MAX_GROUP) and put every layer's tiles in ONE grid:
+ *   forward :  bmnas_conv1x1_fwd_group (U_i = W_i x_i + bias_i, BatchNorm batch sums into stat_i)
+ *              bmnas_bn_relu_fwd_group (x'_i = dropout(relu(bn(U_i))), statistics finalised in the launch)
+ *   backward:  bmnas_bn_relu_bwd_group (dV_i, BatchNorm affine gradients)
+ *              bmnas_conv1x1_bwd_group (dW_i, dbias_i and — dsrc_i != NULL — the gradient of the pooled
+ *                                       input, with the BatchNorm input gradient applied while the operands
+ *                                       are staged, as bmnas_conv1x1_bwd_all does for one conv)
+ * Same arithmetic, operation by operation, as the single-conv entry points they stand for (the tile bodies are
+ * shared); b, L, M = C and the BatchNorm mode are common to the group, C_in_i % 16 == 0, M <= 384. */
+#define BMNAS_MAX_GROUP 8
+typedef struct {
+  const float* src;      /* (b, C_in, L) */
+  const float* W;        /* (M, ldw) row-major, first C_in columns used */
+  const float* bias;     /* (M), nullable */
+  float* U;              /* (b, M, L) */
+  float* stat;           /* stat_shards x M x 2 zero-filled sums (bmnas_conv1x1_fwd), or NULL with stat_shards 0 */
+  int C_in, ldw;
+} bmnas_conv_fwd_prob_t;
+typedef struct {
+  const float* U;
+  float* chan;
+  float* out;
+  bmnas_bn_fin_t fin;
+  bmnas_dropout_t drop;
+} bmnas_bn_relu_fwd_prob_t;
+typedef struct {
+  const float* g;
+  const float* U;
+  const float* chan;
+  float* dV;
+  float* bn_grad;        /* [dBN.weight (M) | dBN.bias (M)], += (atomics: caller zeroes) */
+  bmnas_dropout_t drop;
+} bmnas_bn_relu_bwd_prob_t;
+typedef struct {
+  const float* dV;       /* (b, M, L): gradient w.r.t. the BatchNorm OUTPUT when bn_U != NULL, else dU */
+  const float* W;
+  const float* src;      /* the layer's input (b, C_in, L) */
+  float* dsrc;           /* its gradient, NULL = not needed */
+  float* dW;             /* (M, ldw_grad), += (atomics) */
+  float* dbias;          /* (M), +=, nullable */
+  const float* bn_U;     /* raw conv output, bn_chan, bn_grad: as bmnas_conv1x1_bwd_all */
+  const float* bn_chan;
+  const float* bn_grad;
+  int C_in, ldw, ldw_grad, accumulate;   /* accumulate: dsrc += instead of = */
+} bmnas_conv_bwd_prob_t;
+int bmnas_conv1x1_group_ok(int n, const int* C_in, int b, int L, int M);
+int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n, int stat_shards, int b, int L, int M,
+                            void* stream);
+int bmnas_bn_relu_fwd_group(const bmnas_bn_relu_fwd_prob_t* probs, int n, int b, int M, int L, void* stream);
+int bmnas_bn_relu_bwd_group(const bmnas_bn_relu_bwd_prob_t* probs, int n, int b, int M, int L, void* stream);
+int bmnas_conv1x1_bwd_group(const bmnas_conv_bwd_prob_t* probs, int n, int bn_training, int b, int L, int M,
+                            void* stream);
+
 /* NodeCell's whole tail for node_multiplier != 1 (reference node_search.py:64-69) as one launch per
  * direction:  o = dropout(relu(bn(U)));  out = LayerNorm_[C,L](o + resid).
  * fwd: U (b, C, L) raw out_conv output; chan / fin as in bmnas_bn_relu_fwd; o and out (b, C, L) written;

@@ -382,12 +382,15 @@ def test_search_step_with_live_dropout_under_graph_replay(name, batch, nout, los
     assert not torch.equal(seen[0][0], seen[2][0]) and not torch.equal(seen[0][0], seen[1][0])
 
 
-def test_dropout_in_front_of_the_cell_prologue_keeps_its_mask_in_a_captured_step():
+@pytest.mark.parametrize('grouped', [False, True])
+def test_dropout_in_front_of_the_cell_prologue_keeps_its_mask_in_a_captured_step(grouped):
     """Reshape layers -> hypernet -> classifier captured as one step (bench.py --tier R, the trainers' graphed
     step): the reshape layers' dropout sites are issued BEFORE the cell prologue.  The prologue must then not be
     the one that advances the step counter (their backward would regenerate a mask the forward never applied,
     ADVICE r02): the add stays at the end of the graph and every site, in forward and backward, reads the same
-    value.  Compared with the oracle (reshape layers + hypernet) under the exported masks."""
+    value.  grouped: the reshape layers as ONE grouped set of launches (aux.reshape_all, what the drivers call):
+    its first launch — the zero-fill of the group's accumulation buffers, in front of every site — advances the
+    counter instead.  Compared with the oracle (reshape layers + hypernet) under the exported masks."""
     import models.auxiliary.aux_models as aux
     from bmnas import nn as bnn
     from bmnas.functions import unit_grad
@@ -421,7 +424,8 @@ def test_dropout_in_front_of_the_cell_prologue_keeps_its_mask_in_a_captured_step
 
     def fn():
         with bnn.fused_criterion(True):
-            logits = net.forward_classified([layer(r) for layer, r in zip(layers, raw_d)], cls)
+            feats = aux.reshape_all(layers, raw_d) if grouped else [layer(r) for layer, r in zip(layers, raw_d)]
+            logits = net.forward_classified(feats, cls)
             loss = crit(logits, y)
         return (loss, logits, *torch.autograd.grad(loss, params, grad_outputs=unit_grad(loss.device)))
 
@@ -429,7 +433,8 @@ def test_dropout_in_front_of_the_cell_prologue_keeps_its_mask_in_a_captured_step
         g = GraphedStep(fn, warmup=2)
     rec = [r for r in rec if r[0].step]
     assert len(rec) == len(c_ins) + 2 * 3
-    assert not g.advanced_first                          # sites in front of the prologue: add at the graph's end
+    # per layer: sites in front of the prologue -> the add ends the graph; grouped: the group's first launch advances
+    assert g.advanced_first == grouped
     for replay in range(2):
         for m, st in zip(layers + [net], states):
             m.load_state_dict(st)

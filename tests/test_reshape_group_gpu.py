@@ -1,0 +1,126 @@
+"""-m gpu: the reshape layers of all modalities as ONE grouped set of launches (SURVEY.md row f1;
+bmnas.functions.ReshapeGroupFn, bmnas_conv1x1_{fwd,bwd}_group, bmnas_bn_relu_{fwd,bwd}_group) against the CPU oracle
+(oracle.reshape_layer, pinned by the reference's aux_layers*.npz goldens) — the real channel widths of the three
+datasets (mmimdb_darts_searchable.py:86, ntu_darts_searchable.py:104, ego_darts_searchable.py:104), large and small
+grids (pipelined tiles / multi-round split-K inside the group), training with live dropout (exported masks), training
+without, eval — and against the per-layer path it replaces."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as fo
+from oracle import synth
+from gpu_util import assert_close_scaled, dev
+
+pytestmark = pytest.mark.gpu
+
+C_INS = {'mmimdb': [512, 512, 512, 512, 64, 128],
+         'ntu': [512, 1024, 2048, 2048, 128, 256, 1024, 512],
+         'mixed': [64, 16, 48, 2064, 32]}                  # off-grid widths: not a multiple of 32, K > 2048
+
+
+class _A:
+    def __init__(self, drpt):
+        self.drpt = drpt
+
+
+def _build(kind, C, L, drpt, seed):
+    import models.auxiliary.aux_models as aux
+    cls = aux.ReshapeInputLayer_MMIMDB if kind == 'mmimdb' else aux.ReshapeInputLayer
+    layers, params = [], []
+    for i, c_in in enumerate(C_INS[kind]):
+        shapes = {'conv.weight': (C, c_in, 1), 'conv.bias': (C,), 'bn.weight': (C,), 'bn.bias': (C,),
+                  'bn.running_mean': (C,), 'bn.running_var': (C,), 'bn.num_batches_tracked': ()}
+        prm = synth.make_params(fo.make_cfg(N=2, C=C, L=L), seed + i, shapes)
+        layer = cls(c_in, C, L, _A(drpt))
+        layer.load_state_dict({k: v.clone() for k, v in prm.items()})
+        layers.append(layer.to(dev()))
+        params.append(prm)
+    return layers, params
+
+
+@pytest.mark.parametrize('kind,b,C,L,mode', [
+    ('mmimdb', 128, 192, 16, 'train_drop'), ('mmimdb', 128, 192, 16, 'eval'), ('mmimdb', 16, 192, 16, 'train'),
+    ('ntu', 64, 128, 8, 'train_drop'), ('ntu', 8, 128, 8, 'train'), ('ntu', 250, 128, 8, 'train'),
+    ('mixed', 37, 32, 8, 'train_drop'), ('mixed', 300, 48, 4, 'train'), ('ntu', 6, 128, 8, 'eval')])
+def test_grouped_reshape_layers_match_oracle(kind, b, C, L, mode):
+    import models.auxiliary.aux_models as aux
+    from bmnas import cell as K
+    from bmnas import lib
+    drpt = 0.2 if mode == 'train_drop' else 0.0
+    layers, params = _build(kind, C, L, drpt, 700)
+    for m in layers:
+        m.train(mode != 'eval')
+    rng = np.random.Generator(np.random.PCG64(11))
+    xs = [torch.from_numpy(np.maximum(rng.standard_normal((b, c, L)), 0).astype(np.float32)) for c in C_INS[kind]]
+    ws = [torch.from_numpy(rng.standard_normal((b, C, L)).astype(np.float32)) for _ in xs]
+    xd = [x.to(dev()).requires_grad_(True) for x in xs]
+    lib.conv_family_calls(reset=True)
+    assert K.DROP.record is None
+    K.DROP.record = rec = []
+    try:
+        outs = aux.reshape_tails(layers, xd)
+        sum((o * w.to(dev())).sum() for o, w in zip(outs, ws)).backward()
+    finally:
+        K.DROP.record = None
+    calls = lib.conv_family_calls()
+    assert calls['fwd_group'] == 1 and calls['bwd_group'] == 1, calls
+    assert sum(v for k, v in calls.items() if not k.endswith('_group')) == 0, calls      # nothing per layer
+    assert len(rec) == (len(layers) if mode == 'train_drop' else 0)
+    masks = [lib.dropout_mask(d, n, dev()).cpu() for d, n in rec]
+    # oracle, layer by layer, under the same masks
+    xo = [x.clone().requires_grad_(True) for x in xs]
+    pls = [{'r.' + k: (v.clone() if fo.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in prm.items()}
+           for prm in params]
+    import contextlib
+    with (fo.injected_masks(masks) if masks else contextlib.nullcontext()):
+        oo = [fo._dropout(fo._relu(fo._conv_bn(x, q['r.conv.weight'], q['r.conv.bias'], q['r.bn.weight'],
+                                               q['r.bn.bias'], q['r.bn.running_mean'], q['r.bn.running_var'],
+                                               mode != 'eval')), drpt, mode != 'eval') for x, q in zip(xo, pls)]
+    sum((o * w).sum() for o, w in zip(oo, ws)).backward()
+    for i, (layer, q) in enumerate(zip(layers, pls)):
+        tag = f'{kind}[{i}] C_in {C_INS[kind][i]}'
+        assert_close_scaled(tag + ' out', outs[i], oo[i])
+        assert_close_scaled(tag + ' dx', xd[i].grad, xo[i].grad, rel=2e-4)
+        assert_close_scaled(tag + ' dconv.weight', layer.conv.weight.grad, q['r.conv.weight'].grad, rel=2e-4)
+        assert_close_scaled(tag + ' dbn.weight', layer.bn.weight.grad, q['r.bn.weight'].grad, rel=2e-4)
+        assert_close_scaled(tag + ' dbn.bias', layer.bn.bias.grad, q['r.bn.bias'].grad, rel=2e-4)
+        if mode == 'eval':
+            assert_close_scaled(tag + ' dconv.bias', layer.conv.bias.grad, q['r.conv.bias'].grad, rel=2e-4)
+        else:
+            assert float(layer.conv.bias.grad.abs().max()) < 1e-4
+            assert_close_scaled(tag + ' rm', layer.bn.running_mean, q['r.bn.running_mean'])
+            assert_close_scaled(tag + ' rv', layer.bn.running_var, q['r.bn.running_var'])
+            assert int(layer.bn.num_batches_tracked) == 1
+
+
+def test_grouped_path_equals_the_per_layer_path_and_serves_the_drivers():
+    """reshape_tails vs [layer._tail(x)]: same results (same tile bodies; 1e-5 of scale covers the different
+    atomics order), a found net's nn.ReLU placeholders pass through, inputs without gradient get none."""
+    import models.auxiliary.aux_models as aux
+    layers, _ = _build('mmimdb', 192, 16, 0.0, 900)
+    for m in layers:
+        m.train()
+    rng = np.random.Generator(np.random.PCG64(5))
+    xs = [torch.from_numpy(rng.standard_normal((32, c, 16)).astype(np.float32)).to(dev()) for c in C_INS['mmimdb']]
+    state = [{k: v.clone() for k, v in m.state_dict().items()} for m in layers]
+    xa = [x.clone().requires_grad_(i != 1) for i, x in enumerate(xs)]            # input 1: no gradient wanted
+    mixed = list(layers)
+    mixed[3] = torch.nn.ReLU()                                                   # a found net's placeholder
+    outs = aux.reshape_tails(mixed, xa)
+    sum(o.sum() * (i + 1) for i, o in enumerate(outs)).backward()
+    assert xa[1].grad is None and torch.equal(outs[3], torch.relu(xa[3]))
+    got = [(o.detach().clone(), None if x.grad is None else x.grad.clone(), m.conv.weight.grad.clone()
+            if isinstance(m, aux._ReshapeBase) else None) for o, x, m in zip(outs, xa, mixed)]
+    for m, st in zip(layers, state):
+        m.load_state_dict(st)
+        m.zero_grad()
+    xb = [x.clone().requires_grad_(i != 1) for i, x in enumerate(xs)]
+    ref = [m._tail(x) if isinstance(m, aux._ReshapeBase) else m(x) for m, x in zip(mixed, xb)]
+    sum(o.sum() * (i + 1) for i, o in enumerate(ref)).backward()
+    for i, (m, x) in enumerate(zip(mixed, xb)):
+        assert_close_scaled(f'out {i}', got[i][0], ref[i], rel=1e-5)
+        if x.grad is not None:
+            assert_close_scaled(f'dx {i}', got[i][1], x.grad, rel=1e-5)
+        if got[i][2] is not None:
+            assert_close_scaled(f'dW {i}', got[i][2], m.conv.weight.grad, rel=1e-5)
