@@ -1468,7 +1468,7 @@ struct ConvBwdGroup {
   int dstart[kGroupMax + 1];     // data-gradient blocks (after all weight-gradient blocks); empty: no input gradient
   int wx[kGroupMax], wy[kGroupMax];
   int gx[kGroupMax];
-  int kind[kGroupMax];           // 0: conv_pipe_bwd_body<48, 2>; 3 / 6: conv_ksplit_body<false, 1, 1, KPW>
+  int kind[kGroupMax];           // 0 / 1: conv_pipe_bwd_body<48 / 32, 2>; 3 / 6: conv_ksplit_body<false, 1, 1, KPW>
   int n, n_w;
 };
 
@@ -1489,6 +1489,9 @@ __global__ __launch_bounds__(256, 3) void conv_bwd_group_k(ConvBwdGroup G) {
     if (kind == 0) {
       if (a.bn_U != nullptr) conv_pipe_bwd_body<48, 2, true, kLa2>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
       else conv_pipe_bwd_body<48, 2, false>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+    } else if (kind == 1) {
+      if (a.bn_U != nullptr) conv_pipe_bwd_body<32, 2, true, kLa2>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+      else conv_pipe_bwd_body<32, 2, false>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
     } else if (kind == 3) {
       conv_ksplit_body<false, 1, 1, 3>(a, t % gx, t / gx, group_smem);
     } else {
@@ -2171,6 +2174,15 @@ extern "C" int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n
   for (int p = 0; p < n; ++p) order[p] = p;
   for (int i = 1; i < n; ++i)
     for (int j = i; j > 0 && probs[order[j]].C_in > probs[order[j - 1]].C_in; --j) std::swap(order[j], order[j - 1]);
+  // tile family, decided for the GROUP: the pipelined 32 x 96 tiles reuse their operands 3-6x better than the
+  // 16 x 16 split-K tiles and the group as a whole fills the chip with them from ~96 tiles up, even where a
+  // single layer would not (NTU at 64 samples: 32 tiles per layer, 256 for the group)
+  int Lb0, spw0, ng0;
+  if (int e = check_shape(b > 0 ? b : 1, L, &Lb0, &spw0, &ng0)) return e;
+  long pipe_tiles = 0;
+  for (int q = 0; q < n; ++q)
+    if (probs[q].C_in % 32 == 0) pipe_tiles += (long)((ng0 + 1) / 2) * ((M + kPipeJ - 1) / kPipeJ);
+  const bool use_pipe = pipe_tiles >= 96;
   for (int q = 0; q < n; ++q) {
     const bmnas_conv_fwd_prob_t& P = probs[order[q]];
     if (!P.src || !P.W || !P.U || P.C_in < 16) return BMNAS_E_ARG;
@@ -2183,7 +2195,7 @@ extern "C" int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n
     a.Ci = P.C_in; a.I = P.C_in; a.Cj = M; a.J = M; a.b = b; a.L = L; a.n_part = a.n_groups;
     const int pgx = (a.n_groups + 1) / 2, pgy = (M + kPipeJ - 1) / kPipeJ;
     G.start[q] = blocks;
-    if (P.C_in % 32 == 0 && pgx * pgy >= 48) {
+    if (P.C_in % 32 == 0 && use_pipe) {
       G.kind[q] = 0; G.gx[q] = pgx;
       blocks += pgx * pgy;
       lds = std::max(lds, conv_pipe_lds<32, 2>(L));
@@ -2242,6 +2254,14 @@ extern "C" int bmnas_conv1x1_bwd_group(const bmnas_conv_bwd_prob_t* probs, int n
   }
   G.wstart[n] = blocks;
   G.n_w = blocks;
+  // data-gradient tile family, for the group as a whole (see bmnas_conv1x1_fwd_group)
+  long pipe_tiles = 0;
+  {
+    int Lb0, spw0, ng0;
+    if (int e = check_shape(b > 0 ? b : 1, L, &Lb0, &spw0, &ng0)) return e;
+    for (int q = 0; q < n; ++q)
+      if (probs[q].dsrc != nullptr) pipe_tiles += (long)((ng0 + 1) / 2) * ((probs[q].C_in + kPipeBJ - 1) / kPipeBJ);
+  }
   for (int q = 0; q < n; ++q) {                      // data-gradient tiles
     const bmnas_conv_bwd_prob_t& P = probs[order[q]];
     ConvArgs& a = G.a[q];
@@ -2253,10 +2273,14 @@ extern "C" int bmnas_conv1x1_bwd_group(const bmnas_conv_bwd_prob_t* probs, int n
     a.bn_U = P.bn_U; a.bn_chan = P.bn_chan; a.bn_grad = P.bn_grad; a.bn_train = bn_training;
     const int pgx = (a.n_groups + 1) / 2, pgy = (a.J + kPipeBJ - 1) / kPipeBJ;
     const size_t coef = a.bn_U ? (size_t)a.I * sizeof(float4) : 0;
-    if (M % 48 == 0 && pgx * pgy >= 48) {
+    if (M % 48 == 0 && pipe_tiles >= 96) {
       G.kind[q] = 0; G.gx[q] = pgx;
       blocks += pgx * pgy;
       lds = std::max(lds, conv_pipe_bwd_lds<48, 2>(L) + coef);
+    } else if (M % 32 == 0 && pipe_tiles >= 96) {
+      G.kind[q] = 1; G.gx[q] = pgx;
+      blocks += pgx * pgy;
+      lds = std::max(lds, conv_pipe_bwd_lds<32, 2>(L) + coef);
     } else {
       G.kind[q] = (M / 16 + 3) / 4 <= 3 ? 3 : 6;
       G.gx[q] = a.n_groups;

@@ -88,7 +88,9 @@ def test_grouped_reshape_layers_match_oracle(kind, b, C, L, mode):
         if mode == 'eval':
             assert_close_scaled(tag + ' dconv.bias', layer.conv.bias.grad, q['r.conv.bias'].grad, rel=2e-4)
         else:
-            assert float(layer.conv.bias.grad.abs().max()) < 1e-4
+            # mathematically zero (BatchNorm removes the mean): what is left is the round-off of a sum of b * L
+            # terms of O(1) (the upstream gradients here are N(0, 1), not a loss's 1e-3)
+            assert float(layer.conv.bias.grad.abs().max()) < 2e-6 * b * L + 1e-4
             assert_close_scaled(tag + ' rm', layer.bn.running_mean, q['r.bn.running_mean'])
             assert_close_scaled(tag + ' rv', layer.bn.running_var, q['r.bn.running_var'])
             assert int(layer.bn.num_batches_tracked) == 1

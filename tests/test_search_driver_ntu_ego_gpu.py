@@ -159,7 +159,9 @@ def test_ntu_search_found_and_test_stages(tmp_path, monkeypatch):
     test_acc, g2 = tr.train_ntu_track_acc(found, None, criterion, opt, sched, loaders, sizes, device=device,
                                           num_epochs=2, parallel=False, logger=logger, plotter=Plotter(a), args=a,
                                           status='eval')
-    assert 0.0 <= test_acc <= 1.0 and g2 == genotype
+    # reference quirk kept: with status != 'search' the NTU / Ego trainers return the best DEV genotype
+    # (train_searchable/ntu.py:182, ego.py:177), which their found-stage phases ['train', 'test'] never set
+    assert 0.0 <= test_acc <= 1.0 and g2 is None
     assert float((found.central_classifier.weight.detach() - w0).abs().max()) > 0
     acc = tr.test_ntu_track_acc(found, loaders, criterion, genotype, sizes, device, logger, a)
     found.eval()
@@ -207,7 +209,7 @@ def test_ego_search_found_and_test_stages(tmp_path, monkeypatch):
     test_acc, g2 = tr.train_ego_track_acc(found, None, criterion, opt, sched, loaders, sizes, device=device,
                                           num_epochs=2, parallel=False, logger=logger, plotter=Plotter(a), args=a,
                                           status='eval')
-    assert 0.0 <= test_acc <= 1.0 and g2 == genotype
+    assert 0.0 <= test_acc <= 1.0 and g2 is None          # (the same reference quirk as NTU)
     acc = tr.test_ego_track_acc(found, loaders, criterion, genotype, sizes, device, logger, a)
     found.eval()
     hit = 0
