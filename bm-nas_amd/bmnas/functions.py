@@ -299,6 +299,37 @@ class ConvBnActFn(Function):
                 *dsrcs)
 
 
+class PoolGroupFn(Function):
+    """The AdaptiveMaxPool2d in front of every reshape conv (aux_models.py:62-70, 101-108), all modalities in ONE
+    launch per direction (csrc/pool.hip), output in the (b, C_in, L) layout the grouped GEMM reads.
+    dims[i] = (C, H, W, oh, ow) of input i viewed as (b, C, H, W)."""
+
+    @staticmethod
+    def forward(ctx, dims, *xs):
+        xs = [_c(_f32(x)) for x in xs]
+        _require_gpu(xs[0], 'reshape-layer pooling')
+        b, dev = xs[0].shape[0], xs[0].device
+        outs = [torch.empty((b, d[0], d[3] * d[4]), device=dev, dtype=torch.float32) for d in dims]
+        need = any(ctx.needs_input_grad)
+        idxs = [torch.empty((b, d[0], d[3] * d[4]), device=dev, dtype=torch.int32) if need else None for d in dims]
+        lib.adaptive_maxpool_group(xs, dims, outs, idxs, b)
+        ctx.dims, ctx.idxs, ctx.shapes, ctx.b = dims, idxs, [tuple(x.shape) for x in xs], b
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        sel = [i for i in range(len(gs)) if ctx.needs_input_grad[1 + i]]
+        dxs = [None] * len(gs)
+        if sel:
+            dev = ctx.idxs[sel[0]].device
+            g = [torch.zeros_like(ctx.idxs[i], dtype=torch.float32) if gs[i] is None else _c(gs[i]) for i in sel]
+            dx = [torch.empty(ctx.shapes[i], device=dev, dtype=torch.float32) for i in sel]
+            lib.adaptive_maxpool_group_bwd(g, [ctx.idxs[i] for i in sel], dx, [ctx.dims[i] for i in sel], ctx.b)
+            for i, t in zip(sel, dx):
+                dxs[i] = t
+        return (None, *dxs)
+
+
 class ReshapeGroupFn(Function):
     """The N reshape layers in front of the fusion cell (ReshapeInputLayer{,_MMIMDB}.forward after the pooling,
     aux_models.py:71-74 / 111-114: Conv1d(C_in_i, C, 1) -> BatchNorm1d(C) -> ReLU -> Dropout(drpt) on each of the

@@ -65,6 +65,12 @@ NO_FIN = BnFin()
 MAX_GROUP = 8
 
 
+class PoolProb(C.Structure):
+    """bmnas_pool_prob_t"""
+    _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('idx', C.c_void_p), ('g', C.c_void_p), ('dx', C.c_void_p),
+                ('C', C.c_int), ('H', C.c_int), ('W', C.c_int), ('oh', C.c_int), ('ow', C.c_int)]
+
+
 class ConvFwdProb(C.Structure):
     """bmnas_conv_fwd_prob_t"""
     _fields_ = [('src', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p), ('U', C.c_void_p),
@@ -155,6 +161,8 @@ SIGNATURES = {
     'bmnas_bn_glu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_fwd': ([_P, _P, BnFin, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_adaptive_maxpool_fwd_group': ([C.POINTER(PoolProb), _I, _I, _P], _I),
+    'bmnas_adaptive_maxpool_bwd_group': ([C.POINTER(PoolProb), _I, _I, _P], _I),
     'bmnas_conv1x1_group_ok': ([_I, C.POINTER(C.c_int), _I, _I, _I], _I),
     'bmnas_conv1x1_fwd_group': ([C.POINTER(ConvFwdProb), _I, _I, _I, _I, _I, _P], _I),
     'bmnas_bn_relu_fwd_group': ([C.POINTER(BnReluFwdProb), _I, _I, _I, _I, _P], _I),
@@ -395,6 +403,27 @@ def head_bwd(srcs, sums, dsrcs, acc_mask, ln_w, ln_b, W, hb, stats, mode, g, gsc
                                  None if labels is None else labels.data_ptr(), _ptr(loss), _ptr(part),
                                  b, Cc, L, O, _ptr(scrub),
                                  0 if scrub is None else scrub.numel(), _stream()), 'head_bwd')
+
+
+def adaptive_maxpool_group(xs, dims, outs, idxs, b):
+    """Forward of the grouped AdaptiveMaxPool2d: xs[i] contiguous (b, C_i, ...) viewed as (b, C_i, H_i, W_i) with
+    dims[i] = (C, H, W, oh, ow); outs[i] (b, C, oh * ow); idxs[i] int32 like outs[i], or None."""
+    n = len(xs)
+    probs = (PoolProb * n)()
+    for i in range(n):
+        Cc, H, W, oh, ow = dims[i]
+        probs[i] = PoolProb(_ptr(xs[i]), _ptr(outs[i]), None if idxs[i] is None else idxs[i].data_ptr(), None, None,
+                            Cc, H, W, oh, ow)
+    _check(load().bmnas_adaptive_maxpool_fwd_group(probs, n, b, _stream()), 'adaptive_maxpool_fwd_group')
+
+
+def adaptive_maxpool_group_bwd(gs, idxs, dxs, dims, b):
+    n = len(gs)
+    probs = (PoolProb * n)()
+    for i in range(n):
+        Cc, H, W, oh, ow = dims[i]
+        probs[i] = PoolProb(None, None, idxs[i].data_ptr(), _ptr(gs[i]), _ptr(dxs[i]), Cc, H, W, oh, ow)
+    _check(load().bmnas_adaptive_maxpool_bwd_group(probs, n, b, _stream()), 'adaptive_maxpool_bwd_group')
 
 
 def conv1x1_group_ok(c_ins, b, L, M):

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from bmnas.functions import ConvBnActFn, ReshapeGroupFn
+from bmnas.functions import ConvBnActFn, PoolGroupFn, ReshapeGroupFn
 
 
 class Identity(nn.Module):
@@ -65,6 +65,12 @@ class ReshapeInputLayer(_ReshapeBase):
         out = self.pool(out).view(out.size(0), out.size(1), -1)
         return F.interpolate(out, self.L)
 
+    def pool_dims(self, x):
+        """(C, H, W, oh, ow) of the AdaptiveMaxPool2d that `pooled` applies to x viewed as (b, C, H, W); the
+        F.interpolate(., L) after it is an identity at that size."""
+        H = x.size(2) if x.dim() > 2 else 1
+        return (x.size(1), H, max(1, x[0, 0].numel() // H), self.L, 1)
+
     def forward(self, x):
         return self._tail(self.pooled(x))
 
@@ -82,6 +88,11 @@ class ReshapeInputLayer_MMIMDB(_ReshapeBase):
         out = x.unsqueeze(-1).unsqueeze(-1)
         out = out.view(out.size(0), out.size(1), out.size(2), -1)
         return self.pool(out).view(out.size(0), out.size(1), -1)
+
+    def pool_dims(self, x):
+        H = x.size(2) if x.dim() > 2 else 1
+        side = int(math.sqrt(self.L * 1.0))
+        return (x.size(1), H, max(1, x[0, 0].numel() // H), side, side)
 
     def forward(self, x):
         return self._tail(self.pooled(x))
@@ -126,5 +137,22 @@ def reshape_tails(layers, pooled):
 
 def reshape_all(layers, features):
     """[layer(f) for layer, f in zip(layers, features)] with the conv stacks grouped (reshape_tails)."""
-    pooled = [layer.pooled(f) if isinstance(layer, _ReshapeBase) else f for layer, f in zip(layers, features)]
+    idx = [i for i, (layer, f) in enumerate(zip(layers, features))
+           if isinstance(layer, _ReshapeBase) and torch.is_tensor(f) and f.is_cuda and f.dtype == torch.float32
+           and f.dim() >= 2 and f.numel() > 0 and f[0, 0].numel() < (1 << 31)]
+    pooled = list(features)
+    if len(idx) >= 2 and len({features[i].shape[0] for i in idx}) == 1:
+        # the adaptive max pools of all modalities in one launch (PoolGroupFn), at most lib.MAX_GROUP at a time
+        from bmnas import lib
+        for k in range(0, len(idx), lib.MAX_GROUP):
+            part = idx[k:k + lib.MAX_GROUP]
+            dims = [layers[i].pool_dims(features[i]) for i in part]
+            res = PoolGroupFn.apply(dims, *[features[i] for i in part])
+            for i, r in zip(part, res):
+                pooled[i] = r
+        idx = set(idx)
+    else:
+        idx = set()
+    pooled = [f if (i in idx or not isinstance(layer, _ReshapeBase)) else layer.pooled(f)
+              for i, (layer, f) in enumerate(zip(layers, pooled))]
     return reshape_tails(layers, pooled)

@@ -437,6 +437,23 @@ typedef struct {
   const float* bn_grad;
   int C_in, ldw, ldw_grad, accumulate;   /* accumulate: dsrc += instead of = */
 } bmnas_conv_bwd_prob_t;
+/* The pooling in front of those convs, for the whole group in one launch per direction: AdaptiveMaxPool2d of
+ * x_i viewed as (b, C_i, H_i, W_i) to (oh_i, ow_i), written as (b, C_i, oh_i * ow_i) — the GEMM's operand layout.
+ * ReshapeInputLayer (aux_models.py:62-70): view (b, C_in, T, R), pool to (L, 1), then F.interpolate(., L) which is
+ * an identity at that size; ReshapeInputLayer_MMIMDB (:101-108): view (b, C_in, H, W), pool to (sqrt L, sqrt L).
+ * torch's rule: window of output row i = [floor(i H / oh), ceil((i + 1) H / oh)), first maximum in row-major order,
+ * NaN counts as a maximum.  idx (int32, flat h * W + w, nullable in forward) feeds the backward, which writes EVERY
+ * element of dx (gather form: no zero-fill, no atomics). */
+typedef struct {
+  const float* x;        /* forward: (b, C, H, W) */
+  float* out;            /* forward: (b, C, oh * ow) */
+  int* idx;              /* forward: written if not NULL; backward: read */
+  const float* g;        /* backward: gradient of out */
+  float* dx;             /* backward: (b, C, H, W), every element written */
+  int C, H, W, oh, ow;
+} bmnas_pool_prob_t;
+int bmnas_adaptive_maxpool_fwd_group(const bmnas_pool_prob_t* probs, int n, int b, void* stream);
+int bmnas_adaptive_maxpool_bwd_group(const bmnas_pool_prob_t* probs, int n, int b, void* stream);
 int bmnas_conv1x1_group_ok(int n, const int* C_in, int b, int L, int M);
 int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n, int stat_shards, int b, int L, int M,
                             void* stream);

@@ -126,3 +126,56 @@ def test_grouped_path_equals_the_per_layer_path_and_serves_the_drivers():
             assert_close_scaled(f'dx {i}', got[i][1], x.grad, rel=1e-5)
         if got[i][2] is not None:
             assert_close_scaled(f'dW {i}', got[i][2], m.conv.weight.grad, rel=1e-5)
+
+
+@pytest.mark.parametrize('kind,L,shapes', [
+    # MM-IMDB: VGG feature maps + a vector (mmimdb_darts_searchable.py:99-111); 4x4 pooling of 20x32, 10x16, 5x8 maps
+    ('mmimdb', 16, [(7, 64, 20, 32), (7, 64, 10, 16), (7, 32, 5, 8), (7, 48), (7, 16, 3, 3), (7, 16, 4, 4)]),
+    # NTU / Ego: video maps (T, H, W), skeleton maps (T, J), vectors; T > L, T < L, T == L
+    ('video', 8, [(3, 32, 8, 6, 6), (3, 64, 13, 3, 3), (3, 16, 3, 4), (3, 48), (3, 16, 4, 4), (3, 32, 1, 5, 5)]),
+    ('video', 4, [(2, 16, 9, 7), (2, 32, 4, 2, 2)])])
+def test_grouped_adaptive_max_pool_matches_torch(kind, L, shapes):
+    """PoolGroupFn (csrc/pool.hip) against the reference's own pooling ops (layer.pooled = the aten
+    AdaptiveMaxPool2d + F.interpolate of aux_models.py:62-70 / 101-108): values bit for bit, and the input gradient
+    routed to the same elements (ties included: duplicated maxima are planted), overlapping and repeating windows."""
+    import models.auxiliary.aux_models as aux
+    from bmnas.functions import PoolGroupFn
+    cls = aux.ReshapeInputLayer_MMIMDB if kind == 'mmimdb' else aux.ReshapeInputLayer
+    rng = np.random.Generator(np.random.PCG64(3))
+    layers = [cls(s[1], 16, L, _A(0.0)).to(dev()) for s in shapes]
+    xs = []
+    for s in shapes:
+        x = rng.standard_normal(s).astype(np.float32)
+        x = np.round(x * 2) / 2                               # few distinct values: many ties inside every window
+        xs.append(torch.from_numpy(x).to(dev()))
+    xa = [x.clone().requires_grad_(True) for x in xs]
+    xb = [x.clone().requires_grad_(True) for x in xs]
+    outs = PoolGroupFn.apply([m.pool_dims(x) for m, x in zip(layers, xa)], *xa)
+    ref = [m.pooled(x) for m, x in zip(layers, xb)]
+    ws = [torch.from_numpy(rng.standard_normal(tuple(r.shape)).astype(np.float32)).to(dev()) for r in ref]
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    sum((o * w).sum() for o, w in zip(ref, ws)).backward()
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        assert o.shape == r.shape and torch.equal(o, r), (kind, i)
+        # an input element that is the argmax of several windows (repeating / overlapping windows) receives a SUM:
+        # same terms as torch's scatter, another order -> equal up to fp32 round-off; where it is zero it is exactly zero
+        assert torch.equal(xa[i].grad == 0, xb[i].grad == 0), (kind, i)
+        assert_close_scaled(f'{kind} dx {i}', xa[i].grad, xb[i].grad, rel=1e-6)
+
+
+def test_reshape_all_is_pool_plus_grouped_convs():
+    """aux.reshape_all on raw feature maps = [layer(f)]: 1 pooling launch + the grouped conv launches."""
+    import models.auxiliary.aux_models as aux
+    layers, _ = _build('mmimdb', 192, 16, 0.0, 950)
+    for m in layers:
+        m.train()
+    rng = np.random.Generator(np.random.PCG64(8))
+    shapes = [(16, 512, 20, 32), (16, 512, 20, 32), (16, 512, 10, 16), (16, 512, 5, 8), (16, 64), (16, 128)]
+    raws = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev()) for s in shapes]
+    state = [{k: v.clone() for k, v in m.state_dict().items()} for m in layers]
+    got = aux.reshape_all(layers, raws)
+    for m, st in zip(layers, state):
+        m.load_state_dict(st)
+    ref = [m(f) for m, f in zip(layers, raws)]
+    for i, (a, b_) in enumerate(zip(got, ref)):
+        assert_close_scaled(f'modality {i}', a, b_, rel=1e-4)        # (different tile families: other summation orders)
