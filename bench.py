@@ -184,6 +184,12 @@ def algo_table(C, L):
         'head_fwd': lambda srcs, sums, lw, lb, W, bias, hb, st, b, Cc, L_, O: ('mfma', 2.0 * b * O * len(srcs) * Cc * L_),
         'head_bwd': lambda srcs, sums, ds, m, lw, lb, W, hb, st, mode, g, gs, lab, loss, part, b, Cc, L_, O, *_:
             ('mfma', 4.0 * b * O * len(srcs) * Cc * L_),
+        # the N reshape layers as grouped launches (row f1): sum over the layers of 2 M C_in b L (fwd), twice that bwd
+        'conv1x1_fwd_group': lambda srcs, Ws, bs, Us, st, sh, b, L_, M: ('mfma', sum(2.0 * M * x.shape[1] * b * L_ for x in srcs)),
+        'conv1x1_bwd_group': lambda dVs, Ws, srcs, dsrcs, dWs, dbs, bU, bc, bg, tr, b, L_, M:
+            ('mfma', sum((2.0 + 2.0 * (d is not None)) * M * x.shape[1] * b * L_ for x, d in zip(srcs, dsrcs))),
+        'bn_relu_fwd_group': lambda Us, chans, outs, fins, drops, b, M, L_: ('hbm', sum(2 * T(U) for U in Us)),
+        'bn_relu_bwd_group': lambda gs, Us, chans, dVs, bgs, drops, b, M, L_: ('hbm', sum(3 * T(U) for U in Us)),
         'linear_fwd': lambda feat, W, bias, out, b, O, Kd: ('mfma', 2.0 * b * O * Kd),
         'linear_bwd': lambda g, gs, feat, W, df, dW, db, b, O, Kd: ('mfma', 4.0 * b * O * Kd),
     }
@@ -243,9 +249,11 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
                            'hipGraph replay + one flat RCCL all-reduce + one-launch Adam per step')}
 
 
-def cpu_baseline(cname, c, batch, max_seconds=20.0):
+def cpu_baseline(cname, c, batch, max_seconds=20.0, tier='F'):
     """The CPU oracle (a port of the reference's path: same aten op sequence, pinned against
-    the reference by tests/golden) on this host's cores; same synthetic batch, dropout on."""
+    the reference by tests/golden) on this host's cores; same synthetic batch, dropout on.
+    tier 'R': the reshape layers' conv -> BatchNorm -> ReLU -> dropout stacks on pooled (b, C_in, L)
+    features in front of the hypernet (oracle.reshape_layer minus its pooling), gradients for them too."""
     from oracle import fusion_oracle as fo, synth
     cfg = fo.CONFIGS[cname]
     p = synth.make_params(cfg, 2)
@@ -253,10 +261,31 @@ def cpu_baseline(cname, c, batch, max_seconds=20.0):
     cw, cb = synth.make_classifier(cfg, c['nout'], 2)
     xs = synth.make_inputs(cfg, batch, 0)
     y = synth.make_labels(c['loss'], batch, c['nout'], 0)
+    if tier == 'R':
+        g = torch.Generator().manual_seed(0)
+        raws = [torch.relu(torch.randn(batch, ci, cfg.L, generator=g)) for ci in C_INS[cname]]
+        rp = []
+        for i, ci in enumerate(C_INS[cname]):
+            shapes = {'conv.weight': (cfg.C, ci, 1), 'conv.bias': (cfg.C,), 'bn.weight': (cfg.C,), 'bn.bias': (cfg.C,),
+                      'bn.running_mean': (cfg.C,), 'bn.running_var': (cfg.C,), 'bn.num_batches_tracked': ()}
+            rp.append(synth.make_params(cfg, 100 + i, shapes))
 
     def one():
         t0 = time.perf_counter()
-        fo.search_step(xs, y, arch, p, cw, cb, cfg, c['loss'], training=True)
+        if tier == 'R':
+            leaves = [[v.detach().requires_grad_(True) if v.is_floating_point() and v.dim() > 0 and 'running' not in k
+                       else v for k, v in q.items()] for q in rp]
+            qs = [dict(zip(q.keys(), lv)) for q, lv in zip(rp, leaves)]
+            xr = [x.detach().requires_grad_(True) for x in raws]
+            feats = [fo._dropout(fo._relu(fo._conv_bn(x, q['conv.weight'], q['conv.bias'], q['bn.weight'], q['bn.bias'],
+                                                      q['bn.running_mean'], q['bn.running_var'], True)), cfg.drpt, True)
+                     for x, q in zip(xr, qs)]
+            pp = {k: (v if fo.is_buffer(k) else v.detach().requires_grad_(True)) for k, v in p.items()}
+            a = [t.detach().requires_grad_(True) for t in arch]
+            cwl, cbl = cw.detach().requires_grad_(True), cb.detach().requires_grad_(True)
+            fo.loss_fn(c['loss'])(fo.hypernet_logits(feats, a, pp, cwl, cbl, cfg, True), y).backward()
+        else:
+            fo.search_step(xs, y, arch, p, cw, cb, cfg, c['loss'], training=True)
         return time.perf_counter() - t0
 
     # the op mix is ~1000 small aten calls: more threads than a few cores make it SLOWER
@@ -294,7 +323,8 @@ def cpu_baseline(cname, c, batch, max_seconds=20.0):
             'host_cpus': ncpu,
             'thread_probe_ms': {str(k): round(v * 1e3, 2) for k, v in probe.items()},
             'sample': f'{len(timed)} timed fwd+bwd steps (after {len(times) - len(timed)} warm-up) of the '
-                      f'same {cname} batch-{batch} synthetic workload, torch CPU fp32, median; threads = '
+                      f'same {cname} batch-{batch} synthetic workload' + (' incl. the reshape layers (tier R)' if tier == 'R' else '') + ', torch CPU fp32, median; threads = '
+                      
                       f'faster of the two best of a probe over {sorted(probe)} on a {ncpu}-cpu host'}
 
 
@@ -327,6 +357,8 @@ KERNELS_OF = {
     'head_fwd': ('head_fwd_k',), 'head_bwd': ('head_bwd_k',), 'head_loss_bwd': ('head_loss_bwd_k',),
     'cell_prologue': ('cell_prologue_k',), 'cell_prologue_pair': ('cell_prologue_pair_k',),
     'adam_multi': ('adam_multi_k',),
+    'conv1x1_fwd_group': ('conv_fwd_group_k',), 'conv1x1_bwd_group': ('conv_bwd_group_k',),
+    'bn_relu_fwd_group': ('bn_relu_fwd_group_k',), 'bn_relu_bwd_group': ('bn_relu_bwd_group_k',),
 }
 
 
@@ -439,7 +471,8 @@ def roofline_report(a, c, step, ms_per_step, log):
                 ptr = q + 1
                 break
     unmatched = skipped + [cname for cname, _, _ in calls[ptr:]]
-    tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f'r0{r}_traffic.json') for r in (3, 2))
+                  if os.path.exists(q)), '')
     traffic = {}
     if a.config == 'mmimdb' and a.batch == 128 and a.tier == 'F' and os.path.exists(tpath):
         with open(tpath) as f:
@@ -502,7 +535,7 @@ def roofline_report(a, c, step, ms_per_step, log):
     if top is not None:
         top = dict(top)
         top['measured'] = (source + f'; mean over {len(replays)} replays of End - Start per dispatch; '
-                           'cross-check: profiles/r02_kernel_stats_<config>_b<batch>.csv (rocprofv3 --kernel-trace --stats of the same command)')
+                           'cross-check: profiles/r03_kernel_stats_<config>_b<batch>.csv (rocprofv3 --kernel-trace --stats of the same command)')
         out['roofline'] = top
     return out
 
@@ -974,9 +1007,9 @@ def main():
             result['roofline_error'] = f'{type(e).__name__}: {e}'[:300]
             log(f'roofline pass failed: {e}')
     log('roofline pass done')
-    if rank == 0 and not a.no_cpu_baseline and world == 1 and a.tier == 'F':
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
         try:
-            result['cpu_baseline'] = cpu_baseline(a.config, c, a.batch)
+            result['cpu_baseline'] = cpu_baseline(a.config, c, a.batch, tier=a.tier)
             result['speedup_vs_cpu_baseline'] = round(result['value'] / result['cpu_baseline']['value'], 1)
         except Exception as e:                       # noqa: BLE001
             result['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}

@@ -904,7 +904,8 @@ _TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'cell_prologue_pair', '
                 'bn_relu_ln_fwd', 'bn_relu_ln_bwd',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'node_mix_ln_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',
-                'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy', 'adam_multi')
+                'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy', 'adam_multi', 'conv1x1_fwd_group',
+                'conv1x1_bwd_group', 'bn_relu_fwd_group', 'bn_relu_bwd_group')
 _PLAIN = {}
 
 

@@ -1470,11 +1470,14 @@ struct ConvBwdGroup {
   int gx[kGroupMax];
   int kind[kGroupMax];           // 0 / 1: conv_pipe_bwd_body<48 / 32, 2>; 3 / 6: conv_ksplit_body<false, 1, 1, KPW>
   int n, n_w;
+  int probe;                     // BMNAS_CONV_PROBE bits 32 / 64: drop the weight- / data-gradient blocks (timing only)
 };
 
 __global__ __launch_bounds__(256, 3) void conv_bwd_group_k(ConvBwdGroup G) {
   extern __shared__ __attribute__((aligned(16))) char group_smem[];
   const int n_w = G.n_w;
+  if ((G.probe & 32) && (int)blockIdx.x < n_w) return;
+  if ((G.probe & 64) && (int)blockIdx.x >= n_w) return;
   if ((int)blockIdx.x < n_w) {
     const int p = group_problem(G.wstart, G.n);
     const ConvWArgs w = uni(pick_uniform(G.w, p));
@@ -2289,6 +2292,7 @@ extern "C" int bmnas_conv1x1_bwd_group(const bmnas_conv_bwd_prob_t* probs, int n
     }
   }
   G.dstart[n] = blocks;
+  G.probe = conv_probe();
   if (b == 0) return 0;
   BMNAS_COUNT(F_BWD_GROUP);
   hipLaunchKernelGGL(conv_bwd_group_k, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, G);

@@ -138,6 +138,15 @@ def test_every_family_is_reachable(monkeypatch):
         net = build_search_net(cfg, 3, 'train_nodrop')
         xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, 3)]
         net(xs).sum().backward()
+    # the grouped reshape-layer launches (fwd_group / bwd_group; parity: tests/test_reshape_group_gpu.py)
+    import models.auxiliary.aux_models as aux
+
+    class A:
+        drpt = 0.0
+
+    layers = [aux.ReshapeInputLayer(c_in, 32, 8, A()).to(dev()).train() for c_in in (64, 32)]
+    feats = [torch.randn(4, c_in, 8, device=dev(), requires_grad=True) for c_in in (64, 32)]
+    sum(o.sum() for o in aux.reshape_tails(layers, feats)).backward()
     monkeypatch.setattr(cell, 'FUSE_BWD_ALL', False)
     cfg = fo.Cfg({**fo.CONFIGS['mmimdb'], 'drpt': 0.0})
     net = build_search_net(cfg, 3, 'train_nodrop')
