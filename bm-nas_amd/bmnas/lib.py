@@ -143,6 +143,7 @@ SIGNATURES = {
     'bmnas_conv1x1_bwd_weight': ([_P, _PP, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_fold_weight': ([_P, _P, _I, _I, _P], _I),
     'bmnas_probe_read': ([_P, _I64, _I, _I, _P, _P], _I),
+    'bmnas_probe_barrier': ([_P, _P, _P, _I64, _I, _I, _P, _I, _P], _I),
     'bmnas_conv_family_calls': ([C.POINTER(C.c_long), _I, _I], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),

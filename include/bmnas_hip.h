@@ -663,6 +663,12 @@ int bmnas_comm_info(void* comm, int* n_ranks, int* user_rank, int* hip_device, i
  * 64-byte rows at row_stride floats — the operand pattern of the split-K GEMM kernels, which then reads
  * 64 bytes of every row_stride * 4.  Not part of the hypernet path. */
 int bmnas_probe_read(const float* p, int64_t n_floats, int width, int row_stride, float* sink, void* stream);
+/* Diagnostics (tools/barrier_probe.py; DESIGN.md, the persistent cell-step question): two dependent streaming phases
+ * over n_floats (phase B reads what other workgroups wrote in phase A) as two launches (mode 0) or as ONE launch with a
+ * grid-wide barrier between them (mode 1: agent-scope release -> counter -> poll -> acquire; `counter` zeroed once,
+ * `round` = 1-based call number).  blocks <= 256 (all resident).  Not part of the hypernet path. */
+int bmnas_probe_barrier(const float* in, float* tmp, float* out, int64_t n_floats, int blocks, int mode,
+                        unsigned int* counter, int round, void* stream);
 
 #ifdef __cplusplus
 }
