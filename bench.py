@@ -155,8 +155,6 @@ def algo_table(C, L):
             ('mfma', 2.0 * M * len(ds) * Cs * b * L_),
         'conv1x1_fwd_sdpa': lambda srcs, Cs, W, ldw, bias, U, part, b, L_, M, *_:
             ('mfma', 2.0 * M * len(srcs) * Cs * b * L_ + 4.0 * b * L_ * L_ * Cs),
-        'conv1x1_bwd_data_sdpa': lambda dU, W, ldw, ds, Cs, m, b, L_, M, *_:
-            ('mfma', 2.0 * M * len(ds) * Cs * b * L_ + 12.0 * b * L_ * L_ * Cs),
         'conv1x1_bwd_all_sdpa': lambda dU, W, ldw, ds, Cs, m, b, L_, M, *_:
             ('mfma', 4.0 * M * len(ds) * Cs * b * L_ + 12.0 * b * L_ * L_ * Cs),
         'conv1x1_bwd_all': lambda dU, W, ldw, ds, Cs, m, b, L_, M, *_:
@@ -342,7 +340,6 @@ KERNELS_OF = {
     'conv1x1_bwd_data': ('conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_bwd_k'),
     'conv1x1_bwd_weight': ('conv_w_k',),
     'conv1x1_fwd_sdpa': ('conv_pipe_fwd_sdpa_k', 'conv_fwd_sdpa_k'),
-    'conv1x1_bwd_data_sdpa': ('conv_pipe_bwd_sdpa_k', 'conv_bwd_sdpa_k'),
     'conv1x1_bwd_all_sdpa': ('conv_bwd_all_pipe_k', 'conv_bwd_all_k'),
     # (large grids run as bn_bwd_apply + data + weight launches: the units go to the data-gradient kernel)
     'conv1x1_bwd_all': ('conv_bwd_pair_k', 'conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_bwd_k'),

@@ -302,7 +302,7 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None, mix
     b, L = sv.U.shape[0], sv.U.shape[2]
     # search mode: the merged backward launch applies the BatchNorm input gradient while it stages its
     # operands (bmnas_conv1x1_bwd_all_sdpa, bn_U) — no launch in between
-    fold_bn = attn is not None and dW is not None and FUSE_BWD_ALL and FUSE_BN_APPLY
+    fold_bn = attn is not None and dW is not None and FUSE_BN_APPLY
     # a conv with no attention beside it (out_conv): BatchNorm apply + both gradients behind one C-ABI
     # call, which is one launch at small grids
     live = [s for s in src_slots if s is not None]
@@ -329,7 +329,7 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None, mix
                             dW.shape[1], dbias, sv.dup, (sv.U, sv.chan, bn_grad, sv.training), mix)
         return
     assert mix is None, 'mix epilogue: only with the one-launch out_conv backward'
-    if attn is not None and dW is not None and FUSE_BWD_ALL:
+    if attn is not None and dW is not None:
         # data gradient, weight gradient and the attention backward share one grid
         lib.conv1x1_bwd_all_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, sv.srcs, dW,
                                  dW.shape[1], dbias, sv.dup, *attn,
@@ -337,9 +337,8 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None, mix
         for s, tmp in extra:
             s.buf().add_(tmp.buf())
         return
-    if attn is not None:
-        lib.conv1x1_bwd_data_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, *attn)
-    elif any(x is not None for x in bufs):
+    assert attn is None, 'an attention branch beside the conv needs the weight-gradient buffers (one merged launch)'
+    if any(x is not None for x in bufs):
         lib.conv1x1_bwd_data(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold)
     for s, tmp in extra:
         s.buf().add_(tmp.buf())
@@ -397,8 +396,6 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None,
 
 # search mode: attention branch and conv GEMM share a launch (fwd and bwd); BMNAS_FUSE_ATTN_GEMM=0 for A/B runs
 FUSE_ATTN_GEMM = os.environ.get('BMNAS_FUSE_ATTN_GEMM', '1') != '0'
-# ... and the weight-gradient GEMM joins the backward launch
-FUSE_BWD_ALL = os.environ.get('BMNAS_FUSE_BWD_ALL', '1') != '0'
 # arch softmaxes + folded conv weights of a cell in one launch
 FUSE_PROLOGUE = os.environ.get('BMNAS_FUSE_PROLOGUE', '1') != '0'
 # LayerNorm affine gradients + arch-softmax backward in one launch at the end of a cell's backward

@@ -131,8 +131,6 @@ SIGNATURES = {
     'bmnas_conv1x1_bwd_data': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _P], _I),
     'bmnas_conv1x1_fwd_sdpa': ([_PP, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P, _I, Dropout, _P], _I),
-    'bmnas_conv1x1_bwd_data_sdpa': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I,
-                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P], _I),
     'bmnas_conv1x1_bwd_all_sdpa': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _PP, _P, _I, _P, _I,
                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _I, Dropout, _P, _P, _P, _I, _P], _I),
     'bmnas_conv1x1_bwd_all': ([_P, _P, _I, _I, _PP, _I, _I, _U32, _I, _I, _I, _PP, _P, _I, _P, _I,
@@ -553,15 +551,6 @@ def conv1x1_fwd_sdpa(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold, x, y, ln
            'conv1x1_fwd_sdpa')
 
 
-def conv1x1_bwd_data_sdpa(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, g, gscale, x, y, ln_w, xhat, stats,
-                          dx, dy, sdpa_acc_mask, Cc, drop):
-    _check(load().bmnas_conv1x1_bwd_data_sdpa(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs),
-                                              C_src, acc_mask, b, L, M, _ptr(g),
-                                              None if gscale is None else gscale.data_ptr(), _ptr(x), _ptr(y),
-                                              _ptr(ln_w), _ptr(xhat), _ptr(stats), _ptr(dx), _ptr(dy),
-                                              sdpa_acc_mask, Cc, drop, _stream()), 'conv1x1_bwd_data_sdpa')
-
-
 def conv1x1_bwd_all_sdpa(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, wsrcs, dW, ldw_grad, dbias, dup_cols,
                          g, gscale, x, y, ln_w, xhat, stats, dx, dy, sdpa_acc_mask, Cc, drop, bn=None):
     """bn = (U, chan, bn_grad, training): dU holds dV and the launch applies the BatchNorm input
@@ -901,7 +890,7 @@ def profile_end_calls():
 
 _TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'cell_prologue_pair', 'mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
-                'conv1x1_fwd_sdpa', 'conv1x1_bwd_data_sdpa', 'conv1x1_bwd_all_sdpa', 'conv1x1_bwd_all',
+                'conv1x1_fwd_sdpa', 'conv1x1_bwd_all_sdpa', 'conv1x1_bwd_all',
                 'bn_relu_ln_fwd', 'bn_relu_ln_bwd',
                 'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'node_mix_ln_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',

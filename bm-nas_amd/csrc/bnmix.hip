@@ -1216,8 +1216,6 @@ inline int pick_chunk(int b, int slots4) {
   // chunk 4: 10.2 us, 8: 10.2 us, 16: 12.8 us, 32: 16.5 us.  (Before the dgamma adds were
   // sharded, small chunks were much WORSE: every extra workgroup queued on the same 4 scalars.)
   (void)slots4;
-  static const int forced = []() { const char* e = getenv("BMNAS_MIX_CHUNK"); return e ? atoi(e) : 0; }();
-  if (forced > 0) return forced;           // tuning hook
   return b >= 32 ? 8 : 4;
 }
 

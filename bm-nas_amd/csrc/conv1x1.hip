@@ -862,19 +862,6 @@ __global__ __launch_bounds__(256) void conv_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s
   }
 }
 
-template <int TN, int TJ, int KCH>
-__global__ __launch_bounds__(256) void conv_bwd_sdpa_k(ConvArgs a, SdpaBwdArgs s, int gx) {
-  constexpr int KPW = 3 * KCH;
-  extern __shared__ __attribute__((aligned(16))) char merged_smem[];
-  if ((int)blockIdx.x < s.groups) {
-    sdpa_bwd_body<KCH>(blockIdx.x, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask,
-                       s.G, s.drop, merged_smem);
-  } else {
-    const int t = blockIdx.x - s.groups;
-    conv_ksplit_body<false, TN, TJ, KPW>(a, t % gx, t / gx, merged_smem);
-  }
-}
-
 // the same merged forward launch with the pipelined tile kernel as the GEMM half
 template <int KC, int KCH, int NG>
 __global__ __launch_bounds__(256) void conv_pipe_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s, int gx) {
@@ -1517,7 +1504,7 @@ __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W
 // Which GEMM family a call was dispatched to (diagnostics for tests/test_dispatch_gpu.py: host-side
 // counters, never read by a kernel).  Order = bmnas_conv_family_name().
 enum ConvFamily { F_KSPLIT, F_PIPE_FWD, F_PIPE_BWD, F_LDS, F_FWD_SDPA_PIPE, F_FWD_SDPA_KSPLIT,
-                  F_BWD_SDPA_KSPLIT, F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_BWD_PAIR, F_FWD_GROUP, F_BWD_GROUP, F_COUNT };
+                  F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_BWD_PAIR, F_FWD_GROUP, F_BWD_GROUP, F_COUNT };
 long g_family_calls[F_COUNT] = {0};
 #define BMNAS_COUNT(f) (++g_family_calls[f])
 
@@ -1591,29 +1578,9 @@ bool launch_ksplit_sdpa_fwd(const ConvArgs& a, const SdpaFwdArgs& s, hipStream_t
   return false;
 }
 
-template <int TN, int TJ>
-bool launch_ksplit_sdpa_bwd(const ConvArgs& a, const SdpaBwdArgs& s, hipStream_t st) {
-  const int kch = sdpa_kch(s.G.C);
-  if (a.I != 3 * s.G.C || s.G.C % 64 != 0 || kch > 4) return false;   // K = 3C = 4 waves x 3 KCH blocks
-  if (3 * kch * 4 * (TN + TJ) + 4 * TN * TJ > 232) return false;
-  const int gx = (a.n_groups + TN - 1) / TN, gy = (a.J / 16 + TJ - 1) / TJ;
-  dim3 grid((unsigned)(s.groups + gx * gy));
-  const size_t lds = std::max(sdpa_bwd_lds(s.G.C), conv_ksplit_lds<TN, TJ>());
-#define KS_CASE(K)                                                                                   \
-  if (kch == K) {                                                                                    \
-    BMNAS_COUNT(F_BWD_SDPA_KSPLIT);                                                                  \
-    hipLaunchKernelGGL((conv_bwd_sdpa_k<TN, TJ, K>), grid, dim3(256), lds, st, a, s, gx);            \
-    return true;                                                                                     \
-  }
-  KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4)
-#undef KS_CASE
-  return false;
-}
-
-inline int conv_pipe_min() {         // fewest GEMM workgroups for which the tile kernels are used
-  static const int v = []() { const char* e = getenv("BMNAS_PIPE_MIN"); return e ? atoi(e) : 96; }();
-  return v;
-}
+// fewest GEMM workgroups for which the tile kernels are used (tuned in round 2: 96; the data-gradient tiles pay
+// from half of that)
+inline int conv_pipe_min() { return 96; }
 
 inline int conv_pipe_mode() {        // BMNAS_CONV_PIPE=0 falls back to the split-K kernels (A/B runs)
   static const int v = []() { const char* e = getenv("BMNAS_CONV_PIPE"); return e ? atoi(e) : 1; }();
@@ -1772,9 +1739,8 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
     const int kch = sdpa_kch(C);
     // 64-column tiles only when they already give every CU two workgroups; else 32-column tiles
     // (MM-IMDB batch 128: 384 instead of 192 GEMM workgroups, 8 us per step faster)
-    static const int ng_forced = []() { const char* e = getenv("BMNAS_PIPE_NG"); return e ? atoi(e) : 0; }();
     const int gy = (a.J + kPipeJ - 1) / kPipeJ;
-    const int ngv = ng_forced ? ng_forced : ((a.n_groups + 3) / 4 * gy >= 512 ? 4 : 2);
+    const int ngv = (a.n_groups + 3) / 4 * gy >= 512 ? 4 : 2;
     const int gx = (a.n_groups + ngv - 1) / ngv;
     if (conv_pipe_mode() && a.I == C && a.fold == 0 && a.ldw % 4 == 0 && gx * gy >= conv_pipe_min() && kch <= 4) {
       dim3 grid((unsigned)(s.groups + gx * gy));
@@ -1809,49 +1775,6 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
   return 0;
 }
 
-extern "C" int bmnas_conv1x1_bwd_data_sdpa(const float* dU, const float* W, int ldw, int fold_cols,
-                                           float* const* dsrcs, int n_src, int C_src,
-                                           uint32_t accumulate_mask, int b, int L, int M,
-                                           const float* g, const float* gscale, const float* x,
-                                           const float* y, const float* ln_w, const float* xhat,
-                                           const float* stats, float* dx, float* dy,
-                                           uint32_t sdpa_accumulate_mask, int C, bmnas_dropout_t drop,
-                                           void* stream) {
-  if (!dU || !W || !dsrcs || n_src < 1 || C_src < 1 || b < 0 || M < 1 || fold_cols < 0) return BMNAS_E_ARG;
-  if (!g || !x || !y || !ln_w || !xhat || !stats || !dx) return BMNAS_E_ARG;
-  if (fold_cols % 4 || (fold_cols > 0 && ldw < n_src * C_src + fold_cols)) return BMNAS_E_SHAPE;
-  if (n_src > kConvPtrs) return BMNAS_E_LIMIT;
-  if (C_src % 16 || M % 16 || ldw < n_src * C_src) return BMNAS_E_SHAPE;
-  for (int q = 0; q < n_src; ++q)                    // the two halves run concurrently: no shared output
-    if (dsrcs[q] == dx || (dy && dsrcs[q] == dy)) return BMNAS_E_ARG;
-  ConvArgs a{};
-  if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
-  SdpaBwdArgs s{};
-  if (int e = geom(b, C, L, &s.G)) return e;
-  if (b == 0) return 0;
-  a.act.p[0] = dU;
-  for (int q = 0; q < n_src; ++q) a.dst.p[q] = dsrcs[q];
-  a.W = W; a.bias = nullptr; a.part = nullptr; a.ldw = ldw;
-  a.Ci = M; a.I = M; a.Cj = C_src; a.J = n_src * C_src;
-  a.b = b; a.L = L; a.acc_mask = accumulate_mask; a.probe = 0; a.fold = fold_cols;
-  s.g = g; s.gscale = gscale; s.x = x; s.y = y; s.ln_w = ln_w; s.xhat = xhat; s.stats = stats;
-  s.dx = dx; s.dy = dy; s.acc_mask = sdpa_accumulate_mask; s.drop = to_cfg(drop);
-  s.groups = (b + s.G.spw - 1) / s.G.spw;
-  hipStream_t st = (hipStream_t)stream;
-  const long jt = a.J / 16, ng = a.n_groups;
-  bool done = false;
-  if (((ng + 1) / 2) * ((jt + 1) / 2) >= 1024) done = launch_ksplit_sdpa_bwd<2, 2>(a, s, st);
-  if (!done) done = launch_ksplit_sdpa_bwd<1, 1>(a, s, st);
-  if (!done) {
-    launch_gemm<false>(a, st);
-    BMNAS_CHECK_LAUNCH();
-    return bmnas_sdpa_ln_bwd(g, gscale, x, y, ln_w, xhat, stats, dx, dy, sdpa_accumulate_mask, b, C, L,
-                             drop, stream);
-  }
-  BMNAS_CHECK_LAUNCH();
-  return 0;
-}
-
 namespace {
 // fill the weight-gradient arguments; waves = waves per workgroup of the kernel that will run them
 int fill_w_args(ConvWArgs& a, const float* dU, const float* const* srcs, int n_src, int C_src, float* dW,
@@ -1872,10 +1795,6 @@ int fill_w_args(ConvWArgs& a, const float* dU, const float* const* srcs, int n_s
   // 108 tiles: 2 splits 9.1 us, 3: 10.9, 4: 9.8, 1: 16.8 — every extra split is another round of
   // fp32 atomics on dW), at most 8 n-groups per wave per split, never fewer than one
   int splits = (256 * 8 / waves) / tiles;
-  {
-    static const int forced = []() { const char* e = getenv("BMNAS_CONVW_SPLITS"); return e ? atoi(e) : 0; }();
-    if (forced > 0) splits = forced;
-  }
   const int max_splits = (a.n_groups + 7) / 8;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -1941,9 +1860,8 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   hipStream_t st = (hipStream_t)stream;
   const int kch = sdpa_kch(C);
   bool done = false;
-  static const int ng_forced = []() { const char* e = getenv("BMNAS_PIPE_BNG"); return e ? atoi(e) : 0; }();
   const int gy = (a.J + kPipeBJ - 1) / kPipeBJ;
-  const int ngv = ng_forced ? ng_forced : 2;
+  const int ngv = 2;                                  // 32 x 64 data-gradient tiles (16 x 64 measured slower: +4 us per step)
   const int gx = (a.n_groups + ngv - 1) / ngv;
   const bool pipe_ok = conv_pipe_mode() && a.I % 48 == 0 && a.fold == 0 && a.ldw % 4 == 0 && a.J % 16 == 0 &&
                        kch <= 4 && gx * gy >= conv_pipe_min() / 2;   // measured: pays from ~48 data-gradient tiles up
@@ -1970,17 +1888,12 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
       const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()),
                                   (conv_pipe_bwd_lds<48, 2>(a.L)) + (a.bn_U ? (size_t)a.I * sizeof(float4) : 0));
     // negative wx = XCD-aware weight-gradient tile order (see the kernel)
-    static const bool no_xcd = getenv("BMNAS_CONVW_XCD") && atoi(getenv("BMNAS_CONVW_XCD")) == 0;
-    const int wxa = (!no_xcd && wgrid.z == 4 && wgrid.x % 2 == 0) ? -(int)wgrid.x : (int)wgrid.x;
+    const int wxa = (wgrid.z == 4 && wgrid.x % 2 == 0) ? -(int)wgrid.x : (int)wgrid.x;
 #define PB_CASE(K)                                                                                     \
   if (!done && kch == K) {                                                                             \
     BMNAS_COUNT(F_BWD_ALL_PIPE);                                                                       \
-    if (ngv == 1)                                                                                      \
-      hipLaunchKernelGGL((conv_bwd_all_pipe_k<48, K, 1>), grid, dim3(256), lds, st, a, s, w, gx, n_w,  \
-                         wxa, (int)wgrid.y);                                                  \
-    else                                                                                               \
-      hipLaunchKernelGGL((conv_bwd_all_pipe_k<48, K, 2>), grid, dim3(256), lds, st, a, s, w, gx, n_w,  \
-                         wxa, (int)wgrid.y);                                                  \
+    hipLaunchKernelGGL((conv_bwd_all_pipe_k<48, K, 2>), grid, dim3(256), lds, st, a, s, w, gx, n_w,    \
+                       wxa, (int)wgrid.y);                                                             \
     done = true;                                                                                       \
   }
       PB_CASE(1) PB_CASE(2) PB_CASE(3) PB_CASE(4)
@@ -2310,7 +2223,7 @@ extern "C" int bmnas_conv_family_calls(long* out, int n, int reset) {
 
 extern "C" const char* bmnas_conv_family_name(int i) {
   static const char* names[F_COUNT] = {"ksplit", "pipe_fwd", "pipe_bwd", "lds", "fwd_sdpa_pipe",
-                                       "fwd_sdpa_ksplit", "bwd_sdpa_ksplit", "bwd_all_pipe", "bwd_all_ksplit",
+                                       "fwd_sdpa_ksplit", "bwd_all_pipe", "bwd_all_ksplit",
                                        "conv_w", "bwd_pair", "fwd_group", "bwd_group"};
   return (i >= 0 && i < F_COUNT) ? names[i] : nullptr;
 }

@@ -432,10 +432,8 @@ int fill_prob(LnAffineProb& P, const float* g, const float* gscale, const float*
 
 // samples per workgroup of the LayerNorm affine reductions: 16 up to 256 samples (smaller chunks = more
 // atomics: measured slower, 6.5 vs 4.6 us at b = 128), then b / 16 — every chunk ends in one atomic per
-// element, and at b = 1024 sixteen-sample chunks meant 1.5 M atomics per pass (BMNAS_LN_CHUNK: tuning hook)
+// element, and at b = 1024 sixteen-sample chunks meant 1.5 M atomics per pass
 inline int ln_affine_chunk(int b) {
-  static const int forced = []() { const char* e = getenv("BMNAS_LN_CHUNK"); return e ? atoi(e) : 0; }();
-  if (forced > 0) return forced;
   return b <= 256 ? 16 : (b + 15) / 16;
 }
 

@@ -10,7 +10,7 @@ import torch.nn as nn
 from bmnas.cell import Pack
 from bmnas.functions import CatLnFn, ConvBnActFn, arch_softmax
 
-from .genotypes import STEP_EDGE_PRIMITIVES, STEP_STEP_PRIMITIVES, StepGenotype
+from .genotypes import PRIMITIVES, STEP_EDGE_PRIMITIVES, STEP_STEP_PRIMITIVES, StepGenotype
 from .node_operations import NodeMixedOp
 from .operations import FusionMixedOp, mixed_edge_sum
 
@@ -167,7 +167,11 @@ class FusionNode(nn.Module):
         for i in range(self.node_steps):
             n = self.num_input_nodes + i
             W = ew[start:start + n]
-            strength = [max(W[j][k] for k in range(W.shape[1]) if k != none_idx) for j in range(n)]
+            # the edge RANKING skips PRIMITIVES.index('none') — the cell-level list — as the reference does
+            # (node_search.py:121); the op choice below skips STEP_EDGE_PRIMITIVES.index('none') (:126).  The two
+            # coincide unless someone moves 'none' in an edited PRIMITIVES
+            rank_none = PRIMITIVES.index('none')
+            strength = [max(W[j][k] for k in range(W.shape[1]) if k != rank_none) for j in range(n)]
             # stable descending sort: ties keep the lower edge index first
             keep = sorted(range(n), key=lambda j: -strength[j])[:self.num_keep_edges]
             edge_gene += [(STEP_EDGE_PRIMITIVES[best_op(W[j])], j) for j in keep]

@@ -76,7 +76,7 @@ int bmnas_mixsum_fwd(const float* const* xs, int n_in, const float* w, int w_str
  * products).  The adds of the workgroups are spread round-robin over dw_shards (>= 1) copies of
  * the buffer so that they do not serialise on n_in addresses; the consumer sums the copies
  * (bmnas_arch_softmax_multi does).  g2 (nullable): a second tensor added to g on load — the
- * gradient of the summed state arrives in two parts when bmnas_conv1x1_bwd_data_sdpa produced it. */
+ * gradient of the summed state arrives in two parts when bmnas_conv1x1_bwd_all_sdpa produced it. */
 int bmnas_mixsum_bwd(const float* const* xs, float* const* dxs, int n_in, const float* w,
                      int w_stride, const float* g, const float* g2, float* dw, int dw_shards,
                      int64_t dw_shard_stride, uint32_t accumulate_mask, int64_t n_elem,
@@ -186,20 +186,12 @@ int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C_src, const
                            int b, int L, int M, const float* x, const float* y, const float* ln_w,
                            const float* ln_b, float* out, float* xhat, float* stats, int C,
                            bmnas_dropout_t drop, void* stream);
-/* bmnas_conv1x1_bwd_data and bmnas_sdpa_ln_bwd in ONE launch.  The two halves run concurrently, so
- * dx / dy must not be among dsrcs: the attention gradient goes to its own buffer and the consumer
- * adds the parts (g2 of bmnas_mixsum_bwd / gz2 of bmnas_mixsum_pair_bwd). */
-int bmnas_conv1x1_bwd_data_sdpa(const float* dU, const float* W, int ldw, int fold_cols,
-                                float* const* dsrcs, int n_src, int C_src, uint32_t accumulate_mask,
-                                int b, int L, int M, const float* g, const float* gscale,
-                                const float* x, const float* y, const float* ln_w, const float* xhat,
-                                const float* stats, float* dx, float* dy,
-                                uint32_t sdpa_accumulate_mask, int C, bmnas_dropout_t drop,
-                                void* stream);
 /* bmnas_conv1x1_bwd_data + bmnas_sdpa_ln_bwd + bmnas_conv1x1_bwd_weight in ONE launch: every
  * contraction of a NodeMixedOp's backward (search mode).  wsrcs: the conv's forward inputs
  * (n_src x (b, C_src, L)) for the weight gradient; dW / ldw_grad / dbias / dup_cols as in
- * bmnas_conv1x1_bwd_weight; the rest as in bmnas_conv1x1_bwd_data_sdpa.  Shapes outside the merged
+ * bmnas_conv1x1_bwd_weight.  The three block classes run concurrently, so dx / dy must not be among dsrcs: the
+ * attention gradient goes to its own buffer and the consumer adds the parts (g2 of bmnas_mixsum_bwd / gz2 of
+ * bmnas_mixsum_pair_bwd).  Shapes outside the merged
  * kernels (M != 3C, C > 256) run as the three separate launches. 
  * bn_U != NULL folds the BatchNorm input gradient into the launch: dU then holds dV (the gradient
  * w.r.t. the BatchNorm OUTPUT, bn_grad already reduced) and the tile kernels form

@@ -14,7 +14,6 @@ fp32 torch contraction in the same test, so no family runs unverified:
                             ones) — no reference shape needs it (round 3 removed the second fallback, conv_nj_k)
     fwd_sdpa_pipe / _ksplit conv + attention in one launch (search NodeMixedOp, large / small batch)
     bwd_all_pipe / _ksplit  data-gradient + weight-gradient + attention backward in one launch
-    bwd_sdpa_ksplit         data-gradient + attention backward (BMNAS_FUSE_BWD_ALL=0 path)
     conv_w                  weight-gradient GEMM alone
 """
 import numpy as np
@@ -29,8 +28,7 @@ import os
 
 # the expectations below describe the DEFAULT dispatch; tools/test_matrix.sh forces other kernel families
 # through these switches on purpose (their results are checked by the parity tests, not here)
-_FORCED = [k for k in ('BMNAS_KSPLIT_MULTI', 'BMNAS_CONV_PIPE', 'BMNAS_FUSE_ATTN_GEMM', 'BMNAS_FUSE_BWD_ALL', 'BMNAS_PIPE_MIN',
-                       'BMNAS_PIPE_NG', 'BMNAS_PIPE_BNG', 'BMNAS_FUSE_BWD_PAIR') if os.environ.get(k) is not None]
+_FORCED = [k for k in ('BMNAS_KSPLIT_MULTI', 'BMNAS_CONV_PIPE', 'BMNAS_FUSE_ATTN_GEMM', 'BMNAS_FUSE_BWD_PAIR') if os.environ.get(k) is not None]
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(bool(_FORCED), reason=f'kernel family forced by {_FORCED}')]
 
@@ -127,7 +125,7 @@ def test_cat_of_two_sources_with_long_contraction_takes_the_generic_kernel():
 
 
 def test_every_family_is_reachable(monkeypatch):
-    """Union over the cases above + the BMNAS_FUSE_BWD_ALL=0 route: no dead GEMM family."""
+    """Union over the cases above: no dead GEMM family."""
     from bmnas import cell, lib
     lib.conv_family_calls(reset=True)
     _conv_case(6, 2048, 128, 8, n_src=2)
@@ -147,11 +145,6 @@ def test_every_family_is_reachable(monkeypatch):
     layers = [aux.ReshapeInputLayer(c_in, 32, 8, A()).to(dev()).train() for c_in in (64, 32)]
     feats = [torch.randn(4, c_in, 8, device=dev(), requires_grad=True) for c_in in (64, 32)]
     sum(o.sum() for o in aux.reshape_tails(layers, feats)).backward()
-    monkeypatch.setattr(cell, 'FUSE_BWD_ALL', False)
-    cfg = fo.Cfg({**fo.CONFIGS['mmimdb'], 'drpt': 0.0})
-    net = build_search_net(cfg, 3, 'train_nodrop')
-    xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, 8, 3)]
-    net(xs).sum().backward()
     torch.cuda.synchronize()
     calls = lib.conv_family_calls()
     dead = [k for k, v in calls.items() if v == 0]
