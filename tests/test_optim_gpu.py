@@ -263,5 +263,7 @@ def test_overlapped_bucket_reduction_gives_the_same_gradients():
             # (fp32 atomics accumulate these in a run-dependent order: 1e-5 of scale, not bit equality; a part
             # copied before its gradients were final, or overwritten by the final copy, would be off by O(1))
             assert torch.isfinite(over).all(), (cname, k)
+            if k.endswith('conv.bias'):
+                continue                     # mathematically zero in front of a train-mode BatchNorm: pure round-off
             # (the arch gradients are small differences of sharded atomic sums: 1e-4-level run-to-run)
             assert_close_scaled(f'{cname}:{k}', over, plain, rel=1e-3 if k.startswith('arch.') else 2e-5, floor=1e-9)
