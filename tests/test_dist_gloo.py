@@ -92,6 +92,11 @@ def _worker(rank, world, port, tmp):
     # must NOT average a second time.  gloo has no ReduceOp.AVG: avg_supported() must say so.
     assert bdist.avg_supported(torch.device('cpu')) is False
     red = opt._bmnas_reducer
+    # the collective plan is decided once, for captured and eager steps alike (gloo: pre-scaled sum)
+    assert red.plan() == 'presum' and red.loss_scale == 1.0 / world
+    # ranks agree on a locally decided flag: true only if true everywhere (capture success, communicator creation)
+    assert bdist.all_ranks_agree(True, torch.device('cpu')) is True
+    assert bdist.all_ranks_agree(rank == 0, torch.device('cpu')) is False
     views = red.ensure_bucket()
     xs, ys = bdist.shard(X, rank, world), bdist.shard(Y, rank, world)
     grads = torch.autograd.grad(crit(model(xs), ys) / world, list(model.parameters()))

@@ -362,3 +362,28 @@ def test_searcher_facades_build_loaders_and_hand_over(monkeypatch):
     s2 = S.MMIMDB_Searcher(A(), 'dev0', 'log')
     ld = s2.dataloaders['train']
     assert isinstance(ld.sampler, DistributedSampler) and ld.batch_size == 2 and len(list(ld.sampler)) == 5
+
+
+def test_bench_line_is_the_median_region_of_the_fastest_shape():
+    """bench.headline (host logic of the JSON line): value / ms_per_step come from the MEDIAN timed region of the
+    fastest measured step shape, every shape is reported, `steps` stays the per-region count."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as B
+
+    class A:
+        config, tier, batch, steps, warmup, mode = 'mmimdb', 'F', 128, 20, 5, 'graph'
+
+    c = B.CONFIGS['mmimdb']
+    shapes = {'host': [0.0050, 0.0046, 0.0048, 0.0047, 0.0100], 'graph': [0.0040, 0.0041, 0.0039, 0.0040, 0.0042]}
+    d = B.headline(A(), c, 8, shapes, 'graph', 1.4, {'ranks': 8})
+    assert d['n_gpus'] == 8 and d['steps'] == 20 and d['scaling'] == 'weak' and d['unit'] == 'steps/s'
+    assert abs(d['ms_per_step'] - 0.2) < 1e-9 and abs(d['value'] - 8 * 20 / 0.0040) < 1e-6
+    assert d['timed_regions'] == {'n': 5, 'steps_each': 20, 'headline': 'median',
+                                  'ms_per_step': [0.2, 0.205, 0.195, 0.2, 0.21]}
+    assert d['step_shapes']['headline'] == 'graph' and d['step_shapes']['host']['ms_per_step_median'] == 0.24
+    assert 'inside one hipGraph' in d['config']['step'] and d['config']['global_batch'] == 1024
+    assert d['rccl'] == {'ranks': 8} and d['vs_baseline'] is None and d['dtype'] == 'f32'
+    single = B.headline(A(), c, 1, {'single': [0.0033] * 5}, 'single', None, None)
+    assert 'step_shapes' not in single and 'rccl' not in single and single['config']['parallelism'] == 'dp1'
