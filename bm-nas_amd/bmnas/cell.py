@@ -300,9 +300,11 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None, mix
     """dV (gradient w.r.t. the BN output, with bn_grad already reduced) -> in place dU;
     then data gradient into src_slots and weight/bias gradient (+=) into dW / dbias."""
     b, L = sv.U.shape[0], sv.U.shape[2]
+    if not WANT_PARAM_GRADS:
+        dW = dbias = None                     # (the merged launch then carries no weight-gradient tiles)
     # search mode: the merged backward launch applies the BatchNorm input gradient while it stages its
     # operands (bmnas_conv1x1_bwd_all_sdpa, bn_U) — no launch in between
-    fold_bn = attn is not None and dW is not None and FUSE_BN_APPLY
+    fold_bn = attn is not None and FUSE_BN_APPLY
     # a conv with no attention beside it (out_conv): BatchNorm apply + both gradients behind one C-ABI
     # call, which is one launch at small grids
     live = [s for s in src_slots if s is not None]
@@ -329,10 +331,10 @@ def conv_bn_bwd(sv, dV, bn_grad, src_slots, dW, dbias, fork=None, attn=None, mix
                             dW.shape[1], dbias, sv.dup, (sv.U, sv.chan, bn_grad, sv.training), mix)
         return
     assert mix is None, 'mix epilogue: only with the one-launch out_conv backward'
-    if attn is not None and dW is not None:
-        # data gradient, weight gradient and the attention backward share one grid
+    if attn is not None:
+        # data gradient, weight gradient (if wanted) and the attention backward share one grid
         lib.conv1x1_bwd_all_sdpa(dV, sv.W, sv.ldw, bufs, sv.C_src, mask, b, L, sv.M, sv.fold, sv.srcs, dW,
-                                 dW.shape[1], dbias, sv.dup, *attn,
+                                 0 if dW is None else dW.shape[1], dbias, sv.dup, *attn,
                                  (sv.U, sv.chan, bn_grad, sv.training) if fold_bn else None)
         for s, tmp in extra:
             s.buf().add_(tmp.buf())
@@ -464,6 +466,8 @@ class Deferred:
 
 
 def _ln_affine(deferred, g, gscale, srcs, resid, ln_w, ln_b, stats, dln_w, dln_b, b, C, L, relu, prenorm):
+    if not WANT_PARAM_GRADS:
+        return
     if deferred is None:
         lib.ln_affine_bwd(g, gscale, srcs, resid, ln_w, ln_b, stats, dln_w, dln_b, b, C, L, relu, prenorm)
     else:
@@ -663,7 +667,7 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
         mix = None
         mlast = sv.mixed[ns - 1]
         last_slot = slots[2 + ns - 1]
-        if (FUSE_MIX_EPILOGUE and FUSE_BWD_PAIR and mlast.same and last_slot.get() is None
+        if (FUSE_MIX_EPILOGUE and FUSE_BWD_PAIR and WANT_PARAM_GRADS and mlast.same and last_slot.get() is None
                 and len({id(slots[j]) for j in tail}) == nm and sv.oconv.fold == 0
                 and lib.conv1x1_bwd_all_mix_ok(b, L, C, nm, C)):
             # the last inner step's mix backward rides in the out_conv data-gradient tiles of its channels
@@ -786,6 +790,32 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
     return out, sv
 
 
+# False while a backward runs in which NO parameter of the cell (nor of the fused classifier) needs a gradient — the
+# architecture step of the search loop (architect.py:21-29) differentiates alpha / beta / gamma only.  The reference
+# computes every weight gradient there anyway (loss.backward()) and throws them away at the next zero_grad(); a
+# captured architecture step (bmnas.graph.GraphedTrainStep over the arch optimizer) asks for the arch gradients only
+# and says so with `arch_grads_only()`: the weight-gradient GEMM tiles, the LayerNorm-affine reductions and the
+# classifier's weight-gradient product are then not launched / carried.  (autograd cannot tell a custom Function which
+# of its inputs a torch.autograd.grad call is after: ctx.needs_input_grad is fixed at forward time.)
+WANT_PARAM_GRADS = True
+_ARCH_ONLY = [False]
+
+
+class arch_grads_only:
+    """with arch_grads_only(on): a backward that runs inside differentiates architecture tensors only — no module
+    parameter and no input of the fused cell gets a gradient (so nothing upstream of the cell runs its backward)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _ARCH_ONLY[0] = _ARCH_ONLY[0], self.on
+        return self
+
+    def __exit__(self, *exc):
+        _ARCH_ONLY[0] = self.prev
+        return False
+
 # Data-parallel overlap (bench.py's 'overlap' shape): a callable (i, NG) invoked right after the launches of
 # step node i's backward have been issued.  From that point the node's conv / BatchNorm gradients in NG
 # (stack_dW, stack_dbias, stack_bn_grad, out_conv_dW / _db, bn_grad) are final — its LayerNorm-affine gradients
@@ -810,14 +840,18 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
         # (dWcls, dbcls, the K7 affine gradients) leave as per-chunk partials summed by the epilogue
         O, D = head.W.shape[0], M * C * L
         n_chunk = lib.head_chunks(b)
-        part = _empty(x0, n_chunk * (O + 3) * D)
-        hsum = _empty(x0, (O + 3) * D)
+        want = WANT_PARAM_GRADS
+        part = _empty(x0, n_chunk * (O + 3) * D) if want else None
         mode, gten, gscale, labels = head.resolve(g)
         lib.head_bwd(sv.states[-M:], head.sums, bufs, mask, CP.ln_w, CP.ln_b, head.W, head.hb, sv.stats, mode,
                      gten, gscale, labels, head.loss, part, b, C, L, O, getattr(CG, 'scrub', None))
-        sums = ((part, hsum, n_chunk),)
-        head.dW, head.dbias = hsum[:O * D].view(O, D), hsum[(O + 2) * D:(O + 2) * D + O]
-        CG.dln_w, CG.dln_b = hsum[O * D:(O + 1) * D].view(M * C, L), hsum[(O + 1) * D:(O + 2) * D].view(M * C, L)
+        head.dW = head.dbias = None
+        if want:
+            hsum = _empty(x0, (O + 3) * D)
+            sums = ((part, hsum, n_chunk),)
+            head.dW, head.dbias = hsum[:O * D].view(O, D), hsum[(O + 2) * D:(O + 2) * D + O]
+            CG.dln_w = hsum[O * D:(O + 1) * D].view(M * C, L)
+            CG.dln_b = hsum[(O + 1) * D:(O + 2) * D].view(M * C, L)
     else:
         lib.cat_ln_bwd(g, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, bufs, None, mask, None, None,
                        b, C, L, True, getattr(CG, 'scrub', None))

@@ -532,7 +532,7 @@ class FusedCellFn(Function):
     def backward(ctx, g):
         cell, sv, N, S = ctx.cell, ctx.sv, ctx.N, ctx.S
         dev = ctx.dev
-        need_in = [ctx.needs_input_grad[5 + j] for j in range(N)]
+        need_in = [ctx.needs_input_grad[5 + j] and not K._ARCH_ONLY[0] for j in range(N)]
         # one zero-filled arena for every gradient that is accumulated with atomics
         CG, dalpha_w, dbeta_ws, dgamma_ws = cell.grad_pack(dev, sv.alpha_w, ctx.beta_ws, ctx.gamma_ws)
         ws, dws = [], []
@@ -542,8 +542,16 @@ class FusedCellFn(Function):
         if ctx.alpha_is_logits:
             ws, dws = [sv.alpha_w] + ws, [dalpha_w] + dws
         darch = [torch.empty_like(w) for w in ws]
-        dxs = K.fusion_cell_bwd(sv, g if sv.head is not None else _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws,
-                                CG, (ws, dws, darch))
+        # does ANY parameter of the cell / the fused classifier need its gradient?  (a captured architecture step
+        # says no: K.arch_grads_only)
+        first_param = 5 + N + 2 * S
+        want = any(ctx.needs_input_grad[first_param:]) and not K._ARCH_ONLY[0]
+        saved, K.WANT_PARAM_GRADS = K.WANT_PARAM_GRADS, want
+        try:
+            dxs = K.fusion_cell_bwd(sv, g if sv.head is not None else _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws,
+                                    CG, (ws, dws, darch))
+        finally:
+            K.WANT_PARAM_GRADS = saved
         if not sv.epilogue_done:
             lib.arch_softmax_multi(ws, dws, darch, True, CG.shards, CG.shard_stride)
         if ctx.alpha_is_logits:
@@ -554,7 +562,8 @@ class FusedCellFn(Function):
                                       (CG.shard_stride, *dalpha_w.stride()),
                                       dalpha_w.storage_offset()).sum(0)
         head_grads = (sv.head.dW, sv.head.dbias) if ctx.n_head else ()
-        return (None, None, None, dalpha, None, *dxs, *darch, *cell.grads_in_param_order(CG), *head_grads)
+        pgrads = cell.grads_in_param_order(CG) if want else [None] * len(cell.param_list())
+        return (None, None, None, dalpha, None, *dxs, *darch, *pgrads, *head_grads)
 
 
 # ------------------------------------------------------- classifier + criterion epilogue

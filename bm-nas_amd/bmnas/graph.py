@@ -130,6 +130,10 @@ class GraphedTrainStep:
                                'drop them (or call this before the first eager backward)')
         self.optimizer = optimizer
         self.targets = [p for g in optimizer.param_groups for p in g['params']]
+        # the architecture step differentiates alpha / beta / gamma only: no module parameter among the targets
+        # -> the fused cell skips every weight-gradient product of its backward (bmnas.cell.arch_grads_only)
+        pids = {id(p) for p in model.parameters()}
+        self.arch_only = not any(id(t) in pids for t in self.targets)
         reducer = getattr(optimizer, '_bmnas_reducer', None)
         if reducer is not None and reducer.world <= 1:
             reducer = None
@@ -157,11 +161,12 @@ class GraphedTrainStep:
                 if isinstance(logits, tuple):
                     logits = logits[-1]
                 loss = criterion(logits, self.labels)
-            if scale != 1.0:
-                grads = torch.autograd.grad(loss * scale, self.targets, allow_unused=True)
-            else:
-                grads = torch.autograd.grad(loss, self.targets, grad_outputs=unit_grad(loss.device),
-                                            allow_unused=True)
+            with K.arch_grads_only(self.arch_only):
+                if scale != 1.0:
+                    grads = torch.autograd.grad(loss * scale, self.targets, allow_unused=True)
+                else:
+                    grads = torch.autograd.grad(loss, self.targets, grad_outputs=unit_grad(loss.device),
+                                                allow_unused=True)
             if reducer is not None:
                 have = [(v, g) for v, g in zip(views, grads) if g is not None]
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])

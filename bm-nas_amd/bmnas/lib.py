@@ -554,10 +554,11 @@ def conv1x1_fwd_sdpa(srcs, C_src, W, ldw, bias, U, part, b, L, M, fold, x, y, ln
 def conv1x1_bwd_all_sdpa(dU, W, ldw, dsrcs, C_src, acc_mask, b, L, M, fold, wsrcs, dW, ldw_grad, dbias, dup_cols,
                          g, gscale, x, y, ln_w, xhat, stats, dx, dy, sdpa_acc_mask, Cc, drop, bn=None):
     """bn = (U, chan, bn_grad, training): dU holds dV and the launch applies the BatchNorm input
-    gradient on the fly (no bn_bwd_apply launch)."""
+    gradient on the fly (no bn_bwd_apply launch).  dW None: no weight-gradient tiles in the launch."""
     bU, bchan, bgrad, btrain = (None, None, None, 0) if bn is None else bn
     _check(load().bmnas_conv1x1_bwd_all_sdpa(_ptr(dU), W.data_ptr(), ldw, fold, _ptrs(dsrcs), len(dsrcs),
-                                             C_src, acc_mask, b, L, M, _ptrs(wsrcs), dW.data_ptr(), ldw_grad,
+                                             C_src, acc_mask, b, L, M, _ptrs(wsrcs),
+                                             None if dW is None else dW.data_ptr(), ldw_grad,
                                              None if dbias is None else dbias.data_ptr(), dup_cols, _ptr(g),
                                              None if gscale is None else gscale.data_ptr(), _ptr(x), _ptr(y),
                                              _ptr(ln_w), _ptr(xhat), _ptr(stats), _ptr(dx), _ptr(dy),

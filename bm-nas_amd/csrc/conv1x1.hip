@@ -1841,9 +1841,13 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   for (int q = 0; q < n_src; ++q)
     if (dsrcs[q] == dx || (dy && dsrcs[q] == dy)) return BMNAS_E_ARG;
   ConvWArgs w{};
-  dim3 wgrid;
-  if (int e = fill_w_args(w, dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, 4, &wgrid))
-    return e;
+  dim3 wgrid(0, 1, 1);
+  // dW == NULL: nobody wants the weight / bias gradients (the architecture step of the search loop differentiates
+  // alpha / beta / gamma only): the launch then carries no weight-gradient tiles
+  if (dW != nullptr) {
+    if (int e = fill_w_args(w, dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, 4, &wgrid))
+      return e;
+  }
   ConvArgs a{};
   if (int e = check_shape(b, L, &a.Lb, &a.spw, &a.n_groups)) return e;
   SdpaBwdArgs s{};
@@ -1929,6 +1933,7 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
     if (int e = bmnas_sdpa_ln_bwd(g, gscale, x, y, ln_w, xhat, stats, dx, dy, sdpa_accumulate_mask, b, C, L,
                                   drop, stream))
       return e;
+    if (dW == nullptr) return 0;
     return bmnas_conv1x1_bwd_weight(dU, wsrcs, n_src, C_src, dW, ldw_grad, dbias, dup_cols, b, L, M, stream);
   }
   BMNAS_CHECK_LAUNCH();

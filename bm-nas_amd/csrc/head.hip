@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
     }
   }
   __syncthreads();
-  if (blockIdx.x == 0 && (int)threadIdx.x < a.O) {              // dbias partial of this chunk
+  if (a.part != nullptr && blockIdx.x == 0 && (int)threadIdx.x < a.O) {   // dbias partial of this chunk
     float t = 0.f;
 #pragma unroll
     for (int rr = 0; rr < kRows; ++rr) t += dl_s[rr][threadIdx.x];
@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
     gw[r] = group16_sum(gw[r]);
     gb[r] = group16_sum(gb[r]);
   }
+  // (part == NULL: nobody wants the classifier / K7-affine gradients — the architecture step of the search loop
+  // differentiates alpha / beta / gamma only — so the affine partials and GEMM 2 are skipped)
+  if (a.part == nullptr) return;
   if (lo == 0) {
     st4(part + (int64_t)a.O * a.D + k0 + 4 * h, make_float4(gw[0], gw[1], gw[2], gw[3]));
     st4(part + (int64_t)(a.O + 1) * a.D + k0 + 4 * h, make_float4(gb[0], gb[1], gb[2], gb[3]));
@@ -484,8 +487,8 @@ extern "C" int bmnas_head_bwd(const float* const* srcs, const float* const* sums
                               const float* W, const float* hb, const float* stats, int mode, const float* g,
                               const float* gscale, const void* labels, float* loss, float* part,
                               int b, int C, int L, int O, float* scrub, int64_t scrub_n, void* stream) {
-  if (!dsrcs || !ln_w || !ln_b || !W || !hb || !stats || !part || b < 0 || C < 1 || L < 1 || O < 1)
-    return BMNAS_E_ARG;
+  if (!dsrcs || !ln_w || !ln_b || !W || !hb || !stats || b < 0 || C < 1 || L < 1 || O < 1)
+    return BMNAS_E_ARG;                          // (part may be NULL: no classifier / K7-affine gradients wanted)
   if (mode < 0 || mode > 2 || (mode == 0 && !g) || (mode != 0 && (!labels || !loss))) return BMNAS_E_ARG;
   if (scrub_n < 0 || (scrub_n > 0 && !scrub) || scrub_n % 4) return BMNAS_E_ARG;
   if (O > kMaxO) return BMNAS_E_LIMIT;

@@ -492,3 +492,71 @@ def test_graph_steps_survive_eager_steps_in_between():
     model0 = _interleave_model(cfg, seed, nout)
     moved = max(float((a - p.detach().cpu()).abs().max()) for a, p in zip(finals['eager'], model0.parameters()))
     assert moved > 1e-3
+
+
+@pytest.mark.parametrize('name,batch,nout,loss_kind', [('mmimdb', 32, 23, 'bce'), ('ntu', 8, 60, 'ce'), ('ego', 6, 83, 'ce')])
+@pytest.mark.parametrize('head', [None, 'deferred'])
+def test_architecture_step_backward_skips_the_weight_gradients(name, batch, nout, loss_kind, head, monkeypatch):
+    """Architect.step differentiates alpha / beta / gamma only (architect.py:21-29; the captured step calls
+    torch.autograd.grad(loss, arch_parameters) inside bmnas.cell.arch_grads_only()).  The backward then carries no weight-gradient tiles, no
+    LayerNorm-affine reductions and no classifier weight-gradient product — and the architecture gradients are the
+    ones a full backward gives."""
+    from bmnas import lib
+    cfg = fo.Cfg({**fo.CONFIGS[name], 'drpt': 0.0})
+    meta = dict(cfg=dict(cfg), seed=17, batch=batch, num_outputs=nout, loss=loss_kind, mode='train_nodrop',
+                has_grads=False)
+
+    def forward():
+        from bmnas import nn as bnn
+        net = build_search_net(cfg, 17, 'train_nodrop')
+        cls = (torch.nn.Linear if head is None else bnn.Linear)(cfg.M * cfg.C * cfg.L, nout).to(dev())
+        cw, cb = synth.make_classifier(cfg, nout, 17)
+        cls.weight.data.copy_(cw)
+        cls.bias.data.copy_(cb)
+        xs = [x.to(dev()) for x in synth.make_inputs(cfg, batch, 17)]
+        y = synth.make_labels(loss_kind, batch, nout, 17).to(dev())
+        if head is None:
+            crit = torch.nn.BCEWithLogitsLoss() if loss_kind == 'bce' else torch.nn.CrossEntropyLoss()
+            return net, cls, crit(cls(net(xs)), y)
+        crit = bnn.BCEWithLogitsLoss() if loss_kind == 'bce' else bnn.CrossEntropyLoss()
+        with bnn.fused_criterion(True):
+            return net, cls, crit(net.forward_classified(xs, cls), y)
+
+    net, cls, loss = forward()
+    full = torch.autograd.grad(loss, list(net.arch_parameters()) + list(net.parameters()) + list(cls.parameters()))
+    want = [g.clone() for g in full[:len(net.arch_parameters())]]
+    seen = {'dW_none': 0, 'dW': 0, 'ln': 0, 'part_none': 0}
+    real_all, real_ln, real_ep, real_head = lib.conv1x1_bwd_all_sdpa, lib.ln_affine_bwd_multi, lib.backward_epilogue, lib.head_bwd
+
+    def spy_all(*a, **k):
+        seen['dW_none' if a[11] is None else 'dW'] += 1
+        return real_all(*a, **k)
+
+    def spy_ln(*a, **k):
+        seen['ln'] += 1
+        return real_ln(*a, **k)
+
+    def spy_ep(probs, *a, **k):
+        seen['ln'] += len(probs)
+        return real_ep(probs, *a, **k)
+
+    def spy_head(*a, **k):
+        seen['part_none'] += a[14] is None
+        return real_head(*a, **k)
+
+    monkeypatch.setattr(lib, 'conv1x1_bwd_all_sdpa', spy_all)
+    monkeypatch.setattr(lib, 'ln_affine_bwd_multi', spy_ln)
+    monkeypatch.setattr(lib, 'backward_epilogue', spy_ep)
+    monkeypatch.setattr(lib, 'head_bwd', spy_head)
+    from bmnas import cell as K
+    net2, cls2, loss2 = forward()
+    with K.arch_grads_only():                             # what GraphedTrainStep does for the arch optimizer
+        got = torch.autograd.grad(loss2, list(net2.arch_parameters()))
+    assert seen['dW'] == 0 and seen['dW_none'] == cfg.S * cfg.ns and seen['ln'] == 0, seen
+    assert seen['part_none'] == (1 if head is not None else 0), seen
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert_close_scaled(f'arch.{i}', g, w, rel=1e-4)
+    # ... and a full backward afterwards still produces every gradient (the switch is per backward)
+    net3, cls3, loss3 = forward()
+    loss3.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net3.parameters())
