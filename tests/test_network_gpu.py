@@ -552,8 +552,10 @@ def test_architecture_step_backward_skips_the_weight_gradients(name, batch, nout
     net2, cls2, loss2 = forward()
     with K.arch_grads_only():                             # what GraphedTrainStep does for the arch optimizer
         got = torch.autograd.grad(loss2, list(net2.arch_parameters()))
-    assert seen['dW'] == 0 and seen['dW_none'] == cfg.S * cfg.ns and seen['ln'] == 0, seen
-    assert seen['part_none'] == (1 if head is not None else 0), seen
+    assert seen['dW'] == 0 and seen['ln'] == 0, seen
+    if K.FUSE_ATTN_GEMM:                                  # (default dispatch: one merged backward launch per inner step)
+        assert seen['dW_none'] == cfg.S * cfg.ns, seen
+    assert seen['part_none'] == (1 if (head is not None and K.FUSE_HEAD) else 0), seen
     for i, (g, w) in enumerate(zip(got, want)):
         assert_close_scaled(f'arch.{i}', g, w, rel=1e-4)
     # ... and a full backward afterwards still produces every gradient (the switch is per backward)
