@@ -86,6 +86,15 @@ __global__ __launch_bounds__(256) void linear_fwd_k(const float* __restrict__ fe
   }
 }
 
+// the zero fill in front of linear_fwd_k's atomics.  A kernel, not hipMemsetAsync: captured into a hipGraph
+// (bmnas.graph.GraphedStep around a classifier that is not fused into the cell's tail) the memset node cleared `out`
+// on the first replay only — later replays left 1e21-sized values under the atomics (ROCm 7.2, round 3;
+// tools/memset_node_probe.py shows it with nothing but the memset and an add in the graph).
+__global__ __launch_bounds__(256) void zero_fill_k(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 // ---- backward.  Tiles are oriented with k on the accumulator rows so results leave as float4
 // along k.  Both kernels are built for ONE memory round trip per wave (the first version
 // walked 8 row blocks x 6 steps + 32 steps serially per wave: 22 us for 100 MFLOP).
@@ -273,8 +282,8 @@ extern "C" int bmnas_linear_fwd(const float* feat, const float* W, const float* 
   const int tj = (O + 15) / 16;
   if (tj > kMaxTJ) return BMNAS_E_LIMIT;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t me = hipMemsetAsync(out, 0, (size_t)b * O * sizeof(float), st);
-  if (me != hipSuccess) return (int)me;
+  if ((int64_t)b * O > (int64_t)1 << 30) return BMNAS_E_LIMIT;
+  hipLaunchKernelGGL(zero_fill_k, dim3((b * O + 255) / 256), dim3(256), 0, st, out, b * O);
   const int nblk = K / 16;
   const int splits = (nblk + 15) / 16;                       // <= 4 blocks per wave, 4 waves
   const int bpw = (nblk + splits * 4 - 1) / (splits * 4);

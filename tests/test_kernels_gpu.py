@@ -261,6 +261,36 @@ def test_linear_classifier_fwd_bwd(b, O, K):
     assert list(mod.state_dict()) == list(ref.state_dict())
 
 
+@pytest.mark.parametrize('b,O,K', [(128, 23, 6144), (8, 60, 2048), (6, 83, 2048)])
+def test_linear_classifier_under_graph_replay(b, O, K):
+    """The classifier that is NOT fused into the cell's tail (BMNAS_FUSE_HEAD=0, a cell that concatenates an input
+    state) inside a captured step: its split-K forward adds into a zero-filled output.  The fill used to be a
+    hipMemsetAsync; as a hipGraph memset node it cleared the buffer on the first replay only and left 1e21-sized
+    values on later ones (ROCm 7.2; tools/memset_node_probe.py), which every replay after the first then returned
+    as logits.  Every replay must reproduce the eager result."""
+    from bmnas import nn as bnn
+    from bmnas.graph import GraphedStep
+    g = _gen(540 + b + O)
+    mod = bnn.Linear(K, O).to(dev())
+    x = _rand(g, b, K).to(dev()).requires_grad_(True)
+    y = torch.from_numpy(g.integers(0, O, size=(b,))).to(dev())
+    crit = bnn.CrossEntropyLoss()
+    tg = [x, mod.weight, mod.bias]
+
+    def fn():
+        z = mod(x)
+        loss = crit(z, y)
+        return (loss, z, *torch.autograd.grad(loss, tg))
+
+    want = [t.detach().clone() for t in fn()]
+    step = GraphedStep(fn, warmup=1)
+    for replay in range(4):
+        got = step.replay()
+        torch.cuda.synchronize()
+        for name, a, w in zip(('loss', 'logits', 'dx', 'dW', 'db'), got, want):
+            assert_close_scaled(f'replay {replay} {name}', a, w, rel=1e-5)
+
+
 @pytest.mark.parametrize('b,O', [(128, 23), (5, 7), (1, 3)])
 def test_bce_with_logits_loss(b, O):
     from bmnas import nn as bnn
