@@ -34,6 +34,8 @@ def timeit(fn, n=50):
 
 print('probe', os.environ.get('BMNAS_CONV_PROBE', '0'), 'B', b)
 print('fwd      us', round(timeit(lambda: lib.conv1x1_fwd([z], C, Wf, C, bias, U, part, b, L, 3 * C)), 2))
+stat = torch.zeros(4 * 3 * C * 2, device=dev)
+print('fwd stat us', round(timeit(lambda: lib.conv1x1_fwd([z], C, Wf, C, bias, U, stat, b, L, 3 * C, stat_shards=4)), 2))
 print('fwd nost us', round(timeit(lambda: lib.conv1x1_fwd([z], C, Wf, C, bias, U, None, b, L, 3 * C)), 2))
 print('bwd_data us', round(timeit(lambda: lib.conv1x1_bwd_data(dU, Wf, C, [dz], C, 0, b, L, 3 * C)), 2))
 print('bwd_wght us', round(timeit(lambda: lib.conv1x1_bwd_weight(dU, [z], C, dW, 2 * C, db, C, b, L, 3 * C)), 2))
