@@ -754,7 +754,7 @@ def headline(a, c, world, shapes, best, eager_ms, rccl, note=None):
     return result
 
 
-def dp_report(bdist, comm, comm_err, flat, n_early, device, world, rank, host_reduce, log):
+def dp_report(bdist, comm, comm_err, flat, n_early, device, world, rank, host_reduce, log, base=None):
     """The N > 1 line's evidence that the collective really spans the ranks: what the process group and the
     C-ABI communicator report, every rank's device (all-gathered), and the bucket's all-reduce timed alone."""
     import torch.distributed as tdist
@@ -795,7 +795,9 @@ def dp_report(bdist, comm, comm_err, flat, n_early, device, world, rank, host_re
         return round(float(t.item()), 2)
 
     us = {}
-    if host_reduce is not None:
+    if base is not None:
+        us = dict(base.get('allreduce_us', {}))          # the torch.distributed figure of the first call
+    elif host_reduce is not None:
         us['torch_distributed'] = timed(host_reduce)
     if comm is not None:
         us['c_abi'] = timed(lambda: comm.all_reduce(flat, average=True))
@@ -872,15 +874,10 @@ def main():
     loss_scale = 1.0 if (world == 1 or use_avg) else 1.0 / world
     # RCCL through the C ABI (bmnas_allreduce_f32): a plain launch on the current stream, so it can be captured
     # INSIDE the step's hipGraph.  Tried whenever the process group is RCCL; every rank must succeed.
+    # (built AFTER a complete host-issued measurement exists and under the watchdog, see below: a communicator
+    # that never comes up on some node must not cost the line)
     comm, comm_err = None, None
     want_native = a.mode == 'graph' and ((world > 1 and torch.distributed.get_backend() == 'nccl') or a.dp_selftest)
-    if want_native:
-        try:
-            comm = bdist.NativeComm.get()
-        except Exception as e:                       # noqa: BLE001
-            comm_err = f'{type(e).__name__}: {e}'[:200]
-        if not bdist.all_ranks_agree(comm is not None, device):
-            comm = None
     dp = DPStep(model, c, crit, xs, y, params, arch, device, comm, loss_scale, bucket=world > 1 or a.dp_selftest)
     flat, n_early, make_step = dp.flat, dp.n_early, dp.make_step
 
@@ -952,24 +949,40 @@ def main():
     rccl = None
     guard = None
     if world > 1 or a.dp_selftest:
-        rccl = dp_report(bdist, comm, comm_err, flat, n_early, device, world, rank, host_reduce if world > 1 else None, log)
-    if comm is not None and a.mode == 'graph':
-        # the in-graph shapes are measured AFTER a complete, valid measurement exists: should a captured RCCL
-        # launch wedge on some node, the watchdog prints the line with what has been measured and ends the run
-        pending = {'line': None}
+        rccl = dp_report(bdist, None, None, flat, n_early, device, world, rank, host_reduce if world > 1 else None, log)
+    if want_native:
+        # everything that goes through the C-ABI communicator — its rendezvous, its all-reduce timed alone, the
+        # in-graph step shapes — runs AFTER a complete, valid measurement exists and under a watchdog: should the
+        # communicator not come up or a captured RCCL launch wedge on some node, every rank prints / exits with
+        # what has been measured
+        pending = {'line': headline(a, c, world, shapes, best, eager_ms, rccl,
+                                    note='C-ABI RCCL communicator / in-graph all-reduce shapes did not finish '
+                                         '(watchdog): host-issued all-reduce only')}
 
         def bail():
-            if rank == 0 and pending['line'] is not None:
+            if rank == 0:
                 print(json.dumps(pending['line']), flush=True)
             os._exit(0)
 
         import threading
-        guard = threading.Timer(float(os.environ.get('BMNAS_BENCH_WATCHDOG_S', '240')), bail)
+        guard = threading.Timer(float(os.environ.get('BMNAS_BENCH_WATCHDOG_S', '120')), bail)
         guard.daemon = True
-        pending['line'] = headline(a, c, world, shapes, best, eager_ms, rccl, note='in-graph RCCL shapes did not finish '
-                                   '(watchdog): host-issued all-reduce only')
         guard.start()
-        for shape in ('graph', 'overlap'):
+        try:
+            comm = bdist.NativeComm.get()
+        except Exception as e:                       # noqa: BLE001
+            comm_err = f'{type(e).__name__}: {e}'[:200]
+        if not bdist.all_ranks_agree(comm is not None, device):
+            comm = None
+        if comm is not None:
+            dp.comm, dp.side = comm, torch.cuda.Stream(device)
+            rccl = dp_report(bdist, comm, comm_err, flat, n_early, device, world, rank,
+                             host_reduce if world > 1 else None, log, base=rccl)
+            pending['line'] = headline(a, c, world, shapes, best, eager_ms, rccl,
+                                       note='in-graph RCCL shapes did not finish (watchdog): host-issued all-reduce only')
+        elif comm_err:
+            rccl['native_comm_error'] = comm_err
+        for shape in (('graph', 'overlap') if comm is not None else ()):
             try:
                 g2 = GraphedStep(make_step(shape), warmup=1)
                 ok = True
