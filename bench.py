@@ -165,6 +165,9 @@ def algo_table(C, L):
             ('hbm', T(U) + 3 * T(out) + (0 if nxt is None else (len(nxt[0]) + 1) * T(out))),
         'node_mix_ln_fwd': lambda x, y, p1, U, ch, gm, resid, w, b_, pre, out, *_:
             ('hbm', T(U) + 5 * T(out) + 2 * T(w)),
+        # the mix as producer of out_conv's last operand: the GEMM's product (the mix bytes ride along)
+        'node_mix_conv_fwd': lambda x, y, p1, U, ch, gm, out, dg, df, fin, srcs, W, ldw, bias, V, st, sh, b, Cc, L_:
+            ('mfma', 2.0 * Cc * (len(srcs) + 1) * Cc * b * L_),
         'node_mix_bwd': lambda g, x, y, p1, U, ch, gm, dgm, dx, dy, m, dV, bg, b, Cc, L_, dg, df, sh=1, st=0, nxt=None:
             ('hbm', 2 * T(U) + 4 * T(x) + (0 if nxt is None else (2 * len(nxt[0]) + 4) * T(x))),
         # K6 backward + K2 backward: gy, pre, x, p1, U read; g_in, dresid, dx, dV written (rmw where accumulated)
@@ -344,6 +347,7 @@ KERNELS_OF = {
     # (large grids run as bn_bwd_apply + data + weight launches: the units go to the data-gradient kernel)
     'conv1x1_bwd_all': ('conv_bwd_pair_k', 'conv_pipe_bwd_k', 'conv_ksplit_k', 'conv_ksplit_multi_k', 'conv_lds_k', 'conv_bwd_k'),
     'node_mix_fwd': ('node_mix_fwd_k',), 'node_mix_ln_fwd': ('node_mix_ln_fwd_k',),
+    'node_mix_conv_fwd': ('mix_conv_fwd_k',),
     'node_mix_bwd': ('node_mix_bwd_k',), 'node_mix_ln_bwd': ('node_mix_ln_bwd_k',),
     'bn_relu_fwd': ('bn_relu_fwd_k',), 'bn_relu_bwd': ('bn_relu_bwd_k',),
     'bn_relu_ln_fwd': ('bn_relu_ln_fwd_k',), 'bn_relu_ln_bwd': ('bn_relu_ln_bwd_k',),

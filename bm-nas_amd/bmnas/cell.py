@@ -358,7 +358,7 @@ class MixedSaved:
     pass
 
 
-def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None, nxt=None):
+def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None, nxt=None, launch_mix=True):
     """NodeMixedOp.forward (node_operations.py:118-120).  P: parameter pack of one NodeMixedOp
     (see models.search.darts.node_operations.NodeMixedOp.pack()).  x may be y (search).
     ln = (resid, ln_w, ln_b, stats): fuse the NodeCell tail `out += x; ln(out)` (node_search.py:67-68)
@@ -386,6 +386,9 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None,
             U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C, Weff=Weff, stats=stats)
     out = torch.empty_like(x)
     fin = sv.conv.fin                        # BatchNorm finalised inside the mix kernel (or NO_FIN)
+    if not launch_mix:                       # the caller's out_conv launch forms `out` (bmnas_node_mix_conv_fwd)
+        sv.pending_mix = (x, y, p1, U, chan, gamma_row, out, sv.d_glu, sv.d_fc, fin)
+        return out, sv
     if ln is None:
         lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc, fin, nxt)
     else:
@@ -407,6 +410,8 @@ FUSE_EPILOGUE = os.environ.get('BMNAS_FUSE_EPILOGUE', '1') != '0'
 FUSE_BN_FINALIZE = os.environ.get('BMNAS_FUSE_BN_FINALIZE', '1') != '0'
 # BatchNorm input gradient applied inside the merged backward GEMM launch (no bn_bwd_apply launch)
 FUSE_BN_APPLY = os.environ.get('BMNAS_FUSE_BN_APPLY', '1') != '0'
+# small grids, node_multiplier != 1: the last inner step's mix as the producer of out_conv's last operand
+FUSE_MIX_GEMM = os.environ.get('BMNAS_FUSE_MIX_GEMM', '1') != '0'
 # out_conv backward (no attention beside it): BatchNorm apply + data + weight gradient as one launch at small grids
 FUSE_BWD_PAIR = os.environ.get('BMNAS_FUSE_BWD_PAIR', '1') != '0'
 # NodeCell tail with node_multiplier != 1: BatchNorm + ReLU + dropout + residual + LayerNorm as one launch per
@@ -559,6 +564,29 @@ FUSE_TAIL = True   # node_multiplier == 1: NodeMixedOp + residual + LayerNorm in
 FUSE_PAIR = True   # search mode: cell-level mixed sum + the node's first inner sum in one launch
 
 
+def _mix_conv_fwd(pending, tail, C, Wo, ldw, NP, training, stats):
+    """out_conv over cat(tail) whose LAST tensor is the mix output that `pending` describes and nobody has formed
+    yet: mix + GEMM in one launch (bmnas_node_mix_conv_fwd).  Returns what conv_bn_fwd would (the BatchNorm is
+    finalised by the consumer, like every conv of the fused cell)."""
+    x, y, p1, U, chan_mix, gamma_row, out, d_glu, d_fc, fin = pending
+    assert out is tail[-1]
+    b, L = x.shape[0], x.shape[2]
+    V = _empty(x, b, C, L)
+    part, shards = None, 0
+    if training:
+        if b * L < 2:
+            raise ValueError('Expected more than 1 value per channel when training, got input size '
+                             f'{[b, C, L]}')
+        part, shards = stats.take(C), STAT_SHARDS
+    lib.node_mix_conv_fwd(x, y, p1, U, chan_mix, gamma_row, out, d_glu, d_fc, fin, tail[:-1], Wo, ldw,
+                          NP.out_conv_b, V, part, shards, b, C, L)
+    sv = ConvBnSaved()
+    sv.fin = lib.make_bn_fin(part, shards, NP.out_conv_b, NP.bn_w, NP.bn_b, NP.bn_rm, NP.bn_rv, NP.bn_nbt, training)
+    sv.srcs, sv.C_src, sv.W, sv.ldw, sv.U, sv.chan, sv.M = list(tail), C, Wo, ldw, V, _empty(x, 4 * C), C
+    sv.training, sv.dup, sv.fold = training, 0, 0
+    return V, sv.chan, sv
+
+
 def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=None, stats=None,
                   want_sums=False, next_pair=None):
     """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
@@ -589,9 +617,12 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
             z_next = torch.empty_like(x)
             nxt = (list(states), beta_w[offset + len(states):, 1], 2, z_next)
         sv.next_fused.append(nxt is not None)
+        # the last inner step's mix rides in the out_conv launch below (small grids)
+        defer = (FUSE_MIX_GEMM and nm != 1 and t == ns - 1 and stats is not None and x.is_cuda
+                 and lib.node_mix_conv_fwd_ok(b, C, L, nm - 1))
         s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
                                 (x, NP.ln_w, NP.ln_b, sv.stats, sv.osum) if last else None,
-                                None if weffs is None else weffs[t], stats, nxt)
+                                None if weffs is None else weffs[t], stats, nxt, launch_mix=not defer)
         sv.zs.append(z)
         sv.mixed.append(msv)
         sv.offsets.append(offset)
@@ -604,8 +635,12 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
     tail = states[-nm:]
     if nm != 1:
         Wo = NP.out_conv_w.view(C, nm * C)
-        V, chan, sv.oconv = conv_bn_fwd(tail, C, Wo, nm * C, NP.out_conv_b, NP.bn_w, NP.bn_b,
-                                        NP.bn_rm, NP.bn_rv, NP.bn_nbt, training, stats=stats)
+        pending = getattr(sv.mixed[-1], 'pending_mix', None)
+        if pending is not None:
+            V, chan, sv.oconv = _mix_conv_fwd(pending, tail, C, Wo, nm * C, NP, training, stats)
+        else:
+            V, chan, sv.oconv = conv_bn_fwd(tail, C, Wo, nm * C, NP.out_conv_b, NP.bn_w, NP.bn_b,
+                                            NP.bn_rm, NP.bn_rv, NP.bn_nbt, training, stats=stats)
         sv.d_out = DROP.make(NP.out_p, x.numel(), training)
         o = torch.empty_like(x)
         sv.fused_bn_tail = FUSE_BN_TAIL and b <= BN_TAIL_MAX_B and C <= 1024

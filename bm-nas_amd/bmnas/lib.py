@@ -145,6 +145,9 @@ SIGNATURES = {
     'bmnas_conv_family_calls': ([C.POINTER(C.c_long), _I, _I], _I),
     'bmnas_bn_finalize': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'bmnas_node_mix_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
+    'bmnas_node_mix_conv_fwd_ok': ([_I, _I, _I, _I], _I),
+    'bmnas_node_mix_conv_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, Dropout, Dropout, _PP, _I, _P, _I, _P, _P, _P, _I,
+                                 _I, _I, _I, _P], _I),
     'bmnas_node_mix_fwd_next': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _I, _I, _I, Dropout, Dropout, _PP, _I, _P, _I,
                                  _P, _P], _I),
     'bmnas_node_mix_bwd_next': ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32, _P, _P, _I, _I, _I,
@@ -642,6 +645,19 @@ def node_mix_fwd(x, y, p1, U, chan, gamma, out, b, Cc, L, dglu, dfc, fin=NO_FIN,
                                           ws, _ptr(z), _stream()), 'node_mix_fwd_next')
 
 
+def node_mix_conv_fwd_ok(b, Cc, L, n_src):
+    return bool(load().bmnas_node_mix_conv_fwd_ok(b, Cc, L, n_src))
+
+
+def node_mix_conv_fwd(x, y, p1, U, chan, gamma, mix_out, dglu, dfc, fin, srcs, W, ldw, bias, V, stat, stat_shards,
+                      b, Cc, L):
+    """The last inner step's mix + out_conv over cat(srcs, mix) in one launch (small grids)."""
+    _check(load().bmnas_node_mix_conv_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin, gamma.data_ptr(),
+                                          _ptr(mix_out), dglu, dfc, _ptrs(srcs), len(srcs), _ptr(W), ldw, _ptr(bias),
+                                          _ptr(V), _ptr(stat), stat_shards, b, Cc, L, _stream()),
+           'node_mix_conv_fwd')
+
+
 def node_mix_ln_fwd(x, y, p1, U, chan, gamma, resid, ln_w, ln_b, pre, out, stats, b, Cc, L, dglu, dfc,
                     fin=NO_FIN, out_sums=None):
     _check(load().bmnas_node_mix_ln_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin,
@@ -893,7 +909,7 @@ _TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'cell_prologue_pair', '
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'conv1x1_fwd_sdpa', 'conv1x1_bwd_all_sdpa', 'conv1x1_bwd_all',
                 'bn_relu_ln_fwd', 'bn_relu_ln_bwd',
-                'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'node_mix_ln_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
+                'fold_weight', 'bn_finalize', 'node_mix_fwd', 'node_mix_conv_fwd', 'node_mix_ln_fwd', 'node_mix_bwd', 'node_mix_ln_bwd', 'bn_glu_fwd', 'bn_glu_bwd',
                 'bn_relu_fwd', 'bn_relu_bwd', 'bn_bwd_apply', 'arch_softmax_fwd', 'arch_softmax_bwd',
                 'linear_fwd', 'linear_bwd', 'bce_logits', 'cross_entropy', 'adam_multi', 'conv1x1_fwd_group',
                 'conv1x1_bwd_group', 'bn_relu_fwd_group', 'bn_relu_bwd_group')

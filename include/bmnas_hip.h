@@ -314,6 +314,22 @@ int bmnas_node_mix_ln_fwd(const float* x, const float* y, const float* p1, const
                           const float* ln_w, const float* ln_b, float* pre, float* out, float* stats,
                           int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
                           float* out_sums, void* stream);
+/* K2 as the PRODUCER of out_conv's last operand (small grids, node_multiplier != 1; reference
+ * node_search.py:55 `out = node_op(x, y, gammas[i])` of the last inner step, then :59-61
+ * `out = out_conv(torch.cat(states[-node_multiplier:], dim=1))`): ONE launch instead of bmnas_node_mix_fwd +
+ * bmnas_conv1x1_fwd.  mix_out (b, C, L) receives s exactly as bmnas_node_mix_fwd would write it (the backward
+ * pass and later states read it); V (b, C, L) = W cat(srcs[0..n_src), s) + bias with W (C, ldw) row-major,
+ * the first (n_src + 1) * C columns used; `stat` (stat_shards, C, 2): zero-filled batch sums of V - bias as in
+ * bmnas_conv1x1_fwd (NULL with stat_shards 0: no statistics).  x, y, p1, U, chan, fin, gamma, drop_*: as
+ * bmnas_node_mix_fwd.  bmnas_node_mix_conv_fwd_ok: the shapes it takes (n_src <= 3, C % 64 == 0, C <= 256,
+ * (b L / 16) (C / 16) <= 256 workgroups: every output tile recomputes its 16 columns of s); BMNAS_E_LIMIT
+ * otherwise. */
+int bmnas_node_mix_conv_fwd_ok(int b, int C, int L, int n_src);
+int bmnas_node_mix_conv_fwd(const float* x, const float* y, const float* p1, const float* U, float* chan,
+                            bmnas_bn_fin_t fin, const float* gamma, float* mix_out, bmnas_dropout_t drop_glu,
+                            bmnas_dropout_t drop_fc, const float* const* srcs, int n_src, const float* W, int ldw,
+                            const float* bias, float* V, float* stat, int stat_shards, int b, int C, int L,
+                            void* stream);
 /* Backward, phase A (elementwise + reductions):  g = grad of s.
  *   dgamma[shard*dgamma_shard_stride + q] += <g, p_q> (shards as in bmnas_mixsum_bwd);
  *   dx / dy (=|+=) g0*g (dy NULL: both into dx);

@@ -170,7 +170,7 @@ def test_small_batch_launch_merges_are_taken(name, batch, monkeypatch):
     net = build_search_net(cfg, 5, 'train')
     xs = [x.cuda().requires_grad_(True) for x in synth.make_inputs(cfg, batch, 5)]
     counted = ('node_mix_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'bn_relu_ln_fwd', 'bn_relu_ln_bwd',
-               'conv1x1_bwd_all')
+               'conv1x1_bwd_all', 'node_mix_fwd', 'node_mix_conv_fwd', 'conv1x1_fwd')
     calls = {}
 
     def wrap(fn_name):
@@ -196,8 +196,13 @@ def test_small_batch_launch_merges_are_taken(name, batch, monkeypatch):
     assert on['mixsum_pair_bwd'] == 1                        # only the first cell step's (no node before it)
     assert on['node_mix_bwd'] == S * (ns - 1)                # the last inner step's rides in conv1x1_bwd_all
     assert on['bn_relu_ln_fwd'] == S and on['bn_relu_ln_bwd'] == S and on['conv1x1_bwd_all'] == S
+    # round 3: the last inner step's mix forward rides in the out_conv launch (bmnas_node_mix_conv_fwd)
+    if K.FUSE_MIX_GEMM and K.FUSE_PROLOGUE and K.FUSE_BN_FINALIZE:
+        assert on['node_mix_conv_fwd'] == S and on.get('conv1x1_fwd', 0) == 0 and on['node_mix_fwd'] == S * (ns - 1)
     monkeypatch.setattr(K, 'FUSE_NEXT_PAIR', False)
     monkeypatch.setattr(K, 'FUSE_MIX_EPILOGUE', False)
+    monkeypatch.setattr(K, 'FUSE_MIX_GEMM', False)
     off = step()
     assert off['mixsum_pair_fwd'] == S - 1 and off['mixsum_pair_bwd'] == S
     assert off['node_mix_bwd'] == S * ns
+    assert off.get('node_mix_conv_fwd', 0) == 0 and off['conv1x1_fwd'] == S and off['node_mix_fwd'] == S * ns

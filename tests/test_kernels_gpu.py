@@ -261,6 +261,77 @@ def test_linear_classifier_fwd_bwd(b, O, K):
     assert list(mod.state_dict()) == list(ref.state_dict())
 
 
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('b,C,L,nm,p', [(8, 128, 8, 2, 0.2), (6, 128, 8, 3, 0.0), (7, 64, 16, 2, 0.3), (5, 128, 4, 2, 0.1),
+                                        (3, 192, 8, 4, 0.25), (16, 256, 8, 2, 0.0)])
+def test_mix_as_producer_of_out_conv(b, C, L, nm, p, training):
+    """bmnas_node_mix_conv_fwd (the last inner step's NodeMixedOp combine inside the out_conv launch, small grids)
+    against the two launches it replaces — bmnas_node_mix_fwd, then bmnas_conv1x1_fwd over cat(states, mix) — on the
+    same inputs, dropout masks, BatchNorm batch sums and running statistics: the mix output bit for bit (same
+    arithmetic, element by element), the conv output and its batch sums to fp32 round-off (another summation
+    order), the mixed op's finalised BatchNorm (chan, running statistics, num_batches_tracked) bit for bit."""
+    from bmnas import lib
+    from bmnas import cell as K
+    assert lib.node_mix_conv_fwd_ok(b, C, L, nm - 1)
+    g = _gen(900 + b + C + L + nm)
+    d = dev()
+    z = _rand(g, b, C, L).to(d)
+    p1 = _rand(g, b, C, L).to(d)
+    prev = [_rand(g, b, C, L).to(d) for _ in range(nm - 1)]
+    Wm = (_rand(g, 3 * C, C) / C ** 0.5).to(d)
+    bm = _rand(g, 3 * C).to(d)
+    bn_w, bn_b = (1 + 0.1 * _rand(g, 3 * C)).to(d), (0.1 * _rand(g, 3 * C)).to(d)
+    Wo = (_rand(g, C, nm * C) / (nm * C) ** 0.5).to(d)
+    bo = _rand(g, C).to(d)
+    gamma = torch.softmax(_rand(g, 4), 0).to(d)
+    shards = K.STAT_SHARDS
+    # the producer GEMM of the mixed op, with its batch sums
+    U = torch.empty(b, 3 * C, L, device=d)
+    stat = torch.zeros(shards * 3 * C * 2, device=d) if training else None
+    lib.conv1x1_fwd([z], C, Wm, C, bm, U, stat, b, L, 3 * C, stat_shards=shards if training else 0)
+    dg = lib.make_dropout(p, 1234, 0, None) if (training and p > 0) else lib.NO_DROP
+    df = lib.make_dropout(p, 1234, 10 ** 6, None) if (training and p > 0) else lib.NO_DROP
+
+    def run(fused):
+        rm, rv = (0.1 * _rand(_gen(5), 3 * C)).to(d), (1 + 0.1 * _rand(_gen(6), 3 * C).abs()).to(d)
+        nbt = torch.full((2,), 7, dtype=torch.int64, device=d)
+        fin = lib.make_bn_fin(stat, shards if training else 0, bm, bn_w, bn_b, rm, rv, nbt, training)
+        chan = torch.zeros(4 * 3 * C, device=d)
+        mix = torch.empty(b, C, L, device=d)
+        V = torch.empty(b, C, L, device=d)
+        ostat = torch.zeros(shards * C * 2, device=d) if training else None
+        osh = shards if training else 0
+        if fused:
+            lib.node_mix_conv_fwd(z, z, p1, U, chan, gamma, mix, dg, df, fin, prev, Wo, nm * C, bo, V, ostat, osh,
+                                  b, C, L)
+        else:
+            lib.node_mix_fwd(z, z, p1, U, chan, gamma, mix, b, C, L, dg, df, fin)
+            lib.conv1x1_fwd(prev + [mix], C, Wo, nm * C, bo, V, ostat, b, L, C, stat_shards=osh)
+        torch.cuda.synchronize()
+        return mix, V, ostat, chan, rm, rv, nbt
+
+    a, r = run(True), run(False)
+    assert torch.equal(a[0], r[0]), float((a[0] - r[0]).abs().max())
+    assert_close_scaled('V', a[1], r[1], rel=1e-5)
+    if training:
+        sa, sr = a[2].view(shards, C, 2).sum(0), r[2].view(shards, C, 2).sum(0)
+        assert_close_scaled('out_conv batch sums', sa, sr, rel=1e-5)
+    for name, x_, y_ in zip(('chan', 'running_mean', 'running_var', 'num_batches_tracked'), a[3:], r[3:]):
+        assert torch.equal(x_, y_), name
+    # and against torch, for the pair as a whole
+    ch = r[3].view(4, 3 * C)
+    Un = U * ch[2][None, :, None] + ch[3][None, :, None]
+    ones = torch.ones(b * C * L, device=d)
+    m2 = ones if dg.thr == 0 else lib.dropout_mask(dg, b * C * L, d)
+    m3 = ones if df.thr == 0 else lib.dropout_mask(df, b * C * L, d)
+    glu = Un[:, :C] * torch.sigmoid(Un[:, C:2 * C]) * m2.view(b, C, L)
+    fc = torch.relu(Un[:, 2 * C:]) * m3.view(b, C, L)
+    s_ref = gamma[0] * (z + z) + gamma[1] * p1 + gamma[2] * glu + gamma[3] * fc
+    assert_close_scaled('mix vs torch', a[0], s_ref, rel=1e-5)
+    V_ref = torch.einsum('jk,bkl->bjl', Wo.double(), torch.cat(prev + [s_ref], 1).double()) + bo.double()[None, :, None]
+    assert_close_scaled('V vs torch', a[1], V_ref.float(), rel=1e-5)
+
+
 @pytest.mark.parametrize('b,O,K', [(128, 23, 6144), (8, 60, 2048), (6, 83, 2048)])
 def test_linear_classifier_under_graph_replay(b, O, K):
     """The classifier that is NOT fused into the cell's tail (BMNAS_FUSE_HEAD=0, a cell that concatenates an input
