@@ -896,14 +896,14 @@ def main():
         """W untimed warm-up steps, then `regions` timed regions of EXACTLY a.steps steps, each bracketed by a
         barrier + synchronize on both sides, MAX over ranks per region -> list of region times (s)."""
         # the chip's clocks need some tens of ms of continuous work to settle after the capture (timed regions of 20
-        # steps right after a 20-step warm-up read 0.170, 0.172, 0.220, 0.170, 0.163 ms/step; after 60 ms of replays
+        # steps right after a 20-step warm-up read 0.170, 0.172, 0.220, 0.170, 0.163 ms/step; after 400 replays (~65 ms)
         # all five read 0.163): untimed replays first, THEN the contract's W warm-up steps and the timed regions
+        # (a fixed COUNT, not a duration: under N > 1 `run` contains a collective and every rank must issue the same
+        # number of them)
         if a.mode == 'graph':
-            t_settle = time.perf_counter()
-            while time.perf_counter() - t_settle < 0.08:
-                for _ in range(25):
-                    run()
-                torch.cuda.synchronize()
+            for _ in range(400):
+                run()
+            torch.cuda.synchronize()
         for _ in range(a.warmup):
             run()
         out = []
