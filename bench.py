@@ -1016,13 +1016,27 @@ def main():
     dt = statistics.median(shapes[best])
     log(f'timed region done: {dt / a.steps * 1e3:.4f} ms/step')
     if not a.no_full_step:
-        # secondary figure: never allowed to take the headline line down with it
+        # secondary figure: never allowed to take the headline line down with it — neither by raising nor (N > 1: it
+        # contains collectives) by never returning: past the watchdog every rank leaves with the line as it stands
+        import threading
+
+        def bail2():
+            if rank == 0:
+                print(json.dumps(dict(result, full_search_step={'error': 'did not finish (watchdog)'})), flush=True)
+            os._exit(0)
+
+        guard2 = threading.Timer(float(os.environ.get('BMNAS_BENCH_WATCHDOG_S', '120')), bail2)
+        guard2.daemon = True
+        guard2.start()
         try:
             result['full_search_step'] = full_search_step(model, crit, params, arch, xs, y, c, a, world, device,
                                                           log)
         except Exception as e:                       # noqa: BLE001
             result['full_search_step'] = {'error': f'{type(e).__name__}: {e}'[:300]}
             log(f'full search step failed: {e}')
+        if world > 1:
+            torch.distributed.barrier()
+        guard2.cancel()
     if rank == 0 and not a.no_roofline and world == 1:
         try:
             result.update(roofline_report(a, c, step, result['ms_per_step'], log))
