@@ -272,20 +272,7 @@ class GraphedTrainStep:
                 all(a.shape == b.shape for a, b in zip(inputs, self.inputs)))
 
     def __call__(self, inputs, labels):
-        with torch.no_grad():
-            # the batch into the graph's static tensors: ONE multi-tensor copy launch for the modalities that
-            # are already on the device (seven separate copy launches cost ~23 us of a 190 us step), plain
-            # copies for anything else (host tensors: the copy IS the H2D transfer)
-            same = [(d, s_) for d, s_ in zip(self.inputs, inputs)
-                    if s_.device == d.device and s_.dtype == d.dtype and s_.data_ptr() != d.data_ptr()]
-            batched = {id(d) for d, _ in same} if len(same) > 1 else set()
-            if batched:
-                torch._foreach_copy_([d for d, _ in same], [s_ for _, s_ in same])
-            for dst, src in zip(self.inputs, inputs):
-                if id(dst) not in batched and src.data_ptr() != dst.data_ptr():
-                    dst.copy_(src, non_blocking=True)
-            if labels.data_ptr() != self.labels.data_ptr():
-                self.labels.copy_(labels, non_blocking=True)
+        _copy_batch_in(self.inputs, self.labels, inputs, labels)
         opt = self.optimizer
         if self.in_graph_step:
             opt.activate(self.plan)          # an eager step in between must not leak into the replay
@@ -301,3 +288,94 @@ class GraphedTrainStep:
             self.reducer.all_reduce_bucket()
             opt.step()
         return loss, logits
+
+
+def _copy_batch_in(static_inputs, static_labels, inputs, labels):
+    """The batch into a graph's static tensors: ONE multi-tensor copy launch for the modalities that are already on
+    the device, plain copies for anything else (host tensors: the copy IS the H2D transfer)."""
+    with torch.no_grad():
+        same = [(d, s_) for d, s_ in zip(static_inputs, inputs)
+                if s_.device == d.device and s_.dtype == d.dtype and s_.data_ptr() != d.data_ptr()]
+        batched = {id(d) for d, _ in same} if len(same) > 1 else set()
+        if batched:
+            torch._foreach_copy_([d for d, _ in same], [s_ for _, s_ in same])
+        for dst, src in zip(static_inputs, inputs):
+            if id(dst) not in batched and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        if labels.data_ptr() != static_labels.data_ptr():
+            static_labels.copy_(labels, non_blocking=True)
+
+
+class GraphedForward:
+    """`output = model(inputs); loss = criterion(output, labels)` WITHOUT gradients as one hipGraph replay: the
+    metric pass of the search loop's dev phase (after `architect.step`, reference train_searchable/mmimdb.py:66-84
+    with `phase == 'dev'`: model.train(), so dropout is live and BatchNorm keeps updating — both stay so under
+    replay) and the eval / test passes (`test_*_track_acc`).  Issued eagerly that forward is host-bound: 0.55 ms for
+    reshape layers + hypernet + classifier + criterion at MM-IMDB batch 128, 0.86 ms at NTU batch 8, against 0.11 ms
+    as a replay.  The module's mode (train / eval) and the batch shape are fixed at capture: `matches()`.
+
+        fwd = GraphedForward.try_build(model, criterion, inputs, labels)
+        loss, output = fwd(inputs, labels)            # static tensors, overwritten by the next call"""
+
+    def __init__(self, model, criterion, inputs, labels, warmup=2):
+        self.training = model.training
+        self.inputs = [x.detach().clone() for x in inputs]
+        self.labels = labels.detach().clone()
+
+        def fn():
+            with torch.no_grad():
+                out = model(self.inputs)
+                if isinstance(out, tuple):
+                    out = out[-1]
+                return criterion(out, self.labels), out
+
+        # warm-up passes must not change training: their BatchNorm updates are undone
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    fn()
+                mode = torch.cuda.get_sync_debug_mode()      # dress rehearsal (see GraphedTrainStep)
+                torch.cuda.set_sync_debug_mode('error')
+                try:
+                    fn()
+                finally:
+                    torch.cuda.set_sync_debug_mode(mode)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._g = GraphedStep(fn, warmup=0)
+        finally:
+            torch.cuda.synchronize()
+            model.load_state_dict(state)
+
+    @staticmethod
+    def try_build(model, criterion, inputs, labels, logger=None):
+        """-> a GraphedForward, or False (inputs that are not a flat list of device tensors, a module that
+        synchronises with the host, a capture error): the caller keeps the eager forward.  No collective is
+        involved, so under data parallelism every rank decides for itself."""
+        if not (isinstance(inputs, (list, tuple)) and all(torch.is_tensor(x) and x.is_cuda for x in inputs)
+                and torch.is_tensor(labels) and labels.is_cuda):
+            return False
+        try:
+            return GraphedForward(model, criterion, inputs, labels)
+        except Exception as e:                       # noqa: BLE001 — capture errors are of many types
+            torch.cuda.synchronize()
+            from . import functions
+            functions.reset_pools()
+            if logger is not None:
+                logger.info('hipGraph capture of the forward pass failed ({}: {}); staying eager'.format(
+                    type(e).__name__, e))
+            return False
+
+    def matches(self, model, inputs, labels):
+        return (model.training == self.training and isinstance(inputs, (list, tuple))
+                and len(inputs) == len(self.inputs) and labels.shape == self.labels.shape
+                and labels.dtype == self.labels.dtype
+                and all(torch.is_tensor(a) and a.shape == b.shape and a.dtype == b.dtype
+                        for a, b in zip(inputs, self.inputs)))
+
+    def __call__(self, inputs, labels):
+        _copy_batch_in(self.inputs, self.labels, inputs, labels)
+        return self._g.replay()

@@ -1,0 +1,98 @@
+"""bmnas.graph.GraphedForward: the gradient-free passes of the loops (metric pass of the dev phase, eval / test) as
+one hipGraph replay each."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(cname, batch, training):
+    import bench as B
+    from bmnas import nn as bnn
+    c = dict(B.CONFIGS[cname], drpt=0.0)                  # deterministic: dropout parity has its own tests
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    model = B.HyperNet(c, 'R', cname).to(dev)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train(training)
+    crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
+    return model, crit, dev, c
+
+
+@pytest.mark.parametrize('cname,batch', [('mmimdb', 16), ('ntu', 8)])
+@pytest.mark.parametrize('training', [False, True])
+def test_graphed_forward_equals_the_eager_forward(cname, batch, training):
+    """Replays on NEW batches (copied into the static inputs) against the eager no-grad forward of an identical
+    module: outputs and loss to fp32 round-off (the classifier's split-K partials and the BatchNorm batch sums are
+    added with atomics: their order differs between any two runs); in train mode also the BatchNorm running statistics
+    after every pass (the replays keep updating them, like the reference's dev phase does under model.train()), and
+    the warm-up passes of the capture must not have moved them."""
+    import bench as B
+    from bmnas.graph import GraphedForward
+    from gpu_util import assert_close_scaled
+    model, crit, dev, c = _case(cname, batch, training)
+    twin = copy.deepcopy(model)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    xs, y = B.synth_batch(c, batch, dev, 0, 'R', cname)
+    fwd = GraphedForward.try_build(model, crit, xs, y)
+    assert fwd, 'capture failed'
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), f'the capture moved {k}'
+    for it in range(3):
+        xs, y = B.synth_batch(c, batch, dev, 10 + it, 'R', cname)
+        assert fwd.matches(model, xs, y)
+        loss, out = fwd(xs, y)
+        with torch.no_grad():
+            want = twin(xs)
+            wloss = crit(want, y)
+        torch.cuda.synchronize()
+        assert_close_scaled(f'pass {it} output', out, want, rel=1e-5)
+        assert_close_scaled(f'pass {it} loss', loss.reshape(1), wloss.reshape(1), rel=1e-5)
+        for (k, a), (_, b) in zip(model.state_dict().items(), twin.state_dict().items()):
+            if a.dtype.is_floating_point:
+                assert_close_scaled(f'pass {it} {k}', a, b, rel=1e-5)
+            else:
+                assert torch.equal(a, b), (it, k)
+    # another mode or another batch size is not this graph's
+    model.train(not training)
+    assert not fwd.matches(model, xs, y)
+    model.train(training)
+    xs2, y2 = B.synth_batch(c, batch + 1, dev, 0, 'R', cname)
+    assert not fwd.matches(model, xs2, y2)
+
+
+def test_graphed_forward_declines_what_it_cannot_capture():
+    """Host tensors, or a module that synchronises with the host: try_build returns False, the module's state is as
+    before and the GPU is usable."""
+    import bench as B
+    from bmnas.graph import GraphedForward
+    model, crit, dev, c = _case('mmimdb', 8, True)
+    xs, y = B.synth_batch(c, 8, dev, 0, 'R', 'mmimdb')
+    assert GraphedForward.try_build(model, crit, [x.cpu() for x in xs], y) is False
+
+    class Syncing(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, inputs):
+            out = self.inner(inputs)
+            float(out.sum())                               # a host read inside the forward pass
+            return out
+
+    bad = Syncing(model)
+    before = {k: v.clone() for k, v in bad.state_dict().items()}
+    assert GraphedForward.try_build(bad, crit, xs, y) is False
+    for k, v in bad.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    with torch.no_grad():
+        assert torch.isfinite(model(xs)).all()

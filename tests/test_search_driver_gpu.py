@@ -136,6 +136,8 @@ def test_mmimdb_search_driver_with_hip_graph_steps(tmp_path, monkeypatch):
     assert len(genotype.edges) == 4 and len(genotype.steps) == 2
     # 2 epochs x (2 full + 1 ragged) train batches
     assert loop.run.stats['graph_replays'] == 4, loop.run.stats
+    # the metric pass of every dev batch (2 epochs x (1 full + 1 ragged): the ragged shape gets a graph of its own)
+    assert loop.run.stats['forward_replays'] == 4, loop.run.stats
     sd = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
 
