@@ -241,8 +241,15 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     ms_pair = timed(pair, pairs)
     ms_w = timed(lambda: gw(xs, y), pairs)
     ms_a = timed(lambda: ga(xv, yv), pairs)
+    # the dev phase's metric pass (a gradient-free forward after every architect.step, train mode): one replay
+    ms_f = None
+    from bmnas.graph import GraphedForward
+    gf = GraphedForward.try_build(model, crit, xv, yv)
+    if gf:
+        ms_f = round(timed(lambda: gf(xv, yv), pairs), 4)
     log(f'full search step: {ms_pair:.4f} ms per (w-step + alpha-step) pair')
     return {'ms_per_pair': round(ms_pair, 4), 'w_step_ms': round(ms_w, 4), 'alpha_step_ms': round(ms_a, 4),
+            'metric_forward_ms': ms_f,
             'pairs_per_s': round(world * 1e3 / ms_pair, 1), 'pairs_timed': pairs,
             'includes': 'w-step: fwd + criterion + bwd (weights, arch and input grads) + Adam(w, wd 1e-4); '
                         'alpha-step: the same with Adam(alpha/beta/gamma, betas (0.5, 0.999), wd 1e-3); '
