@@ -294,16 +294,17 @@ def _copy_batch_in(static_inputs, static_labels, inputs, labels):
     """The batch into a graph's static tensors: ONE multi-tensor copy launch for the modalities that are already on
     the device, plain copies for anything else (host tensors: the copy IS the H2D transfer)."""
     with torch.no_grad():
-        same = [(d, s_) for d, s_ in zip(static_inputs, inputs)
+        pairs = list(zip(static_inputs, inputs)) + [(static_labels, labels)]
+        # (the labels ride in the same launch when they have the features' dtype — BCE targets; class indices make
+        # a dtype group, i.e. a launch, of their own inside _foreach_copy_)
+        same = [(d, s_) for d, s_ in pairs
                 if s_.device == d.device and s_.dtype == d.dtype and s_.data_ptr() != d.data_ptr()]
         batched = {id(d) for d, _ in same} if len(same) > 1 else set()
         if batched:
             torch._foreach_copy_([d for d, _ in same], [s_ for _, s_ in same])
-        for dst, src in zip(static_inputs, inputs):
+        for dst, src in pairs:
             if id(dst) not in batched and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        if labels.data_ptr() != static_labels.data_ptr():
-            static_labels.copy_(labels, non_blocking=True)
 
 
 class GraphedForward:
