@@ -216,7 +216,8 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     ga = GraphedTrainStep(model, crit, a_opt, xv, yv)
 
     def timed(fn, n):
-        for _ in range(5):
+        # (the captures above left the chip idle for a second: a fixed number of untimed calls first, see measure())
+        for _ in range(300):
             fn()
         if world > 1:
             torch.distributed.barrier()
