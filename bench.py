@@ -1023,6 +1023,29 @@ def main():
     result = headline(a, c, world, shapes, best, eager_ms, rccl)
     dt = statistics.median(shapes[best])
     log(f'timed region done: {dt / a.steps * 1e3:.4f} ms/step')
+    if world == 1 and a.mode == 'graph' and not a.no_full_step and not a.dp_selftest:
+        # NOT the headline (one step per replay, above): what the ~8 us between two replays of a graph are worth,
+        # measured by capturing FOUR consecutive steps into one graph (same kernels, same batch, fresh dropout masks
+        # per step) — what a trainer that keeps several batches resident per replay would see
+        try:
+            one = make_step('single')
+
+            def four():
+                out = None
+                for _ in range(4):
+                    out = one()
+                return out
+            g4 = GraphedStep(four, warmup=1)
+            saved_steps, a.steps = a.steps, max(1, a.steps // 4)
+            t4 = measure(g4.replay, 3)
+            a.steps = saved_steps
+            result['four_steps_per_replay'] = {
+                'ms_per_step': round(statistics.median(t4) / (max(1, a.steps // 4) * 4) * 1e3, 4),
+                'note': 'secondary: four consecutive steps captured into ONE hipGraph; the headline replays one step '
+                        'per graph launch'}
+            del g4
+        except Exception as e:                       # noqa: BLE001 — diagnostics must not cost the headline
+            result['four_steps_per_replay'] = {'error': f'{type(e).__name__}: {e}'[:200]}
     if not a.no_full_step:
         # secondary figure: never allowed to take the headline line down with it — neither by raising nor (N > 1: it
         # contains collectives) by never returning: past the watchdog every rank leaves with the line as it stands
