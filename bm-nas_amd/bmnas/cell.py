@@ -392,10 +392,19 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None,
     if ln is None:
         lib.node_mix_fwd(x, y, p1, U, chan, gamma_row, out, b, C, L, sv.d_glu, sv.d_fc, fin, nxt)
     else:
-        resid, ln_w, ln_b, ln_stats, out_sums = ln
+        resid, ln_w, ln_b, ln_stats, out_sums, lazy = ln
         sv.pre = torch.empty_like(x)
-        lib.node_mix_ln_fwd(x, y, p1, U, chan, gamma_row, resid, ln_w, ln_b, sv.pre, out, ln_stats, b, C, L,
-                            sv.d_glu, sv.d_fc, fin, out_sums)
+        if lazy:
+            # streaming producer: pre + moment records; `out` is formed by its first consumer (if any)
+            P = lib.lazy_ln_parts(C, L)
+            rec, prm = _empty(x, b * P * 8), _empty(x, P * 8)
+            lib.node_mix_pre_fwd(x, y, p1, U, chan, gamma_row, resid, ln_w, ln_b, sv.pre, rec, prm, b, C, L,
+                                 sv.d_glu, sv.d_fc, fin)
+            sv.lazy = LazyNode(desc=lib.make_lazy(sv.pre, rec, prm, ln_w, ln_b, ln_stats), out=out, P=P,
+                               rec=rec, prm=prm)
+        else:
+            lib.node_mix_ln_fwd(x, y, p1, U, chan, gamma_row, resid, ln_w, ln_b, sv.pre, out, ln_stats, b, C, L,
+                                sv.d_glu, sv.d_fc, fin, out_sums)
     return out, sv
 
 
@@ -433,6 +442,20 @@ FUSE_NEXT_PAIR = os.environ.get('BMNAS_FUSE_NEXT_PAIR', '1') != '0'
 FUSE_MIX_EPILOGUE = os.environ.get('BMNAS_FUSE_MIX_EPILOGUE', '1') != '0'
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
 FUSE_HEAD = os.environ.get('BMNAS_FUSE_HEAD', '1') != '0'
+# node_multiplier == 1 under the fused head: the step node's LayerNorm is applied by its consumers (the next step's K1
+# pair sum, the head) and differentiated from per-workgroup partial sums — streaming grids instead of one workgroup
+# per sample in both directions (csrc/lazyln.hip)
+LAZY_LN = os.environ.get('BMNAS_LAZY_LN', '1') != '0'
+
+
+class LazyNode(Pack):
+    """A step-node output whose LayerNorm is pending: desc (lib.LazyLn over pre / rec / prm / affine / stats),
+    out (the (b, C, L) tensor the first K1 consumer fills; never written for the last node), P parts per sample;
+    backward: lnp_head (b, C L / 64, 2) and lnp_k1 (b, k1_n P, 2) partial sums of the LayerNorm backward."""
+    materialised = False
+    lnp_head = None
+    lnp_k1 = None
+    k1_n = 0
 
 
 def _mixed_conv_fwd(sv, x, y, same, P, training, C, attn=None, Weff=None, stats=None):
@@ -515,12 +538,16 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
                                 sv.d_attn)
         elif sv.same:
             if ln is not None:
-                gy, pre, ln_w, stats, r_slot, g_slot = ln
+                gy, pre, ln_w, stats, r_slot, g_slot, lazy = ln
                 g = g_slot.buf()
                 g_slot.written = True
                 rbuf, racc = r_slot.buf(), r_slot.acc_bit()
             dxb, acc = x_slot.buf(), x_slot.acc_bit()
-            if ln is not None:
+            if ln is not None and lazy is not None:
+                lib.node_mix_lnp_bwd(gy, pre, ln_w, stats, lazy.lnp_head, lazy.lnp_k1, g, rbuf, racc, x, y, sv.p1,
+                                     sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc, dV, bn_grad,
+                                     b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
+            elif ln is not None:
                 lib.node_mix_ln_bwd(gy, pre, ln_w, stats, g, rbuf, racc, x, y, sv.p1, sv.conv.U, sv.conv.chan,
                                     sv.gamma, dgamma_row, dxb, None, acc, dV, bn_grad, b, C, L, sv.d_glu,
                                     sv.d_fc, shards, shard_stride)
@@ -588,7 +615,7 @@ def _mix_conv_fwd(pending, tail, C, Wo, ldw, NP, training, stats):
 
 
 def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=None, stats=None,
-                  want_sums=False, next_pair=None):
+                  want_sums=False, next_pair=None, lazy=False):
     """NodeCell.forward (node_search.py:48-70).  beta_w (k_in, 2), gamma_w (ns, 4): softmaxed
     device tensors.  NP: parameter pack of the NodeCell.  z0: the first inner mixed sum when the
     caller already formed it (bmnas_mixsum_pair_fwd)."""
@@ -621,7 +648,7 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
         defer = (FUSE_MIX_GEMM and nm != 1 and t == ns - 1 and stats is not None and x.is_cuda
                  and lib.node_mix_conv_fwd_ok(b, C, L, nm - 1))
         s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
-                                (x, NP.ln_w, NP.ln_b, sv.stats, sv.osum) if last else None,
+                                (x, NP.ln_w, NP.ln_b, sv.stats, sv.osum, lazy) if last else None,
                                 None if weffs is None else weffs[t], stats, nxt, launch_mix=not defer)
         sv.zs.append(z)
         sv.mixed.append(msv)
@@ -629,8 +656,10 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
         offset += len(states)
         states.append(s)
     sv.states = states
+    sv.lazy = None
     if sv.fused_tail:
         sv.o = sv.mixed[-1].pre                          # pre-norm sum o + x; states[-1] is LN(o + x)
+        sv.lazy = getattr(sv.mixed[-1], 'lazy', None)    # ... once a consumer has applied the LayerNorm
         return states[-1], sv
     tail = states[-nm:]
     if nm != 1:
@@ -715,10 +744,14 @@ def node_cell_bwd(sv, g, x_slot, y_slot, dbeta_w, dgamma_w, NG, deferred=None, d
             mix_done = (mdV, mz_slot)
         conv_bn_bwd(sv.oconv, dV, NG.bn_grad, [slots[j] for j in tail],
                     NG.out_conv_dW.view(C, nm * C), NG.out_conv_db, mix=mix)
+    elif sv.lazy is not None:
+        # streaming LayerNorm + mix backward from the partial sums its gradient's producers left (lazyln.hip)
+        assert sv.mixed[ns - 1].same and slots[tail[0]].get() is None
+        ln_job = (g, sv.o, NP.ln_w, sv.stats, x_slot, slots[tail[0]], sv.lazy)
     elif (FUSE_LN_BWD and sv.fused_tail and sv.mixed[ns - 1].same and slots[tail[0]].get() is None
           and lib.node_mix_ln_bwd_ok(b, C, L)):
         # the LayerNorm backward rides in the last inner step's mix-backward launch
-        ln_job = (g, sv.o, NP.ln_w, sv.stats, x_slot, slots[tail[0]])
+        ln_job = (g, sv.o, NP.ln_w, sv.stats, x_slot, slots[tail[0]], None)
     else:
         bufs, mask = _write_group([slots[tail[0]]])
         racc = x_slot.acc_bit()
@@ -780,14 +813,23 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
     sv.sifs, sv.nodes, sv.offsets = [], [], []
     offset = 0
     pending_pair = None                          # (sif, z0) of step i formed by step i - 1's tail launch
+    # the step nodes' LayerNorm applied by their consumers (streaming grids, csrc/lazyln.hip)
+    sv.lazy_on = bool(LAZY_LN and head is not None and nm == 1 and FUSE_TAIL and FUSE_PAIR and N + S <= 15
+                      and 1 <= S <= 3 and M <= S and (C * L) % 64 == 0 and xs[0].is_cuda and lib.lazy_ln_ok(C, L))
     for i in range(S):
         if pending_pair is not None:
             sif, z0 = pending_pair
             pending_pair = None
         elif FUSE_PAIR and len(states) <= 15:
             sif, z0 = torch.empty_like(xs[0]), torch.empty_like(xs[0])
+            lz = sv.nodes[-1].lazy if (sv.lazy_on and i >= 1) else None
             if i == 0 and prologue is not None:
                 prologue(states, sif, z0)        # the cell prologue rides in this launch (bmnas_cell_prologue_pair)
+            elif lz is not None and not lz.materialised:
+                # the previous node's output is still un-normalised: this launch applies its LayerNorm and writes it
+                lib.mixsum_pair_fwd_lazy(states[:-1], alpha_w[offset:, 1], 2, beta_ws[i][:, 1], 2, lz.desc,
+                                         states[-1], sv.nodes[-1].osum, sif, z0, b, C, L)
+                lz.materialised = True
             else:
                 lib.mixsum_pair_fwd(states, alpha_w[offset:, 1], 2, beta_ws[i][:, 1], 2, sif, z0)
         else:
@@ -801,7 +843,7 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
             next_pair = (list(states), alpha_w[offset + len(states):, 1], 2, beta_ws[i + 1][:, 1], 2, nsif, nz0)
         out, nsv = node_cell_fwd(sif, sif, beta_ws[i], gamma_ws[i], CP.nodes[i], training, ns, nm, z0,
                                  None if weffs is None else weffs[i * ns:(i + 1) * ns], stats,
-                                 want_sums=head is not None, next_pair=next_pair)
+                                 want_sums=head is not None, next_pair=next_pair, lazy=sv.lazy_on)
         if next_pair is not None and nsv.next_pair_done:
             pending_pair = (next_pair[5], next_pair[6])
         nsv.paired = z0 is not None
@@ -817,8 +859,14 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
         if M > S:
             raise lib.BmnasError('fused head: the cell concatenates input states (multiplier > steps)')
         head.sums = [nsv.osum for nsv in sv.nodes[S - M:]]
-        lib.head_fwd(states[-M:], head.sums, CP.ln_w, CP.ln_b, head.W, head.bias, head.hb, sv.stats, b, C, L,
-                     head.W.shape[0])
+        last = sv.nodes[-1].lazy if sv.lazy_on else None
+        if last is not None and not last.materialised:
+            # the last node's output exists only inside the classifier GEMM's operand fetch
+            lib.head_fwd_lazy(states[-M:-1] + [sv.nodes[-1].o], head.sums[:-1] + [None], M - 1, last.desc, CP.ln_w,
+                              CP.ln_b, head.W, head.bias, head.hb, sv.stats, b, C, L, head.W.shape[0])
+        else:
+            lib.head_fwd(states[-M:], head.sums, CP.ln_w, CP.ln_b, head.W, head.bias, head.hb, sv.stats, b, C, L,
+                         head.W.shape[0])
         return head.hb[0], sv
     out = _empty(xs[0], b, M * C * L)
     lib.cat_ln_fwd(states[-M:], None, CP.ln_w, CP.ln_b, out, sv.stats, b, C, L, True)
@@ -878,8 +926,22 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
         want = WANT_PARAM_GRADS
         part = _empty(x0, n_chunk * (O + 3) * D) if want else None
         mode, gten, gscale, labels = head.resolve(g)
-        lib.head_bwd(sv.states[-M:], head.sums, bufs, mask, CP.ln_w, CP.ln_b, head.W, head.hb, sv.stats, mode,
-                     gten, gscale, labels, head.loss, part, b, C, L, O, getattr(CG, 'scrub', None))
+        if sv.lazy_on:
+            # every source as (pre, node LayerNorm): the launch also leaves the partial sums of the nodes' LayerNorm
+            # backward; later cell steps' K1 backward launches add theirs (k1 buffers allocated here)
+            P = sv.nodes[0].lazy.P
+            for t, nsv in enumerate(sv.nodes):
+                lzn = nsv.lazy
+                lzn.lnp_head = _empty(x0, b * (C * L // 64) * 2) if t >= S - M else None
+                lzn.k1_n = S - 1 - t
+                lzn.lnp_k1 = _empty(x0, b * lzn.k1_n * P * 2) if lzn.k1_n else None
+            tailn = sv.nodes[S - M:]
+            lib.head_bwd_lazy([n.lazy.desc for n in tailn], [n.lazy.lnp_head for n in tailn], bufs, mask, CP.ln_w,
+                              CP.ln_b, head.W, head.hb, sv.stats, mode, gten, gscale, labels, head.loss, part, b, C,
+                              L, O, getattr(CG, 'scrub', None))
+        else:
+            lib.head_bwd(sv.states[-M:], head.sums, bufs, mask, CP.ln_w, CP.ln_b, head.W, head.hb, sv.stats, mode,
+                         gten, gscale, labels, head.loss, part, b, C, L, O, getattr(CG, 'scrub', None))
         head.dW = head.dbias = None
         if want:
             hsum = _empty(x0, (O + 3) * D)
@@ -919,9 +981,19 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
                                dw2=dbeta_ws[i][:, 1], shards=CG.shards, stride=CG.shard_stride)
                 continue
             bufs, mask = _write_group(slots[:n_in])
-            lib.mixsum_pair_bwd(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
-                                sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1],
-                                mask, CG.shards, CG.shard_stride, gz2)
+            if sv.lazy_on and i >= 1:
+                # its last i inputs are step-node outputs with a streaming LayerNorm backward: leave their partials
+                P = sv.nodes[0].lazy.P
+                lzs = [sv.nodes[t].lazy for t in range(i)]
+                views = [lz.lnp_k1[(i - 1 - t) * P * 2:] for t, lz in enumerate(lzs)]
+                lib.mixsum_pair_bwd_lazy(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
+                                         sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1], mask,
+                                         [lz.desc for lz in lzs], views, [lz.k1_n * P for lz in lzs], b, C, L,
+                                         CG.shards, CG.shard_stride, gz2)
+            else:
+                lib.mixsum_pair_bwd(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
+                                    sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1],
+                                    mask, CG.shards, CG.shard_stride, gz2)
         else:
             mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
                        dalpha_w[off:, 1], 2, CG.shards, CG.shard_stride)

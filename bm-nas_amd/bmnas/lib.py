@@ -62,6 +62,12 @@ class BnFin(C.Structure):
 
 NO_FIN = BnFin()
 
+
+class LazyLn(C.Structure):
+    """bmnas_lazy_ln_t: a step-node output whose LayerNorm its consumers apply (csrc/lazyln.hip)"""
+    _fields_ = [('pre', C.c_void_p), ('rec', C.c_void_p), ('prm', C.c_void_p), ('ln_w', C.c_void_p),
+                ('ln_b', C.c_void_p), ('stats', C.c_void_p)]
+
 MAX_GROUP = 8
 
 
@@ -192,6 +198,18 @@ SIGNATURES = {
                                  _I, _PP, _PP, C.POINTER(C.c_int), C.POINTER(C.c_int64), _P], _I),
     'bmnas_head_chunks': ([_I], _I),
     'bmnas_head_fwd': ([_PP, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_lazy_ln_ok': ([_I, _I], _I),
+    'bmnas_lazy_ln_parts': ([_I, _I], _I),
+    'bmnas_node_mix_pre_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout,
+                                _P], _I),
+    'bmnas_mixsum_pair_fwd_lazy': ([_PP, _I, _P, _I, _P, _I, C.POINTER(LazyLn), _P, _P, _P, _P, _I, _I, _I, _P], _I),
+    'bmnas_mixsum_pair_bwd_lazy': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _U32,
+                                    C.POINTER(LazyLn), _PP, C.POINTER(C.c_int), _I, _P, _I, _I, _I, _P], _I),
+    'bmnas_head_fwd_lazy': ([_PP, _PP, _I, _I, C.POINTER(LazyLn), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_head_bwd_lazy': ([C.POINTER(LazyLn), _PP, _PP, _I, _U32, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P,
+                             _I, _I, _I, _I, _P, _I64, _P], _I),
+    'bmnas_node_mix_lnp_bwd': ([_P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I64,
+                                _P, _P, _U32, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
     'bmnas_head_bwd': ([_PP, _PP, _PP, _I, _U32, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                         _P, _I64, _P], _I),
     'bmnas_sum_chunks': ([_P, _P, _I, _I64, _P], _I),
@@ -405,6 +423,82 @@ def head_bwd(srcs, sums, dsrcs, acc_mask, ln_w, ln_b, W, hb, stats, mode, g, gsc
                                  None if labels is None else labels.data_ptr(), _ptr(loss), _ptr(part),
                                  b, Cc, L, O, _ptr(scrub),
                                  0 if scrub is None else scrub.numel(), _stream()), 'head_bwd')
+
+
+# ------------------------------------------------- the step node's LayerNorm applied by its consumers (csrc/lazyln.hip)
+def lazy_ln_ok(Cc, L):
+    return bool(load().bmnas_lazy_ln_ok(Cc, L))
+
+
+def lazy_ln_parts(Cc, L):
+    n = load().bmnas_lazy_ln_parts(Cc, L)
+    if n < 1:
+        _check(n, 'lazy_ln_parts')
+    return n
+
+
+def make_lazy(pre, rec, prm, ln_w, ln_b, stats):
+    return LazyLn(_ptr(pre), _ptr(rec), _ptr(prm), _ptr(ln_w), _ptr(ln_b), _ptr(stats))
+
+
+def node_mix_pre_fwd(x, y, p1, U, chan, gamma, resid, ln_w, ln_b, pre, rec, prm, b, Cc, L, dglu, dfc, fin=NO_FIN):
+    _check(load().bmnas_node_mix_pre_fwd(_ptr(x), _ptr(y), _ptr(p1), _ptr(U), _ptr(chan), fin, gamma.data_ptr(),
+                                         _ptr(resid), _ptr(ln_w), _ptr(ln_b), _ptr(pre), _ptr(rec), _ptr(prm),
+                                         b, Cc, L, dglu, dfc, _stream()), 'node_mix_pre_fwd')
+
+
+def mixsum_pair_fwd_lazy(xs, w, w_stride, w2, w2_stride, lazy, last_out, last_sums, out, out2, b, Cc, L):
+    """xs: the plain inputs; the lazy node output is the LAST input (weight w[len(xs) * w_stride])."""
+    _check(load().bmnas_mixsum_pair_fwd_lazy(_ptrs(xs), len(xs), w.data_ptr(), w_stride, w2.data_ptr(), w2_stride,
+                                             C.byref(lazy), _ptr(last_out), _ptr(last_sums), _ptr(out), _ptr(out2),
+                                             b, Cc, L, _stream()), 'mixsum_pair_fwd_lazy')
+
+
+def mixsum_pair_bwd_lazy(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, acc_mask, lazies, lnparts, strides,
+                         b, Cc, L, dw_shards=1, dw_shard_stride=0, gz2=None, g_full=None):
+    """The last len(lazies) inputs of xs are lazy-LayerNorm node outputs; lnparts[t] (views into (b, strides[t], 2)
+    buffers, starting at this consumer's first pair) receive the partials."""
+    n = len(lazies)
+    arr = (LazyLn * n)(*lazies)
+    st = (C.c_int * n)(*strides)
+    _check(load().bmnas_mixsum_pair_bwd_lazy(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, w2.data_ptr(),
+                                             w2_stride, _ptr(h), _ptr(gh), _ptr(gz), _ptr(gz2), dw.data_ptr(),
+                                             dw2.data_ptr(), dw_shards, dw_shard_stride, acc_mask, arr,
+                                             (C.c_void_p * n)(*[t.data_ptr() for t in lnparts]), st, n,
+                                             _ptr(g_full), b, Cc, L, _stream()),
+           'mixsum_pair_bwd_lazy')
+
+
+def head_fwd_lazy(srcs, sums, lazy_q, lazy, ln_w, ln_b, W, bias, hb, stats, b, Cc, L, O):
+    """bmnas_head_fwd whose source lazy_q is srcs[lazy_q] = the un-normalised `pre` described by `lazy`."""
+    _check(load().bmnas_head_fwd_lazy(_ptrs(srcs), _ptrs(sums), len(srcs), lazy_q, C.byref(lazy), _ptr(ln_w),
+                                      _ptr(ln_b), _ptr(W), _ptr(bias), _ptr(hb), _ptr(stats), b, Cc, L, O,
+                                      _stream()), 'head_fwd_lazy')
+
+
+def head_bwd_lazy(lazies, lnparts, dsrcs, acc_mask, ln_w, ln_b, W, hb, stats, mode, g, gscale, labels, loss, part,
+                  b, Cc, L, O, scrub=None):
+    n = len(lazies)
+    arr = (LazyLn * n)(*lazies)
+    _check(load().bmnas_head_bwd_lazy(arr, _ptrs(lnparts), _ptrs(dsrcs), n, acc_mask, _ptr(ln_w), _ptr(ln_b),
+                                      _ptr(W), _ptr(hb), _ptr(stats), mode, _ptr(g),
+                                      None if gscale is None else gscale.data_ptr(),
+                                      None if labels is None else labels.data_ptr(), _ptr(loss), _ptr(part),
+                                      b, Cc, L, O, _ptr(scrub), 0 if scrub is None else scrub.numel(), _stream()),
+           'head_bwd_lazy')
+
+
+def node_mix_lnp_bwd(gy, pre, ln_w, stats, lnp0, lnp1, g_in, dresid, acc_resid, x, y, p1, U, chan, gamma, dgamma, dx,
+                     dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc, dg_shards=1, dg_stride=0):
+    """lnp0 / lnp1: (b, n, 2) partial sums of the LayerNorm backward (None: absent)."""
+    n0 = 0 if lnp0 is None else lnp0.numel() // (2 * b)
+    n1 = 0 if lnp1 is None else lnp1.numel() // (2 * b)
+    _check(load().bmnas_node_mix_lnp_bwd(_ptr(gy), _ptr(pre), _ptr(ln_w), _ptr(stats), _ptr(lnp0), n0, _ptr(lnp1),
+                                         n1, _ptr(g_in), _ptr(dresid), acc_resid, _ptr(x), _ptr(y), _ptr(p1),
+                                         _ptr(U), _ptr(chan), gamma.data_ptr(),
+                                         None if dgamma is None else dgamma.data_ptr(), dg_shards, dg_stride,
+                                         _ptr(dx), _ptr(dy), acc_mask, _ptr(dV), _ptr(bn_grad), b, Cc, L, dglu, dfc,
+                                         _stream()), 'node_mix_lnp_bwd')
 
 
 def adaptive_maxpool_group(xs, dims, outs, idxs, b):

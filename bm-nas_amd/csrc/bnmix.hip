@@ -8,6 +8,7 @@
 #include "../../include/bmnas_hip.h"
 #include "arch_body.hpp"
 #include "bn_fin.hpp"
+#include "mix_common.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -88,10 +89,6 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ p
   }
 }
 
-__device__ __forceinline__ float4 affine4(float4 u, float sc, float sh) {
-  return make_float4(fmaf(u.x, sc, sh), fmaf(u.y, sc, sh), fmaf(u.z, sc, sh), fmaf(u.w, sc, sh));
-}
-__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
 
 // The NEXT inner step's mixed sum riding in this step's mix kernel (NodeCell, node_search.py:54):
 // z_next = sum_{j < n} w_j prev_j + w_n s, with s the state this kernel produces — one launch and one
@@ -279,12 +276,6 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
   }
 }
 
-// reduce v over the l4n adjacent lanes that share a channel row (l4n in {1, 2, 4})
-__device__ __forceinline__ float row_sum(float v, int l4n) {
-  if (l4n >= 2) v += __shfl_xor(v, 1, 64);
-  if (l4n >= 4) v += __shfl_xor(v, 2, 64);
-  return v;
-}
 
 template <int NP>
 __global__ __launch_bounds__(256) void node_mix_bwd_k(
@@ -1183,31 +1174,6 @@ inline int stream_grid(int64_t total) {
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
-}
-
-inline DropCfg to_cfg(const bmnas_dropout_t& d) {
-  DropCfg c;
-  c.thr = d.thr; c.scale = d.scale; c.seed = d.seed; c.offset = d.offset; c.step = d.step;
-  return c;
-}
-
-// bmnas_bn_fin_t -> BnFin; < 0 on a bad descriptor
-inline int to_fin(const bmnas_bn_fin_t& f, BnFin* o) {
-  o->on = f.on ? 1 : 0;
-  if (!o->on) {
-    *o = BnFin{};
-    return 0;
-  }
-  if (!f.bn_w || !f.bn_b || f.shards < 0 || f.n_nbt < 0) return BMNAS_E_ARG;
-  if (f.shards > 4) return BMNAS_E_LIMIT;
-  if (f.training && (!f.stat || f.shards < 1)) return BMNAS_E_ARG;
-  if (!f.training && (!f.running_mean || !f.running_var)) return BMNAS_E_ARG;
-  if ((f.running_mean == nullptr) != (f.running_var == nullptr)) return BMNAS_E_ARG;
-  o->stat = f.stat; o->conv_bias = f.conv_bias; o->bn_w = f.bn_w; o->bn_b = f.bn_b;
-  o->running_mean = f.running_mean; o->running_var = f.running_var;
-  o->nbt = reinterpret_cast<long long*>(f.num_batches_tracked);
-  o->shards = f.shards; o->n_nbt = f.n_nbt; o->training = f.training ? 1 : 0;
-  return 0;
 }
 
 // samples walked per workgroup in the backward reductions: keep >= ~512 workgroups

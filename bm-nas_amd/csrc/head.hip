@@ -26,6 +26,7 @@
 // ~15 MB at MM-IMDB batch 128); algorithmic FLOPs fwd 6 b O D (three accumulator sets), bwd 4 b O D.
 #include "common.hpp"
 #include "../../include/bmnas_hip.h"
+#include "lazy_ln.hpp"
 #include <cstdlib>
 
 namespace {
@@ -37,6 +38,21 @@ constexpr int kMaxO = 128;
 struct HeadSrc {
   const float* p[kHeadSrc];      // M states (b, C, L)
   const float* sums[kHeadSrc];   // per state: (b, 2) = (sum, sum of squares) of each sample
+};
+
+// Step-node outputs whose LayerNorm is applied HERE instead of by their producer (lazyln.hip, lazy_ln.hpp).
+// Forward: source `lq` is given un-normalised (src.p[lq] = pre) with its moment records; it is normalised in the
+// operand fetch, its (mean, rstd) are written to nstats[lq] and its per-sample sums follow from the records.
+// Backward: EVERY source is given as `pre` + nstats + the node LayerNorm's affine, and the launch also leaves,
+// per (sample, 64-k group), the partials of S(gy w), S(gy w xhat) of the node LayerNorm backward in lnpart[q].
+struct HeadLazy {
+  const float* rec;              // forward: (b, P, 8) of source lq
+  const float* prm;              //          (P, 8)
+  const float* nw[kHeadSrc];     // node LayerNorm affine (C, L); forward: entry 0 describes source lq
+  const float* nb[kHeadSrc];
+  float* nstats[kHeadSrc];       // (b, 2) mean | rstd of the node LayerNorm (forward: entry 0, written; backward: read)
+  float* lnpart[kHeadSrc];       // backward: (b, CL / 64, 2), nullable
+  int lq, P;
 };
 
 __device__ __forceinline__ void sample_stats(const HeadSrc& src, int n_src, int s, int D, float* mean, float* rstd) {
@@ -67,19 +83,39 @@ struct HeadFwdArgs {
 
 // grid = (KS k-slices, ceil(b / 16) sample tiles); 4 waves; wave w of slice ks takes the 16-k blocks
 // kb = (j * KS + ks) * 4 + w, j < J.  All operand loads of a wave are issued before its first MFMA.
-template <int J, int TJ>
-__global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a) {
+template <int J, int TJ, bool LZ>
+__global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
   __shared__ float red[4][3][16][16 * TJ + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int ks = blockIdx.x, st = blockIdx.y;
   const int s = st * 16 + lo;
   const int sc = s < a.b ? s : a.b - 1;                       // clamped rows are never stored
-  float mean, rstd;
-  sample_stats(a.src, a.n_src, sc, a.D, &mean, &rstd);
+  float mean, rstd, nmean = 0.f, nrstd = 1.f;
+  if (LZ) {
+    const LazyStats ls = lazy_combine(z.rec, z.prm, z.P, sc);
+    float S = ls.osum, Q = ls.osq;
+    for (int q = 0; q < a.n_src; ++q) {
+      if (q == z.lq) continue;
+      const float2 v = reinterpret_cast<const float2*>(a.src.sums[q])[sc];
+      S += v.x;
+      Q += v.y;
+    }
+    const float inv = 1.f / (float)a.D;
+    mean = S * inv;
+    rstd = 1.f / sqrtf(fmaxf(Q * inv - mean * mean, 0.f) + kEpsLn);
+    nmean = ls.mean;
+    nrstd = ls.rstd;
+  } else {
+    sample_stats(a.src, a.n_src, sc, a.D, &mean, &rstd);
+  }
   if (ks == 0 && wave == 0 && h == 0 && s < a.b) {
     a.stats[2 * s] = mean;
     a.stats[2 * s + 1] = rstd;
+    if (LZ) {
+      z.nstats[0][2 * s] = nmean;
+      z.nstats[0][2 * s + 1] = nrstd;
+    }
   }
   const int nkb = a.D / 16;
   int oc[TJ];
@@ -88,8 +124,8 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a) {
     const int o = 16 * t + lo;
     oc[t] = o < a.O ? o : a.O - 1;
   }
-  float4 xv[J], lw[J], lb[J], wv[J][TJ];
-  bool valid[J];
+  float4 xv[J], lw[J], lb[J], wv[J][TJ], nwv[LZ ? J : 1], nbv[LZ ? J : 1];
+  bool valid[J], lzq[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int kb = (j * a.KS + ks) * 4 + wave;
@@ -100,6 +136,11 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a) {
     xv[j] = ld4(a.src.p[q] + (int64_t)sc * a.CL + (k - q * a.CL));
     lw[j] = ld4(a.ln_w + k);
     lb[j] = ld4(a.ln_b + k);
+    lzq[j] = LZ && q == z.lq;                                 // wave-uniform
+    if (LZ) {                                                 // unconditional loads: an always-valid address otherwise
+      nwv[j] = ld4(lzq[j] ? z.nw[0] + (k - q * a.CL) : a.ln_w + k);
+      nbv[j] = ld4(lzq[j] ? z.nb[0] + (k - q * a.CL) : a.ln_b + k);
+    }
 #pragma unroll
     for (int t = 0; t < TJ; ++t) wv[j][t] = ld4(a.W + (int64_t)oc[t] * a.D + k);
   }
@@ -112,9 +153,15 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a) {
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     if (!valid[j]) continue;
-    const float x4[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+    float x4[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
     const float w4[4] = {lw[j].x, lw[j].y, lw[j].z, lw[j].w};
     const float b4[4] = {lb[j].x, lb[j].y, lb[j].z, lb[j].w};
+    if (LZ && lzq[j]) {                                       // the node's own LayerNorm first (node_search.py:68)
+      const float n4[4] = {nwv[j].x, nwv[j].y, nwv[j].z, nwv[j].w};
+      const float c4[4] = {nbv[j].x, nbv[j].y, nbv[j].z, nbv[j].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x4[r] = (x4[r] - nmean) * nrstd * n4[r] + c4[r];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float xh = (x4[r] - mean) * rstd;
@@ -199,11 +246,12 @@ __device__ __forceinline__ float group16_max(float v) {
   return v;
 }
 
-template <int OT, int SG>
-__global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
+template <int OT, int SG, bool LZ>
+__global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
   constexpr int kSteps = 4 * OT, kRows = 16 * SG;
   __shared__ float dl_s[kRows][16 * OT + 4];
-  __shared__ float ms[4][kRows];         // m1, m2, mean, rstd
+  __shared__ float ms[LZ ? 6 : 4][kRows];         // m1, m2, mean, rstd (, node mean, node rstd)
+  __shared__ float lnp_s[LZ ? 4 : 1][LZ ? kRows : 1][2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int chunk = blockIdx.y, s0 = chunk * kRows;
@@ -228,6 +276,14 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
   }
   const float4 lw = ld4(a.ln_w + k0 + 4 * h), lb = ld4(a.ln_b + k0 + 4 * h);
   const float lwk = a.ln_w[k0 + lo], lbk = a.ln_b[k0 + lo];
+  float4 nw4 = make_float4(1.f, 1.f, 1.f, 1.f), nb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float nwk = 1.f, nbk = 0.f;
+  if (LZ) {                                                     // (q: uniform over the workgroup, CL % 64 == 0)
+    nw4 = ld4(z.nw[q] + kin + 4 * h);
+    nb4 = ld4(z.nb[q] + kin + 4 * h);
+    nwk = z.nw[q][kin + lo];
+    nbk = z.nb[q][kin + lo];
+  }
   float4 x[SG];
   float xr[SG][4];
 #pragma unroll
@@ -242,7 +298,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
   }
   // ---- prologue: thread = (row tid / 16 of sample group g, class stripe lo + 16 u)
   {
-    float zz[SG][OT], aa[SG][OT], bb[SG][OT], yy[SG][OT], st_mean[SG], st_rstd[SG];
+    float zz[SG][OT], aa[SG][OT], bb[SG][OT], yy[SG][OT], st_mean[SG], st_rstd[SG], nd_mean[SG], nd_rstd[SG];
     int lab[SG];
 #pragma unroll
     for (int g = 0; g < SG; ++g) {
@@ -260,6 +316,8 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
       lab[g] = (a.mode == 2) ? (int)a.labels_i[spc] : 0;
       st_mean[g] = a.stats[2 * spc];
       st_rstd[g] = a.stats[2 * spc + 1];
+      nd_mean[g] = LZ ? z.nstats[q][2 * spc] : 0.f;
+      nd_rstd[g] = LZ ? z.nstats[q][2 * spc + 1] : 1.f;
     }
     float loss_acc = 0.f;
 #pragma unroll
@@ -317,6 +375,10 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
         ms[1][rr] = p2 * invD;
         ms[2][rr] = st_mean[g];
         ms[3][rr] = st_rstd[g];
+        if (LZ) {
+          ms[4][rr] = nd_mean[g];
+          ms[5][rr] = nd_rstd[g];
+        }
       }
       loss_acc += vsp ? row_loss : 0.f;
     }
@@ -336,6 +398,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
   // ---- the tile
   float* const part = a.part + (int64_t)chunk * (a.O + 3) * a.D;
   const float wq[4] = {lw.x, lw.y, lw.z, lw.w}, bq[4] = {lb.x, lb.y, lb.z, lb.w};
+  const float nwq[4] = {nw4.x, nw4.y, nw4.z, nw4.w}, nbq[4] = {nb4.x, nb4.y, nb4.z, nb4.w};
   float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
   float fr[SG][4];
 #pragma unroll
@@ -354,7 +417,16 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
                                                    0, 0, 0);
       }
     }
-    const float xq[4] = {x[g].x, x[g].y, x[g].z, x[g].w};
+    float xq[4] = {x[g].x, x[g].y, x[g].z, x[g].w};
+    float xhn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (LZ) {                                                   // the state itself: LayerNorm_node(pre)
+      const float nmean = ms[4][rl], nrstd = ms[5][rl];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xhn[r] = (xq[r] - nmean) * nrstd;
+        xq[r] = xhn[r] * nwq[r] + nbq[r];
+      }
+    }
     float dx[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -364,6 +436,22 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
       dx[r] = rstd * (gy * wq[r] - m1 - xh * m2);
       gw[r] += gy * xh;
       gb[r] += gy;
+    }
+    if (LZ) {
+      // this wave's 16 k of the node LayerNorm backward's two sums, per sample: S(gy w), S(gy w xhat)
+      float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = vs ? dx[r] * nwq[r] : 0.f;
+        q1 += t;
+        q2 += t * xhn[r];
+      }
+      q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+      q2 += __shfl_xor(q2, 16, 64); q2 += __shfl_xor(q2, 32, 64);
+      if (h == 0) {
+        lnp_s[wave][rl][0] = q1;
+        lnp_s[wave][rl][1] = q2;
+      }
     }
     float* d = a.dsrc[q];
     if (d != nullptr && vs && !(a.probe & 2)) {
@@ -376,8 +464,22 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rl2 = 16 * g + 4 * h + r;
-      const float pre = (xr[g][r] - ms[2][rl2]) * ms[3][rl2] * lwk + lbk;
+      float xv2 = xr[g][r];
+      if (LZ) xv2 = (xv2 - ms[4][rl2]) * ms[5][rl2] * nwk + nbk;
+      const float pre = (xv2 - ms[2][rl2]) * ms[3][rl2] * lwk + lbk;
       fr[g][r] = (s0 + rl2 < a.b) ? fmaxf(pre, 0.f) : 0.f;
+    }
+  }
+  if (LZ) {                                                     // (every wave is here: CL % 64 == 0 -> vt)
+    __syncthreads();
+    float* lp = z.lnpart[q];
+    if (lp != nullptr && (int)threadIdx.x < 2 * kRows) {
+      const int rl = threadIdx.x >> 1, cpt = threadIdx.x & 1;
+      if (s0 + rl < a.b) {
+        const int nkg = a.CL / 64, kg = blockIdx.x - q * nkg;
+        lp[((int64_t)(s0 + rl) * nkg + kg) * 2 + cpt] =
+            (lnp_s[0][rl][cpt] + lnp_s[1][rl][cpt]) + (lnp_s[2][rl][cpt] + lnp_s[3][rl][cpt]);
+      }
     }
   }
   // LayerNorm affine partials of this chunk: sum over the samples (lanes lo, groups) per k
@@ -426,17 +528,6 @@ __global__ __launch_bounds__(256) void sum_chunks_k(const float* __restrict__ pa
   }
 }
 
-int fill_src(HeadSrc& s, const float* const* srcs, const float* const* sums, int n_src) {
-  if (!srcs || !sums || n_src < 1) return BMNAS_E_ARG;
-  if (n_src > kHeadSrc) return BMNAS_E_LIMIT;
-  for (int q = 0; q < n_src; ++q) {
-    if (!srcs[q] || !sums[q]) return BMNAS_E_ARG;
-    s.p[q] = srcs[q];
-    s.sums[q] = sums[q];
-  }
-  return 0;
-}
-
 }  // namespace
 
 // samples per partial-sum chunk of the backward: 32 (two MFMA sample groups per workgroup: the W
@@ -449,14 +540,20 @@ extern "C" int bmnas_head_chunks(int b) {
   return (b + rows - 1) / rows;
 }
 
-extern "C" int bmnas_head_fwd(const float* const* srcs, const float* const* sums, int n_src,
-                              const float* ln_w, const float* ln_b, const float* W, const float* bias,
-                              float* hb, float* stats, int b, int C, int L, int O, void* stream) {
+static int head_fwd_impl(const float* const* srcs, const float* const* sums, int n_src, const float* ln_w,
+                         const float* ln_b, const float* W, const float* bias, float* hb, float* stats, int b, int C,
+                         int L, int O, const HeadLazy* lazy, void* stream) {
   if (!ln_w || !ln_b || !W || !bias || !hb || !stats || b < 0 || C < 1 || L < 1 || O < 1) return BMNAS_E_ARG;
   if (O > kMaxO) return BMNAS_E_LIMIT;
   if ((C * L) % 16) return BMNAS_E_SHAPE;
   HeadFwdArgs a{};
-  if (int e = fill_src(a.src, srcs, sums, n_src)) return e;
+  if (!srcs || !sums || n_src < 1) return BMNAS_E_ARG;
+  if (n_src > kHeadSrc) return BMNAS_E_LIMIT;
+  for (int q = 0; q < n_src; ++q) {
+    if (!srcs[q] || (!sums[q] && !(lazy && q == lazy->lq))) return BMNAS_E_ARG;
+    a.src.p[q] = srcs[q];
+    a.src.sums[q] = sums[q];
+  }
   if (b == 0) return 0;
   a.ln_w = ln_w; a.ln_b = ln_b; a.W = W; a.bias = bias; a.hb = hb; a.stats = stats;
   a.b = b; a.O = O; a.CL = C * L; a.D = n_src * C * L; a.n_src = n_src;
@@ -469,7 +566,13 @@ extern "C" int bmnas_head_fwd(const float* const* srcs, const float* const* sums
   dim3 grid((unsigned)a.KS, (unsigned)tiles);
   const int TJ = (O + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-#define HF(Jv, Tv) hipLaunchKernelGGL((head_fwd_k<Jv, Tv>), grid, dim3(256), 0, st, a)
+  HeadLazy z{};
+  if (lazy) z = *lazy;
+#define HF(Jv, Tv)                                                                              \
+  do {                                                                                          \
+    if (lazy) hipLaunchKernelGGL((head_fwd_k<Jv, Tv, true>), grid, dim3(256), 0, st, a, z);     \
+    else hipLaunchKernelGGL((head_fwd_k<Jv, Tv, false>), grid, dim3(256), 0, st, a, z);         \
+  } while (0)
 #define HF_T(Jv)                                                                      \
   do {                                                                                \
     if (TJ <= 2) HF(Jv, 2); else if (TJ <= 4) HF(Jv, 4); else if (TJ <= 6) HF(Jv, 6); \
@@ -482,19 +585,46 @@ extern "C" int bmnas_head_fwd(const float* const* srcs, const float* const* sums
   return 0;
 }
 
-extern "C" int bmnas_head_bwd(const float* const* srcs, const float* const* sums, float* const* dsrcs,
-                              int n_src, uint32_t accumulate_mask, const float* ln_w, const float* ln_b,
-                              const float* W, const float* hb, const float* stats, int mode, const float* g,
-                              const float* gscale, const void* labels, float* loss, float* part,
-                              int b, int C, int L, int O, float* scrub, int64_t scrub_n, void* stream) {
+extern "C" int bmnas_head_fwd(const float* const* srcs, const float* const* sums, int n_src,
+                              const float* ln_w, const float* ln_b, const float* W, const float* bias,
+                              float* hb, float* stats, int b, int C, int L, int O, void* stream) {
+  return head_fwd_impl(srcs, sums, n_src, ln_w, ln_b, W, bias, hb, stats, b, C, L, O, nullptr, stream);
+}
+
+extern "C" int bmnas_head_fwd_lazy(const float* const* srcs, const float* const* sums, int n_src, int lazy_q,
+                                   const bmnas_lazy_ln_t* lazy, const float* ln_w, const float* ln_b,
+                                   const float* W, const float* bias, float* hb, float* stats, int b, int C, int L,
+                                   int O, void* stream) {
+  if (!lazy || lazy_q < 0 || lazy_q >= n_src) return BMNAS_E_ARG;
+  if (!lazy->pre || !lazy->rec || !lazy->prm || !lazy->ln_w || !lazy->ln_b || !lazy->stats) return BMNAS_E_ARG;
+  if (!bmnas_lazy_ln_ok(C, L)) return BMNAS_E_LIMIT;
+  if (!srcs || srcs[lazy_q] != lazy->pre) return BMNAS_E_ARG;      // the lazy source IS given un-normalised
+  HeadLazy z{};
+  z.rec = lazy->rec; z.prm = lazy->prm; z.nw[0] = lazy->ln_w; z.nb[0] = lazy->ln_b; z.nstats[0] = lazy->stats;
+  z.lq = lazy_q; z.P = bmnas_lazy_ln_parts(C, L);
+  return head_fwd_impl(srcs, sums, n_src, ln_w, ln_b, W, bias, hb, stats, b, C, L, O, &z, stream);
+}
+
+static int head_bwd_impl(const float* const* srcs, const float* const* sums, float* const* dsrcs, int n_src,
+                         uint32_t accumulate_mask, const float* ln_w, const float* ln_b, const float* W,
+                         const float* hb, const float* stats, int mode, const float* g, const float* gscale,
+                         const void* labels, float* loss, float* part, int b, int C, int L, int O, float* scrub,
+                         int64_t scrub_n, const HeadLazy* lazy, void* stream) {
   if (!dsrcs || !ln_w || !ln_b || !W || !hb || !stats || b < 0 || C < 1 || L < 1 || O < 1)
     return BMNAS_E_ARG;                          // (part may be NULL: no classifier / K7-affine gradients wanted)
   if (mode < 0 || mode > 2 || (mode == 0 && !g) || (mode != 0 && (!labels || !loss))) return BMNAS_E_ARG;
   if (scrub_n < 0 || (scrub_n > 0 && !scrub) || scrub_n % 4) return BMNAS_E_ARG;
   if (O > kMaxO) return BMNAS_E_LIMIT;
   if ((C * L) % 16) return BMNAS_E_SHAPE;
+  if (lazy && (C * L) % 64) return BMNAS_E_SHAPE;
   HeadBwdArgs a{};
-  if (int e = fill_src(a.src, srcs, sums, n_src)) return e;
+  if (!srcs || n_src < 1) return BMNAS_E_ARG;
+  if (n_src > kHeadSrc) return BMNAS_E_LIMIT;
+  for (int q = 0; q < n_src; ++q) {
+    if (!srcs[q] || (!lazy && (!sums || !sums[q]))) return BMNAS_E_ARG;
+    a.src.p[q] = srcs[q];
+    a.src.sums[q] = sums ? sums[q] : nullptr;
+  }
   if (b == 0) return 0;
   for (int q = 0; q < n_src; ++q) a.dsrc[q] = dsrcs[q];
   a.acc_mask = accumulate_mask; a.ln_w = ln_w; a.ln_b = ln_b; a.W = W; a.hb = hb; a.stats = stats;
@@ -509,15 +639,51 @@ extern "C" int bmnas_head_bwd(const float* const* srcs, const float* const* sums
   dim3 grid((unsigned)((nkt + 3) / 4), (unsigned)chunks);
   const int OT = (O + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-#define HB(OTv)                                                                        \
-  do {                                                                                 \
-    if (sg == 2) hipLaunchKernelGGL((head_bwd_k<OTv, 2>), grid, dim3(256), 0, st, a);  \
-    else hipLaunchKernelGGL((head_bwd_k<OTv, 1>), grid, dim3(256), 0, st, a);          \
+  HeadLazy z{};
+  if (lazy) z = *lazy;
+#define HB2(OTv, SGv)                                                                                   \
+  do {                                                                                                  \
+    if (lazy) hipLaunchKernelGGL((head_bwd_k<OTv, SGv, true>), grid, dim3(256), 0, st, a, z);           \
+    else hipLaunchKernelGGL((head_bwd_k<OTv, SGv, false>), grid, dim3(256), 0, st, a, z);               \
+  } while (0)
+#define HB(OTv)               \
+  do {                        \
+    if (sg == 2) HB2(OTv, 2); \
+    else HB2(OTv, 1);         \
   } while (0)
   if (OT <= 2) HB(2); else if (OT <= 4) HB(4); else if (OT <= 6) HB(6); else HB(8);
 #undef HB
+#undef HB2
   BMNAS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int bmnas_head_bwd(const float* const* srcs, const float* const* sums, float* const* dsrcs,
+                              int n_src, uint32_t accumulate_mask, const float* ln_w, const float* ln_b,
+                              const float* W, const float* hb, const float* stats, int mode, const float* g,
+                              const float* gscale, const void* labels, float* loss, float* part,
+                              int b, int C, int L, int O, float* scrub, int64_t scrub_n, void* stream) {
+  return head_bwd_impl(srcs, sums, dsrcs, n_src, accumulate_mask, ln_w, ln_b, W, hb, stats, mode, g, gscale, labels,
+                       loss, part, b, C, L, O, scrub, scrub_n, nullptr, stream);
+}
+
+extern "C" int bmnas_head_bwd_lazy(const bmnas_lazy_ln_t* lazy, float* const* lnpart, float* const* dsrcs,
+                                   int n_src, uint32_t accumulate_mask, const float* ln_w, const float* ln_b,
+                                   const float* W, const float* hb, const float* stats, int mode, const float* g,
+                                   const float* gscale, const void* labels, float* loss, float* part, int b, int C,
+                                   int L, int O, float* scrub, int64_t scrub_n, void* stream) {
+  if (!lazy || !lnpart || n_src < 1) return BMNAS_E_ARG;
+  if (n_src > kHeadSrc) return BMNAS_E_LIMIT;
+  HeadLazy z{};
+  const float* srcs[kHeadSrc] = {nullptr, nullptr, nullptr, nullptr};
+  for (int q = 0; q < n_src; ++q) {
+    if (!lazy[q].pre || !lazy[q].ln_w || !lazy[q].ln_b || !lazy[q].stats) return BMNAS_E_ARG;
+    srcs[q] = lazy[q].pre;
+    z.nw[q] = lazy[q].ln_w; z.nb[q] = lazy[q].ln_b; z.nstats[q] = lazy[q].stats; z.lnpart[q] = lnpart[q];
+  }
+  z.lq = -1; z.P = 0;
+  return head_bwd_impl(srcs, nullptr, dsrcs, n_src, accumulate_mask, ln_w, ln_b, W, hb, stats, mode, g, gscale,
+                       labels, loss, part, b, C, L, O, scrub, scrub_n, &z, stream);
 }
 
 extern "C" int bmnas_sum_chunks(const float* part, float* out, int n_chunk, int64_t n, void* stream) {

@@ -147,10 +147,20 @@ class _ForwardGraphs:
         return g(inputs, labels)
 
 
+def _observe(event, **info):
+    """tests/test_outer_loop_golden_gpu.py pins the loop against the reference's trainers through this hook
+    (run.observer = callable(event, **info)); None in production: no host synchronisation is added."""
+    obs = getattr(run, 'observer', None)
+    if obs is not None:
+        obs(event, **info)
+
+
 def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_sizes, device,
         num_epochs, logger, plotter, args, status, unpack, meter, eval_phases, better, task=None,
-        nan_escape=False):
-    """-> dict(best_dev, best_dev_genotype, best_test, best_test_genotype, last_genotype, nan_abort)."""
+        nan_escape=False, init=None):
+    """-> dict(best_dev, best_dev_genotype, best_test, best_test_genotype, last_genotype, nan_abort).
+    init: what the first epoch's metric is compared with (the reference starts from best_f1 = init_f1 with `>`,
+    train_searchable/mmimdb.py:19,162, and from best_acc = 0 with `>=`, ntu.py:18,135); None: always accepted."""
     cosine = isinstance(scheduler, sc.LRCosineAnnealingScheduler)
     device = _model_device(model, device)
     from bmnas.graph import GraphedTrainStep
@@ -208,6 +218,8 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                         loss_sum += loss.detach().double() * labels.size(0)
                         meter.update(output.detach(), labels)
                         stats['graph_replays'] += 1
+                        _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
+                                 learn=True, how='graph')
                         continue
                 if not learn:
                     # the metric pass: no gradients, one replay (the step above — architect.step in the dev phase —
@@ -218,6 +230,8 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                         loss_sum += loss.detach().double() * labels.size(0)
                         meter.update(output.detach(), labels)
                         stats['forward_replays'] += 1
+                        _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
+                                 learn=False, how='graph')
                         continue
                 stats['eager_steps'] += 1
                 optimizer.zero_grad()
@@ -234,6 +248,8 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                         optimizer.step()
                 loss_sum += loss.detach().double() * labels.size(0)
                 meter.update(output.detach(), labels)
+                _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
+                         learn=learn, how='eager')
             n = dataset_sizes[phase]
             if _world() > 1:
                 # what the ranks processed together (a DistributedSampler pads, a split drops a remainder)
@@ -245,6 +261,7 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
             genotype = model.genotype()
             best['last_genotype'] = genotype
             logger.info(str(genotype))
+            _observe('phase', epoch=epoch, phase=phase, loss=epoch_loss, metric=epoch_metric, genotype=genotype)
             if nan_escape and phase == 'train' and epoch_loss != epoch_loss:
                 logger.info('Nan loss during training, escaping')
                 model.eval()
@@ -254,7 +271,8 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 if phase != which or (which == 'dev' and status != 'search' and eval_phases[-1] != 'dev'):
                     continue
                 key = 'best_' + which
-                if best[key] is None or better(epoch_metric, best[key]):
+                ref = best[key] if best[key] is not None else init
+                if ref is None or better(epoch_metric, ref):
                     best[key] = epoch_metric
                     best[key + '_genotype'] = copy.deepcopy(genotype)
                     best[key + '_epoch'] = epoch

@@ -16,7 +16,7 @@ def train_mmimdb_track_f1(model, architect, criterion, optimizer, scheduler, dat
         r = _loop.run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_sizes, device,
                       num_epochs, logger, plotter, args, status, _unpack, _loop.F1Meter(f1_type, th_fscore),
                       eval_phases=['train', 'dev', 'test'], better=lambda new, old: new > old,
-                      task='mmimdb', nan_escape=True)
+                      task='mmimdb', nan_escape=True, init=init_f1)
         best_f1 = init_f1 if r['best_dev'] is None else max(init_f1, r['best_dev'])
         if r['nan_abort']:
             return best_f1                     # the reference returns the bare scalar on a NaN loss

@@ -12,7 +12,7 @@ def train_ntu_track_acc(model, architect, criterion, optimizer, scheduler, datal
                         plotter=None, args=None, status='search'):
     r = _loop.run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_sizes, device,
                   num_epochs, logger, plotter, args, status, _unpack, _loop.AccuracyMeter(),
-                  eval_phases=['train', 'test'], better=lambda new, old: new >= old)
+                  eval_phases=['train', 'test'], better=lambda new, old: new >= old, init=0)
     if status == 'search':
         return (r['best_dev'] or 0), r['best_dev_genotype']
     return (r['best_test'] or 0), r['best_dev_genotype']

@@ -602,6 +602,72 @@ int bmnas_head_bwd(const float* const* srcs, const float* const* sums, float* co
 /* out[e] = sum_{c < n_chunk} part[c*n + e], e < n (n % 4 == 0) */
 int bmnas_sum_chunks(const float* part, float* out, int n_chunk, int64_t n, void* stream);
 
+/* ---- the step node's LayerNorm applied by its consumers (csrc/lazyln.hip, csrc/lazy_ln.hpp) ----------
+ * NodeCell with node_multiplier == 1 ends in  out = mix(z);  out += x;  out = LayerNorm_[C,L](out)
+ * (reference node_search.py:57-58, 67-68 with node_operations.py:118-120).  bmnas_node_mix_ln_fwd / _bwd do that as one
+ * workgroup per sample; the entry points below do it with streaming grids over all compute units:
+ *   bmnas_node_mix_pre_fwd       pre = mix + resid (un-normalised) and, per part of 1024 elements of a sample, a
+ *                                record of moments centred on the part's own mean: rec (b, P, 8), prm (P, 8) with
+ *                                P = bmnas_lazy_ln_parts(C, L) (layouts: csrc/lazy_ln.hpp).  Plain stores.
+ *   bmnas_mixsum_pair_fwd_lazy   bmnas_mixsum_pair_fwd whose LAST input (weight w[n_in * w_stride]) is such a node
+ *                                output: it combines the records, normalises in registers, and WRITES the node output
+ *                                last_out (b, C, L), last->stats (b, 2) = mean | rstd and — last_sums nullable —
+ *                                the per-sample (sum, sum of squares) of the output for bmnas_head_fwd.
+ *   bmnas_head_fwd_lazy          bmnas_head_fwd whose source lazy_q is given un-normalised (srcs[lazy_q] == lazy->pre,
+ *                                sums[lazy_q] ignored): normalised in the operand fetch, lazy->stats written.
+ *   bmnas_head_bwd_lazy          bmnas_head_bwd with EVERY source described by lazy[q] (pre, ln_w, ln_b, stats); besides
+ *                                dsrcs[q] (the gradient w.r.t. the node OUTPUT) it stores, per (sample, 64-k group),
+ *                                the partials of the node LayerNorm backward's two sums  S(gy w), S(gy w xhat)  into
+ *                                lnpart[q] (b, C*L/64, 2) (nullable).  (C*L) % 64 == 0.
+ *   bmnas_mixsum_pair_bwd_lazy   bmnas_mixsum_pair_bwd whose last n_lazy (1 or 2) inputs are such node outputs (xs holds
+ *                                their normalised values): additionally stores, per (sample, part), the partials of the
+ *                                same two sums for the gradient piece w_j G it adds to dxs[j], into lnpart[t]
+ *                                [(sample * lnpart_stride[t] + part) * 2 + {0, 1}] (lnpart_stride[t] >= P: the K1
+ *                                launches of several later steps may share one buffer).  g_full (nullable): G =
+ *                                gh + (w2_0 + w2_1)(gz + gz2) is stored as well.
+ *   bmnas_node_mix_lnp_bwd       bmnas_node_mix_ln_bwd for any batch size: g = gradient of the node output, m1 / m2
+ *                                of the LayerNorm backward from the partials lnp0 (b, n0, 2) and lnp1 (b, n1, 2)
+ *                                (either may be absent: n = 0), then the mix backward of bmnas_node_mix_bwd.
+ * bmnas_lazy_ln_ok: L in {4, 8, 16} and C*L <= 4096. */
+typedef struct {
+  const float* pre;    /* (b, C, L) mix + x, before the LayerNorm */
+  const float* rec;    /* (b, P, 8) moment records (forward consumers) */
+  const float* prm;    /* (P, 8) sums of the affine parameters (forward consumers) */
+  const float* ln_w;   /* (C, L) */
+  const float* ln_b;
+  float* stats;        /* (b, 2) mean | rstd: written by the first forward consumer, read by the backward */
+} bmnas_lazy_ln_t;
+int bmnas_lazy_ln_ok(int C, int L);
+int bmnas_lazy_ln_parts(int C, int L);
+int bmnas_node_mix_pre_fwd(const float* x, const float* y, const float* p1, const float* U, float* chan,
+                           bmnas_bn_fin_t fin, const float* gamma, const float* resid, const float* ln_w,
+                           const float* ln_b, float* pre, float* rec, float* prm, int b, int C, int L,
+                           bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream);
+int bmnas_mixsum_pair_fwd_lazy(const float* const* xs, int n_in, const float* w, int w_stride, const float* w2,
+                               int w2_stride, const bmnas_lazy_ln_t* last, float* last_out, float* last_sums,
+                               float* out, float* out2, int b, int C, int L, void* stream);
+int bmnas_mixsum_pair_bwd_lazy(const float* const* xs, float* const* dxs, int n_in, const float* w, int w_stride,
+                               const float* w2, int w2_stride, const float* h, const float* gh, const float* gz,
+                               const float* gz2, float* dw, float* dw2, int dw_shards, int64_t dw_shard_stride,
+                               uint32_t accumulate_mask, const bmnas_lazy_ln_t* lazy, float* const* lnpart,
+                               const int* lnpart_stride, int n_lazy, float* g_full, int b, int C, int L,
+                               void* stream);
+int bmnas_head_fwd_lazy(const float* const* srcs, const float* const* sums, int n_src, int lazy_q,
+                        const bmnas_lazy_ln_t* lazy, const float* ln_w, const float* ln_b, const float* W,
+                        const float* bias, float* hb, float* stats, int b, int C, int L, int O, void* stream);
+int bmnas_head_bwd_lazy(const bmnas_lazy_ln_t* lazy, float* const* lnpart, float* const* dsrcs, int n_src,
+                        uint32_t accumulate_mask, const float* ln_w, const float* ln_b, const float* W,
+                        const float* hb, const float* stats, int mode, const float* g, const float* gscale,
+                        const void* labels, float* loss, float* part, int b, int C, int L, int O, float* scrub,
+                        int64_t scrub_n, void* stream);
+int bmnas_node_mix_lnp_bwd(const float* g, const float* pre, const float* ln_w, const float* stats,
+                           const float* lnp0, int n0, const float* lnp1, int n1, float* g_in, float* dresid,
+                           int accumulate_resid, const float* x, const float* y, const float* p1, const float* U,
+                           const float* chan, const float* gamma, float* dgamma, int dgamma_shards,
+                           int64_t dgamma_shard_stride, float* dx, float* dy, uint32_t accumulate_mask, float* dV,
+                           float* bn_grad, int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
+                           void* stream);
+
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at
  * mmimdb_darts_searchable.py:82-83,114 (O <= 128, K % 16 == 0). */

@@ -1,0 +1,206 @@
+"""-m gpu: the OUTER LOOP against the reference's own trainers.
+
+tests/golden/loop_mmimdb_{search,found}.json were recorded by running the unmodified reference
+(train_darts_model -> train_mmimdb_track_f1 -> Architect.step, models/search/mmimdb_darts_searchable.py:18-55,
+train_searchable/mmimdb.py:10-285, darts/architect.py:21-29; the found stage as main_darts_found_mmimdb.py:95-139
+drives it) on the deterministic in-memory data of tests/helpers/loop_stubs.py (tests/golden/make_golden_r04.py).
+Here this repo's loop (models/search/train_searchable/_loop.py) runs on the same data, eager and with hipGraph
+steps, and must reproduce: every batch's loss and logits, the learning rate every weight step ran with (the
+per-batch cosine schedule), every phase's epoch loss / F1, the genotype after every phase, the best F1 / genotype /
+checkpoint, the final architecture parameters and weights, and the tester's score."""
+import json
+import logging
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from helpers import loop_stubs as stubs
+
+GOLD = os.path.join(HERE, 'golden')
+
+
+def _args(save, found=False, hip_graph=False):
+    class Args:
+        pass
+
+    a = Args()
+    a.C, a.L, a.drpt = 32, 16, 0.1
+    a.num_input_nodes, a.num_keep_edges, a.steps, a.multiplier = 6, 2, 2, 2
+    a.node_steps, a.node_multiplier, a.num_outputs = (2, 2, 23) if found else (1, 1, 23)
+    a.batchsize, a.epochs = 8, 2
+    a.eta_max, a.eta_min, a.Ti, a.Tm = 2e-3, 1e-5, 1, 2
+    a.arch_learning_rate, a.arch_weight_decay, a.weight_decay = 3e-3, 1e-3, 1e-4
+    a.f1_type = 'weighted'
+    a.use_dataparallel = False
+    a.hip_graph = hip_graph
+    a.save = save
+    return a
+
+
+def _loaders(gold):
+    return {k: DataLoader(stubs.MMIMDBData(n, gold['seed_data'] + i), batch_size=8, shuffle=False, drop_last=False)
+            for i, (k, n) in enumerate(gold['sizes'].items())}
+
+
+def _install(monkeypatch):
+    central = types.ModuleType('models.central')
+    fake = types.ModuleType('models.central.mmimdb')
+    fake.GP_VGG, fake.MaxOut_MLP = stubs.StubVGG, stubs.StubMLP
+    central.mmimdb = fake
+    monkeypatch.setitem(sys.modules, 'models.central', central)
+    monkeypatch.setitem(sys.modules, 'models.central.mmimdb', fake)
+    import models.search.mmimdb_darts_searchable as drv
+    import models.search.train_searchable._loop as loop
+    rec = stubs.Recorder()
+
+    def observer(event, **k):
+        if event == 'batch':
+            rec.batch(k['epoch'], k['phase'], k['learn'], k['loss'].detach(), k['output'],
+                      float(k['optimizer'].param_groups[0]['lr']))
+        else:
+            rec.phase(k['epoch'], k['phase'], k['loss'], k['metric'], k['genotype'])
+
+    monkeypatch.setattr(loop.run, 'observer', observer, raising=False)
+    return drv, loop, rec
+
+
+def _compare_batches(got, want, rel, label):
+    assert len(got) == len(want), (label, len(got), len(want))
+    worst = 0.0
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g[:3] == w[:3], (label, i, g[:3], w[:3])                       # epoch, phase, learn
+        assert abs(g[3] - w[3]) <= rel * max(1.0, abs(w[3])), (label, 'loss', i, g[3], w[3])
+        # logits: l2 within rel, the sum within rel * l2 * sqrt(n) (n = batch * 23 <= 184)
+        assert abs(g[5] - w[5]) <= rel * w[5], (label, 'logits l2', i, g[5], w[5])
+        assert abs(g[4] - w[4]) <= rel * w[5] * 14.0, (label, 'logits sum', i, g[4], w[4])
+        if w[2] and w[6] >= 0:
+            assert abs(g[6] - w[6]) <= 1e-9 + 1e-6 * w[6], (label, 'lr', i, g[6], w[6])
+        worst = max(worst, abs(g[3] - w[3]) / max(1.0, abs(w[3])), abs(g[5] - w[5]) / w[5])
+    print(f'{label}: {len(got)} batches, worst relative deviation {worst:.2e}')
+
+
+def _compare_phases(rec, gold, label, f1_tol=1e-9):
+    assert [p[:2] for p in rec.phases] == [p[:2] for p in gold['phases']], label
+    for g, w in zip(rec.phases, gold['phases']):
+        assert abs(g[2] - w[2]) <= 1e-4 + 5e-5, (label, 'epoch loss', g, w)      # the golden has the logged 4 decimals
+        assert abs(g[3] - w[3]) <= f1_tol, (label, 'F1', g, w)
+    assert rec.genotypes == gold['genotypes'], label
+
+
+def _compare_state(model, want, rel, label):
+    sd = model.state_dict()
+    for k, w in want.items():
+        if k == '_nbt':
+            for kk, v in w.items():
+                assert int(sd[kk]) == v, (label, kk)
+            continue
+        g = stubs.summary(sd[k])
+        n = sd[k].numel()
+        l2 = max(abs(w[1]), 1e-12)
+        assert abs(g[1] - w[1]) <= rel * l2 + 1e-7, (label, k, 'l2', g[1], w[1])
+        assert abs(g[0] - w[0]) <= rel * l2 * np.sqrt(n) + 1e-6, (label, k, 'sum', g[0], w[0])
+        assert np.all(np.abs(np.array(g[2:]) - np.array(w[2:])) <= rel * (np.abs(w[2:]) + l2 / np.sqrt(n)) + 1e-7), \
+            (label, k, g[2:], w[2:])
+
+
+def _gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        g = json.load(f)
+    g['seed_data'] = 21                      # make_golden_r04.SEED: loaders are seeded SEED + i
+    return g
+
+
+@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+def test_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip_graph):
+    gold = _gold('loop_mmimdb_search.json')
+    drv, loop, rec = _install(monkeypatch)
+    from models.search.darts.utils import create_exp_dir
+    made = []
+
+    class Pinned(drv.Searchable_Image_Text_Net):
+        def __init__(self, args, criterion):
+            super().__init__(args, criterion)
+            stubs.fill_state(self, gold['seed'])
+            made.append(self)
+
+    monkeypatch.setattr(drv, 'Searchable_Image_Text_Net', Pinned)
+    a = _args(str(tmp_path / 'exp'), hip_graph=hip_graph)
+    create_exp_dir(a.save)
+    best_f1, genotype = drv.train_darts_model(_loaders(gold), a, torch.device('cuda:0'), logging.getLogger('bmnas-test'))
+    label = 'search/' + ('graph' if hip_graph else 'eager')
+    if hip_graph:
+        assert loop.run.stats['graph_replays'] == 4 and loop.run.stats['forward_replays'] >= 2, loop.run.stats
+    else:
+        assert loop.run.stats['graph_replays'] == 0, loop.run.stats
+    _compare_batches(rec.batches, gold['batches'], 2e-4, label)
+    _compare_phases(rec, gold, label)
+    assert abs(best_f1 - gold['best_f1']) <= 1e-9
+    assert str(genotype) == gold['best_genotype']
+    with open(os.path.join(a.save, 'best', 'best_genotype.pkl'), 'rb') as f:
+        assert str(pickle.load(f)) == gold['best_genotype']
+    model = made[0]
+    for p, w in zip(model.arch_parameters(), gold['arch']):
+        want = np.asarray(w, dtype=np.float64)
+        assert np.abs(p.detach().cpu().double().numpy() - want).max() <= 2e-4 * np.abs(want).max(), label
+    _compare_state(model, gold['final'], 5e-4, label + ' final')
+    ckpt = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
+    for k, w in gold['best_ckpt'].items():
+        g = stubs.summary(ckpt[k])
+        assert abs(g[1] - w[1]) <= 5e-4 * max(abs(w[1]), 1e-12) + 1e-7, (label, 'best checkpoint', k, g[1], w[1])
+
+
+@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+def test_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, monkeypatch, hip_graph):
+    gold = _gold('loop_mmimdb_found.json')
+    drv, loop, rec = _install(monkeypatch)
+    import models.auxiliary.scheduler as sc
+    import models.search.train_searchable.mmimdb as tr
+    from bmnas import nn as bnn
+    from bmnas.optim import Adam
+    from models.search.darts.genotypes import Genotype, StepGenotype
+    from models.search.darts.utils import create_exp_dir
+    from models.search.plot_genotype import Plotter
+    genotype = Genotype(
+        edges=[('skip', 1), ('skip', 4), ('skip', 0), ('skip', 5)],
+        steps=[StepGenotype(inner_edges=[('skip', 0), ('skip', 1), ('skip', 2), ('skip', 0)],
+                            inner_steps=['ScaleDotAttn', 'LinearGLU'], inner_concat=[2, 3]),
+               StepGenotype(inner_edges=[('skip', 1), ('skip', 0), ('skip', 1), ('skip', 2)],
+                            inner_steps=['ConcatFC', 'Sum'], inner_concat=[2, 3])],
+        concat=[6, 7])
+    a = _args(str(tmp_path / 'exp'), found=True, hip_graph=hip_graph)
+    create_exp_dir(a.save)
+    device = torch.device('cuda:0')
+    criterion = bnn.BCEWithLogitsLoss()
+    model = stubs.fill_state(drv.Found_Image_Text_Net(a, criterion, genotype), gold['seed'])
+    lds = _loaders(gold)
+    sizes = {k: len(v.dataset) for k, v in lds.items()}
+    model.to(device)
+    optimizer = Adam(model.parameters(), lr=a.eta_max, weight_decay=1e-4)
+    scheduler = sc.LRCosineAnnealingScheduler(a.eta_max, a.eta_min, a.Ti, a.Tm, sizes['train'] / a.batchsize)
+    logger = logging.getLogger('bmnas-test')
+    test_f1, test_genotype = tr.train_mmimdb_track_f1(model, None, criterion, optimizer, scheduler, lds, sizes, device,
+                                                      a.epochs, False, logger, Plotter(a), a, a.f1_type, 0.0, 0.3,
+                                                      'eval')
+    label = 'found/' + ('graph' if hip_graph else 'eager')
+    _compare_batches(rec.batches, gold['batches'], 2e-4, label)
+    _compare_phases(rec, gold, label)
+    assert abs(test_f1 - gold['test_f1']) <= 1e-9 and str(test_genotype) == gold['test_genotype']
+    _compare_state(model, gold['final'], 5e-4, label + ' final')
+    # the tester on the reloaded best-test weights (main_darts_found_mmimdb.py:131-139)
+    model2 = drv.Found_Image_Text_Net(a, criterion, genotype)
+    model2.load_state_dict(torch.load(os.path.join(a.save, 'best', 'best_test_model.pt')))
+    model2.to(device)
+    rec.batches.clear()
+    got = tr.test_mmimdb_track_f1(model2, criterion, lds, sizes, device, False, logger, a, a.f1_type, init_f1=0.0,
+                                  th_fscore=0.3)
+    assert abs(got - gold['tester_f1']) <= 1e-9
