@@ -73,9 +73,13 @@ def fill_state(model, seed, arch_scale=0.05):
             v = synth._fill(rng, k, shape)
         new[k] = torch.from_numpy(np.asarray(v)).reshape(shape)
     model.load_state_dict(new)
-    if hasattr(model, 'arch_parameters'):
+    try:
+        arch = list(model.arch_parameters())
+    except AttributeError:                     # a found network has no architecture parameters
+        arch = []
+    if arch:
         rng = np.random.Generator(np.random.PCG64(seed + 1000003))
-        for p in model.arch_parameters():
+        for p in arch:
             p.data.copy_(torch.from_numpy((arch_scale * rng.standard_normal(tuple(p.shape))).astype(np.float32)))
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):

@@ -107,6 +107,11 @@ def _compare_state(model, want, rel, label):
         g = stubs.summary(sd[k])
         n = sd[k].numel()
         l2 = max(abs(w[1]), 1e-12)
+        if k.endswith('conv.bias'):
+            # a conv bias in front of a train-mode BatchNorm has a mathematically zero gradient: what Adam normalises
+            # there is weight decay + round-off, element by element — only the tensor as a whole is comparable
+            assert abs(g[1] - w[1]) <= 1e-2 * l2, (label, k, 'l2', g[1], w[1])
+            continue
         assert abs(g[1] - w[1]) <= rel * l2 + 1e-7, (label, k, 'l2', g[1], w[1])
         assert abs(g[0] - w[0]) <= rel * l2 * np.sqrt(n) + 1e-6, (label, k, 'sum', g[0], w[0])
         assert np.all(np.abs(np.array(g[2:]) - np.array(w[2:])) <= rel * (np.abs(w[2:]) + l2 / np.sqrt(n)) + 1e-7), \
