@@ -981,9 +981,12 @@ def main():
                                          '(watchdog): host-issued all-reduce only')}
 
         def bail():
+            # a rank wedged inside a collective: the line printed is the complete host-issued measurement, marked
+            # "watchdog": true so that no harness takes it for a finished N > 1 run, and the exit status says so too
+            # (never restart or re-exec from here: a retry has to be a fresh child process)
             if rank == 0:
-                print(json.dumps(pending['line']), flush=True)
-            os._exit(0)
+                print(json.dumps(dict(pending['line'], watchdog=True)), flush=True)
+            os._exit(3)
 
         import threading
         guard = threading.Timer(float(os.environ.get('BMNAS_BENCH_WATCHDOG_S', '120')), bail)
@@ -1053,8 +1056,9 @@ def main():
 
         def bail2():
             if rank == 0:
-                print(json.dumps(dict(result, full_search_step={'error': 'did not finish (watchdog)'})), flush=True)
-            os._exit(0)
+                print(json.dumps(dict(result, full_search_step={'error': 'did not finish (watchdog)'}, watchdog=True)),
+                      flush=True)
+            os._exit(3)
 
         guard2 = threading.Timer(float(os.environ.get('BMNAS_BENCH_WATCHDOG_S', '120')), bail2)
         guard2.daemon = True

@@ -36,8 +36,21 @@ def _sources():
     return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+STAMP = os.path.join(OBJ, '.flags')
+
+
+def _flags_changed():
+    """The compile flags of the objects in .obj (a probe build — BMNAS_HIPCC_EXTRA — must not survive into later
+    normal runs, nor the other way round)."""
+    try:
+        with open(STAMP) as f:
+            return f.read() != ' '.join(FLAGS)
+    except OSError:
+        return True
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or _flags_changed():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in _sources()] + _headers()
@@ -66,6 +79,8 @@ def build(force=False, verbose=False, jobs=None):
         return LIB
     hipcc = hipcc_path()
     os.makedirs(OBJ, exist_ok=True)
+    if _flags_changed():
+        force = True                       # objects compiled with other flags are stale whatever their mtimes say
     srcs = _sources()
     jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
     with ThreadPoolExecutor(jobs) as ex:
@@ -76,6 +91,8 @@ def build(force=False, verbose=False, jobs=None):
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB + '.tmp', LIB)
+    with open(STAMP, 'w') as f:
+        f.write(' '.join(FLAGS))
     return LIB
 
 

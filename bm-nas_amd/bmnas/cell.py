@@ -232,7 +232,7 @@ class ConvBnSaved:
     __slots__ = ('srcs', 'C_src', 'W', 'ldw', 'U', 'chan', 'M', 'training', 'dup', 'fold', 'fin')
 
 
-STAT_SHARDS = int(os.environ.get('BMNAS_STAT_SHARDS', '4'))   # copies of the BatchNorm batch-sum buffers (same-address atomics serialise)
+STAT_SHARDS = 4     # copies of the BatchNorm batch-sum buffers (same-address atomics serialise; 1 / 2 / 4 / 8 measured in round 2)
 
 
 class StatArena:
@@ -446,6 +446,8 @@ FUSE_HEAD = os.environ.get('BMNAS_FUSE_HEAD', '1') != '0'
 # pair sum, the head) and differentiated from per-workgroup partial sums — streaming grids instead of one workgroup
 # per sample in both directions (csrc/lazyln.hip)
 LAZY_LN = os.environ.get('BMNAS_LAZY_LN', '1') != '0'
+# with it: the cell-input gradients written once by the first step's K1 backward from every step's stored G
+WRITE_ONCE = os.environ.get('BMNAS_WRITE_ONCE', '1') != '0'
 
 
 class LazyNode(Pack):
@@ -955,6 +957,7 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
         _ln_affine(deferred, g, None, sv.states[-M:], None, CP.ln_w, CP.ln_b, sv.stats, CG.dln_w, CG.dln_b,
                    b, C, L, True, False)
     pending = None                 # the K1 pair backward of step i + 1, to run inside node i's first launch
+    g_fulls = {}                   # step -> its stored G (write-once input gradients)
     for i in reversed(range(S)):
         gn = slots[N + i].get()
         if gn is None and pending is None:
@@ -980,7 +983,13 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
                                h=sv.sifs[i], gh=sif_slot.get(), gz=gz, gz2=gz2, dw=dalpha_w[off:, 1],
                                dw2=dbeta_ws[i][:, 1], shards=CG.shards, stride=CG.shard_stride)
                 continue
-            bufs, mask = _write_group(slots[:n_in])
+            # write-once input gradients: steps i >= 1 store their G and leave dx_j (j < N) to step 0's launch
+            wonce = sv.lazy_on and WRITE_ONCE and any(s_ is not None for s_ in slots[:N])
+            if wonce and i >= 1:
+                g_fulls[i] = torch.empty_like(x0)
+                bufs, mask = _write_group([None] * N + slots[N:n_in])
+            else:
+                bufs, mask = _write_group(slots[:n_in])
             if sv.lazy_on and i >= 1:
                 # its last i inputs are step-node outputs with a streaming LayerNorm backward: leave their partials
                 P = sv.nodes[0].lazy.P
@@ -989,7 +998,13 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
                 lib.mixsum_pair_bwd_lazy(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
                                          sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1], mask,
                                          [lz.desc for lz in lzs], views, [lz.k1_n * P for lz in lzs], b, C, L,
-                                         CG.shards, CG.shard_stride, gz2)
+                                         CG.shards, CG.shard_stride, gz2, g_fulls.get(i))
+            elif g_fulls:
+                ts = sorted(g_fulls)
+                lib.mixsum_pair_bwd_x(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
+                                      sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1], mask,
+                                      [g_fulls[t] for t in ts], [sv.alpha_w[sv.offsets[t]:, 1] for t in ts],
+                                      CG.shards, CG.shard_stride, gz2)
             else:
                 lib.mixsum_pair_bwd(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
                                     sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1],

@@ -130,10 +130,13 @@ class GraphedTrainStep:
                                'drop them (or call this before the first eager backward)')
         self.optimizer = optimizer
         self.targets = [p for g in optimizer.param_groups for p in g['params']]
-        # the architecture step differentiates alpha / beta / gamma only: no module parameter among the targets
-        # -> the fused cell skips every weight-gradient product of its backward (bmnas.cell.arch_grads_only)
-        pids = {id(p) for p in model.parameters()}
-        self.arch_only = not any(id(t) in pids for t in self.targets)
+        # the architecture step differentiates alpha / beta / gamma only -> the fused cell skips every weight-gradient
+        # product of its backward (bmnas.cell.arch_grads_only).  Only on POSITIVE identification: every target IS one
+        # of the model's architecture tensors.  (An optimizer over anything else that is not a module parameter —
+        # learnable inputs, criterion parameters, a wrapper's own tensors — keeps the full backward.)
+        arch_fn = getattr(model, 'arch_parameters', None)
+        aids = {id(t) for t in arch_fn()} if callable(arch_fn) else set()
+        self.arch_only = bool(self.targets) and bool(aids) and all(id(t) in aids for t in self.targets)
         reducer = getattr(optimizer, '_bmnas_reducer', None)
         if reducer is not None and reducer.world <= 1:
             reducer = None
@@ -330,8 +333,9 @@ class GraphedForward:
                     out = out[-1]
                 return criterion(out, self.labels), out
 
-        # warm-up passes must not change training: their BatchNorm updates are undone
-        state = {k: v.clone() for k, v in model.state_dict().items()}
+        # warm-up passes must not change training: their BatchNorm updates are undone (eval mode updates nothing:
+        # no snapshot, no restore)
+        state = {k: v.clone() for k, v in model.state_dict().items()} if model.training else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         try:
@@ -349,7 +353,8 @@ class GraphedForward:
             self._g = GraphedStep(fn, warmup=0)
         finally:
             torch.cuda.synchronize()
-            model.load_state_dict(state)
+            if state is not None:
+                model.load_state_dict(state)
 
     @staticmethod
     def try_build(model, criterion, inputs, labels, logger=None):

@@ -205,6 +205,8 @@ SIGNATURES = {
     'bmnas_mixsum_pair_fwd_lazy': ([_PP, _I, _P, _I, _P, _I, C.POINTER(LazyLn), _P, _P, _P, _P, _I, _I, _I, _P], _I),
     'bmnas_mixsum_pair_bwd_lazy': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _U32,
                                     C.POINTER(LazyLn), _PP, C.POINTER(C.c_int), _I, _P, _I, _I, _I, _P], _I),
+    'bmnas_mixsum_pair_bwd_x': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _U32, _PP, _PP, _I,
+                                 _I64, _P], _I),
     'bmnas_head_fwd_lazy': ([_PP, _PP, _I, _I, C.POINTER(LazyLn), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_head_bwd_lazy': ([C.POINTER(LazyLn), _PP, _PP, _I, _U32, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P,
                              _I, _I, _I, _I, _P, _I64, _P], _I),
@@ -467,6 +469,17 @@ def mixsum_pair_bwd_lazy(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2
                                              (C.c_void_p * n)(*[t.data_ptr() for t in lnparts]), st, n,
                                              _ptr(g_full), b, Cc, L, _stream()),
            'mixsum_pair_bwd_lazy')
+
+
+def mixsum_pair_bwd_x(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, acc_mask, g_more, w_more, dw_shards=1,
+                      dw_shard_stride=0, gz2=None):
+    """g_more[t]: the stored G of a later cell step, w_more[t]: that step's softmaxed edge-weight column (first edge)."""
+    n = len(g_more)
+    _check(load().bmnas_mixsum_pair_bwd_x(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, w2.data_ptr(),
+                                          w2_stride, _ptr(h), _ptr(gh), _ptr(gz), _ptr(gz2), dw.data_ptr(),
+                                          dw2.data_ptr(), dw_shards, dw_shard_stride, acc_mask, _ptrs(g_more),
+                                          (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in w_more]), n, gz.numel(),
+                                          _stream()), 'mixsum_pair_bwd_x')
 
 
 def head_fwd_lazy(srcs, sums, lazy_q, lazy, ln_w, ln_b, W, bias, hb, stats, b, Cc, L, O):

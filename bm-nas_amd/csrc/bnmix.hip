@@ -1482,7 +1482,11 @@ extern "C" int bmnas_node_mix_ln_bwd(const float* g, const float* pre, const flo
   hipStream_t st = (hipStream_t)stream;
   // BMNAS_MIXLN_PROBE: timing diagnostics only (1: no BatchNorm atomics, 2: half of the first phase,
   // 4: no dgamma atomics — results incomplete)
+#if defined(BMNAS_BODY_PROBES) && BMNAS_BODY_PROBES
   static const int probe = []() { const char* e = getenv("BMNAS_MIXLN_PROBE"); return e ? atoi(e) : 0; }();
+#else
+  const int probe = 0;
+#endif
 #define NMLB(V1, V2)                                                                                         \
   hipLaunchKernelGGL((node_mix_ln_bwd_k<V1, V2, 512>), dim3(2 * b), dim3(512), 0, st, g, pre, ln_w, stats,   \
                      g_in, dresid, accumulate_resid, x, y, p1, U, chan, gamma, dgamma, dgamma_shards,        \

@@ -1509,8 +1509,12 @@ long g_family_calls[F_COUNT] = {0};
 #define BMNAS_COUNT(f) (++g_family_calls[f])
 
 inline int conv_probe() {
+#if BMNAS_BODY_PROBES
   static const int v = []() { const char* e = getenv("BMNAS_CONV_PROBE"); return e ? atoi(e) : 0; }();
   return v;
+#else
+  return 0;       // production builds: a stray BMNAS_CONV_PROBE cannot drop gradient tiles (timing builds only)
+#endif
 }
 
 inline int check_shape(int b, int L, int* Lb, int* spw, int* n_groups) {
@@ -1536,10 +1540,9 @@ bool launch_ksplit(const ConvArgs& a, hipStream_t st) {
   const int nblk = a.I / 16;
   const int kpw = (nblk + 3) / 4;
   dim3 grid((unsigned)((a.n_groups + TN - 1) / TN), (unsigned)((a.J / 16 + TJ - 1) / TJ));
-  static const bool multi_on = !(getenv("BMNAS_KSPLIT_MULTI") && atoi(getenv("BMNAS_KSPLIT_MULTI")) == 0);
   // longer contractions (K > 768: the C_in = 1024 / 2048 reshape layers) at small grids: several register
   // rounds in one launch; large grids keep the LDS tile kernels (operand reuse)
-  if (multi_on && TN == 1 && TJ == 1 && kpw > 12 && a.bn_U == nullptr && a.fold == 0 && a.I == a.Ci &&
+  if (TN == 1 && TJ == 1 && kpw > 12 && a.bn_U == nullptr && a.fold == 0 && a.I == a.Ci &&
       (long)grid.x * grid.y <= 512) {
     BMNAS_COUNT(F_KSPLIT);
     hipLaunchKernelGGL((conv_ksplit_multi_k<TRANS>), grid, dim3(256), 0, st, a);

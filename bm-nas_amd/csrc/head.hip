@@ -633,8 +633,12 @@ static int head_bwd_impl(const float* const* srcs, const float* const* sums, flo
   a.labels_i = mode == 2 ? (const long long*)labels : nullptr;
   a.loss = loss; a.part = part; a.scrub = scrub; a.scrub4 = scrub_n / 4;
   a.b = b; a.O = O; a.CL = C * L; a.D = n_src * C * L; a.n_src = n_src;
+#if defined(BMNAS_BODY_PROBES) && BMNAS_BODY_PROBES
   static const int probe = []() { const char* e = getenv("BMNAS_HEAD_PROBE"); return e ? atoi(e) : 0; }();
   a.probe = probe;
+#else
+  a.probe = 0;    // timing diagnostics exist in -DBMNAS_BODY_PROBES=1 builds only
+#endif
   const int nkt = a.D / 16, sg = head_sg(b), chunks = bmnas_head_chunks(b);
   dim3 grid((unsigned)((nkt + 3) / 4), (unsigned)chunks);
   const int OT = (O + 15) / 16;

@@ -178,6 +178,86 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
   }
 }
 
+// The FIRST cell step's pair backward when the later steps' K1 backward launches left their input gradients to it
+// (write-once: every step's mixed sum reads the same N cell inputs, model_search.py:58, so dx_j is a sum over the
+// steps — instead of S read-modify-write passes over the N tensors, step t > 0 stores only its G_t
+// (bmnas_mixsum_pair_bwd_lazy, g_full) and this launch writes   dx_j = w_j G + sum_t wm_t[j] G_t   once).
+constexpr int kMaxMoreG = 2;
+struct MoreG {
+  const float* g[kMaxMoreG];     // G_t (n_elem)
+  const float* w[kMaxMoreG];     // softmaxed edge weights of step t's sum: w[t][j * w_stride], j < NIN
+};
+
+template <int NIN, int NX>
+__global__ __launch_bounds__(256) void mixsum_pair_bwd_x_k(PtrsIn xs, PtrsOut dxs,
+                                                           const float* __restrict__ w, int w_stride,
+                                                           const float* __restrict__ w2, int w2_stride,
+                                                           const float* __restrict__ h,
+                                                           const float* __restrict__ gh,
+                                                           const float* __restrict__ gz,
+                                                           const float* __restrict__ gz2, float* dw,
+                                                           float* dw2, int dw_shards,
+                                                           int64_t dw_shard_stride, uint32_t acc_mask,
+                                                           MoreG X, int64_t n4) {
+  __shared__ float red[4 * (NIN + 1)];
+  float wj[NIN], wx[NX][NIN], part[NIN + 1];
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) {
+    wj[j] = w[j * w_stride];
+    part[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NX; ++t) wx[t][j] = X.w[t][j * w_stride];
+  }
+  part[NIN] = 0.f;
+  const float s2 = w2[0] + w2[w2_stride];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 z4 = reinterpret_cast<const float4*>(gz)[i];
+    if (gz2 != nullptr) z4 = f4_add(z4, reinterpret_cast<const float4*>(gz2)[i]);
+    const float4 h4 = reinterpret_cast<const float4*>(h)[i];
+    float4 g4 = f4_scale(z4, s2);
+    if (gh != nullptr) g4 = f4_add(g4, reinterpret_cast<const float4*>(gh)[i]);
+    float4 gx[NX];
+#pragma unroll
+    for (int t = 0; t < NX; ++t) gx[t] = reinterpret_cast<const float4*>(X.g[t])[i];
+    float4 v[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) part[j] += f4_dot(g4, v[j]);
+    part[NIN] += f4_dot(z4, h4);
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+      float* d = dxs.p[j];
+      if (d == nullptr) continue;
+      float4 r = f4_scale(g4, wj[j]);
+#pragma unroll
+      for (int t = 0; t < NX; ++t) {
+        r.x = fmaf(wx[t][j], gx[t].x, r.x);
+        r.y = fmaf(wx[t][j], gx[t].y, r.y);
+        r.z = fmaf(wx[t][j], gx[t].z, r.z);
+        r.w = fmaf(wx[t][j], gx[t].w, r.w);
+      }
+      if (acc_mask & (1u << j)) r = f4_add(r, reinterpret_cast<float4*>(d)[i]);
+      reinterpret_cast<float4*>(d)[i] = r;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j <= NIN; ++j) {
+    float s = wave_sum(part[j]);
+    if (lane == 0) red[wave * (NIN + 1) + j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x <= NIN + 1) {
+    const int j = threadIdx.x < NIN ? threadIdx.x : NIN;
+    const float v = red[j] + red[NIN + 1 + j] + red[2 * (NIN + 1) + j] + red[3 * (NIN + 1) + j];
+    const int64_t sh = (int64_t)(blockIdx.x % dw_shards) * dw_shard_stride;
+    if (threadIdx.x < NIN) atomicAdd(dw + sh + j * w_stride, v);
+    else atomicAdd(dw2 + sh + (threadIdx.x - NIN) * w2_stride, v);
+  }
+}
+
 inline int grid_for(int64_t n4) {
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -306,6 +386,59 @@ extern "C" int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, 
     default: return BMNAS_E_LIMIT;
   }
 #undef CALL
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_mixsum_pair_bwd_x(const float* const* xs, float* const* dxs, int n_in,
+                                       const float* w, int w_stride, const float* w2, int w2_stride,
+                                       const float* h, const float* gh, const float* gz,
+                                       const float* gz2, float* dw, float* dw2, int dw_shards,
+                                       int64_t dw_shard_stride, uint32_t accumulate_mask,
+                                       const float* const* g_more, const float* const* w_more, int n_more,
+                                       int64_t n_elem, void* stream) {
+  if (n_more == 0)
+    return bmnas_mixsum_pair_bwd(xs, dxs, n_in, w, w_stride, w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards,
+                                 dw_shard_stride, accumulate_mask, n_elem, stream);
+  if (!xs || !dxs || !w || !w2 || !h || !gz || !dw || !dw2 || !g_more || !w_more || n_in < 1 || n_elem < 0 ||
+      w_stride < 1 || w2_stride < 1 || dw_shards < 1)
+    return BMNAS_E_ARG;
+  if (n_more < 0 || n_more > kMaxMoreG || n_in > BMNAS_MAX_PTRS - 1) return BMNAS_E_LIMIT;
+  if (n_elem % 4 != 0) return BMNAS_E_SHAPE;
+  if (n_elem == 0) return 0;
+  PtrsIn p{};
+  PtrsOut d{};
+  for (int j = 0; j < n_in; ++j) {
+    if (!xs[j]) return BMNAS_E_ARG;
+    p.p[j] = xs[j];
+    d.p[j] = dxs[j];
+  }
+  MoreG X{};
+  for (int t = 0; t < n_more; ++t) {
+    if (!g_more[t] || !w_more[t]) return BMNAS_E_ARG;
+    X.g[t] = g_more[t];
+    X.w[t] = w_more[t];
+  }
+  const int64_t n4 = n_elem / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL2(N, X_)                                                                                             \
+  hipLaunchKernelGGL((mixsum_pair_bwd_x_k<N, X_>), dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, w2,   \
+                     w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards, dw_shard_stride, accumulate_mask, X, n4)
+#define CALL(N)                   \
+  do {                            \
+    if (n_more == 1) CALL2(N, 1); \
+    else CALL2(N, 2);             \
+  } while (0)
+  switch (n_in) {
+    case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;
+    case 4: CALL(4); break;   case 5: CALL(5); break;   case 6: CALL(6); break;
+    case 7: CALL(7); break;   case 8: CALL(8); break;   case 9: CALL(9); break;
+    case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break;
+    case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break;
+    default: return BMNAS_E_LIMIT;
+  }
+#undef CALL
+#undef CALL2
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

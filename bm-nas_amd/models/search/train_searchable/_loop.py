@@ -127,6 +127,20 @@ class _ForwardGraphs:
         self.graphs, self.attempts, self.logger = [], 0, logger
         self.replays = 0
 
+    @staticmethod
+    def of(model, criterion, args, logger=None):
+        """The graphs of (model, criterion), kept ON the model across run() / evaluate() calls: a capture costs three
+        eager warm-ups, a rehearsal and a private pool — more than a short eval loader saves if every epoch's eval
+        pass captured again.  (The graphs read the parameters in place: optimizer steps and load_state_dict are seen.)"""
+        cache = model.__dict__.setdefault('_bmnas_forward_graphs', {})
+        fg = cache.get(id(criterion))
+        if fg is None:
+            fg = cache[id(criterion)] = _ForwardGraphs(args, logger)
+        from bmnas.graph import GraphedTrainStep
+        fg.on = GraphedTrainStep.enabled(args)
+        fg.replays = 0
+        return fg
+
     def __call__(self, model, criterion, inputs, labels):
         """-> (loss, output) from a replay, or None: run the pass eagerly."""
         if not self.on:
@@ -166,7 +180,7 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
     from bmnas.graph import GraphedTrainStep
     use_graph = GraphedTrainStep.enabled(args)
     w_graph, w_attempts = None, 0
-    f_graphs = _ForwardGraphs(args, logger)
+    f_graphs = _ForwardGraphs.of(model, criterion, args, logger)
     stats = run.stats = dict(graph_replays=0, eager_steps=0, forward_replays=0)
     best = dict(best_dev=None, best_dev_genotype=None, best_dev_epoch=0, best_test=None,
                 best_test_genotype=None, best_test_epoch=0, last_genotype=None, nan_abort=False)
@@ -298,7 +312,7 @@ def evaluate(model, criterion, loader, n, device, logger, args, unpack, meter, p
     loss_sum = torch.zeros((), device=device, dtype=torch.float64)
     split = _world() > 1 and not _is_sharded(loader)
     seen = 0
-    f_graphs = _ForwardGraphs(args, logger)
+    f_graphs = _ForwardGraphs.of(model, criterion, args, logger)
     for data in loader:
         inputs, labels = unpack(data, device)
         if split:

@@ -652,6 +652,16 @@ int bmnas_mixsum_pair_bwd_lazy(const float* const* xs, float* const* dxs, int n_
                                uint32_t accumulate_mask, const bmnas_lazy_ln_t* lazy, float* const* lnpart,
                                const int* lnpart_stride, int n_lazy, float* g_full, int b, int C, int L,
                                void* stream);
+/* bmnas_mixsum_pair_bwd for the FIRST cell step when the later steps' K1 backward launches stored their G_t instead
+ * of read-modify-writing the N cell-input gradients (g_full of bmnas_mixsum_pair_bwd_lazy): every step's mixed sum
+ * reads the same cell inputs (reference model_search.py:58), so
+ *   dxs[j] (=|+=) w[j*w_stride] G + sum_{t < n_more} w_more[t][j*w_stride] g_more[t]        written ONCE.
+ * n_more <= 2; n_more == 0 is bmnas_mixsum_pair_bwd. */
+int bmnas_mixsum_pair_bwd_x(const float* const* xs, float* const* dxs, int n_in, const float* w, int w_stride,
+                            const float* w2, int w2_stride, const float* h, const float* gh, const float* gz,
+                            const float* gz2, float* dw, float* dw2, int dw_shards, int64_t dw_shard_stride,
+                            uint32_t accumulate_mask, const float* const* g_more, const float* const* w_more,
+                            int n_more, int64_t n_elem, void* stream);
 int bmnas_head_fwd_lazy(const float* const* srcs, const float* const* sums, int n_src, int lazy_q,
                         const bmnas_lazy_ln_t* lazy, const float* ln_w, const float* ln_b, const float* W,
                         const float* bias, float* hb, float* stats, int b, int C, int L, int O, void* stream);

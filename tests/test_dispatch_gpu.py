@@ -28,7 +28,7 @@ import os
 
 # the expectations below describe the DEFAULT dispatch; tools/test_matrix.sh forces other kernel families
 # through these switches on purpose (their results are checked by the parity tests, not here)
-_FORCED = [k for k in ('BMNAS_KSPLIT_MULTI', 'BMNAS_CONV_PIPE', 'BMNAS_FUSE_ATTN_GEMM', 'BMNAS_FUSE_BWD_PAIR') if os.environ.get(k) is not None]
+_FORCED = [k for k in ('BMNAS_CONV_PIPE', 'BMNAS_FUSE_ATTN_GEMM', 'BMNAS_FUSE_BWD_PAIR') if os.environ.get(k) is not None]
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(bool(_FORCED), reason=f'kernel family forced by {_FORCED}')]
 
