@@ -135,6 +135,32 @@ def algo_table(C, L):
         'mixsum_pair_bwd': lambda xs, dxs, w, ws, w2, ws2, h, gh, gz, dw, dw2, acc, sh=1, st=0, gz2=None:
             ('hbm', _k1((2 + (gh is not None) + (gz2 is not None) + len(xs) + bin(acc).count('1')
                          + sum(d is not None for d in dxs)) * T(gz), len(xs))),
+        # the lazy-LayerNorm forms (csrc/lazyln.hip).  K1 forward with the previous node normalised in the fetch: the
+        # n_in plain inputs + pre read, n + h + z written (+ the LayerNorm affine)
+        'mixsum_pair_fwd_lazy': lambda xs, w, ws, w2, ws2, lz, nout, sums, out, out2, b, Cc, L_:
+            ('hbm', _k1((len(xs) + 1 + 3) * T(out) + 2 * 4 * Cc * L_, len(xs) + 1)),
+        # reads gz (+ gz2) (+ gh) + h + the n_in inputs + pre of the lazy ones + accumulating destinations; writes the
+        # destinations (+ G)
+        'mixsum_pair_bwd_lazy': lambda xs, dxs, w, ws, w2, ws2, h, gh, gz, dw, dw2, acc, lzs, lnp, strides, b, Cc, L_,
+                                       sh=1, st=0, gz2=None, g_full=None:
+            ('hbm', _k1((2 + (gh is not None) + (gz2 is not None) + len(xs) + len(lzs) + bin(acc).count('1')
+                         + sum(d is not None for d in dxs) + (g_full is not None)) * T(gz), len(xs))),
+        'mixsum_pair_bwd_x': lambda xs, dxs, w, ws, w2, ws2, h, gh, gz, dw, dw2, acc, g_more, w_more, sh=1, st=0,
+                                    gz2=None:
+            ('hbm', _k1((2 + (gh is not None) + (gz2 is not None) + len(xs) + len(g_more) + bin(acc).count('1')
+                         + sum(d is not None for d in dxs)) * T(gz), len(xs))),
+        # K2 + residual, un-normalised: U (3T) + z + p1 + resid read, pre written (x is y: one read) + the affine
+        'node_mix_pre_fwd': lambda x, y, p1, U, ch, gm, resid, w, b_, pre, rec, prm, b, Cc, L_, dg, df, fin=None:
+            ('hbm', T(U) + (3 + (x.data_ptr() != y.data_ptr()) + 1) * T(pre) + 2 * T(w)),
+        # LayerNorm backward from partial sums + K2 backward: gy, pre, U, x, p1 read; g_in, dresid, dx, dV written
+        'node_mix_lnp_bwd': lambda gy, pre, w, st, l0, l1, g_in, dres, racc, x, y, p1, U, ch, gm, dgm, dx, dy, m, dV,
+                                   *_:
+            ('hbm', 2 * T(U) + (4 + (g_in is not None) + (dres is not None) + bool(racc) + (dx is not None)
+                                + bin(m).count('1')) * T(x) + T(w)),
+        'head_fwd_lazy': lambda srcs, sums, lq, lz, lw, lb, W, bias, hb, st, b, Cc, L_, O:
+            ('mfma', 2.0 * b * O * len(srcs) * Cc * L_),
+        'head_bwd_lazy': lambda lzs, lnp, ds, m, lw, lb, W, hb, st, mode, g, gs, lab, loss, part, b, Cc, L_, O, *_:
+            ('mfma', 4.0 * b * O * len(lzs) * Cc * L_),
         'cat_ln_fwd': lambda srcs, resid, w, b_, out, *_:
             ('hbm', (len(srcs) + (1 if resid is not None else 0)) * T(srcs[0]) + T(out) + 2 * T(w)),
         'cat_ln_bwd': lambda g, srcs, resid, w, *_:
@@ -338,6 +364,193 @@ def cpu_baseline(cname, c, batch, max_seconds=20.0, tier='F'):
 
 
 
+# ----------------------------------------------------------------------------------------------- row f3: found stage
+# Fixed genotypes of the found stage (what a search on these datasets returns in shape: the ones the reference-
+# generated fixtures tests/golden/found_{mm,nt}_*.npz were computed with).
+FOUND_GENOTYPES = {
+    'mmimdb': {'edges': [['skip', 3], ['skip', 4], ['skip', 2], ['skip', 4]], 'concat': [6, 7],
+               'steps': [{'inner_edges': [['skip', 0], ['skip', 1]], 'inner_steps': ['Sum'], 'inner_concat': [2]},
+                         {'inner_edges': [['skip', 1], ['skip', 0]], 'inner_steps': ['ScaleDotAttn'],
+                          'inner_concat': [2]}]},
+    'ntu': {'edges': [['skip', 0], ['skip', 1], ['skip', 1], ['skip', 5]], 'concat': [8, 9],
+            'steps': [{'inner_edges': [['skip', 1], ['skip', 0], ['skip', 0], ['skip', 2]],
+                       'inner_steps': ['LinearGLU', 'LinearGLU'], 'inner_concat': [2, 3]},
+                      {'inner_edges': [['skip', 0], ['skip', 1], ['skip', 1], ['skip', 2]],
+                       'inner_steps': ['LinearGLU', 'ConcatFC'], 'inner_concat': [2, 3]}]},
+}
+
+
+def found_genotype(cname):
+    from models.search.darts.genotypes import Genotype, StepGenotype
+    g = FOUND_GENOTYPES[cname]
+    return Genotype(edges=[tuple(e) for e in g['edges']],
+                    steps=[StepGenotype(inner_edges=[tuple(e) for e in st['inner_edges']],
+                                        inner_steps=list(st['inner_steps']), inner_concat=list(st['inner_concat']))
+                           for st in g['steps']],
+                    concat=list(g['concat']))
+
+
+class FoundNet(torch.nn.Module):
+    """fusion_net (Found_FusionNetwork, x != y kernels) -> central_classifier, wired like Found_*_Net minus the
+    backbones and reshape layers (models/search/mmimdb_darts_searchable.py:128-190, darts/model.py:133-160)."""
+
+    def __init__(self, c, cname):
+        super().__init__()
+        from bmnas import nn as bnn
+        from models.search.darts.model import Found_FusionNetwork
+        self.fusion_net = Found_FusionNetwork(c['S'], c['M'], c['N'], 2, make_args(c), None, found_genotype(cname))
+        self.central_classifier = bnn.Linear(c['M'] * c['C'] * c['L'], c['nout'])
+
+    def forward(self, xs):
+        return self.central_classifier(self.fusion_net(list(xs)))
+
+
+def found_cpu_baseline(cname, c, batch, max_seconds=15.0):
+    """The oracle's found network (oracle.found_cell: the reference's discrete cell, model.py / node.py) + classifier
+    + criterion, forward and backward, on this host's cores."""
+    from oracle import fusion_oracle as fo, synth
+    cfg = fo.CONFIGS[cname]
+    geno = fo.genotype_from_jsonable(FOUND_GENOTYPES[cname])
+    p = synth.make_params(cfg, 2, fo.found_param_shapes(cfg, geno))
+    cw, cb = synth.make_classifier(cfg, c['nout'], 2)
+    xs = synth.make_inputs(cfg, batch, 0)
+    y = synth.make_labels(c['loss'], batch, c['nout'], 0)
+
+    def one():
+        t0 = time.perf_counter()
+        pp = {k: (v if fo.is_buffer(k) else v.detach().requires_grad_(True)) for k, v in p.items()}
+        cwl, cbl = cw.detach().requires_grad_(True), cb.detach().requires_grad_(True)
+        feat = fo.found_cell([x.detach().requires_grad_(True) for x in xs], geno, pp, cfg, True)
+        fo.loss_fn(c['loss'])(torch.nn.functional.linear(feat.reshape(batch, -1), cwl, cbl), y).backward()
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    probe = {}
+    for nt in sorted({1, 4, 8, 16}):
+        if nt <= ncpu:
+            torch.set_num_threads(nt)
+            one()
+            probe[nt] = min(one(), one())
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    ts, t_start = [], time.time()
+    while len(ts) < 30 and (time.time() - t_start < max_seconds or len(ts) < 8):
+        ts.append(one())
+    med = statistics.median(ts[3:])
+    return {'value': round(1.0 / med, 3), 'unit': 'steps/s', 'cores': best, 'kind': 'port',
+            'ms_per_step': round(med * 1e3, 3), 'host_cpus': ncpu,
+            'sample': f'{len(ts) - 3} timed fwd+bwd steps (after 3 warm-up) of the same {cname} batch-{batch} found '
+                      f'network (oracle.found_cell + classifier + criterion), torch CPU fp32, median; threads = the '
+                      f'fastest of a probe over {sorted(probe)}'}
+
+
+def found_main(a, log):
+    """bench.py --stage found: the found-stage training step (main_darts_found_*.py -> train_*_track_*(status='eval'):
+    forward + criterion + backward + Adam over EVERY parameter, one hipGraph replay per step) of a fixed genotype on
+    synthetic (b, C, L) features, and the evaluation forward (test_*_track_*: GraphedForward)."""
+    from bmnas import lib, nn as bnn
+    from bmnas.graph import GraphedForward, GraphedTrainStep
+    from bmnas.optim import Adam
+    lib.load()
+    if a.config not in FOUND_GENOTYPES:
+        raise SystemExit(f'--stage found: no fixed genotype for {a.config}')
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    c = CONFIGS[a.config]
+    torch.manual_seed(2)
+    model = FoundNet(c, a.config).to(device).train()
+    crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
+    xs, y = synth_batch(c, a.batch, device, 0)
+    xs = [x.detach() for x in xs]
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)      # main_darts_found_mmimdb.py:120
+
+    def step():
+        opt.zero_grad()
+        loss = crit(model(xs), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / 10 * 1e3
+    if a.mode == 'graph':
+        g = GraphedTrainStep(model, crit, opt, xs, y)
+        run = lambda: g(xs, y)
+        for _ in range(400):
+            run()
+    else:
+        run = step
+    torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        run()
+    times = []
+    for _ in range(a.regions):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    result = {
+        'metric': f'found-network train-steps/sec (fwd + criterion + bwd + Adam of the discrete fusion network) on '
+                  f'{a.config} synthetic',
+        'value': round(a.steps / dt, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(dt / a.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{a.config} found network (fixed genotype, x != y kernels), batch {a.batch}, '
+                               f'N{c["N"]} C{c["C"]} L{c["L"]} steps{c["S"]} node_steps{c["ns"]} '
+                               f'node_multiplier{c["nm"]}, train mode, dropout {c["drpt"]}/0.1(attn)',
+                   'genotype': FOUND_GENOTYPES[a.config], 'stage': 'found', 'mode': a.mode,
+                   'step': 'fwd + criterion + bwd + Adam(all parameters, wd 1e-4) as one hipGraph replay'
+                           if a.mode == 'graph' else 'the same issued from Python',
+                   'global_batch': a.batch, 'parallelism': 'dp1'},
+        'samples_per_s': round(a.steps * a.batch / dt, 1),
+        'timed_regions': {'n': len(times), 'steps_each': a.steps, 'headline': 'median',
+                          'ms_per_step': [round(t / a.steps * 1e3, 4) for t in times]},
+        'eager_ms_per_step': round(eager_ms, 4),
+    }
+    log(f'found stage: {result["ms_per_step"]} ms/step (eager {eager_ms:.3f})')
+    # the evaluation pass (test_*_track_*: model.eval(), no gradients): one replay per batch
+    try:
+        model.eval()
+        gf = GraphedForward.try_build(model, crit, xs, y)
+        if gf:
+            for _ in range(50):
+                gf(xs, y)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                gf(xs, y)
+            torch.cuda.synchronize()
+            result['eval_forward_ms'] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
+        model.train()
+    except Exception as e:                           # noqa: BLE001
+        result['eval_forward_ms'] = {'error': f'{type(e).__name__}: {e}'[:200]}
+    if not a.no_roofline:
+        def plain():
+            for p_ in model.parameters():
+                p_.grad = None
+            crit(model(xs), y).backward()
+        try:
+            result.update(roofline_report(a, c, plain, result['ms_per_step'], log))
+        except Exception as e:                       # noqa: BLE001
+            result['roofline_error'] = f'{type(e).__name__}: {e}'[:300]
+    if not a.no_cpu_baseline:
+        try:
+            result['cpu_baseline'] = found_cpu_baseline(a.config, c, a.batch)
+            result['speedup_vs_cpu_baseline'] = round(result['value'] / result['cpu_baseline']['value'], 1)
+        except Exception as e:                       # noqa: BLE001
+            result['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    print(json.dumps(result), flush=True)
+
+
 # wrapper (bmnas.lib) -> substrings of the kernel symbols it may launch; used to attach the
 # algorithmic units of an instrumented eager step to the kernels of a profiled graph replay
 KERNELS_OF = {
@@ -365,6 +578,10 @@ KERNELS_OF = {
     'bce_logits': ('bce_logits_k',), 'cross_entropy': ('ce_rows_k',),
     'head_fwd': ('head_fwd_k',), 'head_bwd': ('head_bwd_k',), 'head_loss_bwd': ('head_loss_bwd_k',),
     'cell_prologue': ('cell_prologue_k',), 'cell_prologue_pair': ('cell_prologue_pair_k',),
+    'node_mix_pre_fwd': ('node_mix_pre_fwd_k',), 'node_mix_lnp_bwd': ('node_mix_lnp_bwd_k',),
+    'mixsum_pair_fwd_lazy': ('mixsum_pair_fwd_lazy_k',), 'mixsum_pair_bwd_lazy': ('mixsum_pair_bwd_lazy_k',),
+    'mixsum_pair_bwd_x': ('mixsum_pair_bwd_x_k', 'mixsum_pair_bwd_k'),
+    'head_fwd_lazy': ('head_fwd_k',), 'head_bwd_lazy': ('head_bwd_k',),
     'adam_multi': ('adam_multi_k',),
     'conv1x1_fwd_group': ('conv_fwd_group_k',), 'conv1x1_bwd_group': ('conv_bwd_group_k',),
     'bn_relu_fwd_group': ('bn_relu_fwd_group_k',), 'bn_relu_bwd_group': ('bn_relu_bwd_group_k',),
@@ -393,7 +610,8 @@ def profile_graph_replay(a, log, steps=60):
     out = tempfile.mkdtemp(prefix='bmnas_prof_', dir='/tmp')
     cmd = [rp, '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable,
            os.path.abspath(__file__), '--config', a.config, '--batch', str(a.batch), '--tier', a.tier,
-           '--steps', str(steps), '--warmup', '5', '--no-cpu-baseline', '--no-roofline', '--no-full-step']
+           '--steps', str(steps), '--warmup', '5', '--no-cpu-baseline', '--no-roofline', '--no-full-step',
+           '--stage', getattr(a, 'stage', 'search')]
     env = dict(os.environ, TMPDIR='/tmp')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
@@ -597,6 +815,40 @@ def roofline_from_events(a, c, step, ms_per_step, log, algo):
     return out
 
 
+def one_gpu_full_batch(a, c, device, log, replays=200):
+    """The same step on ONE GPU holding the whole global batch of --scaling strong (hipGraph replay, local: no
+    collective), for the line of a sharded run to be read against."""
+    from bmnas import nn as bnn
+    from bmnas.functions import unit_grad
+    from bmnas.graph import GraphedStep
+    torch.manual_seed(2)
+    model = HyperNet(c, a.tier, a.config).to(device).train()
+    crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
+    xs, y = synth_batch(c, a.global_batch, device, 0, a.tier, a.config)
+    leaves = list(model.parameters()) + list(model.arch_parameters()) + xs
+
+    def fn():
+        with bnn.fused_criterion():
+            loss = crit(model(xs), y)
+        grads = torch.autograd.grad(loss, leaves, grad_outputs=unit_grad(device), allow_unused=True)
+        for t, g in zip(leaves, grads):
+            t.grad = g
+        return loss
+
+    g = GraphedStep(fn)
+    for _ in range(400):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        g.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / replays * 1e3
+    log(f'one GPU, whole global batch {a.global_batch}: {ms:.4f} ms/step')
+    return {'global_batch': a.global_batch, 'ms_per_step': round(ms, 4), 'steps_per_s': round(1e3 / ms, 1),
+            'what': 'fwd+bwd of the same hypernet on ONE GPU holding the whole global batch (hipGraph replay)'}
+
+
 class DPStep:
     """The benchmarked step in its data-parallel shapes.  Every gradient that is averaged across ranks (weights +
     alpha/beta/gamma) lives in ONE flat fp32 bucket; the captured step writes into it, so the per-step
@@ -730,14 +982,16 @@ def headline(a, c, world, shapes, best, eager_ms, rccl, note=None):
                    if a.config == 'mmimdb' else
                    f'search-steps/sec (fwd+bwd of fusion hypernet) on {a.config} synthetic')
                   + (' [tier R: reshape layers + hypernet]' if a.tier == 'R' else ''),
-        'value': round(world * a.steps / dt, 3),
+        # weak: every rank steps its own --batch samples (N steps' worth of samples per step interval); strong: a step
+        # IS the global batch, whatever the number of ranks
+        'value': round((1 if getattr(a, 'scaling', 'weak') == 'strong' else world) * a.steps / dt, 3),
         'unit': 'steps/s',
         'n_gpus': world,
         'steps': a.steps,
         'warmup': a.warmup,
         'ms_per_step': round(dt / a.steps * 1e3, 4),
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': getattr(a, 'scaling', 'weak'),
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
@@ -837,10 +1091,32 @@ def main():
     ap.add_argument('--regions', type=int, default=5,
                     help='timed regions of --steps steps each; the headline is their median (each region is the '
                          'contract\'s measurement: barrier + synchronize on both sides, max over ranks)')
+    ap.add_argument('--stage', default='search', choices=['search', 'found'],
+                    help='search: the hypernet step (headline); found: the found-stage training step of a fixed '
+                         'genotype (SURVEY.md 8 row f3), one GPU')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='N > 1: weak = --batch samples per GPU (headline); strong = the GLOBAL batch of the BASELINE '
+                         'config (mmimdb 1024, ntu 64, ego 48) split over the ranks, with the one-GPU time of the '
+                         'whole batch measured beside it')
     ap.add_argument('--dp-selftest', action='store_true',
                     help='one GPU: build a world-size-1 RCCL communicator and run the N > 1 step shapes (bucket, '
                          'in-graph all-reduce, forked-stream overlap) through it')
     a = ap.parse_args()
+    if a.stage == 'found':
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            raise SystemExit('--stage found is a one-GPU line')
+
+        def flog(msg):
+            print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+        return found_main(a, flog)
+
+    if a.scaling == 'strong':
+        # the BASELINE configs' GLOBAL batches (BASELINE.json configs 3-5), split over the ranks
+        a.global_batch = {'mmimdb': 1024, 'ntu': 64, 'ego': 48}[a.config]
+        w_env = max(1, int(os.environ.get('WORLD_SIZE', '1')))
+        if a.global_batch % w_env:
+            raise SystemExit(f'--scaling strong: global batch {a.global_batch} does not divide over {w_env} ranks')
+        a.batch = a.global_batch // w_env
 
     from bmnas import dist as bdist
     from bmnas import lib
@@ -1085,6 +1361,15 @@ def main():
             result['speedup_vs_cpu_baseline'] = round(result['value'] / result['cpu_baseline']['value'], 1)
         except Exception as e:                       # noqa: BLE001
             result['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    if rank == 0 and a.scaling == 'strong':
+        # what ONE GPU takes for the whole global batch, measured here beside the sharded figure: at 8 / 6 samples per
+        # GPU configs 4 / 5 are launch-count-bound, and a scaling record read without this number would be misread
+        try:
+            result['strong_scaling'] = one_gpu_full_batch(a, c, device, log)
+            result['strong_scaling']['speedup_over_one_gpu_full_batch'] = round(
+                result['strong_scaling']['ms_per_step'] / result['ms_per_step'], 3)
+        except Exception as e:                       # noqa: BLE001
+            result['strong_scaling'] = {'error': f'{type(e).__name__}: {e}'[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -1012,7 +1012,8 @@ def profile_end_calls():
     return prof['calls']
 
 
-_TIMED_NAMES = ('head_fwd', 'head_bwd', 'cell_prologue', 'cell_prologue_pair', 'mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
+_TIMED_NAMES = ('node_mix_pre_fwd', 'mixsum_pair_fwd_lazy', 'mixsum_pair_bwd_lazy', 'mixsum_pair_bwd_x', 'head_fwd_lazy',
+                'head_bwd_lazy', 'node_mix_lnp_bwd', 'head_fwd', 'head_bwd', 'cell_prologue', 'cell_prologue_pair', 'mixsum_fwd', 'mixsum_bwd', 'mixsum_pair_fwd', 'mixsum_pair_bwd', 'cat_ln_fwd', 'cat_ln_bwd', 'ln_affine_bwd', 'ln_affine_bwd_multi', 'backward_epilogue',
                 'sdpa_ln_fwd', 'sdpa_ln_bwd', 'conv1x1_fwd', 'conv1x1_bwd_data', 'conv1x1_bwd_weight',
                 'conv1x1_fwd_sdpa', 'conv1x1_bwd_all_sdpa', 'conv1x1_bwd_all',
                 'bn_relu_ln_fwd', 'bn_relu_ln_bwd',

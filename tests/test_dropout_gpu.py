@@ -341,7 +341,7 @@ def test_search_step_with_live_dropout_matches_oracle(name, batch, nout, loss_ki
     per_node = cfg.ns * (1 + (2 if cfg.drpt > 0 else 0)) + (1 if cfg.nm != 1 and cfg.drpt > 0 else 0)
     assert len(rec) == cfg.S * per_node
     _compare_step(cfg, batch, nout, loss_kind, site_masks(rec), net, cls, [x.grad for x in xs], logits, loss,
-                  f'{name} b{batch} head={head}')
+                  f'drop: {name} b{batch} head={head}')
 
 
 @pytest.mark.parametrize('name,batch,nout,loss_kind,drpt', REAL[:4])
@@ -381,7 +381,7 @@ def test_search_step_with_live_dropout_under_graph_replay(name, batch, nout, los
         for p, gr in zip(params, grads):
             p.grad = gr
         _compare_step(cfg, batch, nout, loss_kind, masks, net, cls, [x.grad for x in xs], logits, loss,
-                      f'{name} b{batch} replay {replay}')
+                      f'drop: {name} b{batch} replay {replay}')
     assert not torch.equal(seen[0][0], seen[2][0]) and not torch.equal(seen[0][0], seen[1][0])
 
 
