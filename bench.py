@@ -518,7 +518,10 @@ def found_main(a, log):
     }
     log(f'found stage: {result["ms_per_step"]} ms/step (eager {eager_ms:.3f})')
     # the evaluation pass (test_*_track_*: model.eval(), no gradients): one replay per batch
+    # (not in the profiled child: its kernel trace has to END with the training step's replays)
     try:
+        if os.environ.get('BMNAS_BENCH_CHILD'):
+            raise StopIteration
         model.eval()
         gf = GraphedForward.try_build(model, crit, xs, y)
         if gf:
@@ -531,6 +534,8 @@ def found_main(a, log):
             torch.cuda.synchronize()
             result['eval_forward_ms'] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
         model.train()
+    except StopIteration:
+        pass
     except Exception as e:                           # noqa: BLE001
         result['eval_forward_ms'] = {'error': f'{type(e).__name__}: {e}'[:200]}
     if not a.no_roofline:
@@ -612,7 +617,7 @@ def profile_graph_replay(a, log, steps=60):
            os.path.abspath(__file__), '--config', a.config, '--batch', str(a.batch), '--tier', a.tier,
            '--steps', str(steps), '--warmup', '5', '--no-cpu-baseline', '--no-roofline', '--no-full-step',
            '--stage', getattr(a, 'stage', 'search')]
-    env = dict(os.environ, TMPDIR='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp', BMNAS_BENCH_CHILD='1')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
     try:

@@ -77,7 +77,9 @@ class NativeComm:
     torch.distributed's process group: the collective is a plain asynchronous launch on the current
     HIP stream, which is what lets GraphedTrainStep capture it BETWEEN the backward and the Adam
     launch — fwd + bwd + all-reduce + Adam as one hipGraph replay.  The unique id travels over the
-    already-initialised torch.distributed group (any backend).  Opt-in: BMNAS_NATIVE_RCCL=1."""
+    already-initialised torch.distributed group (any backend).  Tried by default under an RCCL process group
+    (FlatGradAllReducer.plan: every rank must succeed, else all of them keep the host-issued all-reduce);
+    BMNAS_NATIVE_RCCL=0 turns it off."""
 
     _instance = None
 
@@ -115,7 +117,38 @@ class NativeComm:
 
 
 def native_rccl_enabled():
-    return os.environ.get('BMNAS_NATIVE_RCCL', '0') not in ('0', '', 'false', 'False')
+    """Default ON: under N > 1 the trainers run the step bench.py reports — fwd + bwd + all-reduce + Adam inside one
+    hipGraph replay — whenever every rank can create the C-ABI communicator; BMNAS_NATIVE_RCCL=0 keeps the
+    host-issued torch.distributed all-reduce between the replay and an eager Adam launch."""
+    return os.environ.get('BMNAS_NATIVE_RCCL', '1') not in ('0', '', 'false', 'False')
+
+
+class _Watchdog:
+    """`with _Watchdog(what):` — a rendezvous that never returns on some rank (ncclCommInitRank waiting for a peer
+    that died) cannot be turned into an exception from inside: after BMNAS_COMM_WATCHDOG_S seconds (default 180) the
+    process says what it was waiting for and exits with status 3, so that the launcher tears the job down instead of
+    hanging forever.  Nothing is retried or re-executed from here."""
+
+    def __init__(self, what):
+        self.what, self.timer = what, None
+
+    def __enter__(self):
+        import sys
+        import threading
+
+        def bail():
+            print(f'bmnas.dist: {self.what} did not finish within the watchdog; leaving (exit 3)', file=sys.stderr,
+                  flush=True)
+            os._exit(3)
+
+        self.timer = threading.Timer(float(os.environ.get('BMNAS_COMM_WATCHDOG_S', '180')), bail)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
 
 
 _AVG = {}
@@ -166,7 +199,7 @@ class FlatGradAllReducer:
         self.reduced = False
 
     def plan(self):
-        """How the bucket is averaged: 'native' — RCCL through the C ABI, ncclAvg (BMNAS_NATIVE_RCCL=1; a plain
+        """How the bucket is averaged: 'native' — RCCL through the C ABI, ncclAvg (the default under an RCCL group; a plain
         launch on the current stream, capturable); 'avg' — torch.distributed with ReduceOp.AVG (RCCL);
         'presum' — the bucket holds gradients pre-scaled by 1/world and is summed (gloo has no AVG).
         Probing AVG support is a 1-element collective: every rank calls plan() at its first step."""
@@ -175,8 +208,21 @@ class FlatGradAllReducer:
             if self.world <= 1:
                 self._plan = 'single'
             elif native_rccl_enabled() and dev.type == 'cuda' and dist.get_backend(self.group) == 'nccl':
-                self._plan = 'native'
-                NativeComm.get(self.group)                  # collective init, here rather than inside a capture
+                # collective init, here rather than inside a capture; a rank that cannot bind librccl / create the
+                # communicator takes every rank back to the host-issued plan (all ranks agree, or none goes native)
+                ok = True
+                try:
+                    with _Watchdog('the C-ABI RCCL communicator (ncclCommInitRank)'):
+                        NativeComm.get(self.group)
+                except Exception as e:                      # noqa: BLE001
+                    import warnings
+                    warnings.warn(f'bmnas.dist: C-ABI RCCL communicator unavailable ({type(e).__name__}: {e}); '
+                                  'host-issued all-reduce', RuntimeWarning)
+                    ok = False
+                if all_ranks_agree(ok, dev, self.group):
+                    self._plan = 'native'
+                else:
+                    self._plan = 'avg' if avg_supported(dev, self.group) else 'presum'
             else:
                 self._plan = 'avg' if avg_supported(dev, self.group) else 'presum'
         return self._plan

@@ -143,7 +143,7 @@ class GraphedTrainStep:
         self.reducer = reducer
         self.inputs = [x.detach().clone().requires_grad_(x.requires_grad) for x in inputs]
         self.labels = labels.detach().clone()
-        # RCCL through the C ABI (bmnas.dist.NativeComm, opt-in BMNAS_NATIVE_RCCL=1) is a plain launch
+        # RCCL through the C ABI (bmnas.dist.NativeComm; BMNAS_NATIVE_RCCL=0 turns it off) is a plain launch
         # on the capture stream: the all-reduce and the Adam step then live INSIDE the graph.
         # reducer.plan() is decided once, collectively, and is the same for captured and eager steps.
         self.native = reducer is not None and reducer.plan() == 'native'
