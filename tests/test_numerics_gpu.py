@@ -25,7 +25,7 @@ def _rel(got, want):
 
 # (input offset mu, weight row sum c): the pre-BatchNorm activation d = W x has mean mu c and spread sqrt(1 + c^2 / C_in)
 CASES = [(512, 192, 16, 128, 1.0, 0.0), (512, 192, 16, 128, 1.0, 10.0), (512, 192, 16, 128, 2.0, 17.0),
-         (512, 192, 16, 128, 4.0, 30.0), (2048, 128, 8, 64, 1.0, 0.0), (2048, 128, 8, 64, 1.0, 10.0),
+         (512, 192, 16, 128, 3.0, 22.0), (512, 192, 16, 128, 4.0, 30.0), (2048, 128, 8, 64, 1.0, 0.0), (2048, 128, 8, 64, 1.0, 10.0),
          (2048, 128, 8, 64, 1.0, 32.0), (2048, 128, 8, 64, 3.0, 40.0)]
 
 
@@ -73,9 +73,26 @@ def test_batchnorm_after_conv_with_offset_activations(c_in, C, L, batch, mu, row
     errs = {'y': _rel(y.reshape(yd.shape), yd), 'dx': _rel(xg.grad.reshape(xd.shape), xd.grad),
             'dW': _rel(layer.conv.weight.grad.reshape(C, c_in), Wd.grad),
             'running_var': _rel(layer.bn.running_var, 0.9 + 0.1 * u.var((0, 2), unbiased=True))}
-    print(f'|mean|/std = {got_ratio:.1f} (C_in {c_in}): ' + ', '.join(f'{k} {v:.1e}' for k, v in errs.items()))
+    # the reference's OWN arithmetic (torch CPU fp32: nn.Conv1d -> nn.BatchNorm1d -> relu, aux_models.py:58-60) against
+    # the same float64 evaluation: far out, where a ReLU input within round-off of zero decides a gradient element,
+    # fp32 itself is the limit — the kernels have to be as good as that, not better
+    ref = torch.nn.Sequential(torch.nn.Conv1d(c_in, C, 1), torch.nn.BatchNorm1d(C))
+    ref.load_state_dict({'0.weight': torch.from_numpy(sd['conv.weight']), '0.bias': torch.from_numpy(sd['conv.bias']),
+                         '1.weight': torch.from_numpy(sd['bn.weight']), '1.bias': torch.from_numpy(sd['bn.bias']),
+                         '1.running_mean': torch.zeros(C), '1.running_var': torch.ones(C),
+                         '1.num_batches_tracked': torch.zeros((), dtype=torch.long)})
+    ref.train()
+    xr = x.clone().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    (yr * wgt).sum().backward()
+    ref_errs = {'y': _rel(yr, yd), 'dx': _rel(xr.grad, xd.grad), 'dW': _rel(ref[0].weight.grad.reshape(C, c_in), Wd.grad),
+                'running_var': _rel(ref[1].running_var, 0.9 + 0.1 * u.var((0, 2), unbiased=True))}
+    flips = int(((y.reshape(yd.shape).detach().cpu() > 0) != (yd > 0)).sum())
+    print(f'|mean|/std = {got_ratio:.1f} (C_in {c_in}): ' + ', '.join(f'{k} {v:.1e} (torch fp32 {ref_errs[k]:.1e})'
+                                                                      for k, v in errs.items())
+          + f'; ReLU decisions differing from float64: {flips} (torch fp32: {int(((yr > 0) != (yd > 0)).sum())})')
     for k, v in errs.items():
-        assert v <= bound * (3.0 if k in ('dx', 'dW') else 1.0), (k, v, bound)
+        assert v <= max(bound * (3.0 if k in ('dx', 'dW') else 1.0), 3.0 * ref_errs[k]), (k, v, bound, ref_errs[k])
 
 
 @pytest.mark.parametrize('offset,bound', [(0.0, 1e-4), (10.0, 1e-4), (30.0, 1e-4)])
