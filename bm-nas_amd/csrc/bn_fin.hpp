@@ -126,127 +126,3 @@ __device__ __forceinline__ void bn_fin_fill(const BnFin& f, float* __restrict__ 
   }
   __syncthreads();
 }
-
-// The same in TWO phases, for consumers whose own operand loads are many: vector loads complete in issue order
-// (s_waitcnt vmcnt counts them), so a finalisation whose loads are issued AFTER the consumer's 9-18 operand loads can
-// only start once all of those have returned — the sums' round trip, the arithmetic, the LDS round trip and the
-// barrier then sit behind the operands' latency instead of inside it.  bn_fin_load() goes first (its ~13 float4 per
-// thread are the oldest loads in flight), the consumer issues its operand loads, bn_fin_finish() finalises while
-// they are still travelling.  One trip: M <= 4 * BS (host-checked by the launchers that use this form).
-struct BnFinRegs {
-  float4 v[4][2];
-  float4 w4, b4, cb4, rm4, rv4;
-  long long nb;
-  bool mine, bump;
-};
-
-template <int BS>
-__device__ __forceinline__ void bn_fin_load(const BnFin& f, const float* __restrict__ chan, const int M,
-                                            const bool writer, BnFinRegs& R) {
-  const int m0 = 4 * (int)threadIdx.x;
-  R.mine = m0 < M;
-  const int mc = R.mine ? m0 : 0;                               // clamped: every load unconditional
-  if (!f.on) {
-    R.w4 = ld4(chan + 2 * M + mc);
-    R.b4 = ld4(chan + 3 * M + mc);
-    return;
-  }
-  const bool wr = writer && !(f.on & 2);
-  const bool tr = f.training != 0;
-  const bool has_cb = tr && f.conv_bias != nullptr, need_run = (wr && tr && f.running_mean != nullptr) || !tr;
-  const int mv = mc + 8 <= M ? mc : (M >= 8 ? M - 8 : 0);
-  const float4* st = tr ? reinterpret_cast<const float4*>(f.stat + 2 * mc) : reinterpret_cast<const float4*>(f.bn_w + mv);
-  const int64_t sstr = tr ? (int64_t)(M / 2) : 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float4* p = st + (int64_t)(k < f.shards ? k : 0) * sstr;
-    R.v[k][0] = p[0];
-    R.v[k][1] = p[1];
-  }
-  R.w4 = ld4(f.bn_w + mc);
-  R.b4 = ld4(f.bn_b + mc);
-  R.cb4 = ld4((has_cb ? f.conv_bias : f.bn_w) + mc);
-  R.rm4 = ld4((need_run ? f.running_mean : f.bn_w) + mc);
-  R.rv4 = ld4((need_run ? f.running_var : f.bn_w) + mc);
-  R.nb = 0;
-  R.bump = wr && tr && f.nbt != nullptr && R.mine && m0 < f.n_nbt;
-  if (R.bump) R.nb = f.nbt[m0];
-}
-
-// sc / sh: LDS, M floats each.  Ends with a __syncthreads().
-template <int BS>
-__device__ __forceinline__ void bn_fin_finish(const BnFin& f, float* __restrict__ chan, const int M, const int N,
-                                              float* sc, float* sh, const bool writer, const BnFinRegs& R) {
-  constexpr float kEpsBn = 1e-5f, kMom = 0.1f;
-  const int m0 = 4 * (int)threadIdx.x;
-  if (!f.on) {
-    if (R.mine) {
-      st4(sc + m0, R.w4);
-      st4(sh + m0, R.b4);
-    }
-    __syncthreads();
-    return;
-  }
-  if (R.mine) {
-    const bool wr = writer && !(f.on & 2);
-    const bool tr = f.training != 0;
-    const bool has_cb = tr && f.conv_bias != nullptr;
-    const bool upd = wr && tr && f.running_mean != nullptr, need_run = upd || !tr;
-    float4 cb4 = R.cb4, rm4 = R.rm4, rv4 = R.rv4;
-    if (!has_cb) cb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!need_run) {
-      rm4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      rv4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    }
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tr) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float on = k < f.shards ? 1.f : 0.f;
-        s[0] += on * R.v[k][0].x; q[0] += on * R.v[k][0].y;
-        s[1] += on * R.v[k][0].z; q[1] += on * R.v[k][0].w;
-        s[2] += on * R.v[k][1].x; q[2] += on * R.v[k][1].y;
-        s[3] += on * R.v[k][1].z; q[3] += on * R.v[k][1].w;
-      }
-    }
-    const float wq[4] = {R.w4.x, R.w4.y, R.w4.z, R.w4.w}, bq[4] = {R.b4.x, R.b4.y, R.b4.z, R.b4.w};
-    const float cq[4] = {cb4.x, cb4.y, cb4.z, cb4.w}, rmq[4] = {rm4.x, rm4.y, rm4.z, rm4.w};
-    const float rvq[4] = {rv4.x, rv4.y, rv4.z, rv4.w};
-    float mean[4], rstd[4], scale[4], shift[4], nrm[4], nrv[4];
-    const float inv = 1.f / (float)N;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (tr) {
-        const float dm = s[j] * inv;
-        const float var = fmaxf(q[j] * inv - dm * dm, 0.f);
-        mean[j] = dm + cq[j];
-        rstd[j] = 1.f / sqrtf(var + kEpsBn);
-        nrm[j] = (1.f - kMom) * rmq[j] + kMom * mean[j];
-        nrv[j] = (1.f - kMom) * rvq[j] + kMom * (var * (float)N / (float)(N - 1));
-      } else {
-        mean[j] = rmq[j];
-        rstd[j] = 1.f / sqrtf(rvq[j] + kEpsBn);
-        nrm[j] = nrv[j] = 0.f;
-      }
-      scale[j] = wq[j] * rstd[j];
-      shift[j] = bq[j] - mean[j] * scale[j];
-    }
-    st4(sc + m0, make_float4(scale[0], scale[1], scale[2], scale[3]));
-    st4(sh + m0, make_float4(shift[0], shift[1], shift[2], shift[3]));
-    if (wr) {
-      st4(chan + m0, make_float4(mean[0], mean[1], mean[2], mean[3]));
-      st4(chan + M + m0, make_float4(rstd[0], rstd[1], rstd[2], rstd[3]));
-      st4(chan + 2 * M + m0, make_float4(scale[0], scale[1], scale[2], scale[3]));
-      st4(chan + 3 * M + m0, make_float4(shift[0], shift[1], shift[2], shift[3]));
-      if (upd) {
-        st4(f.running_mean + m0, make_float4(nrm[0], nrm[1], nrm[2], nrm[3]));
-        st4(f.running_var + m0, make_float4(nrv[0], nrv[1], nrv[2], nrv[3]));
-      }
-      if (R.bump) {
-        f.nbt[m0] = R.nb + 1;
-        for (int j = 1; j < 4 && m0 + j < f.n_nbt; ++j) f.nbt[m0 + j] += 1;
-      }
-    }
-  }
-  __syncthreads();
-}

@@ -87,7 +87,7 @@ def test_lazy_layernorm_equals_the_per_sample_kernels(case, mode):
         # accumulate their BatchNorm sums with atomics, and a ReLU input within round-off of zero may fall on
         # either side from one run to the next (gpu_util.match_step) — the bound is what one such element moves;
         # a wrong partial sum or a missed piece of gradient is off by O(1)
-        assert_close_scaled(k, lazy[k], eager[k], rel=2e-5 if k in ('logits', 'loss') else 5e-3)
+        assert_close_scaled(k, lazy[k], eager[k], rel=2e-5 if k in ('logits', 'loss') else 2e-2)
 
 
 @pytest.mark.parametrize('case', CASES[:5], ids=[f'N{c[0]}C{c[1]}L{c[2]}S{c[3]}M{c[4]}ns{c[5]}b{c[6]}' for c in CASES[:5]])

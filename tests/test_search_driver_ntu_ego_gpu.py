@@ -138,7 +138,9 @@ def test_ntu_search_found_and_test_stages(tmp_path, monkeypatch):
     assert 0.0 <= best_acc <= 1.0
     assert len(genotype.edges) == 4 and len(genotype.steps) == 2 and len(genotype.steps[0].inner_steps) == 2
     # full batches of both phases were graph replays, the ragged ones eager
-    assert loop.run.stats['graph_replays'] >= 2 * 2 and loop.run.stats['eager_steps'] >= 2
+    from bmnas.graph import GraphedTrainStep
+    if GraphedTrainStep.enabled(a):                      # (BMNAS_HIP_GRAPH=0 runs of the switch matrix: all eager)
+        assert loop.run.stats['graph_replays'] >= 2 * 2 and loop.run.stats['eager_steps'] >= 2
     with open(os.path.join(a.save, 'best', 'best_genotype.pkl'), 'rb') as f:
         assert pickle.load(f) == genotype
     sd = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
@@ -195,7 +197,9 @@ def test_ego_search_found_and_test_stages(tmp_path, monkeypatch):
     assert 0.0 <= best_acc <= 1.0
     assert len(genotype.steps) == 2 and len(genotype.steps[0].inner_steps) == 3
     assert genotype.steps[0].inner_concat == [2, 3, 4]
-    assert loop.run.stats['graph_replays'] >= 2 * 2
+    from bmnas.graph import GraphedTrainStep
+    if GraphedTrainStep.enabled(a):
+        assert loop.run.stats['graph_replays'] >= 2 * 2
     sd = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
     assert 'fusion_net.cell._step_nodes.0.node_cell.node_ops.2._ops.2.conv.weight' in sd
     # Ego optimises fusion_net, classifier AND the reshape layers (ego_darts_searchable.py:160-166)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round 3.  Evidence for the BASELINE configs (MI355X box, via gpurun): bench lines with roofline for MM-IMDB b128
+# Round 4.  Evidence for the BASELINE configs (MI355X box, via gpurun): bench lines with roofline for MM-IMDB b128
 # (headline), NTU b8 / b64, Ego b6 / b48 (configs 4/5 per GPU and whole), tier R, rocprofv3 kernel stats of
 # the same commands, the two PMC passes for HBM traffic and the K1 batch sweep.
-# Usage: bash tools/collect_r03.sh <tag>
-TAG=${1:-r03}
+# Usage: bash tools/collect_r04.sh <tag>
+TAG=${1:-r04}
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
@@ -14,7 +14,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --mode eager --steps 6 --warmup 2 $B > $OUT/pmc_write.log 2>&1
 ff=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1)
 fw=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
-[ -n "$ff" ] && [ -n "$fw" ] && python3 tools/traffic_r02.py "$ff" "$fw" $OUT/${TAG}_traffic.json > $OUT/traffic.log 2>&1 && cp $OUT/${TAG}_traffic.json profiles/r03_traffic.json
+[ -n "$ff" ] && [ -n "$fw" ] && python3 tools/traffic_two_pass.py "$ff" "$fw" $OUT/${TAG}_traffic.json > $OUT/traffic.log 2>&1 && cp $OUT/${TAG}_traffic.json profiles/r04_traffic.json
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
 run() {  # name, bench args
   local n=$1; shift
@@ -36,6 +36,12 @@ run ntu_b64_tierR --config ntu --batch 64 --tier R --steps 100
 run ntu_b8_tierR --config ntu --batch 8 --tier R --steps 100
 run ego_b48_tierR --config ego --batch 48 --tier R --steps 100
 run mmimdb_b1024 --batch 1024 --steps 100
+# row f3: the found-stage training step of a fixed genotype (x != y kernels) + its evaluation forward
+timeout 400 python3 bench.py --stage found --steps 200 2> $OUT/found_mm.log | tail -1 > $OUT/${TAG}_bench_found_mmimdb_b128.json
+timeout 400 python3 bench.py --stage found --config ntu --batch 64 --steps 200 2> $OUT/found_ntu.log | tail -1 > $OUT/${TAG}_bench_found_ntu_b64.json
+# configs 4 / 5 with their GLOBAL batch fixed (one GPU here: the sharded figure equals the one-GPU full-batch figure)
+timeout 400 python3 bench.py --scaling strong --config ntu --steps 200 --no-full-step 2> $OUT/strong_ntu.log | tail -1 > $OUT/${TAG}_bench_strong_ntu.json
+timeout 400 python3 bench.py --scaling strong --config ego --steps 200 --no-full-step 2> $OUT/strong_ego.log | tail -1 > $OUT/${TAG}_bench_strong_ego.json
 # the N > 1 step shapes through a world-size-1 communicator (what one GPU can show of them)
 timeout 300 python3 bench.py --dp-selftest --steps 100 --no-full-step --no-roofline --no-cpu-baseline 2> $OUT/dp.log | tail -1 > $OUT/${TAG}_bench_dp_selftest.json
 # K1 (the MixedOp kernel) against the HBM roofline over the batch: launch-inclusive rocprofv3 durations
@@ -45,7 +51,7 @@ for b in 32 64 128 256 512 1024; do
   python3 - $OUT/sweep_$b.json $b >> $OUT/${TAG}_k1_batch_sweep.txt <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-rows = [r for r in d.get('roofline_kernels', []) if r['kernel'].startswith(('mixsum', 'cell_prologue_pair'))]
+rows = [r for r in d.get('roofline_kernels', []) if r['kernel'].startswith(('mixsum', 'cell_prologue_pair')) and r.get('frac') is not None]
 print(f"batch {int(sys.argv[2]):5d}: step {d['ms_per_step']:.4f} ms  " + '  '.join(
     f"{r['kernel'].replace('mixsum_pair_', '').replace('cell_prologue_pair_k', 'fwd_k+prologue')}: {r['avg_us']:.2f} us {r['algorithmic_units_per_launch'] / 1e6:.1f} MB frac {r['frac']:.3f}"
     for r in sorted(rows, key=lambda r: r['kernel'])))

@@ -6,7 +6,7 @@ profiles/r02_fetch_calibration.txt (tools/calibrate_fetch.sh: a 256 MiB buffer r
 bytes per lane and as the GEMM kernels' 64-byte operand rows) gives x2.000 for all dense patterns, and
 shows that rows using 64 of every 128 bytes still move whole 128-byte lines.  WRITE_SIZE is exact for
 16-B streaming stores and float atomics.
-usage: traffic_r02.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
+usage: traffic_two_pass.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
 import collections
 import csv
 import json
