@@ -73,6 +73,53 @@ __device__ __forceinline__ float4 drop_mult4(const DropCfg& d, uint64_t e) {
                      r.z >= d.thr ? d.scale : 0.f, r.w >= d.thr ? d.scale : 0.f);
 }
 
+// ---- in-kernel stamps (diagnostic builds only: -DBMNAS_BODY_PROBES=1; tools/stamp_probe.py) -------------------
+// Thread 0 of every workgroup records the shader clock (s_memtime) at up to 6 points plus the 100 MHz wall clock
+// (s_memrealtime) at entry and exit into a buffer of its own that nothing else reads (bmnas_debug_stamps).  In a
+// production build the macros expand to nothing and no stamp executes.
+#ifndef BMNAS_BODY_PROBES
+#define BMNAS_BODY_PROBES 0
+#endif
+#if BMNAS_BODY_PROBES
+// (no relocatable device code in this build: every translation unit that stamps has its OWN pointer, set by the
+// setter it defines with BMNAS_DEFINE_STAMP_SETTER)
+static __device__ unsigned long long* g_bmnas_stamps = nullptr;
+static __device__ int g_bmnas_stamp_slots = 0;
+#define BMNAS_DEFINE_STAMP_SETTER(name)                                                                   \
+  extern "C" int name(void* buf, int slots) {                                                             \
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);                                   \
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bmnas_stamps), &p, sizeof(p)) != hipSuccess) return -1;            \
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bmnas_stamp_slots), &slots, sizeof(slots)) != hipSuccess) return -1; \
+    return 0;                                                                                             \
+  }
+__device__ __forceinline__ unsigned long long stamp_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+__device__ __forceinline__ unsigned long long stamp_wall() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+// slot: which kernel of the probe (0 ... 7); wg: linear workgroup index; i: stamp index 0 ... 5 (6 = wall at entry, 7 = wall now)
+#define STAMP(slot, wg, i)                                                                         \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (threadIdx.x == 0 && g_bmnas_stamps != nullptr && (wg) < g_bmnas_stamp_slots) {             \
+      unsigned long long* p__ = g_bmnas_stamps + ((size_t)(slot) * g_bmnas_stamp_slots + (wg)) * 8; \
+      p__[i] = stamp_clock();                                                                      \
+      if ((i) == 0) p__[6] = stamp_wall();                                                         \
+      p__[7] = stamp_wall();                                                                       \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define STAMP(slot, wg, i) do { } while (0)
+#define BMNAS_DEFINE_STAMP_SETTER(name) \
+  extern "C" int name(void* buf, int slots) { (void)buf; (void)slots; return -3; /* BMNAS_E_LIMIT: no stamps here */ }
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
   extern __shared__ float fin_lds[];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   const int part = blockIdx.x, smp = blockIdx.y, P = gridDim.x;
+  STAMP(0, smp * P + part, 0);
   float* sc = fin_lds;
   float* sh = fin_lds + M;
   const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
@@ -59,7 +60,9 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
   const float4 lw = ld4(ln_w + (int64_t)r * 4), lb = ld4(ln_b + (int64_t)r * 4);
   const float4 ua = ld4(U + ub), ug = ld4(U + ub + (int64_t)C * L), uf = ld4(U + ub + (int64_t)2 * C * L);
   const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e), rv = ld4(resid + e);
+  STAMP(0, smp * P + part, 1);
   bn_fin_fill<256>(fin, chan, M, b * L, sc, sh, part == 0 && smp == 0);
+  STAMP(0, smp * P + part, 2);
   const float4 va = affine4(ua, sc[c], sh[c]);
   const float4 vg = affine4(ug, sc[C + c], sh[C + c]);
   const float4 vf = affine4(uf, sc[2 * C + c], sh[2 * C + c]);
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
   o.w = g0 * (xv.w + yv.w) + g1 * pv.w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
   const float4 v = f4_add(o, rv);
   if (act) st4(pre + e, v);
+  STAMP(0, smp * P + part, 3);
   const int n4 = cl4 - part * kLazyPart < kLazyPart ? cl4 - part * kLazyPart : kLazyPart;
   const float nk = (float)(4 * n4);
   const float mk = block_sum<4>(act ? f4_hsum(v) : 0.f, red) / nk;
@@ -90,6 +94,7 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
     st4(rr, make_float4(mk, acc[0], acc[1], acc[2]));
     st4(rr + 4, make_float4(acc[3], acc[4], 0.f, 0.f));
   }
+  STAMP(0, smp * P + part, 4);
   if (smp == 0) {                                             // uniform: the affine parameters' own sums, once
     float pa[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (act) {
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_fwd_lazy_k(
     float* __restrict__ stats, float* __restrict__ osum, float* __restrict__ out, float* __restrict__ out2,
     int cl4) {
   const int part = blockIdx.x, smp = blockIdx.y, P = gridDim.x;
+  STAMP(1, smp * P + part, 0);
   const int r0 = part * kLazyPart + threadIdx.x;
   const bool act = r0 < cl4;
   const int r = act ? r0 : cl4 - 1;
@@ -151,6 +157,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_fwd_lazy_k(
     reinterpret_cast<float4*>(out)[i] = acc;
     reinterpret_cast<float4*>(out2)[i] = f4_scale(acc, s2);
   }
+  STAMP(1, smp * P + part, 1);
   if (part == 0 && threadIdx.x == 0) {
     stats[2 * smp] = st.mean;
     stats[2 * smp + 1] = st.rstd;
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
   constexpr int NR = NIN + 1 + 2 * NLZ;
   __shared__ float red[4 * NR];
   const int part = blockIdx.x, smp = blockIdx.y, P = gridDim.x;
+  STAMP(2, smp * P + part, 0);
   const int r0 = part * kLazyPart + threadIdx.x;
   const bool act = r0 < cl4;
   const int r = act ? r0 : cl4 - 1;
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
     z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     g4 = z4;
   }
+  STAMP(2, smp * P + part, 1);
   float part_[NR];
 #pragma unroll
   for (int j = 0; j < NIN; ++j) part_[j] = f4_dot(g4, v[j]);
@@ -237,6 +246,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
       reinterpret_cast<float4*>(d)[i] = rr;
     }
   }
+  STAMP(2, smp * P + part, 2);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int q = 0; q < NR; ++q) {
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
       Z.lnpart[u >> 1][((int64_t)smp * Z.stride[u >> 1] + part) * 2 + (u & 1)] = val;
     }
   }
+  STAMP(2, smp * P + part, 3);
 }
 
 // ------------------------------------------------------------------------------- backward: LayerNorm + mix, streaming
@@ -276,6 +287,7 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
   __shared__ float red16[16];
   __shared__ float csum[3][6][64];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
+  STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 0);
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int r0 = blockIdx.x * 64 + col;
   const bool active = r0 < cl4;
@@ -322,6 +334,7 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
     if (dx != nullptr && (acc_mask & 1u)) oldx = ld4(dx + e);
     if (dy != nullptr && (acc_mask & 2u)) oldy = ld4(dy + e);
     const float m1 = wave_sum(q1) * inv_d, m2 = wave_sum(q2) * inv_d;
+    STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 1);
     if (on) {
       const float4 xh = make_float4((prv.x - mean) * rstd, (prv.y - mean) * rstd, (prv.z - mean) * rstd,
                                     (prv.w - mean) * rstd);
@@ -365,6 +378,7 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
       if (dy != nullptr) st4(dy + e, f4_add(d0, oldy));
     }
   }
+  STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 2);
   float cs[6];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -385,15 +399,21 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
       atomicAdd(bn_grad + M + k * C + c, cs[3 + k]);
     }
   }
+  STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 3);
   block_sum_lead<4, 4>(dgam, red16);
   if (threadIdx.x == 0 && dgamma != nullptr) {
     float* p = dgamma + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % dg_shards) * dg_stride;
 #pragma unroll
     for (int q = 0; q < 4; ++q) atomicAdd(p + q, dgam[q]);
   }
+  STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 4);
 }
 
 }  // namespace
+
+// tools/stamp_probe.py (timing builds): slot 0 node_mix_pre_fwd_k, 1 mixsum_pair_fwd_lazy_k, 2 mixsum_pair_bwd_lazy_k,
+// 3 node_mix_lnp_bwd_k
+BMNAS_DEFINE_STAMP_SETTER(bmnas_debug_stamps)
 
 extern "C" int bmnas_lazy_ln_ok(int C, int L) {
   return C >= 1 && L >= 4 && L % 4 == 0 && L <= 16 && lazy_parts(C * L / 4) <= kLazyMaxParts;

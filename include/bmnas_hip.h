@@ -678,6 +678,11 @@ int bmnas_node_mix_lnp_bwd(const float* g, const float* pre, const float* ln_w, 
                            float* bn_grad, int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
                            void* stream);
 
+/* Diagnostics (timing builds with -DBMNAS_BODY_PROBES=1 only; BMNAS_E_LIMIT otherwise): thread 0 of every workgroup
+ * of the instrumented kernels records the shader clock at up to six points and the 100 MHz wall clock at entry / exit
+ * into buf[kernel slot][workgroup][8] (uint64; slots workgroups per kernel, 8 kernel slots).  tools/stamp_probe.py. */
+int bmnas_debug_stamps(void* buf, int slots);
+
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at
  * mmimdb_darts_searchable.py:82-83,114 (O <= 128, K % 16 == 0). */
