@@ -27,13 +27,12 @@ __device__ __forceinline__ void arch_softmax_bwd_row(const ArchPack& P, int r, i
         for (int sh = sg; sh < P.n_shards; sh += 16) dw += dwp[(int64_t)sh * P.shard_stride];
         w = P.a[t][r * cols + col];
       }
-      dw += __shfl_xor(dw, 4, 64);
-      dw += __shfl_xor(dw, 8, 64);
-      dw += __shfl_xor(dw, 16, 64);
-      dw += __shfl_xor(dw, 32, 64);                      // every lane: total of its column
+      dw = row_stride4_sum(dw);
+      dw = xor16_sum(dw);
+      dw = xor32_sum(dw);                                          // every lane: total of its column
       float dot = w * dw;
-      dot += __shfl_xor(dot, 1, 64);
-      dot += __shfl_xor(dot, 2, 64);                     // sum over the 4 columns
+      dot += lane_xor1(dot);
+      dot += lane_xor2(dot);                                       // sum over the 4 columns
       if (sg == 0 && col < cols) P.o[t][r * cols + col] = w * (dw - dot);
       return;
     }

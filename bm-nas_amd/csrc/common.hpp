@@ -120,11 +120,58 @@ __device__ __forceinline__ unsigned long long stamp_wall() {
   extern "C" int name(void* buf, int slots) { (void)buf; (void)slots; return -3; /* BMNAS_E_LIMIT: no stamps here */ }
 #endif
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions WITHOUT the LDS pipe ------------------------------------------------------------
+// hipcc lowers every __shfl_xor to ds_bpermute_b32 + s_waitcnt lgkmcnt: an LDS round trip per step.  A block
+// reduction of ten values was 60 of them back to back — in-kernel stamps put 2.8 us of an 8 us K1 backward launch
+// there (tools/stamp_probe.py, profiles/r04_stamp_probe.txt).  These forms stay in the vector ALU:
+//   inside a 16-lane row: DPP quad_perm (exact xor 1 / xor 2 partners) and row_ror:4 / row_ror:8;
+//   across rows: gfx950's v_permlane16_swap / v_permlane32_swap — after swap(v, v) the two results hold, lane for
+//   lane, the value of the lane itself and of its xor-16 (xor-32) partner, in one order or the other: a symmetric
+//   op (+, max) needs no select.
+// All of them expect the wave's 64 lanes active (as __shfl_xor did).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_f<0xB1>(v); }     // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_f<0x4E>(v); }     // quad_perm:[2,3,0,1]
+__device__ __forceinline__ float xor16_sum(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// sum of the lanes {i, i^4, i^8, i^12} of a row (the lanes with the same lane & 3), in every one of them
+__device__ __forceinline__ float row_stride4_sum(float v) {
+  v += dpp_f<0x124>(v);                                                            // row_ror:4
+  v += dpp_f<0x128>(v);                                                            // row_ror:8
   return v;
 }
+// sum / max over the 16 lanes of a row (lanes 16 r .. 16 r + 15), in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += lane_xor1(v);
+  v += lane_xor2(v);
+  return row_stride4_sum(v);
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, lane_xor1(v));
+  v = fmaxf(v, lane_xor2(v));
+  v = fmaxf(v, dpp_f<0x124>(v));
+  v = fmaxf(v, dpp_f<0x128>(v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 
 // Sum over the 256 threads of a block; every thread gets the result.
 // red must hold >= 4 floats; two __syncthreads.

@@ -64,10 +64,10 @@ __device__ __forceinline__ void bn_tile_stats(const ConvArgs& a, const float4 o,
       sum = f4_hsum(d);
       sq = f4_dot(d, d);
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    sq += __shfl_xor(sq, 16, 64);
-    sq += __shfl_xor(sq, 32, 64);
+    sum = xor16_sum(sum);
+    sum = xor32_sum(sum);
+    sq = xor16_sum(sq);
+    sq = xor32_sum(sq);
     if (h == 0) {
       float* pp = a.stat + ((int64_t)(g % a.stat_shards) * a.J + jj) * 2;
       atomicAdd(pp, sum);
@@ -77,8 +77,8 @@ __device__ __forceinline__ void bn_tile_stats(const ConvArgs& a, const float4 o,
   }
   if (a.part == nullptr) return;
   float sum = vo ? f4_hsum(o) : 0.f;
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
+  sum = xor16_sum(sum);
+  sum = xor32_sum(sum);
   int cnt = a.b * a.L - 16 * g;
   cnt = cnt > 16 ? 16 : cnt;
   const float mean = sum / (float)cnt;
@@ -87,8 +87,8 @@ __device__ __forceinline__ void bn_tile_stats(const ConvArgs& a, const float4 o,
     const float4 c = make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean);
     m2 = f4_dot(c, c);
   }
-  m2 += __shfl_xor(m2, 16, 64);
-  m2 += __shfl_xor(m2, 32, 64);
+  m2 = xor16_sum(m2);
+  m2 = xor32_sum(m2);
   if (h == 0) {
     float* pp = a.part + ((int64_t)jj * a.n_part + g) * 2;
     pp[0] = sum;
@@ -186,8 +186,8 @@ __device__ __forceinline__ void mix_ep_tile(const MixEp& m, const float4 gv, con
   // atomic pair per channel and primitive; dgamma over the wave, one atomic each into this tile's shard
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    sw[k] += __shfl_xor(sw[k], 16, 64); sw[k] += __shfl_xor(sw[k], 32, 64);
-    sb[k] += __shfl_xor(sb[k], 16, 64); sb[k] += __shfl_xor(sb[k], 32, 64);
+    sw[k] = xor16_sum(sw[k]); sw[k] = xor32_sum(sw[k]);
+    sb[k] = xor16_sum(sb[k]); sb[k] = xor32_sum(sb[k]);
   }
   const int lane = threadIdx.x & 63;
   if ((lane >> 4) == 0) {
@@ -581,10 +581,10 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     float2* xch = reinterpret_cast<float2*>(smem);               // [2][3][16]
 #pragma unroll
     for (int tj = 0; tj < 3; ++tj) {
-      ssum[tj] += __shfl_xor(ssum[tj], 16, 64);
-      ssum[tj] += __shfl_xor(ssum[tj], 32, 64);
-      ssq[tj] += __shfl_xor(ssq[tj], 16, 64);
-      ssq[tj] += __shfl_xor(ssq[tj], 32, 64);
+      ssum[tj] = xor16_sum(ssum[tj]);
+      ssum[tj] = xor32_sum(ssum[tj]);
+      ssq[tj] = xor16_sum(ssq[tj]);
+      ssq[tj] = xor32_sum(ssq[tj]);
     }
     __syncthreads();                                           // every wave is done reading operands
     if ((wave & 1) && h == 0) {
@@ -1227,8 +1227,8 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
   if (want_bias) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
-      bsum[tm] += __shfl_xor(bsum[tm], 16, 64);
-      bsum[tm] += __shfl_xor(bsum[tm], 32, 64);
+      bsum[tm] = xor16_sum(bsum[tm]);
+      bsum[tm] = xor32_sum(bsum[tm]);
       if (h == 0) brow[wave][16 * tm + lo] = bsum[tm];
     }
   }

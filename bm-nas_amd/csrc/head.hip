@@ -235,16 +235,8 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf
 // LayerNorm backward and the state-gradient store are coalesced), and dW = dl^T feat accumulated
 // over the SG groups, with feat recomputed in B-operand layout straight from the states.
 // OT = class tiles of 16 the kernel is built for (O <= 16 OT).
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int sh = 1; sh < 16; sh <<= 1) v += __shfl_xor(v, sh, 64);
-  return v;
-}
-__device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-  for (int sh = 1; sh < 16; sh <<= 1) v = fmaxf(v, __shfl_xor(v, sh, 64));
-  return v;
-}
+__device__ __forceinline__ float group16_sum(float v) { return row16_sum(v); }
+__device__ __forceinline__ float group16_max(float v) { return row16_max(v); }
 
 template <int OT, int SG, bool LZ>
 __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
@@ -446,8 +438,8 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
         q1 += t;
         q2 += t * xhn[r];
       }
-      q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
-      q2 += __shfl_xor(q2, 16, 64); q2 += __shfl_xor(q2, 32, 64);
+      q1 = xor16_sum(q1); q1 = xor32_sum(q1);
+      q2 = xor16_sum(q2); q2 = xor32_sum(q2);
       if (h == 0) {
         lnp_s[wave][rl][0] = q1;
         lnp_s[wave][rl][1] = q2;

@@ -241,8 +241,7 @@ __global__ __launch_bounds__(256) void ce_rows_k(const float* __restrict__ z,
   const float* zr = z + (int64_t)m * O;
   float mx = -INFINITY;
   for (int o = lane; o < O; o += 64) mx = fmaxf(mx, zr[o]);
-#pragma unroll
-  for (int k = 32; k > 0; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k, 64));
+  mx = wave_max(mx);
   float den = 0.f;
   for (int o = lane; o < O; o += 64) den += expf(zr[o] - mx);
   den = wave_sum(den);

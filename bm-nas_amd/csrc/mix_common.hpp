@@ -13,8 +13,8 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(
 
 // reduce v over the l4n adjacent lanes that share a channel row (l4n in {1, 2, 4})
 __device__ __forceinline__ float row_sum(float v, int l4n) {
-  if (l4n >= 2) v += __shfl_xor(v, 1, 64);
-  if (l4n >= 4) v += __shfl_xor(v, 2, 64);
+  if (l4n >= 2) v += lane_xor1(v);
+  if (l4n >= 4) v += lane_xor2(v);
   return v;
 }
 

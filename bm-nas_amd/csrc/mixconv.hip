@@ -149,10 +149,10 @@ __global__ __launch_bounds__(256) void mix_conv_fwd_k(MixConvArgs a) {
   if (vo) st4(a.V + ((int64_t)so * C + jj) * L + l0, make_float4(d.x + bj, d.y + bj, d.z + bj, d.w + bj));
   if (a.stat != nullptr) {                                      // batch sums of d = v - bias (bn_tile_stats, conv1x1.hip)
     float sum = vo ? f4_hsum(d) : 0.f, sq = vo ? f4_dot(d, d) : 0.f;
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    sq += __shfl_xor(sq, 16, 64);
-    sq += __shfl_xor(sq, 32, 64);
+    sum = xor16_sum(sum);
+    sum = xor32_sum(sum);
+    sq = xor16_sum(sq);
+    sq = xor32_sum(sq);
     if (h == 0) {
       float* pp = a.stat + ((int64_t)(bx % a.stat_shards) * C + jj) * 2;
       atomicAdd(pp, sum);

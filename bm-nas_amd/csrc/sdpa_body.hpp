@@ -23,12 +23,9 @@ struct SdpaGeom {
 
 // sum over the lanes of this wave that belong to the same sample as this lane
 __device__ __forceinline__ float sample_sum(float v, int L) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  if (L >= 8) v += __shfl_xor(v, 16, 64);
-  if (L >= 16) v += __shfl_xor(v, 32, 64);
+  v = row16_sum(v);
+  if (L >= 8) v = xor16_sum(v);
+  if (L >= 16) v = xor32_sum(v);
   return v;
 }
 
@@ -95,16 +92,16 @@ __device__ __forceinline__ void attn_probs(const float* __restrict__ x, const fl
     sc[r] = same ? raw[r] * inv : -INFINITY;
     mx = fmaxf(mx, sc[r]);
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  mx = xor16_max(mx);
+  mx = xor32_max(mx);
   float den = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     p[r] = same ? __expf(sc[r] - mx) : 0.f;
     den += p[r];
   }
-  den += __shfl_xor(den, 16, 64);
-  den += __shfl_xor(den, 32, 64);
+  den = xor16_sum(den);
+  den = xor32_sum(den);
   const float rden = 1.f / den;
 #pragma unroll
   for (int r = 0; r < 4; ++r) p[r] *= rden;
@@ -310,8 +307,8 @@ __device__ __forceinline__ void sdpa_bwd_body(
     float rowdot = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) rowdot += dP[r] * p[r];
-    rowdot += __shfl_xor(rowdot, 16, 64);
-    rowdot += __shfl_xor(rowdot, 32, 64);
+    rowdot = xor16_sum(rowdot);
+    rowdot = xor32_sum(rowdot);
     const float inv = 1.f / sqrtf((float)G.C);
 #pragma unroll
     for (int r = 0; r < 4; ++r) ds[r] = p[r] * (dP[r] - rowdot) * inv;
