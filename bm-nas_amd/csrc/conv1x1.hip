@@ -741,13 +741,32 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
   Regs R;
   fetch(R, 0);
   if (FOLD) {
+    // Every load of the coefficients issued at once — three rounds of 256 channels unrolled, clamped channel index,
+    // nothing under `if (bn_train)` — right behind chunk 0's operand loads: written as a run-time loop with the
+    // training-mode loads under a branch, each round waited for its five loads on its own (two to three dependent
+    // round trips in front of every data-gradient tile's first stash).
     const float invN = 1.f / (float)(a.b * a.L);
-    for (int m = t; m < K; m += 256) {
-      const float sc = a.bn_chan[2 * K + m];
-      float4 cf = make_float4(sc, 0.f, 0.f, 0.f);
-      if (a.bn_train)
-        cf = bn_fold_coef(sc, a.bn_grad[K + m] * invN, a.bn_chan[m], a.bn_chan[K + m] * (a.bn_grad[m] * invN));
-      coef[m] = cf;
+    const float* const bg = a.bn_train ? a.bn_grad : a.bn_chan;   // (eval mode: bn_grad is null; the values are unused)
+    constexpr int kRounds = 3;                                  // K <= 768 in one pass; longer contractions loop
+    for (int m0 = 0; m0 < K; m0 += 256 * kRounds) {
+      float scv[kRounds], g1[kRounds], mu[kRounds], rs[kRounds], g0[kRounds];
+#pragma unroll
+      for (int rd = 0; rd < kRounds; ++rd) {
+        const int m = m0 + rd * 256 + t;
+        const int mc = m < K ? m : K - 1;
+        scv[rd] = a.bn_chan[2 * K + mc];
+        g1[rd] = bg[K + mc];
+        mu[rd] = a.bn_chan[mc];
+        rs[rd] = a.bn_chan[K + mc];
+        g0[rd] = bg[mc];
+      }
+#pragma unroll
+      for (int rd = 0; rd < kRounds; ++rd) {
+        const int m = m0 + rd * 256 + t;
+        float4 cf = make_float4(scv[rd], 0.f, 0.f, 0.f);
+        if (a.bn_train) cf = bn_fold_coef(scv[rd], g1[rd] * invN, mu[rd], rs[rd] * (g0[rd] * invN));
+        if (m < K) coef[m] = cf;
+      }
     }
     __syncthreads();
   }
@@ -1136,15 +1155,24 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
   float4 cf[2] = {z4, z4};
   if (FOLD) {
     const float invN = 1.f / (float)(a.b * a.L);
+    // (all ten loads unconditional and first — eval mode, where bn_grad is null, reads bn_chan in its place and
+    // discards it: loads under `if (bn_train)` were waited for at the join, one channel tile after the other)
+    const float* const bg = a.bn_train ? a.bn_grad : a.bn_chan;
+    float scv[2], g1[2], mu[2], rs[2], g0[2];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int mt = m0 + 16 * tm;
       const int m = (mt < a.M ? mt : a.M - 16) + lo;
-      const float sc = a.bn_chan[2 * a.M + m];
-      cf[tm] = make_float4(sc, 0.f, 0.f, 0.f);
-      if (a.bn_train)                                                     // (outside the loop; bn_grad is null in eval)
-        cf[tm] = bn_fold_coef(sc, a.bn_grad[a.M + m] * invN, a.bn_chan[m],
-                              a.bn_chan[a.M + m] * (a.bn_grad[m] * invN));
+      scv[tm] = a.bn_chan[2 * a.M + m];
+      g1[tm] = bg[a.M + m];
+      mu[tm] = a.bn_chan[m];
+      rs[tm] = a.bn_chan[a.M + m];
+      g0[tm] = bg[m];
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      cf[tm] = make_float4(scv[tm], 0.f, 0.f, 0.f);
+      if (a.bn_train) cf[tm] = bn_fold_coef(scv[tm], g1[tm] * invN, mu[tm], rs[tm] * (g0[tm] * invN));
     }
   }
 
@@ -1324,11 +1352,14 @@ __global__ __launch_bounds__(256) void conv_bwd_pair_k(ConvArgs a, ConvWArgs w, 
 #define BMNAS_PIPE_LA2 1
 #endif
 constexpr bool kLa2 = BMNAS_PIPE_LA2 != 0;
+#ifndef BMNAS_MERGED_OCC
+#define BMNAS_MERGED_OCC 3
+#endif
 
 // (second __launch_bounds__ argument: at least 3 waves per SIMD, i.e. <= 168 VGPRs — the grid is ~750
 // workgroups and all of them must be resident at once)
 template <int KC, int KCH, int NG>
-__global__ __launch_bounds__(256, 3) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
+__global__ __launch_bounds__(256, BMNAS_MERGED_OCC) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
                                                            int n_w, int wx, int wy) {
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   const int blk = blockIdx.x;

@@ -57,10 +57,14 @@ struct HeadLazy {
 
 __device__ __forceinline__ void sample_stats(const HeadSrc& src, int n_src, int s, int D, float* mean, float* rstd) {
   float S = 0.f, Q = 0.f;
-  for (int q = 0; q < n_src; ++q) {
-    const float2 v = reinterpret_cast<const float2*>(src.sums[q])[s];
-    S += v.x;
-    Q += v.y;
+  float2 sv[kHeadSrc];
+#pragma unroll
+  for (int q = 0; q < kHeadSrc; ++q)                          // (every load first, clamped source index: no load in a loop)
+    sv[q] = reinterpret_cast<const float2*>(pick_ptr(src.sums, q < n_src ? q : 0))[s];
+#pragma unroll
+  for (int q = 0; q < kHeadSrc; ++q) {
+    S += q < n_src ? sv[q].x : 0.f;
+    Q += q < n_src ? sv[q].y : 0.f;
   }
   const float inv = 1.f / (float)D;
   const float m = S * inv;
@@ -91,32 +95,6 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
   const int ks = blockIdx.x, st = blockIdx.y;
   const int s = st * 16 + lo;
   const int sc = s < a.b ? s : a.b - 1;                       // clamped rows are never stored
-  float mean, rstd, nmean = 0.f, nrstd = 1.f;
-  if (LZ) {
-    const LazyStats ls = lazy_combine(z.rec, z.prm, z.P, sc);
-    float S = ls.osum, Q = ls.osq;
-    for (int q = 0; q < a.n_src; ++q) {
-      if (q == z.lq) continue;
-      const float2 v = reinterpret_cast<const float2*>(a.src.sums[q])[sc];
-      S += v.x;
-      Q += v.y;
-    }
-    const float inv = 1.f / (float)a.D;
-    mean = S * inv;
-    rstd = 1.f / sqrtf(fmaxf(Q * inv - mean * mean, 0.f) + kEpsLn);
-    nmean = ls.mean;
-    nrstd = ls.rstd;
-  } else {
-    sample_stats(a.src, a.n_src, sc, a.D, &mean, &rstd);
-  }
-  if (ks == 0 && wave == 0 && h == 0 && s < a.b) {
-    a.stats[2 * s] = mean;
-    a.stats[2 * s + 1] = rstd;
-    if (LZ) {
-      z.nstats[0][2 * s] = nmean;
-      z.nstats[0][2 * s + 1] = nrstd;
-    }
-  }
   const int nkb = a.D / 16;
   int oc[TJ];
 #pragma unroll
@@ -133,7 +111,9 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
     const int kbc = valid[j] ? kb : nkb - 1;
     const int k = kbc * 16 + 4 * h;
     const int q = (kbc * 16) / a.CL;
-    xv[j] = ld4(a.src.p[q] + (int64_t)sc * a.CL + (k - q * a.CL));
+    // (a select chain over the pointers, not a.src.p[q]: a run-time index into the argument block is a MEMORY load of
+    // the pointer with a wait in front of the operand load it feeds — common.hpp pick_ptr)
+    xv[j] = ld4(pick_ptr(a.src.p, q) + (int64_t)sc * a.CL + (k - q * a.CL));
     lw[j] = ld4(a.ln_w + k);
     lb[j] = ld4(a.ln_b + k);
     lzq[j] = LZ && q == z.lq;                                 // wave-uniform
@@ -143,6 +123,46 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
     }
 #pragma unroll
     for (int t = 0; t < TJ; ++t) wv[j][t] = ld4(a.W + (int64_t)oc[t] * a.D + k);
+  }
+  // the statistics AFTER the operand loads have been issued: their own loads (moment records, per-sample sums) are a
+  // dependent round trip that the operands do not wait for — in front of them it was one (two with a lazy source)
+  // full memory latency before the first operand load went out
+  __builtin_amdgcn_sched_barrier(0);
+  float mean, rstd, nmean = 0.f, nrstd = 1.f;
+  if (LZ) {
+    // (all kHeadSrc per-sample sums fetched unconditionally, from a valid slot where there is no such source or it is
+    // the lazy one: no load inside a run-time loop, where each would be waited for on its own)
+    float2 sv[kHeadSrc];
+#pragma unroll
+    for (int q = 0; q < kHeadSrc; ++q) {
+      const bool use = q < a.n_src && q != z.lq;
+      const int qq = use ? q : (z.lq == 0 ? (a.n_src > 1 ? 1 : 0) : 0);
+      const float* sp = pick_ptr(a.src.sums, qq);
+      sv[q] = reinterpret_cast<const float2*>(sp != nullptr ? sp : z.rec)[sc];
+    }
+    const LazyStats ls = lazy_combine(z.rec, z.prm, z.P, sc);
+    float S = ls.osum, Q = ls.osq;
+#pragma unroll
+    for (int q = 0; q < kHeadSrc; ++q) {
+      const bool use = q < a.n_src && q != z.lq;
+      S += use ? sv[q].x : 0.f;
+      Q += use ? sv[q].y : 0.f;
+    }
+    const float inv = 1.f / (float)a.D;
+    mean = S * inv;
+    rstd = 1.f / sqrtf(fmaxf(Q * inv - mean * mean, 0.f) + kEpsLn);
+    nmean = ls.mean;
+    nrstd = ls.rstd;
+  } else {
+    sample_stats(a.src, a.n_src, sc, a.D, &mean, &rstd);
+  }
+  if (ks == 0 && wave == 0 && h == 0 && s < a.b) {
+    a.stats[2 * s] = mean;
+    a.stats[2 * s + 1] = rstd;
+    if (LZ) {
+      z.nstats[0][2 * s] = nmean;
+      z.nstats[0][2 * s + 1] = nrstd;
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   f32x4 acc[3][TJ];
@@ -268,24 +288,31 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
   }
   const float4 lw = ld4(a.ln_w + k0 + 4 * h), lb = ld4(a.ln_b + k0 + 4 * h);
   const float lwk = a.ln_w[k0 + lo], lbk = a.ln_b[k0 + lo];
+  // the workgroup's source q through select chains (common.hpp pick_ptr), never a.src.p[q]: a run-time index into the
+  // argument block is a memory load of the POINTER and a wait in front of every operand load it feeds
+  const float* const srcq = pick_ptr(a.src.p, q);
   float4 nw4 = make_float4(1.f, 1.f, 1.f, 1.f), nb4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float nwk = 1.f, nbk = 0.f;
+  const float* nstq = nullptr;
   if (LZ) {                                                     // (q: uniform over the workgroup, CL % 64 == 0)
-    nw4 = ld4(z.nw[q] + kin + 4 * h);
-    nb4 = ld4(z.nb[q] + kin + 4 * h);
-    nwk = z.nw[q][kin + lo];
-    nbk = z.nb[q][kin + lo];
+    const float* const nwq_p = pick_ptr(z.nw, q);
+    const float* const nbq_p = pick_ptr(z.nb, q);
+    nstq = pick_ptr(z.nstats, q);
+    nw4 = ld4(nwq_p + kin + 4 * h);
+    nb4 = ld4(nbq_p + kin + 4 * h);
+    nwk = nwq_p[kin + lo];
+    nbk = nbq_p[kin + lo];
   }
   float4 x[SG];
   float xr[SG][4];
 #pragma unroll
   for (int g = 0; g < SG; ++g) {
     const int s = s0 + 16 * g + lo;
-    x[g] = ld4(a.src.p[q] + (int64_t)(s < a.b ? s : a.b - 1) * a.CL + kin + 4 * h);
+    x[g] = ld4(srcq + (int64_t)(s < a.b ? s : a.b - 1) * a.CL + kin + 4 * h);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int sr = s0 + 16 * g + 4 * h + r;
-      xr[g][r] = a.src.p[q][(int64_t)(sr < a.b ? sr : a.b - 1) * a.CL + kin + lo];
+      xr[g][r] = srcq[(int64_t)(sr < a.b ? sr : a.b - 1) * a.CL + kin + lo];
     }
   }
   // ---- prologue: thread = (row tid / 16 of sample group g, class stripe lo + 16 u)
@@ -308,8 +335,8 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
       lab[g] = (a.mode == 2) ? (int)a.labels_i[spc] : 0;
       st_mean[g] = a.stats[2 * spc];
       st_rstd[g] = a.stats[2 * spc + 1];
-      nd_mean[g] = LZ ? z.nstats[q][2 * spc] : 0.f;
-      nd_rstd[g] = LZ ? z.nstats[q][2 * spc + 1] : 1.f;
+      nd_mean[g] = LZ ? nstq[2 * spc] : 0.f;
+      nd_rstd[g] = LZ ? nstq[2 * spc + 1] : 1.f;
     }
     float loss_acc = 0.f;
 #pragma unroll
@@ -445,7 +472,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
         lnp_s[wave][rl][1] = q2;
       }
     }
-    float* d = a.dsrc[q];
+    float* d = pick_ptr(a.dsrc, q);
     if (d != nullptr && vs && !(a.probe & 2)) {
       float* pp = d + (int64_t)s * a.CL + kin + 4 * h;
       float4 o4 = make_float4(dx[0], dx[1], dx[2], dx[3]);
@@ -464,7 +491,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
   }
   if (LZ) {                                                     // (every wave is here: CL % 64 == 0 -> vt)
     __syncthreads();
-    float* lp = z.lnpart[q];
+    float* lp = pick_ptr(z.lnpart, q);
     if (lp != nullptr && (int)threadIdx.x < 2 * kRows) {
       const int rl = threadIdx.x >> 1, cpt = threadIdx.x & 1;
       if (s0 + rl < a.b) {

@@ -46,8 +46,6 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
   STAMP(0, smp * P + part, 0);
   float* sc = fin_lds;
   float* sh = fin_lds + M;
-  const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
-  const DropRt rglu = drop_begin(dglu), rfc = drop_begin(dfc);
   const int r0 = part * kLazyPart + threadIdx.x;
   const bool act = r0 < cl4;
   const int r = act ? r0 : cl4 - 1;                           // clamped address, no predicated loads
@@ -60,6 +58,12 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
   const float4 lw = ld4(ln_w + (int64_t)r * 4), lb = ld4(ln_b + (int64_t)r * 4);
   const float4 ua = ld4(U + ub), ug = ld4(U + ub + (int64_t)C * L), uf = ld4(U + ub + (int64_t)2 * C * L);
   const float4 xv = ld4(x + e), yv = ld4(y + e), pv = ld4(p1 + e), rv = ld4(resid + e);
+  // only now what hangs off a SECOND scalar round trip (the dropout step counters and gamma sit behind pointers of
+  // the argument block): ahead of the operand loads each of them was a kernarg fetch -> wait -> dependent fetch ->
+  // wait chain in front of the first vector load (in-kernel stamps: 1.5 us from entry to "loads issued")
+  __builtin_amdgcn_sched_barrier(0);
+  const float g0 = gamma[0], g1 = gamma[1], g2 = gamma[2], g3 = gamma[3];
+  const DropRt rglu = drop_begin(dglu), rfc = drop_begin(dfc);
   STAMP(0, smp * P + part, 1);
   bn_fin_fill<256>(fin, chan, M, b * L, sc, sh, part == 0 && smp == 0);
   STAMP(0, smp * P + part, 2);
@@ -201,15 +205,19 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
 #pragma unroll
   for (int j = 0; j < NIN; ++j) wj[j] = w[j * w_stride];
   const float s2 = w2[0] + w2[w2_stride];
+  // EVERY load unconditional (an absent optional operand reads gz again and is masked out): a load under `if` is a
+  // branch whose join waits for vmcnt(0) — gz, gz2 and gh were three dependent round trips in front of the operands
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 z4 = reinterpret_cast<const float4*>(gz)[i];
-  if (gz2 != nullptr) z4 = f4_add(z4, reinterpret_cast<const float4*>(gz2)[i]);
+  const float4 z2v = reinterpret_cast<const float4*>(gz2 != nullptr ? gz2 : gz)[i];
   const float4 h4 = reinterpret_cast<const float4*>(h)[i];
-  float4 g4 = f4_scale(z4, s2);
-  if (gh != nullptr) g4 = f4_add(g4, reinterpret_cast<const float4*>(gh)[i]);
+  const float4 ghv = reinterpret_cast<const float4*>(gh != nullptr ? gh : gz)[i];
   float4 v[NIN];
 #pragma unroll
   for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
-  float4 pz[NLZ], lz[NLZ];
+  z4 = f4_add(z4, gz2 != nullptr ? z2v : zero4);
+  float4 g4 = f4_add(f4_scale(z4, s2), gh != nullptr ? ghv : zero4);
+  float4 pz[NLZ], lz[NLZ], oldn[NLZ];
   float mean[NLZ], rstd[NLZ];
 #pragma unroll
   for (int t = 0; t < NLZ; ++t) {
@@ -217,6 +225,11 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
     lz[t] = ld4(Z.ln_w[t] + (int64_t)r * 4);
     mean[t] = Z.stats[t][2 * smp];
     rstd[t] = Z.stats[t][2 * smp + 1];
+    // the node-output gradients are read-modify-written (the head's launch wrote them first): their old values are
+    // fetched HERE, with the operands — next to their store the load was a dependent round trip of its own at the
+    // end of the kernel (load, s_waitcnt vmcnt(0), add, store)
+    const float* od = dxs.p[NIN - NLZ + t];
+    oldn[t] = reinterpret_cast<const float4*>(od != nullptr && (acc_mask & (1u << (NIN - NLZ + t))) ? od : gz)[i];
   }
   if (!act) {
     z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -242,7 +255,10 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
       float* d = dxs.p[j];
       if (d == nullptr) continue;
       float4 rr = f4_scale(g4, wj[j]);
-      if (acc_mask & (1u << j)) rr = f4_add(rr, reinterpret_cast<float4*>(d)[i]);
+      if (acc_mask & (1u << j)) {
+        // (the lazy inputs are pairwise distinct step-node outputs, host-checked: their old values came with the loads)
+        rr = f4_add(rr, j >= NIN - NLZ ? oldn[j - (NIN - NLZ) < 0 ? 0 : j - (NIN - NLZ)] : reinterpret_cast<float4*>(d)[i]);
+      }
       reinterpret_cast<float4*>(d)[i] = rr;
     }
   }
@@ -506,6 +522,11 @@ extern "C" int bmnas_mixsum_pair_bwd_lazy(const float* const* xs, float* const* 
     Z.pre[t] = lazy[t].pre; Z.ln_w[t] = lazy[t].ln_w; Z.stats[t] = lazy[t].stats; Z.lnpart[t] = lnpart[t];
     Z.stride[t] = lnpart_stride[t];
     if (Z.stride[t] < lazy_parts(C * L / 4)) return BMNAS_E_ARG;
+    // the kernel fetches the old value of a lazy input's gradient with its operand loads: no other destination of
+    // this launch may alias it
+    const int jt = n_in - n_lazy + t;
+    for (int j = 0; j < n_in; ++j)
+      if (j != jt && dxs[jt] != nullptr && dxs[j] == dxs[jt]) return BMNAS_E_ARG;
   }
   const int cl4 = C * L / 4;
   dim3 grid(lazy_parts(cl4), b);

@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void mixsum_bwd_k(PtrsIn xs, PtrsOut dxs,
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     float4 g4 = reinterpret_cast<const float4*>(g)[i];
-    if (g2 != nullptr) g4 = f4_add(g4, reinterpret_cast<const float4*>(g2)[i]);
+    {                                                        // (unconditional load: no wait at a join)
+      const float4 g2v = reinterpret_cast<const float4*>(g2 != nullptr ? g2 : g)[i];
+      g4 = f4_add(g4, g2 != nullptr ? g2v : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
     if (dw != nullptr) {
       float4 v[NIN];
 #pragma unroll
@@ -142,14 +145,18 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
   const float s2 = w2[0] + w2[w2_stride];
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    // every load unconditional (an absent optional operand reads gz again and is masked out): a load under `if` is
+    // a branch whose join waits for vmcnt(0) — gz, gz2 and gh were three dependent round trips before the operands
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 z4 = reinterpret_cast<const float4*>(gz)[i];
-    if (gz2 != nullptr) z4 = f4_add(z4, reinterpret_cast<const float4*>(gz2)[i]);
+    const float4 z2v = reinterpret_cast<const float4*>(gz2 != nullptr ? gz2 : gz)[i];
     const float4 h4 = reinterpret_cast<const float4*>(h)[i];
-    float4 g4 = f4_scale(z4, s2);
-    if (gh != nullptr) g4 = f4_add(g4, reinterpret_cast<const float4*>(gh)[i]);
+    const float4 ghv = reinterpret_cast<const float4*>(gh != nullptr ? gh : gz)[i];
     float4 v[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+    z4 = f4_add(z4, gz2 != nullptr ? z2v : zero4);
+    const float4 g4 = f4_add(f4_scale(z4, s2), gh != nullptr ? ghv : zero4);
 #pragma unroll
     for (int j = 0; j < NIN; ++j) part[j] += f4_dot(g4, v[j]);
     part[NIN] += f4_dot(z4, h4);
@@ -212,17 +219,21 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_x_k(PtrsIn xs, PtrsOut dx
   const float s2 = w2[0] + w2[w2_stride];
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    // every load unconditional (an absent optional operand reads gz again and is masked out): a load under `if` is
+    // a branch whose join waits for vmcnt(0) — gz, gz2 and gh were three dependent round trips before the operands
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 z4 = reinterpret_cast<const float4*>(gz)[i];
-    if (gz2 != nullptr) z4 = f4_add(z4, reinterpret_cast<const float4*>(gz2)[i]);
+    const float4 z2v = reinterpret_cast<const float4*>(gz2 != nullptr ? gz2 : gz)[i];
     const float4 h4 = reinterpret_cast<const float4*>(h)[i];
-    float4 g4 = f4_scale(z4, s2);
-    if (gh != nullptr) g4 = f4_add(g4, reinterpret_cast<const float4*>(gh)[i]);
+    const float4 ghv = reinterpret_cast<const float4*>(gh != nullptr ? gh : gz)[i];
     float4 gx[NX];
 #pragma unroll
     for (int t = 0; t < NX; ++t) gx[t] = reinterpret_cast<const float4*>(X.g[t])[i];
     float4 v[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+    z4 = f4_add(z4, gz2 != nullptr ? z2v : zero4);
+    const float4 g4 = f4_add(f4_scale(z4, s2), gh != nullptr ? ghv : zero4);
 #pragma unroll
     for (int j = 0; j < NIN; ++j) part[j] += f4_dot(g4, v[j]);
     part[NIN] += f4_dot(z4, h4);
