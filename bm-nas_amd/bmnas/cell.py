@@ -450,6 +450,34 @@ LAZY_LN = os.environ.get('BMNAS_LAZY_LN', '1') != '0'
 WRITE_ONCE = os.environ.get('BMNAS_WRITE_ONCE', '1') != '0'
 
 
+# Run-to-run bit-identical results (the reference's CPU path is deterministic; the default kernels sum batch reductions
+# with fp32 atomics in whatever order workgroups finish).  Covers the search step with node_multiplier == 1 under the
+# fused head (the lazy-LayerNorm path): BatchNorm statistics as per-n-group partials + bn_finalize, head logits and
+# criterion / BatchNorm affine gradients as partials summed in order, one arch-gradient shard per workgroup, weight
+# gradients without batch splits, LayerNorm affine reductions in one chunk (include/bmnas_hip.h, "deterministic mode").
+DETERMINISTIC = os.environ.get('BMNAS_DETERMINISTIC', '0') not in ('0', '', 'false', 'False')
+_DET_APPLIED = [None]
+
+
+def apply_deterministic():
+    """Hand the current DETERMINISTIC setting to the library (its host-side launch choices); cheap when unchanged."""
+    if _DET_APPLIED[0] != DETERMINISTIC:
+        lib.set_deterministic(DETERMINISTIC)
+        _DET_APPLIED[0] = DETERMINISTIC
+
+
+def arch_shards(b, C, L):
+    """Copies of the arch-gradient buffers: ARCH_SHARDS to spread same-address atomics — or, deterministic mode, one per
+    workgroup of the largest launch that adds into them (a single add per address; the epilogue sums in shard order)."""
+    if not DETERMINISTIC:
+        return ARCH_SHARDS
+    cl4 = C * L // 4
+    parts = (cl4 + 255) // 256
+    streaming = min(2048, (b * cl4 + 255) // 256)
+    mix = ((cl4 + 63) // 64) * lib.node_mix_lnp_bwd_rows(b)
+    return max(ARCH_SHARDS, b * parts, streaming, mix)
+
+
 class LazyNode(Pack):
     """A step-node output whose LayerNorm is pending: desc (lib.LazyLn over pre / rec / prm / affine / stats),
     out (the (b, C, L) tensor the first K1 consumer fills; never written for the last node), P parts per sample;
@@ -546,9 +574,10 @@ def node_mixed_bwd(sv, g, dgamma_row, x_slot, y_slot, G, shards=1, shard_stride=
                 rbuf, racc = r_slot.buf(), r_slot.acc_bit()
             dxb, acc = x_slot.buf(), x_slot.acc_bit()
             if ln is not None and lazy is not None:
+                bn_part = _empty(x, lib.node_mix_lnp_bwd_rows(b) * 6 * C) if DETERMINISTIC else None
                 lib.node_mix_lnp_bwd(gy, pre, ln_w, stats, lazy.lnp_head, lazy.lnp_k1, g, rbuf, racc, x, y, sv.p1,
                                      sv.conv.U, sv.conv.chan, sv.gamma, dgamma_row, dxb, None, acc, dV, bn_grad,
-                                     b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride)
+                                     b, C, L, sv.d_glu, sv.d_fc, shards, shard_stride, bn_part)
             elif ln is not None:
                 lib.node_mix_ln_bwd(gy, pre, ln_w, stats, g, rbuf, racc, x, y, sv.p1, sv.conv.U, sv.conv.chan,
                                     sv.gamma, dgamma_row, dxb, None, acc, dV, bn_grad, b, C, L, sv.d_glu,
@@ -861,11 +890,16 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
         if M > S:
             raise lib.BmnasError('fused head: the cell concatenates input states (multiplier > steps)')
         head.sums = [nsv.osum for nsv in sv.nodes[S - M:]]
+        if DETERMINISTIC and not sv.lazy_on:
+            raise lib.BmnasError('BMNAS_DETERMINISTIC covers the search cell with node_multiplier == 1 under the fused '
+                                 'head (the lazy-LayerNorm path); this configuration is outside it')
         last = sv.nodes[-1].lazy if sv.lazy_on else None
         if last is not None and not last.materialised:
             # the last node's output exists only inside the classifier GEMM's operand fetch
+            O_ = head.W.shape[0]
+            hb_part = _empty(xs[0], lib.head_fwd_part_floats(b, C, L, M, O_)) if DETERMINISTIC else None
             lib.head_fwd_lazy(states[-M:-1] + [sv.nodes[-1].o], head.sums[:-1] + [None], M - 1, last.desc, CP.ln_w,
-                              CP.ln_b, head.W, head.bias, head.hb, sv.stats, b, C, L, head.W.shape[0])
+                              CP.ln_b, head.W, head.bias, head.hb, sv.stats, b, C, L, O_, hb_part)
         else:
             lib.head_fwd(states[-M:], head.sums, CP.ln_w, CP.ln_b, head.W, head.bias, head.hb, sv.stats, b, C, L,
                          head.W.shape[0])
@@ -938,9 +972,12 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
                 lzn.k1_n = S - 1 - t
                 lzn.lnp_k1 = _empty(x0, b * lzn.k1_n * P * 2) if lzn.k1_n else None
             tailn = sv.nodes[S - M:]
+            loss_part = _empty(x0, n_chunk) if (DETERMINISTIC and mode != 0) else None
             lib.head_bwd_lazy([n.lazy.desc for n in tailn], [n.lazy.lnp_head for n in tailn], bufs, mask, CP.ln_w,
                               CP.ln_b, head.W, head.hb, sv.stats, mode, gten, gscale, labels, head.loss, part, b, C,
-                              L, O, getattr(CG, 'scrub', None))
+                              L, O, getattr(CG, 'scrub', None), loss_part)
+            if loss_part is not None:            # the chunks' shares in a fixed order (a four-element sum)
+                head.loss.copy_(loss_part.sum(0, keepdim=True))
         else:
             lib.head_bwd(sv.states[-M:], head.sums, bufs, mask, CP.ln_w, CP.ln_b, head.W, head.hb, sv.stats, mode,
                          gten, gscale, labels, head.loss, part, b, C, L, O, getattr(CG, 'scrub', None))

@@ -474,7 +474,10 @@ class FusedCellFn(Function):
         # the GEMM epilogues add into (finalised by the mix / out_conv kernels: no bn_finalize
         # launches) and the head's logits | A | B | loss
         counts = []
-        if K.FUSE_BN_FINALIZE:
+        K.apply_deterministic()
+        # (deterministic mode: the BatchNorm statistics go through per-n-group partials + bn_finalize launches — plain
+        # stores combined in a fixed order — instead of atomically accumulated sums)
+        if K.FUSE_BN_FINALIZE and not K.DETERMINISTIC:
             for n in CP.nodes:
                 counts += [3 * C_] * len(n.mixed) + ([C_] if cell.args.node_multiplier != 1 else [])
         stat_n = K.StatArena.numel_for(counts)
@@ -534,7 +537,9 @@ class FusedCellFn(Function):
         dev = ctx.dev
         need_in = [ctx.needs_input_grad[5 + j] and not K._ARCH_ONLY[0] for j in range(N)]
         # one zero-filled arena for every gradient that is accumulated with atomics
-        CG, dalpha_w, dbeta_ws, dgamma_ws = cell.grad_pack(dev, sv.alpha_w, ctx.beta_ws, ctx.gamma_ws)
+        x0 = sv.states[0]
+        CG, dalpha_w, dbeta_ws, dgamma_ws = cell.grad_pack(dev, sv.alpha_w, ctx.beta_ws, ctx.gamma_ws,
+                                                           K.arch_shards(x0.shape[0], x0.shape[1], x0.shape[2]))
         ws, dws = [], []
         for i in range(S):
             ws += [ctx.beta_ws[i], ctx.gamma_ws[i]]

@@ -208,11 +208,15 @@ SIGNATURES = {
                                     C.POINTER(LazyLn), _PP, C.POINTER(C.c_int), _I, _P, _I, _I, _I, _P], _I),
     'bmnas_mixsum_pair_bwd_x': ([_PP, _PP, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _U32, _PP, _PP, _I,
                                  _I64, _P], _I),
-    'bmnas_head_fwd_lazy': ([_PP, _PP, _I, _I, C.POINTER(LazyLn), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'bmnas_head_fwd_lazy': ([_PP, _PP, _I, _I, C.POINTER(LazyLn), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], _I),
+    'bmnas_head_fwd_part_floats': ([_I, _I, _I, _I, _I], _I),
+    'bmnas_node_mix_lnp_bwd_rows': ([_I], _I),
+    'bmnas_conv1x1_set_deterministic': ([_I], _I),
+    'bmnas_ln_set_deterministic': ([_I], _I),
     'bmnas_head_bwd_lazy': ([C.POINTER(LazyLn), _PP, _PP, _I, _U32, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P,
-                             _I, _I, _I, _I, _P, _I64, _P], _I),
+                             _I, _I, _I, _I, _P, _I64, _P, _P], _I),
     'bmnas_node_mix_lnp_bwd': ([_P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I64,
-                                _P, _P, _U32, _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
+                                _P, _P, _U32, _P, _P, _I, _I, _I, Dropout, Dropout, _P, _P], _I),
     'bmnas_head_bwd': ([_PP, _PP, _PP, _I, _U32, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                         _P, _I64, _P], _I),
     'bmnas_sum_chunks': ([_P, _P, _I, _I64, _P], _I),
@@ -483,27 +487,47 @@ def mixsum_pair_bwd_x(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, a
                                           _stream()), 'mixsum_pair_bwd_x')
 
 
-def head_fwd_lazy(srcs, sums, lazy_q, lazy, ln_w, ln_b, W, bias, hb, stats, b, Cc, L, O):
-    """bmnas_head_fwd whose source lazy_q is srcs[lazy_q] = the un-normalised `pre` described by `lazy`."""
+def head_fwd_lazy(srcs, sums, lazy_q, lazy, ln_w, ln_b, W, bias, hb, stats, b, Cc, L, O, hb_part=None):
+    """bmnas_head_fwd whose source lazy_q is srcs[lazy_q] = the un-normalised `pre` described by `lazy`.
+    hb_part (deterministic mode): head_fwd_part_floats(...) floats; hb then needs no zero-fill."""
     _check(load().bmnas_head_fwd_lazy(_ptrs(srcs), _ptrs(sums), len(srcs), lazy_q, C.byref(lazy), _ptr(ln_w),
                                       _ptr(ln_b), _ptr(W), _ptr(bias), _ptr(hb), _ptr(stats), b, Cc, L, O,
-                                      _stream()), 'head_fwd_lazy')
+                                      _ptr(hb_part), _stream()), 'head_fwd_lazy')
+
+
+def head_fwd_part_floats(b, Cc, L, n_src, O):
+    n = load().bmnas_head_fwd_part_floats(b, Cc, L, n_src, O)
+    if n < 0:
+        _check(n, 'head_fwd_part_floats')
+    return n
+
+
+def node_mix_lnp_bwd_rows(b):
+    return load().bmnas_node_mix_lnp_bwd_rows(b)
+
+
+def set_deterministic(on):
+    """The two host-side choices of the deterministic mode that live in the library (bmnas.cell.DETERMINISTIC sets
+    them): weight-gradient tiles without batch splits, LayerNorm-affine reductions in one chunk."""
+    _check(load().bmnas_conv1x1_set_deterministic(int(bool(on))), 'conv1x1_set_deterministic')
+    _check(load().bmnas_ln_set_deterministic(int(bool(on))), 'ln_set_deterministic')
 
 
 def head_bwd_lazy(lazies, lnparts, dsrcs, acc_mask, ln_w, ln_b, W, hb, stats, mode, g, gscale, labels, loss, part,
-                  b, Cc, L, O, scrub=None):
+                  b, Cc, L, O, scrub=None, loss_part=None):
     n = len(lazies)
     arr = (LazyLn * n)(*lazies)
     _check(load().bmnas_head_bwd_lazy(arr, _ptrs(lnparts), _ptrs(dsrcs), n, acc_mask, _ptr(ln_w), _ptr(ln_b),
                                       _ptr(W), _ptr(hb), _ptr(stats), mode, _ptr(g),
                                       None if gscale is None else gscale.data_ptr(),
                                       None if labels is None else labels.data_ptr(), _ptr(loss), _ptr(part),
-                                      b, Cc, L, O, _ptr(scrub), 0 if scrub is None else scrub.numel(), _stream()),
+                                      b, Cc, L, O, _ptr(scrub), 0 if scrub is None else scrub.numel(), _ptr(loss_part),
+                                      _stream()),
            'head_bwd_lazy')
 
 
 def node_mix_lnp_bwd(gy, pre, ln_w, stats, lnp0, lnp1, g_in, dresid, acc_resid, x, y, p1, U, chan, gamma, dgamma, dx,
-                     dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc, dg_shards=1, dg_stride=0):
+                     dy, acc_mask, dV, bn_grad, b, Cc, L, dglu, dfc, dg_shards=1, dg_stride=0, bn_part=None):
     """lnp0 / lnp1: (b, n, 2) partial sums of the LayerNorm backward (None: absent)."""
     n0 = 0 if lnp0 is None else lnp0.numel() // (2 * b)
     n1 = 0 if lnp1 is None else lnp1.numel() // (2 * b)
@@ -512,7 +536,7 @@ def node_mix_lnp_bwd(gy, pre, ln_w, stats, lnp0, lnp1, g_in, dresid, acc_resid, 
                                          _ptr(U), _ptr(chan), gamma.data_ptr(),
                                          None if dgamma is None else dgamma.data_ptr(), dg_shards, dg_stride,
                                          _ptr(dx), _ptr(dy), acc_mask, _ptr(dV), _ptr(bn_grad), b, Cc, L, dglu, dfc,
-                                         _stream()), 'node_mix_lnp_bwd')
+                                         _ptr(bn_part), _stream()), 'node_mix_lnp_bwd')
 
 
 def adaptive_maxpool_group(xs, dims, outs, idxs, b):

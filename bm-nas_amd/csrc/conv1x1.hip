@@ -1810,6 +1810,7 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
 }
 
 namespace {
+int g_conv_deterministic = 0;       // bmnas_conv1x1_set_deterministic
 // fill the weight-gradient arguments; waves = waves per workgroup of the kernel that will run them
 int fill_w_args(ConvWArgs& a, const float* dU, const float* const* srcs, int n_src, int C_src, float* dW,
                 int ldw, float* dbias, int dup_cols, int b, int L, int M, int waves, dim3* grid) {
@@ -1831,7 +1832,7 @@ int fill_w_args(ConvWArgs& a, const float* dU, const float* const* srcs, int n_s
   int splits = (256 * 8 / waves) / tiles;
   const int max_splits = (a.n_groups + 7) / 8;
   if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  if (splits < 1 || g_conv_deterministic) splits = 1;           // deterministic mode: one walk over the batch, no atomics
   a.groups_per_split = (a.n_groups + splits - 1) / splits;
   splits = (a.n_groups + a.groups_per_split - 1) / a.groups_per_split;
   a.use_atomic = splits > 1;
@@ -2198,6 +2199,7 @@ extern "C" int bmnas_conv1x1_bwd_group(const bmnas_conv_bwd_prob_t* probs, int n
       int splits = (int)std::max<long>(1, (768 + tiles_all - 1) / tiles_all);
       const int max_splits = (w.n_groups + 7) / 8;
       splits = std::min(splits, std::max(1, max_splits));
+      if (g_conv_deterministic) splits = 1;
       w.groups_per_split = (w.n_groups + splits - 1) / splits;
       splits = (w.n_groups + w.groups_per_split - 1) / w.groups_per_split;
       w.use_atomic = splits > 1;
@@ -2275,5 +2277,10 @@ extern "C" int bmnas_fold_weight(const float* W, float* Weff, int M, int C, void
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(fold_weight_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, Weff, M, C);
   BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int bmnas_conv1x1_set_deterministic(int on) {
+  g_conv_deterministic = on ? 1 : 0;
   return 0;
 }

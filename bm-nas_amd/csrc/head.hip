@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "../../include/bmnas_hip.h"
 #include "lazy_ln.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -81,6 +82,8 @@ struct HeadFwdArgs {
   const float* W;        // (O, D)
   const float* bias;     // (O)
   float* hb;             // [3][b][O], zero-filled: logits | A | B (atomic adds)
+  float* hb_part;        // deterministic mode: [KS][hb_stride] — every k-slice STORES its partial tile (no atomics; the
+  long long hb_stride;   // launcher sums the slices in order, bmnas_sum_chunks); NULL: atomics into hb
   float* stats;          // (b, 2): mean, rstd of the K7 LayerNorm (written by k-slice 0)
   int b, O, D, CL, n_src, KS;
 };
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
     const int sr = e / a.O, o = e - sr * a.O;
     float val = (red[0][v][sr][o] + red[1][v][sr][o]) + (red[2][v][sr][o] + red[3][v][sr][o]);
     if (v == 0 && ks == 0) val += a.bias[o];
-    atomicAdd(a.hb + ((int64_t)v * a.b + st * 16) * a.O + e, val);
+    if (a.hb_part != nullptr) a.hb_part[(int64_t)ks * a.hb_stride + ((int64_t)v * a.b + st * 16) * a.O + e] = val;
+    else atomicAdd(a.hb + ((int64_t)v * a.b + st * 16) * a.O + e, val);
   }
 }
 
@@ -236,6 +240,8 @@ struct HeadBwdArgs {
   const float* labels_f;     // mode 1: (b, O) multi-hot floats
   const long long* labels_i; // mode 2: (b) class ids
   float* loss;               // modes 1, 2: += mean loss (zero-filled by the caller)
+  float* loss_part;          // deterministic mode: [n_chunk] — each sample chunk STORES its share (summed by the host in
+                             // a fixed order); NULL: atomic adds into loss
   float* part;               // [n_chunk][O + 3][D] partials of each sample chunk (bmnas_head_chunks): rows 0..O-1 dW,
                              // O dln_w, O+1 dln_b, O+2 dbias (first O entries)
   float* scrub;              // side job: zero-fill (the caller's backward accumulation arena)
@@ -264,6 +270,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
   __shared__ float dl_s[kRows][16 * OT + 4];
   __shared__ float ms[LZ ? 6 : 4][kRows];         // m1, m2, mean, rstd (, node mean, node rstd)
   __shared__ float lnp_s[LZ ? 4 : 1][LZ ? kRows : 1][2];
+  __shared__ float loss_s[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int chunk = blockIdx.y, s0 = chunk * kRows;
@@ -403,10 +410,19 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
     }
     if (a.mode != 0 && blockIdx.x == 0) {
       loss_acc = wave_sum(loss_acc);
-      if (lane == 0) atomicAdd(a.loss, loss_acc / (a.mode == 1 ? (float)a.b * (float)a.O : (float)a.b));
+      // (the chunk's 16 SG rows are spread over the workgroup's four waves: wave partials meet in LDS first when the
+      // chunk's share has to be ONE number)
+      const float share = loss_acc / (a.mode == 1 ? (float)a.b * (float)a.O : (float)a.b);
+      if (a.loss_part != nullptr) {
+        if (lane == 0) loss_s[wave] = share;
+      } else if (lane == 0) {
+        atomicAdd(a.loss, share);
+      }
     }
   }
   __syncthreads();
+  if (a.loss_part != nullptr && a.mode != 0 && blockIdx.x == 0 && threadIdx.x == 0)
+    a.loss_part[chunk] = (loss_s[0] + loss_s[1]) + (loss_s[2] + loss_s[3]);
   if (a.part != nullptr && blockIdx.x == 0 && (int)threadIdx.x < a.O) {   // dbias partial of this chunk
     float t = 0.f;
 #pragma unroll
@@ -547,6 +563,22 @@ __global__ __launch_bounds__(256) void sum_chunks_k(const float* __restrict__ pa
   }
 }
 
+// out[e] = sum_c part[c * stride + e] in the order c = 0, 1, ... (deterministic head forward): n4 float4 + a scalar tail
+__global__ __launch_bounds__(256) void sum_chunks_strided_k(const float* __restrict__ part, float* __restrict__ out,
+                                                            int n_chunk, long long n4, long long stride, long long tail) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 t = ld4(part + 4 * i);
+    for (int c = 1; c < n_chunk; ++c) t = f4_add(t, ld4(part + (long long)c * stride + 4 * i));
+    st4(out + 4 * i, t);
+  }
+  if (blockIdx.x == 0 && (long long)threadIdx.x < tail) {
+    const long long e = 4 * n4 + threadIdx.x;
+    float t = part[e];
+    for (int c = 1; c < n_chunk; ++c) t += part[(long long)c * stride + e];
+    out[e] = t;
+  }
+}
+
 }  // namespace
 
 // samples per partial-sum chunk of the backward: 32 (two MFMA sample groups per workgroup: the W
@@ -561,7 +593,7 @@ extern "C" int bmnas_head_chunks(int b) {
 
 static int head_fwd_impl(const float* const* srcs, const float* const* sums, int n_src, const float* ln_w,
                          const float* ln_b, const float* W, const float* bias, float* hb, float* stats, int b, int C,
-                         int L, int O, const HeadLazy* lazy, void* stream) {
+                         int L, int O, const HeadLazy* lazy, float* hb_part, void* stream) {
   if (!ln_w || !ln_b || !W || !bias || !hb || !stats || b < 0 || C < 1 || L < 1 || O < 1) return BMNAS_E_ARG;
   if (O > kMaxO) return BMNAS_E_LIMIT;
   if ((C * L) % 16) return BMNAS_E_SHAPE;
@@ -582,6 +614,8 @@ static int head_fwd_impl(const float* const* srcs, const float* const* sums, int
   int J = 3;
   if ((nkb + 11) / 12 * tiles < 128) J = (nkb + 7) / 8 * tiles < 128 ? 1 : 2;
   a.KS = (nkb + 4 * J - 1) / (4 * J);
+  a.hb_part = hb_part;
+  a.hb_stride = ((long long)3 * b * O + 3) / 4 * 4;             // (bmnas_head_fwd_part_floats)
   dim3 grid((unsigned)a.KS, (unsigned)tiles);
   const int TJ = (O + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
@@ -601,19 +635,36 @@ static int head_fwd_impl(const float* const* srcs, const float* const* sums, int
 #undef HF_T
 #undef HF
   BMNAS_CHECK_LAUNCH();
+  if (hb_part != nullptr) {
+    // the k-slices in order (padding floats of a slice are never written: sum exactly 3 b O, rounded down to a
+    // multiple of four, and the tail by hand)
+    const long long n = (long long)3 * b * O, n4 = n / 4 * 4;
+    if (n4 > 0)
+      hipLaunchKernelGGL(sum_chunks_strided_k, dim3((unsigned)std::min<long long>((n4 / 4 + 255) / 256, 2048)), dim3(256),
+                         0, st, hb_part, hb, a.KS, n4 / 4, a.hb_stride, n - n4);
+    BMNAS_CHECK_LAUNCH();
+  }
   return 0;
+}
+
+extern "C" int bmnas_head_fwd_part_floats(int b, int C, int L, int n_src, int O) {
+  // an upper bound of what bmnas_head_fwd_lazy's hb_part needs: one slice per 64 k at most
+  if (b < 1 || C < 1 || L < 1 || n_src < 1 || O < 1) return BMNAS_E_ARG;
+  const long long slices = ((long long)n_src * C * L / 16 + 3) / 4;
+  const long long n = slices * (((long long)3 * b * O + 3) / 4 * 4);
+  return n < (1LL << 31) ? (int)n : BMNAS_E_LIMIT;
 }
 
 extern "C" int bmnas_head_fwd(const float* const* srcs, const float* const* sums, int n_src,
                               const float* ln_w, const float* ln_b, const float* W, const float* bias,
                               float* hb, float* stats, int b, int C, int L, int O, void* stream) {
-  return head_fwd_impl(srcs, sums, n_src, ln_w, ln_b, W, bias, hb, stats, b, C, L, O, nullptr, stream);
+  return head_fwd_impl(srcs, sums, n_src, ln_w, ln_b, W, bias, hb, stats, b, C, L, O, nullptr, nullptr, stream);
 }
 
 extern "C" int bmnas_head_fwd_lazy(const float* const* srcs, const float* const* sums, int n_src, int lazy_q,
                                    const bmnas_lazy_ln_t* lazy, const float* ln_w, const float* ln_b,
                                    const float* W, const float* bias, float* hb, float* stats, int b, int C, int L,
-                                   int O, void* stream) {
+                                   int O, float* hb_part, void* stream) {
   if (!lazy || lazy_q < 0 || lazy_q >= n_src) return BMNAS_E_ARG;
   if (!lazy->pre || !lazy->rec || !lazy->prm || !lazy->ln_w || !lazy->ln_b || !lazy->stats) return BMNAS_E_ARG;
   if (!bmnas_lazy_ln_ok(C, L)) return BMNAS_E_LIMIT;
@@ -621,14 +672,14 @@ extern "C" int bmnas_head_fwd_lazy(const float* const* srcs, const float* const*
   HeadLazy z{};
   z.rec = lazy->rec; z.prm = lazy->prm; z.nw[0] = lazy->ln_w; z.nb[0] = lazy->ln_b; z.nstats[0] = lazy->stats;
   z.lq = lazy_q; z.P = bmnas_lazy_ln_parts(C, L);
-  return head_fwd_impl(srcs, sums, n_src, ln_w, ln_b, W, bias, hb, stats, b, C, L, O, &z, stream);
+  return head_fwd_impl(srcs, sums, n_src, ln_w, ln_b, W, bias, hb, stats, b, C, L, O, &z, hb_part, stream);
 }
 
 static int head_bwd_impl(const float* const* srcs, const float* const* sums, float* const* dsrcs, int n_src,
                          uint32_t accumulate_mask, const float* ln_w, const float* ln_b, const float* W,
                          const float* hb, const float* stats, int mode, const float* g, const float* gscale,
                          const void* labels, float* loss, float* part, int b, int C, int L, int O, float* scrub,
-                         int64_t scrub_n, const HeadLazy* lazy, void* stream) {
+                         int64_t scrub_n, const HeadLazy* lazy, float* loss_part, void* stream) {
   if (!dsrcs || !ln_w || !ln_b || !W || !hb || !stats || b < 0 || C < 1 || L < 1 || O < 1)
     return BMNAS_E_ARG;                          // (part may be NULL: no classifier / K7-affine gradients wanted)
   if (mode < 0 || mode > 2 || (mode == 0 && !g) || (mode != 0 && (!labels || !loss))) return BMNAS_E_ARG;
@@ -650,7 +701,7 @@ static int head_bwd_impl(const float* const* srcs, const float* const* sums, flo
   a.g = g; a.gscale = gscale; a.mode = mode;
   a.labels_f = mode == 1 ? (const float*)labels : nullptr;
   a.labels_i = mode == 2 ? (const long long*)labels : nullptr;
-  a.loss = loss; a.part = part; a.scrub = scrub; a.scrub4 = scrub_n / 4;
+  a.loss = loss; a.loss_part = loss_part; a.part = part; a.scrub = scrub; a.scrub4 = scrub_n / 4;
   a.b = b; a.O = O; a.CL = C * L; a.D = n_src * C * L; a.n_src = n_src;
 #if defined(BMNAS_BODY_PROBES) && BMNAS_BODY_PROBES
   static const int probe = []() { const char* e = getenv("BMNAS_HEAD_PROBE"); return e ? atoi(e) : 0; }();
@@ -687,14 +738,14 @@ extern "C" int bmnas_head_bwd(const float* const* srcs, const float* const* sums
                               const float* gscale, const void* labels, float* loss, float* part,
                               int b, int C, int L, int O, float* scrub, int64_t scrub_n, void* stream) {
   return head_bwd_impl(srcs, sums, dsrcs, n_src, accumulate_mask, ln_w, ln_b, W, hb, stats, mode, g, gscale, labels,
-                       loss, part, b, C, L, O, scrub, scrub_n, nullptr, stream);
+                       loss, part, b, C, L, O, scrub, scrub_n, nullptr, nullptr, stream);
 }
 
 extern "C" int bmnas_head_bwd_lazy(const bmnas_lazy_ln_t* lazy, float* const* lnpart, float* const* dsrcs,
                                    int n_src, uint32_t accumulate_mask, const float* ln_w, const float* ln_b,
                                    const float* W, const float* hb, const float* stats, int mode, const float* g,
                                    const float* gscale, const void* labels, float* loss, float* part, int b, int C,
-                                   int L, int O, float* scrub, int64_t scrub_n, void* stream) {
+                                   int L, int O, float* scrub, int64_t scrub_n, float* loss_part, void* stream) {
   if (!lazy || !lnpart || n_src < 1) return BMNAS_E_ARG;
   if (n_src > kHeadSrc) return BMNAS_E_LIMIT;
   HeadLazy z{};
@@ -706,7 +757,7 @@ extern "C" int bmnas_head_bwd_lazy(const bmnas_lazy_ln_t* lazy, float* const* ln
   }
   z.lq = -1; z.P = 0;
   return head_bwd_impl(srcs, nullptr, dsrcs, n_src, accumulate_mask, ln_w, ln_b, W, hb, stats, mode, g, gscale,
-                       labels, loss, part, b, C, L, O, scrub, scrub_n, &z, stream);
+                       labels, loss, part, b, C, L, O, scrub, scrub_n, &z, loss_part, stream);
 }
 
 extern "C" int bmnas_sum_chunks(const float* part, float* out, int n_chunk, int64_t n, void* stream) {

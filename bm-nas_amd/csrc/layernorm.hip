@@ -433,7 +433,11 @@ int fill_prob(LnAffineProb& P, const float* g, const float* gscale, const float*
 // samples per workgroup of the LayerNorm affine reductions: 16 up to 256 samples (smaller chunks = more
 // atomics: measured slower, 6.5 vs 4.6 us at b = 128), then b / 16 — every chunk ends in one atomic per
 // element, and at b = 1024 sixteen-sample chunks meant 1.5 M atomics per pass
+// Deterministic mode (bmnas_set_deterministic): ONE chunk — every element receives a single add onto its zero-filled
+// slot, so the result does not depend on the order workgroups finish in.
+int g_ln_deterministic = 0;
 inline int ln_affine_chunk(int b) {
+  if (g_ln_deterministic) return b;
   return b <= 256 ? 16 : (b + 15) / 16;
 }
 
@@ -527,5 +531,13 @@ extern "C" int bmnas_backward_epilogue(int n_prob, const float* const* g, const 
   if (grid.x < need_x) grid.x = need_x;
   hipLaunchKernelGGL(backward_epilogue_k, grid, dim3(256), 0, (hipStream_t)stream, B, A, total, S);
   BMNAS_CHECK_LAUNCH();
+  return 0;
+}
+
+// BMNAS_DETERMINISTIC (bmnas.cell.DETERMINISTIC): run-to-run bit-identical results.  The host library keeps one
+// flag per source that has a choice to make (no relocatable device code / shared globals in this build): here the
+// LayerNorm-affine reductions take one sample chunk, in conv1x1.hip the weight-gradient tiles walk the whole batch.
+extern "C" int bmnas_ln_set_deterministic(int on) {
+  g_ln_deterministic = on ? 1 : 0;
   return 0;
 }

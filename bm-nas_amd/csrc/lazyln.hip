@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
     float* __restrict__ gbuf, float* dresid, int acc_resid, const float* __restrict__ x,
     const float* __restrict__ y, const float* __restrict__ p1, const float* __restrict__ U,
     const float* __restrict__ chan, const float* __restrict__ gamma, float* dgamma, int dg_shards, int64_t dg_stride,
-    float* dx, float* dy, uint32_t acc_mask, float* __restrict__ dV, float* bn_grad, int b, int C, int L, int chunk,
-    DropCfg dglu, DropCfg dfc) {
+    float* dx, float* dy, uint32_t acc_mask, float* __restrict__ dV, float* bn_grad, float* __restrict__ bn_part,
+    int b, int C, int L, int chunk, DropCfg dglu, DropCfg dfc) {
   __shared__ float red16[16];
   __shared__ float csum[3][6][64];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
@@ -409,10 +409,20 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
   if (sl == 0 && active && (r % l4n) == 0) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) cs[k] += csum[0][k][col] + csum[1][k][col] + csum[2][k][col];
+    if (bn_part != nullptr) {
+      // deterministic mode: this sample chunk's row of partials, plain stores (the launcher sums the rows in order)
+      float* row = bn_part + (int64_t)blockIdx.y * 2 * M;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      atomicAdd(bn_grad + k * C + c, cs[k]);
-      atomicAdd(bn_grad + M + k * C + c, cs[3 + k]);
+      for (int k = 0; k < 3; ++k) {
+        row[k * C + c] = cs[k];
+        row[M + k * C + c] = cs[3 + k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        atomicAdd(bn_grad + k * C + c, cs[k]);
+        atomicAdd(bn_grad + M + k * C + c, cs[3 + k]);
+      }
     }
   }
   STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 3);
@@ -559,7 +569,8 @@ extern "C" int bmnas_node_mix_lnp_bwd(const float* g, const float* pre, const fl
                                       const float* p1, const float* U, const float* chan, const float* gamma,
                                       float* dgamma, int dgamma_shards, int64_t dgamma_shard_stride, float* dx,
                                       float* dy, uint32_t accumulate_mask, float* dV, float* bn_grad, int b, int C,
-                                      int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, void* stream) {
+                                      int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc, float* bn_part,
+                                      void* stream) {
   if (!g || !pre || !ln_w || !stats || !x || !y || !p1 || !U || !chan || !gamma || !dV || !bn_grad || b < 0 ||
       C < 1 || dgamma_shards < 1 || n0 < 0 || n1 < 0 || (n0 > 0 && !lnp0) || (n1 > 0 && !lnp1) || n0 + n1 < 1)
     return BMNAS_E_ARG;
@@ -573,8 +584,18 @@ extern "C" int bmnas_node_mix_lnp_bwd(const float* g, const float* pre, const fl
   dim3 grid((cl4 + 63) / 64, (b + chunk - 1) / chunk);
   hipLaunchKernelGGL(node_mix_lnp_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, g, pre, ln_w, stats, lnp0, n0,
                      lnp1, n1, g_in, dresid, accumulate_resid, x, y, p1, U, chan, gamma, dgamma, dgamma_shards,
-                     dgamma_shard_stride, dx, dy, accumulate_mask, dV, bn_grad, b, C, L, chunk, to_cfg(drop_glu),
-                     to_cfg(drop_fc));
+                     dgamma_shard_stride, dx, dy, accumulate_mask, dV, bn_grad, bn_part, b, C, L, chunk,
+                     to_cfg(drop_glu), to_cfg(drop_fc));
   BMNAS_CHECK_LAUNCH();
+  if (bn_part != nullptr)      // rows in order -> bn_grad (6 C floats per row; C % 16 == 0)
+    return bmnas_sum_chunks(bn_part, bn_grad, (int)grid.y, (int64_t)6 * C, stream);
   return 0;
+}
+
+// rows of bn_part that bmnas_node_mix_lnp_bwd(bn_part != NULL) writes (each 6 C floats)
+extern "C" int bmnas_node_mix_lnp_bwd_rows(int b) {
+  if (b < 1) return BMNAS_E_ARG;
+  int chunk = 4;
+  while ((b + chunk - 1) / chunk > 64) chunk += 4;
+  return (b + chunk - 1) / chunk;
 }

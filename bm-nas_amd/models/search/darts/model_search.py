@@ -55,10 +55,13 @@ class FusionCell(nn.Module):
             ps += n.node_cell.param_list()
         return ps + [self.ln.weight, self.ln.bias]
 
-    def grad_pack(self, device, alpha_w, beta_ws, gamma_ws):
+    def grad_pack(self, device, alpha_w, beta_ws, gamma_ws, shards=None):
         """One zero-filled arena holding every atomically accumulated gradient of the cell
-        plus the gradients w.r.t. the softmaxed arch weights."""
+        plus the gradients w.r.t. the softmaxed arch weights.  shards: copies of the arch section
+        (bmnas.cell.arch_shards; default ARCH_SHARDS)."""
         from bmnas.cell import ARCH_SHARDS
+        if shards is not None:
+            ARCH_SHARDS = int(shards)
         arena = Arena()
         hn = [n.node_cell.plan_grads(arena) for n in self._step_nodes]
         hl = (arena.ask(self.C * self._multiplier, self.L), arena.ask(self.C * self._multiplier, self.L))

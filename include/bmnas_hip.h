@@ -664,19 +664,40 @@ int bmnas_mixsum_pair_bwd_x(const float* const* xs, float* const* dxs, int n_in,
                             int n_more, int64_t n_elem, void* stream);
 int bmnas_head_fwd_lazy(const float* const* srcs, const float* const* sums, int n_src, int lazy_q,
                         const bmnas_lazy_ln_t* lazy, const float* ln_w, const float* ln_b, const float* W,
-                        const float* bias, float* hb, float* stats, int b, int C, int L, int O, void* stream);
+                        const float* bias, float* hb, float* stats, int b, int C, int L, int O, float* hb_part,
+                        void* stream);
 int bmnas_head_bwd_lazy(const bmnas_lazy_ln_t* lazy, float* const* lnpart, float* const* dsrcs, int n_src,
                         uint32_t accumulate_mask, const float* ln_w, const float* ln_b, const float* W,
                         const float* hb, const float* stats, int mode, const float* g, const float* gscale,
                         const void* labels, float* loss, float* part, int b, int C, int L, int O, float* scrub,
-                        int64_t scrub_n, void* stream);
+                        int64_t scrub_n, float* loss_part, void* stream);
 int bmnas_node_mix_lnp_bwd(const float* g, const float* pre, const float* ln_w, const float* stats,
                            const float* lnp0, int n0, const float* lnp1, int n1, float* g_in, float* dresid,
                            int accumulate_resid, const float* x, const float* y, const float* p1, const float* U,
                            const float* chan, const float* gamma, float* dgamma, int dgamma_shards,
                            int64_t dgamma_shard_stride, float* dx, float* dy, uint32_t accumulate_mask, float* dV,
                            float* bn_grad, int b, int C, int L, bmnas_dropout_t drop_glu, bmnas_dropout_t drop_fc,
-                           void* stream);
+                           float* bn_part, void* stream);
+/* ---- deterministic mode (BMNAS_DETERMINISTIC=1; bmnas.cell.DETERMINISTIC) --------------------------------------
+ * Run-to-run bit-identical results for the search step with node_multiplier == 1 under the fused head.  The reference's
+ * CPU path is deterministic; the default HIP path accumulates batch reductions with fp32 atomics, whose order varies.
+ * In this mode every such reduction is a set of partials written with plain stores and summed in a fixed order:
+ *   BatchNorm batch statistics     per-n-group partials + bmnas_bn_finalize (stat == NULL form of bmnas_conv1x1_fwd*)
+ *   head logits | A | B            hb_part of bmnas_head_fwd_lazy: [slices][round_up(3 b O, 4)] floats
+ *                                  (bmnas_head_fwd_part_floats bounds it); the launcher sums the slices into hb
+ *   criterion                      loss_part of bmnas_head_bwd_lazy: [bmnas_head_chunks(b)] partial losses, summed by
+ *                                  the caller in order
+ *   BatchNorm affine gradients     bn_part of bmnas_node_mix_lnp_bwd: [bmnas_node_mix_lnp_bwd_rows(b)][6 C]; the
+ *                                  launcher sums the rows into bn_grad
+ *   dalpha / dbeta / dgamma        the caller passes as many shard copies as the launches have workgroups: one add
+ *                                  per address, summed in shard order by the epilogue
+ *   weight gradients, LayerNorm    bmnas_conv1x1_set_deterministic / bmnas_ln_set_deterministic: the weight-gradient
+ *   affine gradients               tiles walk the whole batch (no batch splits), the affine reductions take one chunk
+ * hb_part / loss_part / bn_part NULL: the default atomic forms. */
+int bmnas_head_fwd_part_floats(int b, int C, int L, int n_src, int O);   /* < 0: BMNAS_E_* (BMNAS_E_LIMIT above 2^31) */
+int bmnas_node_mix_lnp_bwd_rows(int b);
+int bmnas_conv1x1_set_deterministic(int on);
+int bmnas_ln_set_deterministic(int on);
 
 /* Diagnostics (timing builds with -DBMNAS_BODY_PROBES=1 only; BMNAS_E_LIMIT otherwise): thread 0 of every workgroup
  * of the instrumented kernels records the shader clock at up to six points and the 100 MHz wall clock at entry / exit
