@@ -157,7 +157,7 @@ def algo_table(C, L):
                                    *_:
             ('hbm', 2 * T(U) + (4 + (g_in is not None) + (dres is not None) + bool(racc) + (dx is not None)
                                 + bin(m).count('1')) * T(x) + T(w)),
-        'head_fwd_lazy': lambda srcs, sums, lq, lz, lw, lb, W, bias, hb, st, b, Cc, L_, O:
+        'head_fwd_lazy': lambda srcs, sums, lq, lz, lw, lb, W, bias, hb, st, b, Cc, L_, O, *_:
             ('mfma', 2.0 * b * O * len(srcs) * Cc * L_),
         'head_bwd_lazy': lambda lzs, lnp, ds, m, lw, lb, W, hb, st, mode, g, gs, lab, loss, part, b, Cc, L_, O, *_:
             ('mfma', 4.0 * b * O * len(lzs) * Cc * L_),
