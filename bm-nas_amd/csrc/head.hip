@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int ks = blockIdx.x, st = blockIdx.y;
+  STAMP(4, blockIdx.y * gridDim.x + blockIdx.x, 0);
   const int s = st * 16 + lo;
   const int sc = s < a.b ? s : a.b - 1;                       // clamped rows are never stored
   const int nkb = a.D / 16;
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
       z.nstats[0][2 * s + 1] = nrstd;
     }
   }
+  STAMP(4, blockIdx.y * gridDim.x + blockIdx.x, 1);
   __builtin_amdgcn_sched_barrier(0);
   f32x4 acc[3][TJ];
 #pragma unroll
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
     for (int t = 0; t < TJ; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][v][4 * h + r][16 * t + lo] = acc[v][t][r];
+  STAMP(4, blockIdx.y * gridDim.x + blockIdx.x, 2);
   __syncthreads();
   const int rows = (a.b - st * 16) < 16 ? (a.b - st * 16) : 16;
   const int per_v = rows * a.O;
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadFwdArgs a, HeadLazy z) {
     if (a.hb_part != nullptr) a.hb_part[(int64_t)ks * a.hb_stride + ((int64_t)v * a.b + st * 16) * a.O + e] = val;
     else atomicAdd(a.hb + ((int64_t)v * a.b + st * 16) * a.O + e, val);
   }
+  STAMP(4, blockIdx.y * gridDim.x + blockIdx.x, 3);
 }
 
 // ----------------------------------------------------------------------------- backward
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 15, h = lane >> 4;
   const int chunk = blockIdx.y, s0 = chunk * kRows;
+  STAMP(5, blockIdx.y * gridDim.x + blockIdx.x, 0);
   for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < a.scrub4;
        i += (long long)gridDim.x * gridDim.y * 256)
     st4(a.scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
     for (int rr = 0; rr < kRows; ++rr) t += dl_s[rr][threadIdx.x];
     a.part[((int64_t)chunk * (a.O + 3) + a.O + 2) * a.D + threadIdx.x] = t;
   }
+  STAMP(5, blockIdx.y * gridDim.x + blockIdx.x, 1);
   if (!vt || (a.probe & 8)) return;
   // ---- the tile
   float* const part = a.part + (int64_t)chunk * (a.O + 3) * a.D;
@@ -505,6 +511,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
       fr[g][r] = (s0 + rl2 < a.b) ? fmaxf(pre, 0.f) : 0.f;
     }
   }
+  STAMP(5, blockIdx.y * gridDim.x + blockIdx.x, 2);
   if (LZ) {                                                     // (every wave is here: CL % 64 == 0 -> vt)
     __syncthreads();
     float* lp = pick_ptr(z.lnpart, q);
@@ -525,6 +532,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
   }
   // (part == NULL: nobody wants the classifier / K7-affine gradients — the architecture step of the search loop
   // differentiates alpha / beta / gamma only — so the affine partials and GEMM 2 are skipped)
+  STAMP(5, blockIdx.y * gridDim.x + blockIdx.x, 3);
   if (a.part == nullptr) return;
   if (lo == 0) {
     st4(part + (int64_t)a.O * a.D + k0 + 4 * h, make_float4(gw[0], gw[1], gw[2], gw[3]));
@@ -550,6 +558,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
       }
     }
   }
+  STAMP(5, blockIdx.y * gridDim.x + blockIdx.x, 4);
 }
 
 // Sum of per-chunk partials: out[e] = sum_c part[c][e]  (float4 stream).  Runs as a slice of the
@@ -580,6 +589,9 @@ __global__ __launch_bounds__(256) void sum_chunks_strided_k(const float* __restr
 }
 
 }  // namespace
+
+// tools/stamp_probe.py (timing builds): slot 4 head_fwd_k, 5 head_bwd_k
+BMNAS_DEFINE_STAMP_SETTER(bmnas_debug_stamps_head)
 
 // samples per partial-sum chunk of the backward: 32 (two MFMA sample groups per workgroup: the W
 // operand and the partial stores are shared) once the batch fills the chip that way, else 16

@@ -702,7 +702,8 @@ int bmnas_ln_set_deterministic(int on);
 /* Diagnostics (timing builds with -DBMNAS_BODY_PROBES=1 only; BMNAS_E_LIMIT otherwise): thread 0 of every workgroup
  * of the instrumented kernels records the shader clock at up to six points and the 100 MHz wall clock at entry / exit
  * into buf[kernel slot][workgroup][8] (uint64; slots workgroups per kernel, 8 kernel slots).  tools/stamp_probe.py. */
-int bmnas_debug_stamps(void* buf, int slots);
+int bmnas_debug_stamps(void* buf, int slots);        /* csrc/lazyln.hip: slots 0-3 */
+int bmnas_debug_stamps_head(void* buf, int slots);   /* csrc/head.hip: slots 4-5 */
 
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at

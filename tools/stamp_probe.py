@@ -29,7 +29,10 @@ NAMES = {0: ('node_mix_pre_fwd_k', ['entry -> loads issued', 'BatchNorm finalise
          1: ('mixsum_pair_fwd_lazy_k', ['whole body']),
          2: ('mixsum_pair_bwd_lazy_k', ['loads + wait', 'dots + dx stores', 'block reduction + atomics / partial stores']),
          3: ('node_mix_lnp_bwd_k', ['partials + operand loads + wave sums', 'LayerNorm + mix backward + stores',
-                                    'BatchNorm sums: LDS + atomics', 'dgamma: block sum + atomics'])}
+                                    'BatchNorm sums: LDS + atomics', 'dgamma: block sum + atomics']),
+         4: ('head_fwd_k', ['loads issued + statistics', 'MFMAs + tiles to LDS', 'barrier + workgroup sum + atomics']),
+         5: ('head_bwd_k', ['scrub + loads + criterion prologue + barrier', 'GEMM 1 + LayerNorm backward + state gradients',
+                            'LayerNorm partials: barrier + stores', 'affine partials + GEMM 2 + dW partial stores'])}
 
 cfg = fo.CONFIGS['mmimdb']
 net = build_search_net(cfg, 2, 'train')
@@ -37,7 +40,8 @@ cls = bnn.Linear(cfg.M * cfg.C * cfg.L, 23).to(dev())
 xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, B, 0)]
 y = synth.make_labels('bce', B, 23, 0).to(dev())
 buf = torch.zeros(8 * SLOTS * 8, dtype=torch.int64, device=dev())
-rc = lib.load().bmnas_debug_stamps(C.c_void_p(buf.data_ptr()), SLOTS)
+rc = lib.load().bmnas_debug_stamps(C.c_void_p(buf.data_ptr()), SLOTS) or \
+    lib.load().bmnas_debug_stamps_head(C.c_void_p(buf.data_ptr()), SLOTS)
 if rc != 0:
     raise SystemExit('this library has no stamps: build with BMNAS_HIPCC_EXTRA=-DBMNAS_BODY_PROBES=1 (rc %d)' % rc)
 
