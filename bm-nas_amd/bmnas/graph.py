@@ -111,13 +111,19 @@ class GraphedTrainStep:
         engine then makes that stream wait on the capture stream, the capture never joins, and
         HIP's capture_end segfaults instead of reporting it."""
         import gc
+        import warnings
         n = 0
-        for o in gc.get_objects():
-            try:
-                if isinstance(o, torch.Tensor) and o.grad_fn is not None and o.device == device:
-                    n += 1
-            except Exception:                    # noqa: BLE001 — objects in odd states during gc walk
-                pass
+        with warnings.catch_warnings():
+            # (the walk touches every live object, among them torch.distributed's deprecated `reduce_op` shim, whose
+            # attribute access warns: one FutureWarning per capture in every log otherwise)
+            warnings.simplefilter('ignore')
+            for o in gc.get_objects():
+                try:
+                    if type(o) is torch.Tensor or type(o) is torch.nn.Parameter or isinstance(o, torch.Tensor):
+                        if o.grad_fn is not None and o.device == device:
+                            n += 1
+                except Exception:                # noqa: BLE001 — objects in odd states during gc walk
+                    pass
         return n
 
     def __init__(self, model, criterion, optimizer, inputs, labels, warmup=2):

@@ -200,6 +200,7 @@ SIGNATURES = {
     'bmnas_head_fwd': ([_PP, _PP, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_debug_stamps': ([_P, _I], _I),
     'bmnas_debug_stamps_head': ([_P, _I], _I),
+    'bmnas_debug_stamps_conv': ([_P, _I], _I),
     'bmnas_lazy_ln_ok': ([_I, _I], _I),
     'bmnas_lazy_ln_parts': ([_I, _I], _I),
     'bmnas_node_mix_pre_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout,

@@ -678,6 +678,9 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
   };
   auto fetch = [&](Regs& R, int c) __attribute__((always_inline)) {
     c = c < nchunk ? c : nchunk - 1;                           // past the end: a harmless repeat, no branch
+#ifdef BMNAS_PROBE_DGRAD_NOLAT
+    c = 0;      // timing experiment (wrong results): every chunk re-reads chunk 0 — the loads hit the CU's L1
+#endif
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       R.ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
@@ -715,9 +718,15 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
   // all LDS operand reads of a chunk first, then its MFMAs back to back: with one wave per SIMD nothing
   // else hides the LDS latency, so it is paid once per chunk instead of per k-block (the fences keep hipcc
   // from re-interleaving them and from hoisting the barrier above the MFMAs)
+#if BMNAS_BODY_PROBES
+  unsigned long long pr_reads = 0, pr_mfma = 0, pr_rest = 0, pr_last = stamp_clock(), pr_t0 = pr_last;
+#endif
   auto compute = [&](const float* cur) __attribute__((always_inline)) {
     constexpr int NKB = KC / 16;
     float av[NKB][4], bv[NKB][WJ][4];
+#if BMNAS_BODY_PROBES
+    { const unsigned long long t = stamp_clock(); pr_rest += t - pr_last; pr_last = t; }
+#endif
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       const int c0 = 16 * kb + 4 * h;
@@ -729,6 +738,10 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
         for (int r = 0; r < 4; ++r) bv[kb][tj][r] = cur[boff[tj] + (16 * kb + r) * JP];
     }
     __builtin_amdgcn_sched_barrier(0);
+#if BMNAS_BODY_PROBES
+    { const unsigned long long t = stamp_clock(); pr_reads += t - pr_last; pr_last = t; }   // (drains the LDS reads)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -737,6 +750,10 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
         for (int r = 0; r < 4; ++r)
           acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][r], bv[kb][tj][r], acc[tj], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+#if BMNAS_BODY_PROBES
+    { const unsigned long long t = stamp_clock(); pr_mfma += t - pr_last; pr_last = t; }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   };
   Regs R;
   fetch(R, 0);
@@ -806,6 +823,15 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
       }
     }
   }
+#if BMNAS_BODY_PROBES
+  if (threadIdx.x == 0 && g_bmnas_stamps != nullptr) {         // slot 6: [wg][reads, mfma, rest, total] summed over chunks
+    const int wg = by * 4096 / 64 + bx;                        // (by < 64 tiles of 64 j, bx < 64 n-tiles at b <= 128)
+    if (wg < g_bmnas_stamp_slots) {
+      unsigned long long* p = g_bmnas_stamps + ((size_t)6 * g_bmnas_stamp_slots + wg) * 8;
+      p[0] = pr_reads; p[1] = pr_mfma; p[2] = pr_rest; p[3] = stamp_clock() - pr_t0; p[6] = 1; p[7] = (unsigned long long)nchunk;
+    }
+  }
+#endif
   const int l0 = (4 * h) & (a.L - 1);
   const int g = bx * NG + gl;
 #pragma unroll
@@ -2284,3 +2310,6 @@ extern "C" int bmnas_conv1x1_set_deterministic(int on) {
   g_conv_deterministic = on ? 1 : 0;
   return 0;
 }
+
+// tools/stamp_probe.py (timing builds): slot 6 = the data-gradient tiles of the pipelined backward GEMM
+BMNAS_DEFINE_STAMP_SETTER(bmnas_debug_stamps_conv)

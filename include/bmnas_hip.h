@@ -704,6 +704,7 @@ int bmnas_ln_set_deterministic(int on);
  * into buf[kernel slot][workgroup][8] (uint64; slots workgroups per kernel, 8 kernel slots).  tools/stamp_probe.py. */
 int bmnas_debug_stamps(void* buf, int slots);        /* csrc/lazyln.hip: slots 0-3 */
 int bmnas_debug_stamps_head(void* buf, int slots);   /* csrc/head.hip: slots 4-5 */
+int bmnas_debug_stamps_conv(void* buf, int slots);   /* csrc/conv1x1.hip: slot 6 (per-chunk phases of the data-gradient tiles) */
 
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at

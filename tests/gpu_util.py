@@ -226,7 +226,7 @@ def match_step(got, specs, evaluate, label='', near=2e-5, max_ambiguous=96):
 
 
 def compare_search_step(cfg, batch, nout, loss_kind, net, cls, input_grads, logits, loss, masks=None, seed=31,
-                        label='', attn_drop=None):
+                        label='', attn_drop=None, max_ambiguous=96):
     """Every tensor of one search step (logits, loss, every weight / arch / input gradient) against the oracle,
     through match_step; BatchNorm running statistics against the fp32 oracle.  masks: the dropout multipliers of
     the step's live sites in issue order (None: dropout is an identity, attn_drop must then be 0)."""
@@ -265,7 +265,7 @@ def compare_search_step(cfg, batch, nout, loss_kind, net, cls, input_grads, logi
         got['grad:central_classifier.' + k] = getattr(cls, k).grad
     for k in got:
         specs.setdefault(k, (2e-4, False))
-    how = match_step(got, specs, evaluate, label)
+    how = match_step(got, specs, evaluate, label, max_ambiguous=max_ambiguous)
     p32 = evaluate(False, (), 0.0)[0]['_params']
     for k, v in net.state_dict().items():
         if fo.is_buffer(k):

@@ -41,7 +41,8 @@ xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, B, 0)]
 y = synth.make_labels('bce', B, 23, 0).to(dev())
 buf = torch.zeros(8 * SLOTS * 8, dtype=torch.int64, device=dev())
 rc = lib.load().bmnas_debug_stamps(C.c_void_p(buf.data_ptr()), SLOTS) or \
-    lib.load().bmnas_debug_stamps_head(C.c_void_p(buf.data_ptr()), SLOTS)
+    lib.load().bmnas_debug_stamps_head(C.c_void_p(buf.data_ptr()), SLOTS) or \
+    lib.load().bmnas_debug_stamps_conv(C.c_void_p(buf.data_ptr()), SLOTS)
 if rc != 0:
     raise SystemExit('this library has no stamps: build with BMNAS_HIPCC_EXTRA=-DBMNAS_BODY_PROBES=1 (rc %d)' % rc)
 
@@ -88,3 +89,12 @@ for slot, (name, segs) in NAMES.items():
     for i, sname in enumerate(segs):
         c = d[:, i + 1].astype(np.int64) - d[:, i].astype(np.int64)
         print(f'   {sname:45s} median {np.median(c):8.0f} cyc ({np.median(c) / (ghz * 1e3):5.2f} us)   90% {np.percentile(c, 90):8.0f}')
+# slot 6: the data-gradient tiles of the merged backward GEMM launch — cycles summed over a tile's chunks
+d = data[6]
+d = d[d[:, 6] != 0]
+if len(d):
+    tot = d[:, 3].astype(np.float64)
+    print(f'conv_bwd_all_pipe_k data-gradient tiles: {len(d)} workgroups x {int(d[0, 7])} chunks; per tile (median cycles): '
+          f'LDS operand reads {np.median(d[:, 0]):.0f} ({np.median(d[:, 0] / tot):.0%}), MFMA issue {np.median(d[:, 1]):.0f} '
+          f'({np.median(d[:, 1] / tot):.0%}), fetch + stash + barrier + rest {np.median(d[:, 2]):.0f} '
+          f'({np.median(d[:, 2] / tot):.0%}), whole chunk loop {np.median(tot):.0f} cycles')
