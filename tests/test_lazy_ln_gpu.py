@@ -69,7 +69,7 @@ CASES = [
 
 
 @pytest.mark.parametrize('case', CASES, ids=[f'N{c[0]}C{c[1]}L{c[2]}S{c[3]}M{c[4]}ns{c[5]}b{c[6]}' for c in CASES])
-@pytest.mark.parametrize('mode', ['train_nodrop', 'train'])
+@pytest.mark.parametrize('mode', ['train_nodrop', 'train', 'eval'])
 def test_lazy_layernorm_equals_the_per_sample_kernels(case, mode):
     N, C, L, S, M, ns, batch, nout, kind = case
     cfg = fo.make_cfg(N=N, C=C, L=L, S=S, M=M, ns=ns, nm=1, drpt=0.2 if mode == 'train' else 0.0)
