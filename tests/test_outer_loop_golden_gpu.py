@@ -7,7 +7,8 @@ drives it) on the deterministic in-memory data of tests/helpers/loop_stubs.py (t
 Here this repo's loop (models/search/train_searchable/_loop.py) runs on the same data, eager and with hipGraph
 steps, and must reproduce: every batch's loss and logits, the learning rate every weight step ran with (the
 per-batch cosine schedule), every phase's epoch loss / F1, the genotype after every phase, the best F1 / genotype /
-checkpoint, the final architecture parameters and weights, and the tester's score."""
+checkpoint, the final architecture parameters and weights, and the tester's score.  Further down: the same for the
+accuracy-tracking trainers of NTU RGB+D (search, found stage, tester) and EgoGesture (search)."""
 import json
 import logging
 import os
@@ -47,19 +48,26 @@ def _args(save, found=False, hip_graph=False):
     return a
 
 
-def _loaders(gold):
-    return {k: DataLoader(stubs.MMIMDBData(n, gold['seed_data'] + i), batch_size=8, shuffle=False, drop_last=False)
+def _loaders(gold, data_cls=stubs.MMIMDBData):
+    return {k: DataLoader(data_cls(n, gold['seed_data'] + i), batch_size=8, shuffle=False, drop_last=False)
             for i, (k, n) in enumerate(gold['sizes'].items())}
 
 
-def _install(monkeypatch):
+CENTRAL = {'mmimdb': dict(GP_VGG=stubs.StubVGG, MaxOut_MLP=stubs.StubMLP),
+           'ntu': dict(Visual=stubs.StubVisual, Skeleton=stubs.StubSkeleton),
+           'ego': dict(get_rgb_model=stubs.ego_rgb_model, get_depth_model=stubs.ego_depth_model)}
+
+
+def _install(monkeypatch, task='mmimdb'):
     central = types.ModuleType('models.central')
-    fake = types.ModuleType('models.central.mmimdb')
-    fake.GP_VGG, fake.MaxOut_MLP = stubs.StubVGG, stubs.StubMLP
-    central.mmimdb = fake
+    fake = types.ModuleType('models.central.' + task)
+    for k, v in CENTRAL[task].items():
+        setattr(fake, k, v)
+    setattr(central, task, fake)
     monkeypatch.setitem(sys.modules, 'models.central', central)
-    monkeypatch.setitem(sys.modules, 'models.central.mmimdb', fake)
-    import models.search.mmimdb_darts_searchable as drv
+    monkeypatch.setitem(sys.modules, 'models.central.' + task, fake)
+    import importlib
+    drv = importlib.import_module('models.search.%s_darts_searchable' % task)
     import models.search.train_searchable._loop as loop
     rec = stubs.Recorder()
 
@@ -118,10 +126,10 @@ def _compare_state(model, want, rel, label):
             (label, k, g[2:], w[2:])
 
 
-def _gold(name):
+def _gold(name, seed_data=21):
     with open(os.path.join(GOLD, name)) as f:
         g = json.load(f)
-    g['seed_data'] = 21                      # make_golden_r04.SEED: loaders are seeded SEED + i
+    g['seed_data'] = seed_data               # make_golden_r04.SEED (21) / _ntu_ego.SEED (33): loaders are seeded SEED + i
     return g
 
 
@@ -209,3 +217,134 @@ def test_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, monke
     got = tr.test_mmimdb_track_f1(model2, criterion, lds, sizes, device, False, logger, a, a.f1_type, init_f1=0.0,
                                   th_fscore=0.3)
     assert abs(got - gold['tester_f1']) <= 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The accuracy-tracking trainers: NTU RGB+D (search, found stage + tester) and EgoGesture (search), against
+# tests/golden/loop_{ntu_search,ntu_found,ego_search}.json (tests/golden/make_golden_r04_ntu_ego.py ran the reference's
+# ntu_darts_searchable.py:21-72 / train_searchable/ntu.py:12-227 / ego_darts_searchable.py:20-69 /
+# train_searchable/ego.py:13-223 on the same stand-in data).
+
+def _acc_args(tmp_path, ns, nm, nout, hip_graph):
+    a = _args(str(tmp_path / 'exp'), hip_graph=hip_graph)
+    a.C, a.L, a.drpt = 32, 8, 0.2
+    a.num_input_nodes = 8
+    a.node_steps, a.node_multiplier, a.num_outputs = ns, nm, nout
+    a.parallel = False
+    a.checkpointdir = str(tmp_path)
+    a.ske_cp, a.rgb_cp, a.depth_cp = 'ske.pt', 'rgb.pt', 'depth.pt'
+    for name in (a.ske_cp, a.rgb_cp, a.depth_cp):
+        torch.save({}, os.path.join(a.checkpointdir, name))
+    return a
+
+
+def _check_search(gold, a, rec, loop, made, best_acc, genotype, label, hip_graph, arch_rel=2e-4):
+    if hip_graph:
+        assert loop.run.stats['graph_replays'] == 4 and loop.run.stats['forward_replays'] >= 2, loop.run.stats
+    else:
+        assert loop.run.stats['graph_replays'] == 0, loop.run.stats
+    _compare_batches(rec.batches, gold['batches'], 2e-4, label)
+    _compare_phases(rec, gold, label)
+    assert abs(float(best_acc) - gold['best_acc']) <= 1e-9
+    assert str(genotype) == gold['best_genotype']
+    with open(os.path.join(a.save, 'best', 'best_genotype.pkl'), 'rb') as f:
+        assert str(pickle.load(f)) == gold['best_genotype']
+    model = made[0]
+    for p, w in zip(model.arch_parameters(), gold['arch']):
+        want = np.asarray(w, dtype=np.float64)
+        assert np.abs(p.detach().cpu().double().numpy() - want).max() <= arch_rel * np.abs(want).max(), label
+    _compare_state(model, gold['final'], 5e-4, label + ' final')
+    ckpt = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
+    for k, w in gold['best_ckpt'].items():
+        g = stubs.summary(ckpt[k])
+        assert abs(g[1] - w[1]) <= 5e-4 * max(abs(w[1]), 1e-12) + 1e-7, (label, 'best checkpoint', k, g[1], w[1])
+
+
+def _pin(monkeypatch, drv, cls_name, seed):
+    made = []
+    base = getattr(drv, cls_name)
+
+    class Pinned(base):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            stubs.fill_state(self, seed)
+            made.append(self)
+
+    monkeypatch.setattr(drv, cls_name, Pinned)
+    return made
+
+
+@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+def test_ntu_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip_graph):
+    gold = _gold('loop_ntu_search.json', 33)
+    drv, loop, rec = _install(monkeypatch, 'ntu')
+    from models.search.darts.utils import create_exp_dir
+    made = _pin(monkeypatch, drv, 'Searchable_Skeleton_Image_Net', gold['seed'])
+    a = _acc_args(tmp_path, 2, 2, stubs.NTU_CLASSES, hip_graph)
+    create_exp_dir(a.save)
+    best_acc, genotype = drv.train_darts_model(_loaders(gold, stubs.NTUData), a, torch.device('cuda:0'),
+                                               logging.getLogger('bmnas-test'))
+    _check_search(gold, a, rec, loop, made, best_acc, genotype, 'ntu search/' + ('graph' if hip_graph else 'eager'),
+                  hip_graph)
+
+
+@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+def test_ego_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip_graph):
+    gold = _gold('loop_ego_search.json', 43)
+    drv, loop, rec = _install(monkeypatch, 'ego')
+    from models.search.darts.utils import create_exp_dir
+    made = _pin(monkeypatch, drv, 'Searchable_RGB_Depth_Net', gold['seed'])
+    a = _acc_args(tmp_path, 3, 3, stubs.EGO_CLASSES, hip_graph)
+    create_exp_dir(a.save)
+    best_acc, genotype = drv.train_darts_model(_loaders(gold, stubs.EgoData), a, None, torch.device('cuda:0'),
+                                               logging.getLogger('bmnas-test'))
+    _check_search(gold, a, rec, loop, made, best_acc, genotype, 'ego search/' + ('graph' if hip_graph else 'eager'),
+                  hip_graph)
+
+
+@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+def test_ntu_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, monkeypatch, hip_graph):
+    gold = _gold('loop_ntu_found.json', 33)
+    drv, loop, rec = _install(monkeypatch, 'ntu')
+    import models.auxiliary.scheduler as sc
+    import models.search.train_searchable.ntu as tr
+    from bmnas import nn as bnn
+    from bmnas.optim import Adam
+    from models.search.darts.genotypes import Genotype, StepGenotype
+    from models.search.darts.utils import create_exp_dir
+    from models.search.plot_genotype import Plotter
+    genotype = Genotype(
+        edges=[('skip', 2), ('skip', 7), ('skip', 4), ('skip', 8)],
+        steps=[StepGenotype(inner_edges=[('skip', 0), ('skip', 1), ('skip', 2), ('skip', 1)],
+                            inner_steps=['LinearGLU', 'ScaleDotAttn'], inner_concat=[2, 3]),
+               StepGenotype(inner_edges=[('skip', 1), ('skip', 0), ('skip', 2), ('skip', 0)],
+                            inner_steps=['Sum', 'ConcatFC'], inner_concat=[2, 3])],
+        concat=[8, 9])
+    a = _acc_args(tmp_path, 2, 2, stubs.NTU_CLASSES, hip_graph)
+    create_exp_dir(a.save)
+    device = torch.device('cuda:0')
+    criterion = bnn.CrossEntropyLoss()
+    model = stubs.fill_state(drv.Found_Skeleton_Image_Net(a, criterion, genotype), gold['seed'])
+    lds = _loaders(gold, stubs.NTUData)
+    sizes = {k: len(v.dataset) for k, v in lds.items()}
+    model.to(device)
+    optimizer = Adam(model.parameters(), lr=a.eta_max, weight_decay=1e-4)
+    scheduler = sc.LRCosineAnnealingScheduler(a.eta_max, a.eta_min, a.Ti, a.Tm, sizes['train'] / a.batchsize)
+    logger = logging.getLogger('bmnas-test')
+    test_acc, test_genotype = tr.train_ntu_track_acc(model, None, criterion, optimizer, scheduler, lds, sizes,
+                                                     device=device, num_epochs=a.epochs, parallel=False, logger=logger,
+                                                     plotter=Plotter(a), args=a, status='eval')
+    label = 'ntu found/' + ('graph' if hip_graph else 'eager')
+    _compare_batches(rec.batches, gold['batches'], 2e-4, label)
+    _compare_phases(rec, gold, label)
+    assert abs(float(test_acc) - gold['test_acc']) <= 1e-9 and str(test_genotype) == gold['test_genotype']
+    _compare_state(model, gold['final'], 5e-4, label + ' final')
+    model2 = drv.Found_Skeleton_Image_Net(a, criterion, genotype)
+    model2.load_state_dict(torch.load(os.path.join(a.save, 'best', 'best_test_model.pt')))
+    model2.to(device)
+    rec.batches.clear()
+    got = tr.test_ntu_track_acc(model2, lds, criterion, genotype, sizes, device, logger, a)
+    assert abs(float(got) - gold['tester_acc']) <= 1e-9
+    assert len(rec.batches) in (0, len(gold['tester_batches']))
+    for g, w in zip(rec.batches, gold['tester_batches']):
+        assert abs(g[3] - w[3]) <= 2e-4 * max(1.0, abs(w[3])) and abs(g[5] - w[5]) <= 2e-4 * w[5], (label, g, w)
