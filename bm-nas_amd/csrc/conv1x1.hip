@@ -44,6 +44,7 @@ struct ConvArgs {
   int fold;              // > 0: effective weight = W[.] + W[. + fold] along its column index
                          // (conv applied to cat[z, z], search mode: no separate folded copy)
   int probe;             // diagnostics only (BMNAS_CONV_PROBE): 1 = no MFMA, 2 = no loads
+  int order;             // conv_bwd_all_pipe_k: block order of its three classes (see the kernel)
 };
 
 // BatchNorm batch statistics of the tile column group g (<= 16 valid columns) for output channel jj,
@@ -911,6 +912,7 @@ __global__ __launch_bounds__(256) void conv_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s
 template <int KC, int KCH, int NG>
 __global__ __launch_bounds__(256) void conv_pipe_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s, int gx) {
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
+  // (attention groups first: the other order measured 11.8 -> 12.1 us at MM-IMDB b128)
   if ((int)blockIdx.x < s.groups) {
     sdpa_fwd_body<KCH>(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop, merged_smem);
   } else {
@@ -1388,7 +1390,26 @@ template <int KC, int KCH, int NG>
 __global__ __launch_bounds__(256, BMNAS_MERGED_OCC) void conv_bwd_all_pipe_k(ConvArgs a, SdpaBwdArgs s, ConvWArgs w, int gx,
                                                            int n_w, int wx, int wy) {
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
-  const int blk = blockIdx.x;
+  // Block order.  The grid (~750 workgroups at MM-IMDB b128: 128 attention groups, 432 weight-gradient tiles, 192
+  // data-gradient tiles) is resident all at once, three workgroups per CU, so the order decides only WHERE a block
+  // lands — and a data-gradient tile's 12 chunk steps are the longest chain of the launch (~18 us of its ~19).  With
+  // those tiles at the front of the grid the dispatcher gives each its own CU; at the back (rounds 2-3) they filled the
+  // last free slots, several to a CU: 20.95 -> 19.05 us (profiles/r04_bwd_block_order.txt; BMNAS_BWD_ORDER = 0 ... 5
+  // selects A W D / D A W / D W A / W D A / W A D / A D W for that table, default 2).
+  const int n_d = (int)gridDim.x - s.groups - n_w;
+  int blk = (int)blockIdx.x;                 // -> logical index in [attention | weight gradient | data gradient]
+  {
+    const int nA = s.groups, nW = n_w, nD = n_d, p = (int)blockIdx.x;
+    const int oA = 0, oW = nA, oD = nA + nW;
+    switch (a.order) {
+      case 1: blk = p < nD ? oD + p : (p < nD + nA ? oA + p - nD : oW + p - nD - nA); break;            // D A W
+      case 2: blk = p < nD ? oD + p : (p < nD + nW ? oW + p - nD : oA + p - nD - nW); break;            // D W A
+      case 3: blk = p < nW ? oW + p : (p < nW + nD ? oD + p - nW : oA + p - nW - nD); break;            // W D A
+      case 4: blk = p < nW ? oW + p : (p < nW + nA ? oA + p - nW : oD + p - nW - nA); break;            // W A D
+      case 5: blk = p < nA ? oA + p : (p < nA + nD ? oD + p - nA : oW + p - nA - nD); break;            // A D W
+      default: break;                                                                                   // A W D
+    }
+  }
   // BMNAS_CONV_PROBE bits 16 / 32 / 64 drop the attention / weight-gradient / data-gradient blocks:
   // timing diagnostics only (tools/ktable.py), the results are then incomplete
   if ((a.probe & 16) && blk < s.groups) return;
@@ -1405,7 +1426,7 @@ __global__ __launch_bounds__(256, BMNAS_MERGED_OCC) void conv_bwd_all_pipe_k(Con
       // batch split x / 2 and one half of the output-channel tiles, so its L2 fetches 1/8 of dU (and U)
       // and 1/4 of the sources instead of every XCD fetching all of them.  Speed only: any
       // placement gives the same tiles.
-      const int hw = (-wx) >> 1, x = blk & 7, q = t >> 3;
+      const int hw = (-wx) >> 1, x = blockIdx.x & 7, q = t >> 3;
       bz = x >> 1;
       bx = (x & 1) * hw + q % hw;
       by = q / hw;
@@ -1949,6 +1970,8 @@ extern "C" int bmnas_conv1x1_bwd_all_sdpa(const float* dU, const float* W, int l
   if (pipe_ok) {
     {
       const int n_w = (int)(wgrid.x * wgrid.y * wgrid.z);
+      static const int order = [] { const char* e = getenv("BMNAS_BWD_ORDER"); return e ? atoi(e) : 2; }();
+      a.order = order;
       dim3 grid((unsigned)(s.groups + n_w + gx * gy));
       const size_t lds = std::max(std::max(sdpa_bwd_lds(C), conv_w_lds<4>()),
                                   (conv_pipe_bwd_lds<48, 2>(a.L)) + (a.bn_U ? (size_t)a.I * sizeof(float4) : 0));
