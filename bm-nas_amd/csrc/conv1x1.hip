@@ -716,20 +716,42 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
   f32x4 acc[WJ];
 #pragma unroll
   for (int tj = 0; tj < WJ; ++tj) acc[tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // all LDS operand reads of a chunk first, then its MFMAs back to back: with one wave per SIMD nothing
-  // else hides the LDS latency, so it is paid once per chunk instead of per k-block (the fences keep hipcc
-  // from re-interleaving them and from hoisting the barrier above the MFMAs)
+  // A chunk step inside one wave: k-block kb + 1's LDS operand reads are issued in front of k-block kb's MFMAs, and
+  // (two-chunks-in-flight loop) the NEXT chunk's fold + stash into the other buffer is dealt over the k-blocks, so its
+  // VALU / LDS-write instructions issue in the shadow of the matrix pipe.  History: rounds 2-3 read the whole chunk's
+  // operands first and ran its 24 MFMAs back to back behind a fence, then stashed (19.05 us for the merged launch);
+  // reads pipelined per k-block 18.5 us; with the stash slices 18.3 us; no fences at all 19.3 us.
 #if BMNAS_BODY_PROBES
   unsigned long long pr_reads = 0, pr_mfma = 0, pr_rest = 0, pr_last = stamp_clock(), pr_t0 = pr_last;
 #endif
-  auto compute = [&](const float* cur) __attribute__((always_inline)) {
+  // one slice (of NKB) of a chunk's stash: the NA + NB register rounds dealt over the k-blocks of the step that runs
+  // while they are written
+  auto stash_slice = [&](float* buf, const Regs& R, int c, int kb, int nkb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if ((i * nkb) / (NA + NB) == kb && (256 * (i + 1) <= A4 || t + 256 * i < A4)) {
+        float4 v = R.ra[i];
+        if (FOLD) {
+          const float4 cf = coef[c * KC + chl[i]];
+          v.x = fmaf(cf.x, v.x, fmaf(cf.y, R.ru[i].x, cf.z));
+          v.y = fmaf(cf.x, v.y, fmaf(cf.y, R.ru[i].y, cf.z));
+          v.z = fmaf(cf.x, v.z, fmaf(cf.y, R.ru[i].z, cf.z));
+          v.w = fmaf(cf.x, v.w, fmaf(cf.y, R.ru[i].w, cf.z));
+        }
+        st4(buf + asl[i], v);
+      }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (((NA + i) * nkb) / (NA + NB) == kb && (256 * (i + 1) <= B4 || t + 256 * i < B4)) st4(buf + bsl[i], R.rb[i]);
+  };
+  auto compute = [&](const float* cur, float* nxt = nullptr, const Regs* Rn = nullptr, int cn = 0)
+      __attribute__((always_inline)) {
     constexpr int NKB = KC / 16;
     float av[NKB][4], bv[NKB][WJ][4];
 #if BMNAS_BODY_PROBES
     { const unsigned long long t = stamp_clock(); pr_rest += t - pr_last; pr_last = t; }
 #endif
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
+    auto rd = [&](int kb) __attribute__((always_inline)) {
       const int c0 = 16 * kb + 4 * h;
 #pragma unroll
       for (int r = 0; r < 4; ++r) av[kb][r] = cur[aoff + (c0 + r) * (a.L + 4)];
@@ -737,20 +759,20 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
       for (int tj = 0; tj < WJ; ++tj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[kb][tj][r] = cur[boff[tj] + (16 * kb + r) * JP];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#if BMNAS_BODY_PROBES
-    { const unsigned long long t = stamp_clock(); pr_reads += t - pr_last; pr_last = t; }   // (drains the LDS reads)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    };
+    rd(0);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb + 1 < NKB) rd(kb + 1);
+      if (nxt != nullptr) stash_slice(nxt, *Rn, cn, kb, NKB);
+      else __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tj = 0; tj < WJ; ++tj)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][r], bv[kb][tj][r], acc[tj], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #if BMNAS_BODY_PROBES
     { const unsigned long long t = stamp_clock(); pr_mfma += t - pr_last; pr_last = t; }
     __builtin_amdgcn_sched_barrier(0);
@@ -800,17 +822,14 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     for (int c = 0; c + 2 < nchunk; c += 2) {
       fetch(R, c + 2);
       __builtin_amdgcn_sched_barrier(0);
-      compute(smem);
-      stash(smem + BUF, Q, c + 1);                             // the other buffer: nobody reads it now
+      compute(smem, smem + BUF, &Q, c + 1);                    // (stash into the other buffer: nobody reads it now)
       __syncthreads();
       fetch(Q, c + 3);
       __builtin_amdgcn_sched_barrier(0);
-      compute(smem + BUF);
-      stash(smem, R, c + 2);
+      compute(smem + BUF, smem, &R, c + 2);
       __syncthreads();
     }
-    compute(smem);
-    stash(smem + BUF, Q, nchunk - 1);
+    compute(smem, smem + BUF, &Q, nchunk - 1);
     __syncthreads();
     compute(smem + BUF);
   } else {
@@ -913,6 +932,9 @@ template <int KC, int KCH, int NG>
 __global__ __launch_bounds__(256) void conv_pipe_fwd_sdpa_k(ConvArgs a, SdpaFwdArgs s, int gx) {
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
   // (attention groups first: the other order measured 11.8 -> 12.1 us at MM-IMDB b128)
+  // BMNAS_CONV_PROBE bits 16 / 64 (timing builds only) drop the attention groups / the GEMM tiles
+  if ((a.probe & 16) && (int)blockIdx.x < s.groups) return;
+  if ((a.probe & 64) && (int)blockIdx.x >= s.groups) return;
   if ((int)blockIdx.x < s.groups) {
     sdpa_fwd_body<KCH>(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop, merged_smem);
   } else {
@@ -1809,7 +1831,7 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
   a.W = W; a.bias = bias; a.ldw = ldw;
   a.part = stat_shards ? nullptr : part; a.stat = stat_shards ? part : nullptr; a.stat_shards = stat_shards;
   a.Ci = C_src; a.I = n_src * C_src; a.Cj = M; a.J = M;
-  a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = 0; a.fold = fold_cols;
+  a.b = b; a.L = L; a.acc_mask = 0; a.n_part = a.n_groups; a.probe = conv_probe(); a.fold = fold_cols;
   s.x = x; s.y = y; s.ln_w = ln_w; s.ln_b = ln_b; s.out = out; s.xhat = xhat; s.stats = stats;
   s.drop = to_cfg(drop);
   s.groups = (b + s.G.spw - 1) / s.G.spw;

@@ -94,7 +94,8 @@ d = data[6]
 d = d[d[:, 6] != 0]
 if len(d):
     tot = d[:, 3].astype(np.float64)
+    # (since the k-block loop is software-pipelined the operand reads are no longer a separate phase: column 0 stays 0)
     print(f'conv_bwd_all_pipe_k data-gradient tiles: {len(d)} workgroups x {int(d[0, 7])} chunks; per tile (median cycles): '
-          f'LDS operand reads {np.median(d[:, 0]):.0f} ({np.median(d[:, 0] / tot):.0%}), MFMA issue {np.median(d[:, 1]):.0f} '
-          f'({np.median(d[:, 1] / tot):.0%}), fetch + stash + barrier + rest {np.median(d[:, 2]):.0f} '
+          f'LDS reads + MFMAs + stash slices {np.median(d[:, 0] + d[:, 1]):.0f} ({np.median((d[:, 0] + d[:, 1]) / tot):.0%}), '
+          f'fetch issue + barrier + rest {np.median(d[:, 2]):.0f} '
           f'({np.median(d[:, 2] / tot):.0%}), whole chunk loop {np.median(tot):.0f} cycles')
