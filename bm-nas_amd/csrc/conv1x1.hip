@@ -10,6 +10,10 @@
 // The k-permutation is legal because A and B use the same one.
 // FLOPs: 2*M*K*b*L each; bound: fp32 MFMA (157 TFLOP/s dense).
 #include "sdpa_body.hpp"
+#ifndef BMNAS_FWD_LA2
+#define BMNAS_FWD_LA2 1
+#endif
+constexpr bool kFwdLa2 = BMNAS_FWD_LA2 != 0;
 #include <algorithm>
 #include <cstdlib>
 
@@ -473,20 +477,24 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     boffg[i] = (int64_t)j * a.ldw + 4 * c4;
     bsl[i] = ABUF + jr * KP + 4 * c4;
   }
-  float4 ra[NA], rb[NB];
-  auto fetch = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = ld4(a.W + boffg[i] + c * KC);
+  struct Regs {
+    float4 ra[NA], rb[NB];
   };
-  auto stash = [&](float* buf) __attribute__((always_inline)) {
+  auto fetch = [&](Regs& R, int c) __attribute__((always_inline)) {
+    c = c < nchunk ? c : nchunk - 1;                           // past the end: a harmless repeat, no branch
+#pragma unroll
+    for (int i = 0; i < NA; ++i) R.ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) R.rb[i] = ld4(a.W + boffg[i] + c * KC);
+  };
+  // slice kb (of nkb) of a chunk's stash; nkb = 1: all of it
+  auto stash = [&](float* buf, const Regs& R, int kb = 0, int nkb = 1) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      if (t + 256 * i < A4) st4(buf + asl[i], ra[i]);
+      if ((i * nkb) / (NA + NB) == kb && t + 256 * i < A4) st4(buf + asl[i], R.ra[i]);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      if (t + 256 * i < B4) st4(buf + bsl[i], rb[i]);
+      if (((NA + i) * nkb) / (NA + NB) == kb && t + 256 * i < B4) st4(buf + bsl[i], R.rb[i]);
   };
 
   const int gl0 = WN * (wave & 1), jl0 = 3 * (wave >> 1);
@@ -510,19 +518,13 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     const int jt = j0 + 16 * (jl0 + tj);
     bjv[tj] = (a.bias != nullptr) ? a.bias[(jt < a.J ? jt : a.J - 16) + lo] : 0.f;
   }
-  fetch(0);
-  stash(smem);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const float* cur = smem + (c & 1) * BUF;
-    if (c + 1 < nchunk) fetch(c + 1);                          // in flight during this chunk's MFMAs
-    // LDS operand reads of the whole chunk first, then its MFMAs back to back (see the
-    // data-gradient body)
+  // A chunk step inside one wave (as in the data-gradient body): k-block kb + 1's LDS operand reads are issued in
+  // front of k-block kb's MFMAs; with `nxt` the next chunk's stash into the other buffer is dealt over the k-blocks.
+  auto compute = [&](const float* cur, float* nxt = nullptr, const Regs* Rn = nullptr) __attribute__((always_inline)) {
     constexpr int NKB = KC / 16;
     float av[NKB][WN][4];
     float4 bv[NKB][3];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
+    auto rd = [&](int kb) __attribute__((always_inline)) {
       const int c0 = 16 * kb + 4 * h;
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn)
@@ -530,10 +532,13 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
         for (int r = 0; r < 4; ++r) av[kb][tn][r] = cur[aoff[tn] + (c0 + r) * (a.L + 4)];
 #pragma unroll
       for (int tj = 0; tj < 3; ++tj) bv[kb][tj] = ld4(cur + boff[tj] + 16 * kb);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    };
+    rd(0);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb + 1 < NKB) rd(kb + 1);
+      if (nxt != nullptr) stash(nxt, *Rn, kb, NKB);
+      else __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
@@ -543,10 +548,39 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
           acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][2], bv[kb][tj].z, acc[tn][tj], 0, 0, 0);
           acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][3], bv[kb][tj].w, acc[tn][tj], 0, 0, 0);
         }
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 1 < nchunk) {
-      stash(smem + ((c + 1) & 1) * BUF);                       // the other buffer: nobody reads it now
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  Regs R;
+  fetch(R, 0);
+  stash(smem, R);
+  __syncthreads();
+  if (kFwdLa2 && (nchunk & 1) == 0 && nchunk >= 4) {
+    // two chunks of global loads in flight (register sets by chunk parity), no conditional fetch / stash in the loop
+    Regs Q;
+    fetch(Q, 1);
+    for (int c = 0; c + 2 < nchunk; c += 2) {
+      fetch(R, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(smem, smem + BUF, &Q);
       __syncthreads();
+      fetch(Q, c + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(smem + BUF, smem, &R);
+      __syncthreads();
+    }
+    compute(smem, smem + BUF, &Q);
+    __syncthreads();
+    compute(smem + BUF);
+  } else {
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk) fetch(R, c + 1);                     // in flight during this chunk's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      compute(smem + (c & 1) * BUF);
+      if (c + 1 < nchunk) {
+        stash(smem + ((c + 1) & 1) * BUF, R);                  // the other buffer: nobody reads it now
+        __syncthreads();
+      }
     }
   }
 
