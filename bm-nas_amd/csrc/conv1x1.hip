@@ -1392,6 +1392,7 @@ __global__ __launch_bounds__(256) void conv_bwd_all_k(ConvArgs a, SdpaBwdArgs s,
                                                       int n_w, int wx, int wy) {
   constexpr int KPW = 3 * KCH;
   extern __shared__ __attribute__((aligned(16))) char merged_smem[];
+  // (block order: permutations measured at NTU b64 / Ego b48 / NTU b8 change nothing — the grid is small)
   const int blk = blockIdx.x;
   // BMNAS_CONV_PROBE bits 16 / 32 / 64: as in conv_bwd_all_pipe_k (timing diagnostics only)
   if ((a.probe & 16) && blk < s.groups) return;
@@ -1496,8 +1497,17 @@ __global__ __launch_bounds__(256, BMNAS_MERGED_OCC) void conv_bwd_all_pipe_k(Con
     else conv_w_body<4, false>(w, bx, by, bz, merged_smem);
   } else {
     const int t = blk - s.groups - n_w;
-    if (a.bn_U != nullptr) conv_pipe_bwd_body<KC, NG, true, kLa2>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
-    else conv_pipe_bwd_body<KC, NG, false>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
+    int bx = t % gx, by = t / gx;
+    if ((a.order == 1 || a.order == 2) && (gx & 7) == 0) {
+      // XCD-aware tile order (tiles at the front of the grid: workgroup p runs on XCD p & 7): XCD x takes the n-tiles
+      // [x gx / 8, (x + 1) gx / 8) — the batch quarter x / 2 whose dU / U its weight-gradient tiles read too (above) —
+      // with every j-tile of an n-tile on the same XCD.  Speed only (18.44 -> 18.30 us).
+      const int hw = gx >> 3, x = blockIdx.x & 7, i = t >> 3;
+      bx = x * hw + i % hw;
+      by = i / hw;
+    }
+    if (a.bn_U != nullptr) conv_pipe_bwd_body<KC, NG, true, kLa2>(a, bx, by, reinterpret_cast<float*>(merged_smem));
+    else conv_pipe_bwd_body<KC, NG, false>(a, bx, by, reinterpret_cast<float*>(merged_smem));
   }
 }
 
