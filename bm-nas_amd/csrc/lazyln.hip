@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
     float* __restrict__ pre, float* __restrict__ rec, float* __restrict__ prm, int b, int C, int L,
     DropCfg dglu, DropCfg dfc) {
   __shared__ float red[4];
-  __shared__ float red5[4 * 5];
+  __shared__ float red5[2 * 4 * 5];
   extern __shared__ float fin_lds[];
   const int cl4 = C * L / 4, l4n = L / 4, M = 3 * C;
   const int part = blockIdx.x, smp = blockIdx.y, P = gridDim.x;
@@ -81,7 +81,13 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
   STAMP(0, smp * P + part, 3);
   const int n4 = cl4 - part * kLazyPart < kLazyPart ? cl4 - part * kLazyPart : kLazyPart;
   const float nk = (float)(4 * n4);
-  const float mk = block_sum<4>(act ? f4_hsum(v) : 0.f, red) / nk;
+  // (each LDS array below is written once per launch: the reductions need no barrier in FRONT of their writes —
+  // block_sum / block_sum_lead carry one for callers that reuse the array)
+  float mk = wave_sum(act ? f4_hsum(v) : 0.f);
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  if (ln == 0) red[wv] = mk;
+  __syncthreads();
+  mk = (((red[0] + red[1]) + red[2]) + red[3]) / nk;
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (act) {
     const float4 cd = make_float4(v.x - mk, v.y - mk, v.z - mk, v.w - mk);
@@ -92,27 +98,46 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
     acc[3] = f4_dot(cw, lb);
     acc[4] = f4_dot(cw, lw);
   }
-  block_sum_lead<4, 5>(acc, red5);
+  // the five centred sums — and, for sample 0's workgroups, the affine parameters' own five — behind ONE barrier
+  float pa[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (smp == 0 && act) {                                      // (smp: uniform)
+    pa[0] = f4_dot(lw, lw);
+    pa[1] = f4_hsum(lw);
+    pa[2] = f4_dot(lw, lb);
+    pa[3] = f4_hsum(lb);
+    pa[4] = f4_dot(lb, lb);
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) acc[i] = wave_sum(acc[i]);
+  if (smp == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) pa[i] = wave_sum(pa[i]);
+  }
+  if (ln == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) red5[i * 4 + wv] = acc[i];
+    if (smp == 0) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) red5[20 + i * 4 + wv] = pa[i];
+    }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    float t[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t[i] = ((red5[i * 4] + red5[i * 4 + 1]) + red5[i * 4 + 2]) + red5[i * 4 + 3];
     float* rr = rec + ((int64_t)smp * P + part) * kLazyRec;
-    st4(rr, make_float4(mk, acc[0], acc[1], acc[2]));
-    st4(rr + 4, make_float4(acc[3], acc[4], 0.f, 0.f));
+    st4(rr, make_float4(mk, t[0], t[1], t[2]));
+    st4(rr + 4, make_float4(t[3], t[4], 0.f, 0.f));
   }
   STAMP(0, smp * P + part, 4);
-  if (smp == 0) {                                             // uniform: the affine parameters' own sums, once
-    float pa[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    if (act) {
-      pa[0] = f4_dot(lw, lw);
-      pa[1] = f4_hsum(lw);
-      pa[2] = f4_dot(lw, lb);
-      pa[3] = f4_hsum(lb);
-      pa[4] = f4_dot(lb, lb);
-    }
-    block_sum_lead<4, 5>(pa, red5);
-    if (threadIdx.x == 0) {
-      st4(prm + part * kLazyRec, make_float4(pa[0], pa[1], pa[2], pa[3]));
-      st4(prm + part * kLazyRec + 4, make_float4(pa[4], nk, 0.f, 0.f));
-    }
+  if (smp == 0 && threadIdx.x == 64) {
+    float t[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      t[i] = ((red5[20 + i * 4] + red5[20 + i * 4 + 1]) + red5[20 + i * 4 + 2]) + red5[20 + i * 4 + 3];
+    st4(prm + part * kLazyRec, make_float4(t[0], t[1], t[2], t[3]));
+    st4(prm + part * kLazyRec + 4, make_float4(t[4], nk, 0.f, 0.f));
   }
 }
 
@@ -405,6 +430,13 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
 #pragma unroll
     for (int k = 0; k < 6; ++k) csum[sl - 1][k][col] = cs[k];
   }
+  // dgamma's wave sums meet in LDS behind the SAME barrier (a block_sum_lead after the BatchNorm sums was two more)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dgam[q] = wave_sum(dgam[q]);
+  if (col == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red16[q * 4 + sl] = dgam[q];
+  }
   __syncthreads();
   if (sl == 0 && active && (r % l4n) == 0) {
 #pragma unroll
@@ -426,11 +458,10 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
     }
   }
   STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 3);
-  block_sum_lead<4, 4>(dgam, red16);
-  if (threadIdx.x == 0 && dgamma != nullptr) {
+  if (threadIdx.x < 4 && dgamma != nullptr) {
+    const int q = threadIdx.x;
     float* p = dgamma + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % dg_shards) * dg_stride;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) atomicAdd(p + q, dgam[q]);
+    atomicAdd(p + q, ((red16[q * 4] + red16[q * 4 + 1]) + red16[q * 4 + 2]) + red16[q * 4 + 3]);
   }
   STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 4);
 }
