@@ -81,6 +81,14 @@ class MixSumFn(Function):
         return (dw, *dxs)
 
 
+def _zero_pair(like):
+    """Two zero-filled tensors shaped like `like` (a LayerNorm's dln_w, dln_b), slices of the backward pass's one
+    zero-filled chunk (ZERO_POOL; the forward announced them)."""
+    n = like.numel()
+    buf = ZERO_POOL.take(2 * n, like.device)
+    return buf[:n].view_as(like), buf[n:2 * n].view_as(like)
+
+
 # ------------------------------------------------------------------------ K6 / K7
 class CatLnFn(Function):
     """LayerNorm([n_src*C, L]) of cat(srcs, 1) (+ resid), optional ReLU; output (b, n_src*C, L)."""
@@ -97,6 +105,8 @@ class CatLnFn(Function):
         lw, lb = _c(ln_w), _c(ln_b)
         lib.cat_ln_fwd(srcs, resid, lw, lb, out, stats, b, C, L, relu)
         ctx.relu, ctx.srcs, ctx.resid, ctx.lw, ctx.lb, ctx.stats = relu, srcs, resid, lw, lb, stats
+        if any(ctx.needs_input_grad):
+            ZERO_POOL.announce(2 * lw.numel())      # dln_w | dln_b of the backward: one fill per pass for all modules
         return out
 
     @staticmethod
@@ -106,8 +116,7 @@ class CatLnFn(Function):
         g = _c(g)
         dsrcs = [torch.empty_like(s) if ctx.needs_input_grad[4 + q] else None for q, s in enumerate(srcs)]
         dres = torch.empty_like(resid) if (resid is not None and ctx.needs_input_grad[3]) else None
-        dw = torch.zeros_like(ctx.lw)
-        db = torch.zeros_like(ctx.lb)
+        dw, db = _zero_pair(ctx.lw)
         lib.cat_ln_bwd(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dsrcs, dres, 0, None, None, b, C, L,
                        ctx.relu)
         lib.ln_affine_bwd(g, None, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, ctx.relu, False)
@@ -130,6 +139,8 @@ class SdpaLnFn(Function):
         xhat = torch.empty_like(x)
         lib.sdpa_ln_fwd(x, y, lw, lb, out, xhat, stats, b, C, L, drop)
         ctx.x, ctx.y, ctx.lw, ctx.stats, ctx.drop, ctx.xhat = x, y, lw, stats, drop, xhat
+        if any(ctx.needs_input_grad):
+            ZERO_POOL.announce(2 * lw.numel())
         return out
 
     @staticmethod
@@ -137,7 +148,7 @@ class SdpaLnFn(Function):
         x, y = ctx.x, ctx.y
         b, C, L = x.shape
         dx, dy = torch.empty_like(x), torch.empty_like(y)
-        dw, db = torch.zeros_like(ctx.lw), torch.zeros_like(ctx.lw)
+        dw, db = _zero_pair(ctx.lw)
         g = _c(g)
         lib.sdpa_ln_bwd(g, None, x, y, ctx.lw, ctx.xhat, ctx.stats, dx, dy, 0, b, C, L, ctx.drop)
         lib.ln_affine_bwd(g, None, [ctx.xhat], None, None, None, None, dw, db, b, C, L, False, True)
