@@ -431,9 +431,14 @@ __device__ __forceinline__ float4 bn_fold_coef(float scale, float kb, float mean
 constexpr int kPipeJ = 96;
 
 // NG = n-groups (16 columns each) per tile: 4 (64 x 96 tile) or 2 (32 x 96: twice the workgroups)
-template <int KC, int NG>
+// NQ > 1 (launch of 256 NQ threads): the contraction is split over NQ groups of four waves ("quads") of ONE workgroup,
+// each with its own pair of operand buffers walking its K / NQ; the partial tiles meet in LDS and quad 0 runs the
+// epilogue — bias, store, BatchNorm statistics of the COMPLETE output, no atomics on it.  For long contractions on few
+// tiles (the reshape layers of NTU / Ego at 64 / 48 samples: K = 2048 on 32 tiles per layer was a chain of 64 chunk
+// steps per workgroup with most of the CU idle).
+template <int KC, int NG, int NQ = 1>
 __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int bx, const int by,
-                                                   float* __restrict__ smem) {
+                                                   float* __restrict__ smem0) {
   constexpr int KP = KC + 4;
   constexpr int TNC = 16 * NG, WN = NG / 2;                    // tile columns, n-groups per wave
   constexpr int A4 = TNC * KC / 4, B4 = kPipeJ * KC / 4;       // float4 per chunk
@@ -442,14 +447,17 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
   // k-slots of a wave then read rows 4 apart on different banks (unpadded: 2-way conflict)
   const int ABUF = ((TNC * KC) >> a.Lb) * (a.L + 4);
   const int BUF = ABUF + kPipeJ * KP;                   // floats per buffer
-  const int t = threadIdx.x;
+  const int quad = NQ > 1 ? (int)(threadIdx.x >> 8) : 0;
+  float* __restrict__ smem = smem0 + quad * 2 * BUF;
+  const int t = NQ > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
   const int wave = t >> 6, lane = t & 63, lo = lane & 15, h = lane >> 4;
   const int spt = TNC >> a.Lb;                                  // samples per tile
   const int s0 = bx * spt, j0 = by * kPipeJ;
   const int K = a.I;
   const int cl4 = (KC << a.Lb) >> 2;                           // float4 per sample per chunk
   const float* __restrict__ act = a.act.p[0];
-  const int nchunk = K / KC;
+  const int nchunk = K / KC / NQ;                               // (the launcher picks NQ | K / KC)
+  const int cbase = quad * nchunk;
 
   // global addresses of this thread's pieces of a chunk (chunk c adds c*KC channels)
   int64_t aoffg[NA];
@@ -481,7 +489,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     float4 ra[NA], rb[NB];
   };
   auto fetch = [&](Regs& R, int c) __attribute__((always_inline)) {
-    c = c < nchunk ? c : nchunk - 1;                           // past the end: a harmless repeat, no branch
+    c = cbase + (c < nchunk ? c : nchunk - 1);                 // past the end: a harmless repeat, no branch
 #pragma unroll
     for (int i = 0; i < NA; ++i) R.ra[i] = ld4(act + aoffg[i] + ((int64_t)(c * KC) << a.Lb));
 #pragma unroll
@@ -584,6 +592,33 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     }
   }
 
+  if (NQ > 1) {
+    // the quads' partial tiles: quads 1 .. NQ - 1 park theirs in quad 0's (now idle) operand buffers — the quads run in
+    // lockstep (same chunk count, same barriers), so behind this barrier nobody reads operands any more
+    __syncthreads();
+    float* red = smem0;                                         // [NQ - 1][WN * 3 * 4][256]
+    if (quad > 0) {
+#pragma unroll
+      for (int tn = 0; tn < WN; ++tn)
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(((quad - 1) * WN * 3 + tn * 3 + tj) * 4 + r) * 256 + t] = acc[tn][tj][r];
+    }
+    __syncthreads();
+    if (quad == 0) {
+#pragma unroll
+      for (int q = 1; q < NQ; ++q)
+#pragma unroll
+        for (int tn = 0; tn < WN; ++tn)
+#pragma unroll
+          for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tn][tj][r] += red[(((q - 1) * WN * 3 + tn * 3 + tj) * 4 + r) * 256 + t];
+    }
+    __syncthreads();                                            // (the statistics exchange below reuses smem0)
+  }
+  const bool lead = NQ == 1 || quad == 0;                       // the quad that owns the epilogue
   // epilogue: acc[tn][tj][r] = OUT[n = 16*g + 4h + r][j = jt + lo]
   const int l0 = (4 * h) & (a.L - 1);
   float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};    // stat mode: this wave's n-groups together
@@ -592,7 +627,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
 #pragma unroll
     for (int tj = 0; tj < 3; ++tj) {
       const int g = bx * NG + gl0 + tn, jt = j0 + 16 * (jl0 + tj);
-      if (g >= a.n_groups || jt >= a.J) continue;              // wave-uniform
+      if (g >= a.n_groups || jt >= a.J || !lead) continue;     // wave-uniform
       const int jj = jt + lo;
       const float bj = bjv[tj];
       const float4 o = make_float4(acc[tn][tj][0] + bj, acc[tn][tj][1] + bj, acc[tn][tj][2] + bj,
@@ -613,7 +648,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     // their sums to waves 0 and 2, which own the same channels, through the idle operand buffer.
     // Same-address atomics serialise at the memory side: halving them again lets half as many shard
     // copies do (the kernel that finalises the statistics reads every shard of every channel).
-    float2* xch = reinterpret_cast<float2*>(smem);               // [2][3][16]
+    float2* xch = reinterpret_cast<float2*>(smem0);              // [2][3][16]
 #pragma unroll
     for (int tj = 0; tj < 3; ++tj) {
       ssum[tj] = xor16_sum(ssum[tj]);
@@ -622,12 +657,12 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
       ssq[tj] = xor32_sum(ssq[tj]);
     }
     __syncthreads();                                           // every wave is done reading operands
-    if ((wave & 1) && h == 0) {
+    if (lead && (wave & 1) && h == 0) {
 #pragma unroll
       for (int tj = 0; tj < 3; ++tj) xch[((wave >> 1) * 3 + tj) * 16 + lo] = make_float2(ssum[tj], ssq[tj]);
     }
     __syncthreads();
-    if (!(wave & 1) && h == 0) {
+    if (lead && !(wave & 1) && h == 0) {
 #pragma unroll
       for (int tj = 0; tj < 3; ++tj) {
         const int jt = j0 + 16 * (jl0 + tj);
@@ -1590,6 +1625,17 @@ __global__ __launch_bounds__(256) void conv_fwd_group_k(ConvFwdGroup G) {
   else conv_ksplit_body<true, 1, 1, 12, true>(a, t % gx, t / gx, group_smem);
 }
 
+// the same group when every layer takes the pipelined tiles and the longest contraction is a chain of >= 32 chunk steps
+// on about one tile per CU: workgroups of NQ quads that split each tile's contraction (conv_pipe_fwd_body<.., NQ>)
+template <int NQ>
+__global__ __launch_bounds__(256 * NQ) void conv_fwd_group_q_k(ConvFwdGroup G) {
+  extern __shared__ __attribute__((aligned(16))) char group_smem[];
+  const int p = group_problem(G.start, G.n);
+  const ConvArgs a = uni(pick_uniform(G.a, p));
+  const int t = blockIdx.x - uni(pick_uniform(G.start, p)), gx = uni(pick_uniform(G.gx, p));
+  conv_pipe_fwd_body<32, 2, NQ>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+}
+
 // backward of the group: every layer's weight-gradient tiles (first: they walk many n-groups each), then every
 // layer's data-gradient tiles, the BatchNorm input gradient applied while the operands are staged (bn_U).
 struct ConvBwdGroup {
@@ -1648,7 +1694,8 @@ __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W
 // Which GEMM family a call was dispatched to (diagnostics for tests/test_dispatch_gpu.py: host-side
 // counters, never read by a kernel).  Order = bmnas_conv_family_name().
 enum ConvFamily { F_KSPLIT, F_PIPE_FWD, F_PIPE_BWD, F_LDS, F_FWD_SDPA_PIPE, F_FWD_SDPA_KSPLIT,
-                  F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_BWD_PAIR, F_FWD_GROUP, F_BWD_GROUP, F_COUNT };
+                  F_BWD_ALL_PIPE, F_BWD_ALL_KSPLIT, F_CONV_W, F_BWD_PAIR, F_FWD_GROUP, F_BWD_GROUP, F_FWD_QUADS_GROUP,
+                  F_COUNT };
 long g_family_calls[F_COUNT] = {0};
 #define BMNAS_COUNT(f) (++g_family_calls[f])
 
@@ -2278,6 +2325,49 @@ extern "C" int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n
   G.start[n] = blocks;
   if (b == 0) return 0;
   BMNAS_COUNT(F_FWD_GROUP);
+  // long contractions on few tiles: split every tile's contraction over the quads of a 512- / 1024-thread workgroup
+  {
+    bool all_pipe = use_pipe;
+    int max_chunks = 0, quads = 4;
+    for (int q = 0; q < n; ++q) {
+      all_pipe = all_pipe && G.kind[q] == 0;
+      const int nc = G.a[q].I / 32;
+      max_chunks = std::max(max_chunks, nc);
+      while (quads > 1 && nc % quads) quads >>= 1;
+    }
+    static const int lds_max = [] {
+      int dev = 0, v = 65536;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+      return v;
+    }();
+    // (measured, NTU b64 / Ego b48: 1 quad 53.4 / 53.6 us, 2 quads 39.7 / 40.2, 4 quads 39.0 / 38.8 — the longest tiles
+    // are then bound by their CU's matrix pipe, 21.8 us for a 32 x 96 x 2048 tile, not by the chain; 2 is the default:
+    // no spills, half the LDS.  BMNAS_FWD_GROUP_QUADS = 1 / 4 for the table)
+    static const int quad_mode = [] { const char* e = getenv("BMNAS_FWD_GROUP_QUADS"); return e ? atoi(e) : 2; }();
+    quads = std::min(quads, quad_mode);
+    const size_t pipe_lds = conv_pipe_lds<32, 2>(L);
+    while (quads > 1 && pipe_lds * quads > (size_t)lds_max) quads >>= 1;
+    if (all_pipe && max_chunks >= 32 && blocks <= 320 && quads > 1) {
+      hipError_t err = hipSuccess;
+      if (quads == 4) {
+        static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_group_q_k<4>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)attr4;
+        hipLaunchKernelGGL(conv_fwd_group_q_k<4>, dim3((unsigned)blocks), dim3(1024), pipe_lds * 4, (hipStream_t)stream, G);
+      } else {
+        static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_group_q_k<2>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)attr2;
+        hipLaunchKernelGGL(conv_fwd_group_q_k<2>, dim3((unsigned)blocks), dim3(512), pipe_lds * 2, (hipStream_t)stream, G);
+      }
+      err = hipGetLastError();
+      if (err == hipSuccess) {
+        BMNAS_COUNT(F_FWD_QUADS_GROUP);                          // (counted on top of fwd_group: the quad form of it)
+        return 0;
+      }
+      // (a runtime that refuses the launch — LDS limit, block size — leaves nothing behind: the plain kernel runs)
+    }
+  }
   hipLaunchKernelGGL(conv_fwd_group_k, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, G);
   BMNAS_CHECK_LAUNCH();
   return 0;
@@ -2380,7 +2470,7 @@ extern "C" int bmnas_conv_family_calls(long* out, int n, int reset) {
 extern "C" const char* bmnas_conv_family_name(int i) {
   static const char* names[F_COUNT] = {"ksplit", "pipe_fwd", "pipe_bwd", "lds", "fwd_sdpa_pipe",
                                        "fwd_sdpa_ksplit", "bwd_all_pipe", "bwd_all_ksplit",
-                                       "conv_w", "bwd_pair", "fwd_group", "bwd_group"};
+                                       "conv_w", "bwd_pair", "fwd_group", "bwd_group", "fwd_quads_group"};
   return (i >= 0 && i < F_COUNT) ? names[i] : nullptr;
 }
 

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 C_INS = {'mmimdb': [512, 512, 512, 512, 64, 128],
          'ntu': [512, 1024, 2048, 2048, 128, 256, 1024, 512],
+         'ego': [512, 1024, 2048, 2048, 512, 1024, 2048, 2048],
          'mixed': [64, 16, 48, 2064, 32]}                  # off-grid widths: not a multiple of 32, K > 2048
 
 
@@ -42,7 +43,8 @@ def _build(kind, C, L, drpt, seed):
 @pytest.mark.parametrize('kind,b,C,L,mode', [
     ('mmimdb', 128, 192, 16, 'train_drop'), ('mmimdb', 128, 192, 16, 'eval'), ('mmimdb', 16, 192, 16, 'train'),
     ('ntu', 64, 128, 8, 'train_drop'), ('ntu', 8, 128, 8, 'train'), ('ntu', 250, 128, 8, 'train'),
-    ('mixed', 37, 32, 8, 'train_drop'), ('mixed', 300, 48, 4, 'train'), ('ntu', 6, 128, 8, 'eval')])
+    ('mixed', 37, 32, 8, 'train_drop'), ('mixed', 300, 48, 4, 'train'), ('ntu', 6, 128, 8, 'eval'),
+    ('ego', 48, 128, 8, 'train'), ('ego', 45, 128, 8, 'eval')])
 def test_grouped_reshape_layers_match_oracle(kind, b, C, L, mode):
     import models.auxiliary.aux_models as aux
     from bmnas import cell as K
@@ -65,6 +67,9 @@ def test_grouped_reshape_layers_match_oracle(kind, b, C, L, mode):
         K.DROP.record = None
     calls = lib.conv_family_calls()
     assert calls['fwd_group'] == 1 and calls['bwd_group'] == 1, calls
+    # long contractions (K >= 1024) on about one tile per CU: the group's forward is the multi-quad kernel, every
+    # tile's contraction split over the quads of one workgroup (conv_fwd_group_q_k)
+    assert calls['fwd_quads_group'] == (1 if (kind, b) in (('ntu', 64), ('ego', 48), ('ego', 45)) else 0), calls
     assert sum(v for k, v in calls.items() if not k.endswith('_group')) == 0, calls      # nothing per layer
     assert len(rec) == (len(layers) if mode == 'train_drop' else 0)
     masks = [lib.dropout_mask(d, n, dev()).cpu() for d, n in rec]
