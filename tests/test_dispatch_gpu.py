@@ -145,6 +145,10 @@ def test_every_family_is_reachable(monkeypatch):
     layers = [aux.ReshapeInputLayer(c_in, 32, 8, A()).to(dev()).train() for c_in in (64, 32)]
     feats = [torch.randn(4, c_in, 8, device=dev(), requires_grad=True) for c_in in (64, 32)]
     sum(o.sum() for o in aux.reshape_tails(layers, feats)).backward()
+    # ... and their multi-quad forward: long contractions (K >= 1024) on about one tile per CU (NTU at 64 samples)
+    layers = [aux.ReshapeInputLayer(c_in, 128, 8, A()).to(dev()).train() for c_in in (1024, 2048, 1024)]
+    feats = [torch.randn(64, c_in, 8, device=dev(), requires_grad=True) for c_in in (1024, 2048, 1024)]
+    sum(o.sum() for o in aux.reshape_tails(layers, feats)).backward()
     torch.cuda.synchronize()
     calls = lib.conv_family_calls()
     dead = [k for k, v in calls.items() if v == 0]
