@@ -1934,6 +1934,7 @@ extern "C" int bmnas_conv1x1_fwd_sdpa(const float* const* srcs, int n_src, int C
     // 64-column tiles only when they already give every CU two workgroups; else 32-column tiles
     // (MM-IMDB batch 128: 384 instead of 192 GEMM workgroups, 8 us per step faster)
     const int gy = (a.J + kPipeJ - 1) / kPipeJ;
+    // (re-measured with the pipelined chunk step, MM-IMDB b128: 64-column tiles 12.5-13.1 us against 11.2)
     const int ngv = (a.n_groups + 3) / 4 * gy >= 512 ? 4 : 2;
     const int gx = (a.n_groups + ngv - 1) / ngv;
     if (conv_pipe_mode() && a.I == C && a.fold == 0 && a.ldw % 4 == 0 && gx * gy >= conv_pipe_min() && kch <= 4) {
