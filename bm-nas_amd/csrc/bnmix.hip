@@ -394,6 +394,24 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
 #pragma unroll
     for (int k = 0; k < 6; ++k) csum[sl - 1][k][col] = cs[k];
   }
+  // The four dgamma sums (and the next step's mixed-sum weight gradients) meet in LDS behind the SAME barrier as the
+  // BatchNorm column sums: a block_sum_lead each after them was four more barriers (node_mix_lnp_bwd_k: 9.2 -> 8.4 us).
+  // Every workgroup adds into the same few scalars: same-address atomics serialise (~25 ns each), so they are spread
+  // over dg_shards copies (summed by the arch-softmax backward).
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dgam[q] = wave_sum(dgam[q]);
+  if (NP > 0) {
+#pragma unroll
+    for (int j = 0; j <= NP; ++j) part[j] = wave_sum(part[j]);
+  }
+  if (col == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red16[q * 4 + sl] = dgam[q];
+    if (NP > 0) {
+#pragma unroll
+      for (int j = 0; j <= NP; ++j) redn[j * 4 + sl] = part[j];
+    }
+  }
   __syncthreads();
   if (sl == 0 && active && (r % l4n) == 0) {
 #pragma unroll
@@ -404,22 +422,16 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
       atomicAdd(bn_grad + M + k * C + c, cs[3 + k]);
     }
   }
-  // the four dgamma sums in ONE reduction round (two barriers instead of eight); every workgroup adds
-  // into the same 4 scalars: same-address atomics serialise (~25 ns each), so they are spread over
-  // dg_shards copies (summed by the arch-softmax backward)
-  block_sum_lead<4, 4>(dgam, red16);
-  if (threadIdx.x == 0 && dgamma != nullptr) {
-    float* p = dgamma + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % dg_shards) * dg_stride;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) atomicAdd(p + q, dgam[q]);
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x >= 64 && threadIdx.x < 68 && dgamma != nullptr) {      // (wave 1: wave 0's lanes are busy above)
+    const int q = threadIdx.x - 64;
+    atomicAdd(dgamma + (int64_t)(wg % dg_shards) * dg_stride + q,
+              ((red16[q * 4] + red16[q * 4 + 1]) + red16[q * 4 + 2]) + red16[q * 4 + 3]);
   }
-  if (NP > 0) {
-    block_sum_lead<4, NP + 1>(part, redn);
-    if (threadIdx.x == 0) {
-      float* p = N.dw + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % N.dw_shards) * N.dw_stride;
-#pragma unroll
-      for (int j = 0; j <= NP; ++j) atomicAdd(p + j * N.ws, part[j]);
-    }
+  if (NP > 0 && threadIdx.x >= 128 && (int)threadIdx.x <= 128 + NP) {
+    const int j = threadIdx.x - 128;
+    atomicAdd(N.dw + (int64_t)(wg % N.dw_shards) * N.dw_stride + j * N.ws,
+              ((redn[j * 4] + redn[j * 4 + 1]) + redn[j * 4 + 2]) + redn[j * 4 + 3]);
   }
 }
 
@@ -977,7 +989,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
     const float* __restrict__ chan, float* __restrict__ dV, float* bn_grad, float* dresid, int acc_resid,
     int b, int C, int L, DropCfg d, PairPrevB P) {
   const DropRt dr = drop_begin(d);
-  __shared__ float red[8];
+  __shared__ float red[2 * (BS / 64)];
   __shared__ float redp[(BS / 64) * (NP + 2)];
   const int cl4 = C * L / 4, l4n = L / 4;
   const int smp = blockIdx.x;
@@ -1031,22 +1043,46 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
       s2 += f4_dot(dxh[k], xh[k]);
     }
   }
+  // the LayerNorm backward's two sums and (NP > 0) the mixed-sum weight gradients behind ONE barrier (three
+  // reductions with two barriers each before); `red` / `redp` are written once per launch
+  constexpr int NWV = BS / 64;
+  const int wv = threadIdx.x >> 6;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
   if (NP > 0) {
-    // dw / dw2: one sharded atomic per weight per workgroup, as bmnas_mixsum_pair_bwd
-    block_sum_n<BS / 64, NP + 2>(part, redp);
-    if ((int)threadIdx.x <= NP + 2) {
-      const int t = threadIdx.x;
-      float val = part[NP + 1];                               // (selects: no run-time index into registers)
 #pragma unroll
-      for (int j = 0; j <= NP; ++j) val = (t == j) ? part[j] : val;
-      const int64_t sh = (int64_t)(blockIdx.x % P.dw_shards) * P.dw_stride;
-      if (t <= NP) atomicAdd(P.dw + sh + t * P.ws, val);
-      else atomicAdd(P.dw2 + sh + (t - NP - 1) * P.w2s, val);
+    for (int j = 0; j < NP + 2; ++j) part[j] = wave_sum(part[j]);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[wv] = s1;
+    red[NWV + wv] = s2;
+    if (NP > 0) {
+#pragma unroll
+      for (int j = 0; j < NP + 2; ++j) redp[j * NWV + wv] = part[j];
     }
   }
+  __syncthreads();
+  if (NP > 0 && (int)threadIdx.x <= NP + 2) {
+    // dw / dw2: one sharded atomic per weight per workgroup, as bmnas_mixsum_pair_bwd (t = NP + 1, NP + 2: the two
+    // dw2 adds of the same sum)
+    const int t = threadIdx.x;
+    const int q = t <= NP ? t : NP + 1;
+    float val = redp[q * NWV];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) val += redp[q * NWV + w];
+    const int64_t sh = (int64_t)(blockIdx.x % P.dw_shards) * P.dw_stride;
+    if (t <= NP) atomicAdd(P.dw + sh + t * P.ws, val);
+    else atomicAdd(P.dw2 + sh + (t - NP - 1) * P.w2s, val);
+  }
   const float inv_d = 1.f / (float)(cl4 * 4);
-  const float m1 = block_sum<BS / 64>(s1, red) * inv_d;
-  const float m2 = block_sum<BS / 64>(s2, red) * inv_d;
+  float m1 = red[0], m2 = red[NWV];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) {
+    m1 += red[w];
+    m2 += red[NWV + w];
+  }
+  m1 *= inv_d;
+  m2 *= inv_d;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int r = threadIdx.x + k * BS;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(BS) void cat_ln_bwd_k(const float* __restrict__ g, 
                                                     float* dresid, uint32_t acc_mask, float* dln_w,
                                                     float* dln_b, int cl4, int d4, int relu,
                                                     float* __restrict__ scrub, int64_t scrub4) {
-  __shared__ float red[8];
+  __shared__ float red[2 * (BS / 64)];
   const int s = blockIdx.x;
   // side job: clear the caller's accumulation arena (saves a memset launch per backward)
   for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < scrub4; i += (int64_t)gridDim.x * BS)
@@ -173,8 +173,23 @@ __global__ __launch_bounds__(BS) void cat_ln_bwd_k(const float* __restrict__ g, 
     }
   }
   const float inv_d = 1.f / (float)(d4 * 4);
-  const float m1 = block_sum<BS / 64>(s1, red) * inv_d;
-  const float m2 = block_sum<BS / 64>(s2, red) * inv_d;
+  // both sums behind ONE barrier (two block_sum calls were four; `red` is written once per launch)
+  constexpr int NWV = BS / 64;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = s1;
+    red[NWV + (threadIdx.x >> 6)] = s2;
+  }
+  __syncthreads();
+  float m1 = red[0], m2 = red[NWV];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) {
+    m1 += red[w];
+    m2 += red[NWV + w];
+  }
+  m1 *= inv_d;
+  m2 *= inv_d;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int i = threadIdx.x + k * BS;
