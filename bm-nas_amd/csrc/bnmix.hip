@@ -228,7 +228,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
     }
   }
   const float inv_d = 1.f / (float)(cl4 * 4);
-  const float mean = block_sum<BS / 64>(sum, red) * inv_d;
+  const float mean = block_sum_fresh<BS / 64>(sum, red) * inv_d;     // (first use of red: no barrier in front)
   // second pass: the centred second moment and — same reduction round — what the per-sample sums of
   // the OUTPUT o = c * rstd * w + b (c = v - mean) need:  sum o = rstd * S(c w) + S(b),
   // sum o^2 = rstd^2 * S(c^2 w^2) + 2 rstd * S(c w b) + S(b^2)   (for the head's K7 LayerNorm)
@@ -250,9 +250,9 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
     }
   }
   if (osum != nullptr) {
-    block_sum_lead<BS / 64, 6>(acc, red6);
+    block_sum_lead_fresh<BS / 64, 6>(acc, red6);
   } else {
-    acc[0] = block_sum<BS / 64>(acc[0], red);
+    acc[0] = block_sum_fresh<BS / 64>(acc[0], red6);        // (red6, not red: threads may still be reading the mean)
   }
   const float var = acc[0] * inv_d;
   const float rstd = 1.f / sqrtf(var + kEps);
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
     }
   }
   const float inv_d = 1.f / (float)(cl4 * 4);
-  const float mean = block_sum<BS / 64>(sum, red) * inv_d;
+  const float mean = block_sum_fresh<BS / 64>(sum, red) * inv_d;     // (first use of red: no barrier in front)
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // see node_mix_ln_fwd_k
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
@@ -910,9 +910,9 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
     }
   }
   if (osum != nullptr) {
-    block_sum_lead<BS / 64, 6>(acc, red6);
+    block_sum_lead_fresh<BS / 64, 6>(acc, red6);
   } else {
-    acc[0] = block_sum<BS / 64>(acc[0], red);
+    acc[0] = block_sum_fresh<BS / 64>(acc[0], red6);        // (red6, not red: threads may still be reading the mean)
   }
   const float var = acc[0] * inv_d;
   const float rstd = 1.f / sqrtf(var + kEps);

@@ -198,6 +198,45 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// The same without the barrier in FRONT of the LDS writes, for an array that no thread can still be reading: one
+// that this launch has not used yet, or whose last readers are separated from this call by a barrier.  (A kernel with
+// two dependent reductions — mean, then centred moments — pays two barriers instead of four with two arrays.)
+template <int NW>
+__device__ __forceinline__ float block_sum_fresh(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t += red[i];
+  return t;
+}
+
+template <int NW, int N>
+__device__ __forceinline__ void block_sum_lead_fresh(float (&v)[N], float* red) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[i * NW + w] = v[i];
+  }
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) t += red[k];
+  v[0] = t;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+      float u = red[i * NW];
+#pragma unroll
+      for (int k = 1; k < NW; ++k) u += red[i * NW + k];
+      v[i] = u;
+    }
+  }
+}
+
 // N sums at once over a block of NW waves (red must hold >= NW * N floats); every thread gets all N.
 template <int NW, int N>
 __device__ __forceinline__ void block_sum_n(float (&v)[N], float* red) {

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
     }
   }
   const float inv_d = 1.f / (float)(d4 * 4);
-  const float mean = block_sum<BS / 64>(sum, red) * inv_d;
+  const float mean = block_sum_fresh<BS / 64>(sum, red) * inv_d;     // (first use of red: no barrier in front)
   // second pass: the centred second moment and — same reduction round, when asked for — what the
   // per-sample sums of the OUTPUT need (see node_mix_ln_fwd_k; without ReLU only)
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -75,9 +75,9 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
     }
   }
   if (sums) {
-    block_sum_lead<BS / 64, 6>(acc, red6);
+    block_sum_lead_fresh<BS / 64, 6>(acc, red6);
   } else {
-    acc[0] = block_sum<BS / 64>(acc[0], red);
+    acc[0] = block_sum_fresh<BS / 64>(acc[0], red6);         // (red6, not red: threads may still be reading the mean)
   }
   const float var = acc[0] * inv_d;
   const float rstd = 1.f / sqrtf(var + kEps);
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
   }
   // with ReLU the sums cannot be derived from the moments: reduce the outputs themselves
   if (osum != nullptr && relu) {
-    os = block_sum<BS / 64>(os, red);
-    oq = block_sum<BS / 64>(oq, red);
+    os = block_sum_fresh<BS / 64>(os, red);                  // (red's readers all passed the second reduction's barrier)
+    oq = block_sum<BS / 64>(oq, red6);
     if (threadIdx.x == 0) {
       osum[2 * s] = os;
       osum[2 * s + 1] = oq;
