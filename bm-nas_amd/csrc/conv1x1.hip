@@ -436,23 +436,26 @@ constexpr int kPipeJ = 96;
 // epilogue — bias, store, BatchNorm statistics of the COMPLETE output, no atomics on it.  For long contractions on few
 // tiles (the reshape layers of NTU / Ego at 64 / 48 samples: K = 2048 on 32 tiles per layer was a chain of 64 chunk
 // steps per workgroup with most of the CU idle).
-template <int KC, int NG, int NQ = 1>
+// JT = 16-column output tiles per wave along j: the workgroup tile is 16 NG (n) x 32 JT (j) — 96 wide by default; 64 / 32
+// for the grouped reshape layers whose width is no multiple of 96, or whose contraction is long (more, smaller tiles).
+template <int KC, int NG, int NQ = 1, int JT = 3>
 __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int bx, const int by,
                                                    float* __restrict__ smem0) {
   constexpr int KP = KC + 4;
+  constexpr int PJ = 32 * JT;                                   // tile width (kPipeJ = 96 for JT = 3)
   constexpr int TNC = 16 * NG, WN = NG / 2;                    // tile columns, n-groups per wave
-  constexpr int A4 = TNC * KC / 4, B4 = kPipeJ * KC / 4;       // float4 per chunk
+  constexpr int A4 = TNC * KC / 4, B4 = PJ * KC / 4;       // float4 per chunk
   constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
   // activation rows (one channel of one sample: L floats) are padded to L + 4 in LDS: the four
   // k-slots of a wave then read rows 4 apart on different banks (unpadded: 2-way conflict)
   const int ABUF = ((TNC * KC) >> a.Lb) * (a.L + 4);
-  const int BUF = ABUF + kPipeJ * KP;                   // floats per buffer
+  const int BUF = ABUF + PJ * KP;                   // floats per buffer
   const int quad = NQ > 1 ? (int)(threadIdx.x >> 8) : 0;
   float* __restrict__ smem = smem0 + quad * 2 * BUF;
   const int t = NQ > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
   const int wave = t >> 6, lane = t & 63, lo = lane & 15, h = lane >> 4;
   const int spt = TNC >> a.Lb;                                  // samples per tile
-  const int s0 = bx * spt, j0 = by * kPipeJ;
+  const int s0 = bx * spt, j0 = by * PJ;
   const int K = a.I;
   const int cl4 = (KC << a.Lb) >> 2;                           // float4 per sample per chunk
   const float* __restrict__ act = a.act.p[0];
@@ -505,24 +508,24 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
       if (((NA + i) * nkb) / (NA + NB) == kb && t + 256 * i < B4) st4(buf + bsl[i], R.rb[i]);
   };
 
-  const int gl0 = WN * (wave & 1), jl0 = 3 * (wave >> 1);
-  int aoff[WN], boff[3];
+  const int gl0 = WN * (wave & 1), jl0 = JT * (wave >> 1);
+  int aoff[WN], boff[JT];
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn)
     aoff[tn] = ((gl0 + tn) * a.spw + (lo >> a.Lb)) * KC * (a.L + 4) + (lo & (a.L - 1));
 #pragma unroll
-  for (int tj = 0; tj < 3; ++tj) boff[tj] = ABUF + ((jl0 + tj) * 16 + lo) * KP + 4 * h;
-  f32x4 acc[WN][3];
+  for (int tj = 0; tj < JT; ++tj) boff[tj] = ABUF + ((jl0 + tj) * 16 + lo) * KP + 4 * h;
+  f32x4 acc[WN][JT];
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
-    for (int tj = 0; tj < 3; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tj = 0; tj < JT; ++tj) acc[tn][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // the epilogue's bias values go out with the first operand loads: fetched where they are used, each
   // output tile ended in load -> s_waitcnt vmcnt(0) -> store, three dependent round trips per wave
-  float bjv[3];
+  float bjv[JT];
 #pragma unroll
-  for (int tj = 0; tj < 3; ++tj) {
+  for (int tj = 0; tj < JT; ++tj) {
     const int jt = j0 + 16 * (jl0 + tj);
     bjv[tj] = (a.bias != nullptr) ? a.bias[(jt < a.J ? jt : a.J - 16) + lo] : 0.f;
   }
@@ -531,7 +534,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
   auto compute = [&](const float* cur, float* nxt = nullptr, const Regs* Rn = nullptr) __attribute__((always_inline)) {
     constexpr int NKB = KC / 16;
     float av[NKB][WN][4];
-    float4 bv[NKB][3];
+    float4 bv[NKB][JT];
     auto rd = [&](int kb) __attribute__((always_inline)) {
       const int c0 = 16 * kb + 4 * h;
 #pragma unroll
@@ -539,7 +542,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) av[kb][tn][r] = cur[aoff[tn] + (c0 + r) * (a.L + 4)];
 #pragma unroll
-      for (int tj = 0; tj < 3; ++tj) bv[kb][tj] = ld4(cur + boff[tj] + 16 * kb);
+      for (int tj = 0; tj < JT; ++tj) bv[kb][tj] = ld4(cur + boff[tj] + 16 * kb);
     };
     rd(0);
 #pragma unroll
@@ -550,7 +553,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
-        for (int tj = 0; tj < 3; ++tj) {
+        for (int tj = 0; tj < JT; ++tj) {
           acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][0], bv[kb][tj].x, acc[tn][tj], 0, 0, 0);
           acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][1], bv[kb][tj].y, acc[tn][tj], 0, 0, 0);
           acc[tn][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][tn][2], bv[kb][tj].z, acc[tn][tj], 0, 0, 0);
@@ -596,14 +599,14 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     // the quads' partial tiles: quads 1 .. NQ - 1 park theirs in quad 0's (now idle) operand buffers — the quads run in
     // lockstep (same chunk count, same barriers), so behind this barrier nobody reads operands any more
     __syncthreads();
-    float* red = smem0;                                         // [NQ - 1][WN * 3 * 4][256]
+    float* red = smem0;                                         // [NQ - 1][WN * JT * 4][256]
     if (quad > 0) {
 #pragma unroll
       for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
-        for (int tj = 0; tj < 3; ++tj)
+        for (int tj = 0; tj < JT; ++tj)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[(((quad - 1) * WN * 3 + tn * 3 + tj) * 4 + r) * 256 + t] = acc[tn][tj][r];
+          for (int r = 0; r < 4; ++r) red[(((quad - 1) * WN * JT + tn * JT + tj) * 4 + r) * 256 + t] = acc[tn][tj][r];
     }
     __syncthreads();
     if (quad == 0) {
@@ -612,20 +615,22 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
 #pragma unroll
         for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
-          for (int tj = 0; tj < 3; ++tj)
+          for (int tj = 0; tj < JT; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tn][tj][r] += red[(((q - 1) * WN * 3 + tn * 3 + tj) * 4 + r) * 256 + t];
+            for (int r = 0; r < 4; ++r) acc[tn][tj][r] += red[(((q - 1) * WN * JT + tn * JT + tj) * 4 + r) * 256 + t];
     }
     __syncthreads();                                            // (the statistics exchange below reuses smem0)
   }
   const bool lead = NQ == 1 || quad == 0;                       // the quad that owns the epilogue
   // epilogue: acc[tn][tj][r] = OUT[n = 16*g + 4h + r][j = jt + lo]
   const int l0 = (4 * h) & (a.L - 1);
-  float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};    // stat mode: this wave's n-groups together
+  float ssum[JT], ssq[JT];                                      // stat mode: this wave's n-groups together
+#pragma unroll
+  for (int tj = 0; tj < JT; ++tj) ssum[tj] = ssq[tj] = 0.f;
 #pragma unroll
   for (int tn = 0; tn < WN; ++tn)
 #pragma unroll
-    for (int tj = 0; tj < 3; ++tj) {
+    for (int tj = 0; tj < JT; ++tj) {
       const int g = bx * NG + gl0 + tn, jt = j0 + 16 * (jl0 + tj);
       if (g >= a.n_groups || jt >= a.J || !lead) continue;     // wave-uniform
       const int jj = jt + lo;
@@ -648,9 +653,9 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     // their sums to waves 0 and 2, which own the same channels, through the idle operand buffer.
     // Same-address atomics serialise at the memory side: halving them again lets half as many shard
     // copies do (the kernel that finalises the statistics reads every shard of every channel).
-    float2* xch = reinterpret_cast<float2*>(smem0);              // [2][3][16]
+    float2* xch = reinterpret_cast<float2*>(smem0);              // [2][JT][16]
 #pragma unroll
-    for (int tj = 0; tj < 3; ++tj) {
+    for (int tj = 0; tj < JT; ++tj) {
       ssum[tj] = xor16_sum(ssum[tj]);
       ssum[tj] = xor32_sum(ssum[tj]);
       ssq[tj] = xor16_sum(ssq[tj]);
@@ -659,15 +664,15 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
     __syncthreads();                                           // every wave is done reading operands
     if (lead && (wave & 1) && h == 0) {
 #pragma unroll
-      for (int tj = 0; tj < 3; ++tj) xch[((wave >> 1) * 3 + tj) * 16 + lo] = make_float2(ssum[tj], ssq[tj]);
+      for (int tj = 0; tj < JT; ++tj) xch[((wave >> 1) * JT + tj) * 16 + lo] = make_float2(ssum[tj], ssq[tj]);
     }
     __syncthreads();
     if (lead && !(wave & 1) && h == 0) {
 #pragma unroll
-      for (int tj = 0; tj < 3; ++tj) {
+      for (int tj = 0; tj < JT; ++tj) {
         const int jt = j0 + 16 * (jl0 + tj);
         if (jt >= a.J) continue;
-        const float2 p = xch[((wave >> 1) * 3 + tj) * 16 + lo];
+        const float2 p = xch[((wave >> 1) * JT + tj) * 16 + lo];
         float* pp = a.stat + ((int64_t)(bx % a.stat_shards) * a.J + jt + lo) * 2;
         atomicAdd(pp, ssum[tj] + p.x);
         atomicAdd(pp + 1, ssq[tj] + p.y);
@@ -953,9 +958,9 @@ inline size_t conv_pipe_bwd_lds(int L) {
   return (size_t)2 * (16 * NG * KC / L * (L + 4) + KC * (kPipeBJ + 4)) * sizeof(float);
 }
 
-template <int KC, int NG>
+template <int KC, int NG, int JT = 3>
 inline size_t conv_pipe_lds(int L) {
-  return (size_t)2 * (16 * NG * KC / L * (L + 4) + kPipeJ * (KC + 4)) * sizeof(float);
+  return (size_t)2 * (16 * NG * KC / L * (L + 4) + 32 * JT * (KC + 4)) * sizeof(float);
 }
 
 // ---- GEMM + attention in one launch ---------------------------------------------------------
@@ -1633,7 +1638,10 @@ __global__ __launch_bounds__(256 * NQ) void conv_fwd_group_q_k(ConvFwdGroup G) {
   const int p = group_problem(G.start, G.n);
   const ConvArgs a = uni(pick_uniform(G.a, p));
   const int t = blockIdx.x - uni(pick_uniform(G.start, p)), gx = uni(pick_uniform(G.gx, p));
-  conv_pipe_fwd_body<32, 2, NQ>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+  const int kind = uni(pick_uniform(G.kind, p));               // here: 0 / 2 / 3 = tiles 96 / 64 / 32 columns wide
+  if (kind == 0) conv_pipe_fwd_body<32, 2, NQ, 3>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+  else if (kind == 2) conv_pipe_fwd_body<32, 2, NQ, 2>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+  else conv_pipe_fwd_body<32, 2, NQ, 1>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
 }
 
 // backward of the group: every layer's weight-gradient tiles (first: they walk many n-groups each), then every
@@ -2341,25 +2349,45 @@ extern "C" int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
       return v;
     }();
-    // (measured, NTU b64 / Ego b48: 1 quad 53.4 / 53.6 us, 2 quads 39.7 / 40.2, 4 quads 39.0 / 38.8 — the longest tiles
-    // are then bound by their CU's matrix pipe, 21.8 us for a 32 x 96 x 2048 tile, not by the chain; 2 is the default:
-    // no spills, half the LDS.  BMNAS_FWD_GROUP_QUADS = 1 / 4 for the table)
-    static const int quad_mode = [] { const char* e = getenv("BMNAS_FWD_GROUP_QUADS"); return e ? atoi(e) : 2; }();
+    // (measured, NTU b64 / Ego b48, us — 96-column tiles: 1 quad 53.4 / 53.6, 2 quads 39.7 / 40.2, 4 quads 39.0 / 38.8:
+    // the longest tiles are then bound by their CU's matrix pipe, 21.8 us for a 32 x 96 x 2048 tile; with the narrow
+    // tiles below: 2 quads 22.3 / 31.2, 4 quads 20.1 / 27.5.  BMNAS_FWD_GROUP_QUADS = 1 / 2 for the table)
+    static const int quad_mode = [] { const char* e = getenv("BMNAS_FWD_GROUP_QUADS"); return e ? atoi(e) : 4; }();
     quads = std::min(quads, quad_mode);
-    const size_t pipe_lds = conv_pipe_lds<32, 2>(L);
+    size_t pipe_lds = conv_pipe_lds<32, 2>(L);
     while (quads > 1 && pipe_lds * quads > (size_t)lds_max) quads >>= 1;
     if (all_pipe && max_chunks >= 32 && blocks <= 320 && quads > 1) {
+      // Tile width per layer.  A width that is no multiple of 96 (NTU / Ego: 128) wastes two thirds of its ragged
+      // tile's MFMAs, and a 32 x 96 x 2048 tile keeps ONE CU's matrix pipe busy for 21.8 us while most CUs idle:
+      // 64-column tiles where 96 does not divide the width, 32-column tiles for the long contractions (4x the
+      // tiles, a quarter of the work each).  BMNAS_FWD_GROUP_NARROW=0: 96-column tiles only (the table in DESIGN.md).
+      static const int narrow = [] { const char* e = getenv("BMNAS_FWD_GROUP_NARROW"); return e ? atoi(e) : 1; }();
+      ConvFwdGroup Gq = G;                                       // (G itself stays as the plain kernel wants it)
+      int qblocks = 0;
+      pipe_lds = 0;
+      for (int q = 0; q < n; ++q) {
+        const int nc = G.a[q].I / 32, pgx = (G.a[q].n_groups + 1) / 2;
+        int jt = 3;
+        if (narrow && M % 96 != 0) jt = (nc >= 32 && M % 32 == 0) ? 1 : (M % 64 == 0 ? 2 : 3);
+        Gq.kind[q] = jt == 3 ? 0 : (jt == 2 ? 2 : 3);
+        Gq.start[q] = qblocks;
+        Gq.gx[q] = pgx;
+        qblocks += pgx * ((M + 32 * jt - 1) / (32 * jt));
+        pipe_lds = std::max(pipe_lds, jt == 3 ? conv_pipe_lds<32, 2, 3>(L)
+                                              : (jt == 2 ? conv_pipe_lds<32, 2, 2>(L) : conv_pipe_lds<32, 2, 1>(L)));
+      }
+      Gq.start[n] = qblocks;
       hipError_t err = hipSuccess;
       if (quads == 4) {
         static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_group_q_k<4>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         (void)attr4;
-        hipLaunchKernelGGL(conv_fwd_group_q_k<4>, dim3((unsigned)blocks), dim3(1024), pipe_lds * 4, (hipStream_t)stream, G);
+        hipLaunchKernelGGL(conv_fwd_group_q_k<4>, dim3((unsigned)qblocks), dim3(1024), pipe_lds * 4, (hipStream_t)stream, Gq);
       } else {
         static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_group_q_k<2>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         (void)attr2;
-        hipLaunchKernelGGL(conv_fwd_group_q_k<2>, dim3((unsigned)blocks), dim3(512), pipe_lds * 2, (hipStream_t)stream, G);
+        hipLaunchKernelGGL(conv_fwd_group_q_k<2>, dim3((unsigned)qblocks), dim3(512), pipe_lds * 2, (hipStream_t)stream, Gq);
       }
       err = hipGetLastError();
       if (err == hipSuccess) {
