@@ -279,9 +279,6 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
   const int lo = lane & 15, h = lane >> 4;
   const int chunk = blockIdx.y, s0 = chunk * kRows;
   STAMP(5, blockIdx.y * gridDim.x + blockIdx.x, 0);
-  for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < a.scrub4;
-       i += (long long)gridDim.x * gridDim.y * 256)
-    st4(a.scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   const float gs = (a.gscale != nullptr) ? a.gscale[0] : 1.f;
   const float invD = 1.f / (float)a.D;
   // ---- the tile's operand loads (independent of everything the prologue computes)
@@ -350,6 +347,13 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
       nd_mean[g] = LZ ? nstq[2 * spc] : 0.f;
       nd_rstd[g] = LZ ? nstq[2 * spc + 1] : 1.f;
     }
+    // the side job (zero-fill of the caller's accumulation arena) AFTER every load of the kernel has been issued: at
+    // the top it stood — with an argument-block fetch and a dependent scalar load of its own — in front of them
+    __builtin_amdgcn_sched_barrier(0);
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < a.scrub4;
+         i += (long long)gridDim.x * gridDim.y * 256)
+      st4(a.scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    __builtin_amdgcn_sched_barrier(0);
     float loss_acc = 0.f;
 #pragma unroll
     for (int g = 0; g < SG; ++g) {
