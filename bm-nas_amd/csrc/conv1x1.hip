@@ -2377,7 +2377,10 @@ extern "C" int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n
                                               : (jt == 2 ? conv_pipe_lds<32, 2, 2>(L) : conv_pipe_lds<32, 2, 1>(L)));
       }
       Gq.start[n] = qblocks;
-      hipError_t err = hipSuccess;
+      // (a stale error of an earlier call must not read as a refused launch: the plain kernel would then run ON TOP
+      // of this one and add the BatchNorm sums twice)
+      hipError_t err = hipGetLastError();
+      if (err != hipSuccess) return (int)err;
       if (quads == 4) {
         static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_group_q_k<4>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
