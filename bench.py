@@ -13,9 +13,13 @@ in HBM before the timed region.  With N > 1 every rank processes its own 128-sam
 (weak scaling, configs[2] = 1024 over 8 GPUs) and the timed step also averages the weight
 and architecture gradients with one flat RCCL all-reduce each; value = N*K / max-rank time.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, live HIP-event
-timing in an instrumented eager pass of the same steps), "roofline_kernels" (all kernels),
-"cpu_baseline" (the CPU oracle — a port of the reference — timed on this host's cores).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel: launch-inclusive device
+durations from a rocprofv3 kernel trace of the hipGraph replay, taken by a child process of this script
+after the timed regions), "roofline_kernels" (every kernel of the step), "k1" (the cell-level mixed sums
+under SURVEY.md 8(d)'s literal bytes), "full_search_step" (w-step, alpha-step and the dev phase's metric
+forward as replays), "cpu_baseline" (the CPU oracle — a port of the reference — timed on this host's
+cores); under N > 1 "rccl" (what the collective saw) and "dp_cost" (compute-only step, exposed all-reduce,
+the efficiency bound it implies).
 """
 import argparse
 import json
@@ -268,15 +272,38 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     ms_pair = timed(pair, pairs)
     ms_w = timed(lambda: gw(xs, y), pairs)
     ms_a = timed(lambda: ga(xv, yv), pairs)
+    # what the batch copy into the graph's static tensors costs: the same replay handed its own static tensors
+    # (GraphedTrainStep.static_batch(): a producer that writes the batch there skips the copy launch)
+    sx, sy = gw.static_batch()
+    ms_w_nocopy = timed(lambda: gw(sx, sy), pairs)
     # the dev phase's metric pass (a gradient-free forward after every architect.step, train mode): one replay
     ms_f = None
     from bmnas.graph import GraphedForward
     gf = GraphedForward.try_build(model, crit, xv, yv)
     if gf:
         ms_f = round(timed(lambda: gf(xv, yv), pairs), 4)
+    # round 5: the architecture step and that metric forward as ONE replay over one copy of the batch (what the trainer
+    # loop runs in the dev phase, models/search/darts/architect.py) -> the loop's cost per (train batch, dev batch)
+    ms_am = ms_loop = None
+    if world == 1:
+        try:
+            gam = GraphedTrainStep(model, crit, a_opt, xv, yv, metric_forward=True)
+            ms_am = round(timed(lambda: gam(xv, yv), pairs), 4)
+
+            def loop_pair():
+                for g in w_opt.param_groups:
+                    g['lr'] *= 0.999
+                gw(xs, y)
+                gam(xv, yv)
+            ms_loop = round(timed(loop_pair, pairs), 4)
+        except Exception as e:                                   # noqa: BLE001
+            log(f'merged alpha + metric step not captured: {type(e).__name__}: {e}')
     log(f'full search step: {ms_pair:.4f} ms per (w-step + alpha-step) pair')
     return {'ms_per_pair': round(ms_pair, 4), 'w_step_ms': round(ms_w, 4), 'alpha_step_ms': round(ms_a, 4),
-            'metric_forward_ms': ms_f,
+            'metric_forward_ms': ms_f, 'alpha_step_with_metric_forward_ms': ms_am,
+            'loop_ms_per_train_dev_batch_pair': ms_loop,
+            'w_step_without_input_copy_ms': round(ms_w_nocopy, 4),
+            'input_copy_us': round((ms_w - ms_w_nocopy) * 1e3, 1),
             'pairs_per_s': round(world * 1e3 / ms_pair, 1), 'pairs_timed': pairs,
             'includes': 'w-step: fwd + criterion + bwd (weights, arch and input grads) + Adam(w, wd 1e-4); '
                         'alpha-step: the same with Adam(alpha/beta/gamma, betas (0.5, 0.999), wd 1e-3); '
@@ -1247,6 +1274,12 @@ def main():
     first = 'single' if world == 1 else ('host' if a.mode == 'graph' else 'eager')
     shapes[first] = times
     best = first
+    # N > 1: the same replay WITHOUT its collective (no rank waits for another: no barrier semantics needed beyond
+    # measure()'s own) — what the all-reduce costs on top is then a difference of two measured numbers, not a model
+    compute_only = None
+    if (world > 1 or a.dp_selftest) and a.mode == 'graph':
+        compute_only = statistics.median(measure(run_local, 3)) / a.steps * 1e3
+        log(f'compute only (no all-reduce): {compute_only:.4f} ms/step')
 
     rccl = None
     guard = None
@@ -1307,6 +1340,26 @@ def main():
     result = headline(a, c, world, shapes, best, eager_ms, rccl)
     dt = statistics.median(shapes[best])
     log(f'timed region done: {dt / a.steps * 1e3:.4f} ms/step')
+    if compute_only is not None and rccl is not None:
+        # what the exchange step costs and what that allows (the driver computes the scaling
+        # efficiency itself from the per-N values — these are the ingredients, measured in this run)
+        step_ms = dt / a.steps * 1e3
+        ar = rccl.get('allreduce_us', {})
+        ar_us = ar.get('c_abi', ar.get('torch_distributed'))
+        exposed_us = max(0.0, (step_ms - compute_only) * 1e3)
+        result['dp_cost'] = {
+            'bucket': 'weights + alpha/beta/gamma in ONE flat fp32 bucket (the headline step differentiates both); the '
+                      'trainers reduce per phase: the w-step its optimizer\'s tensors only, the alpha-step the 42-94 '
+                      'architecture floats alone (bmnas.dist.attach(optimizer))',
+            'bucket_bytes': rccl.get('allreduce_bytes'),
+            'compute_only_ms_per_step': round(compute_only, 4),
+            'step_ms_per_step': round(step_ms, 4),
+            'allreduce_alone_us': ar_us,
+            'allreduce_share_of_step': None if ar_us is None else round(ar_us / (step_ms * 1e3), 3),
+            'exposed_us_per_step': round(exposed_us, 1),
+            'weak_scaling_efficiency_vs_compute_only': round(compute_only / step_ms, 3),
+            'speedup_bound_over_one_gpu': round(world * compute_only / step_ms, 2),
+            'exposed_us_allowed_for_6x_at_8_gpus': round((8.0 / 6.0 - 1.0) * compute_only * 1e3, 1)}
     if world == 1 and a.mode == 'graph' and not a.no_full_step and not a.dp_selftest:
         # NOT the headline (one step per replay, above): what the ~8 us between two replays of a graph are worth,
         # measured by capturing FOUR consecutive steps into one graph (same kernels, same batch, fresh dropout masks

@@ -99,6 +99,43 @@ class _DropState:
 DROP = _DropState()
 
 
+# ---- debug: |mean| / std of every BatchNorm input (BMNAS_BN_RATIO_CHECK=1) ---------------------------------------
+# The batch statistics are one-pass sums of d = u - bias and d^2: the forward error follows
+# ~2 eps r^2 with r = |E[d]| / std(d), pinned to r ~ 27 for the 1e-4 parity bound (tests/test_numerics_gpu.py).  Real
+# pre-BatchNorm activations sit at r ~ 1-3, but nothing at run time noticed a layer far outside — the reshape layers
+# see post-ReLU backbone features with up to 2048 input channels.  With the switch on, every training-mode BatchNorm of
+# the path is noted when launched and evaluated at the next note / bn_ratio_report(): one extra reduction and a host
+# read per layer (a debug mode: never inside a hipGraph capture, where nothing can be read back).
+BN_RATIO_CHECK = os.environ.get('BMNAS_BN_RATIO_CHECK', '0') not in ('0', '', 'false', 'False')
+BN_RATIO_WARN = 20.0
+BN_RATIOS = {}                  # where -> the largest r seen
+_BN_PENDING = []
+
+
+def bn_ratio_note(chan, bias, M, where, training=True):
+    if not BN_RATIO_CHECK or not training or torch.cuda.is_current_stream_capturing():
+        return
+    bn_ratio_report()
+    _BN_PENDING.append((chan, bias, M, where))
+
+
+def bn_ratio_report():
+    """Evaluate the noted layers (their `chan` = mean | rstd | scale | shift is complete once the kernel that applies the
+    BatchNorm has run — it has, by the time the next layer is noted) -> {where: r}; warns above BN_RATIO_WARN."""
+    import warnings
+    while _BN_PENDING:
+        chan, bias, M, where = _BN_PENDING.pop(0)
+        mean, rstd = chan[:M], chan[M:2 * M]
+        d = mean if bias is None else mean - bias.reshape(-1)[:M]
+        r = float((d.abs() * rstd).max())
+        BN_RATIOS[where] = max(BN_RATIOS.get(where, 0.0), r)
+        if r > BN_RATIO_WARN:
+            warnings.warn(f'bmnas: BatchNorm input of {where}: |mean| / std = {r:.1f} > {BN_RATIO_WARN:g} — the one-pass '
+                          f'batch variance loses ~{2.5e-7 * r * r:.1e} of relative precision here (DESIGN.md section 1)',
+                          RuntimeWarning)
+    return dict(BN_RATIOS)
+
+
 def _empty(like, *shape):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
@@ -293,6 +330,7 @@ def conv_bn_fwd(srcs, C_src, W, ldw, bias, bn_w, bn_b, rm, rv, nbt, training, du
         lib.bn_finalize(part, n_part, b, L, M, bn_w, bn_b, rm, rv, nbt, training, chan)
     sv.srcs, sv.C_src, sv.W, sv.ldw, sv.U, sv.chan, sv.M = list(srcs), C_src, W, ldw, U, chan, M
     sv.training, sv.dup, sv.fold = training, dup, fold
+    bn_ratio_note(chan, bias, M, f'conv {len(srcs)}x{C_src}->{M}', training)
     return U, chan, sv
 
 
@@ -642,6 +680,7 @@ def _mix_conv_fwd(pending, tail, C, Wo, ldw, NP, training, stats):
     sv.fin = lib.make_bn_fin(part, shards, NP.out_conv_b, NP.bn_w, NP.bn_b, NP.bn_rm, NP.bn_rv, NP.bn_nbt, training)
     sv.srcs, sv.C_src, sv.W, sv.ldw, sv.U, sv.chan, sv.M = list(tail), C, Wo, ldw, V, _empty(x, 4 * C), C
     sv.training, sv.dup, sv.fold = training, 0, 0
+    bn_ratio_note(sv.chan, NP.out_conv_b, C, f'out_conv {len(tail)}x{C}->{C}', training)
     return V, sv.chan, sv
 
 
@@ -890,9 +929,11 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
         if M > S:
             raise lib.BmnasError('fused head: the cell concatenates input states (multiplier > steps)')
         head.sums = [nsv.osum for nsv in sv.nodes[S - M:]]
-        if DETERMINISTIC and not sv.lazy_on:
-            raise lib.BmnasError('BMNAS_DETERMINISTIC covers the search cell with node_multiplier == 1 under the fused '
-                                 'head (the lazy-LayerNorm path); this configuration is outside it')
+        if DETERMINISTIC and (not sv.lazy_on or ns != 1):
+            # (node_steps >= 2: the inner steps t < ns - 1 run bmnas_node_mix_bwd, whose BatchNorm-affine / dgamma
+            # reductions are atomics from many workgroups — refused rather than silently non-reproducible)
+            raise lib.BmnasError('BMNAS_DETERMINISTIC covers the search cell with node_steps == 1 and node_multiplier '
+                                 '== 1 under the fused head (the lazy-LayerNorm path); this configuration is outside it')
         last = sv.nodes[-1].lazy if sv.lazy_on else None
         if last is not None and not last.materialised:
             # the last node's output exists only inside the classifier GEMM's operand fetch

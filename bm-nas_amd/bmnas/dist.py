@@ -87,10 +87,22 @@ class NativeComm:
         from . import lib
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        uid = [lib.comm_get_unique_id() if self.rank == 0 else None]
+        self.comm = None
+        # Rank 0 ALWAYS reaches the broadcast: it ships the unique id or, when librccl cannot be bound /
+        # ncclGetUniqueId fails, an error sentinel — so the other ranks, which are waiting in the same broadcast, get
+        # an answer and every rank raises together instead of being left in a collective nobody else will enter.
+        msg = [None]
+        if self.rank == 0:
+            try:
+                msg[0] = ('uid', lib.comm_get_unique_id())
+            except Exception as e:                          # noqa: BLE001
+                msg[0] = ('error', f'{type(e).__name__}: {e}')
         if self.world > 1:
-            dist.broadcast_object_list(uid, src=0, group=group)
-        self.comm = lib.comm_init_rank(self.world, self.rank, uid[0])
+            dist.broadcast_object_list(msg, src=0, group=group)
+        kind, payload = msg[0]
+        if kind != 'uid':
+            raise RuntimeError(f'rank 0 could not create the RCCL unique id ({payload})')
+        self.comm = lib.comm_init_rank(self.world, self.rank, payload)
         # the first collective on a communicator sets up its channels (host-side handshakes between ranks):
         # do it here, where every rank is known to be present, not inside somebody's stream capture
         warm = torch.ones(1, device='cuda')
@@ -210,15 +222,24 @@ class FlatGradAllReducer:
             elif native_rccl_enabled() and dev.type == 'cuda' and dist.get_backend(self.group) == 'nccl':
                 # collective init, here rather than inside a capture; a rank that cannot bind librccl / create the
                 # communicator takes every rank back to the host-issued plan (all ranks agree, or none goes native)
-                ok = True
+                # Decide locally and AGREE FIRST: whether librccl binds at all is a per-rank fact; a rank
+                # where it does not must not leave the others inside the unique-id broadcast.  Only when every rank
+                # can bind the library does anybody enter the rendezvous; its outcome is agreed on again.
+                from . import lib
                 try:
-                    with _Watchdog('the C-ABI RCCL communicator (ncclCommInitRank)'):
-                        NativeComm.get(self.group)
-                except Exception as e:                      # noqa: BLE001
-                    import warnings
-                    warnings.warn(f'bmnas.dist: C-ABI RCCL communicator unavailable ({type(e).__name__}: {e}); '
-                                  'host-issued all-reduce', RuntimeWarning)
-                    ok = False
+                    can = bool(lib.comm_available())
+                except Exception:                           # noqa: BLE001
+                    can = False
+                ok = all_ranks_agree(can, dev, self.group)
+                if ok:
+                    try:
+                        with _Watchdog('the C-ABI RCCL communicator (ncclCommInitRank)'):
+                            NativeComm.get(self.group)
+                    except Exception as e:                  # noqa: BLE001
+                        import warnings
+                        warnings.warn(f'bmnas.dist: C-ABI RCCL communicator unavailable ({type(e).__name__}: {e}); '
+                                      'host-issued all-reduce', RuntimeWarning)
+                        ok = False
                 if all_ranks_agree(ok, dev, self.group):
                     self._plan = 'native'
                 else:

@@ -389,6 +389,8 @@ class ReshapeGroupFn(Function):
                                 buffers[i][0], buffers[i][1], buffers[i][2], training) for i in range(n)]
         lib.bn_relu_fwd_group(Us, chans, outs, fins, drops, b, M, L)
         ctx.n, ctx.xs, ctx.Ws, ctx.Us, ctx.chans, ctx.drops, ctx.training = n, xs, Ws, Us, chans, drops, training
+        for i in range(n):
+            K.bn_ratio_note(chans[i], cbs[i], M, f'reshape layer {i} ({Ws[i].shape[1]}->{M})', training)
         ctx.wshapes = [tuple(w.shape) for w, _, _, _ in prm]
         return tuple(outs)
 

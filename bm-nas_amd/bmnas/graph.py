@@ -126,7 +126,12 @@ class GraphedTrainStep:
                     pass
         return n
 
-    def __init__(self, model, criterion, optimizer, inputs, labels, warmup=2):
+    def __init__(self, model, criterion, optimizer, inputs, labels, warmup=2, metric_forward=False):
+        """metric_forward: the replay ENDS with a gradient-free `criterion(model(inputs), labels)` over the same static
+        batch, evaluated after the update — the dev phase of a search does exactly this after every `architect.step`
+        (train_searchable/mmimdb.py:66-84: Architect.step, then the metric forward on the same batch, which sees the
+        updated alphas).  One batch copy and one replay instead of two of each; `__call__` then returns
+        (loss, logits, metric_loss, metric_logits).  Needs the update inside the graph (`in_graph_step`)."""
         import gc
         gc.collect()
         live = self._live_graph_tensors(labels.device)
@@ -154,6 +159,9 @@ class GraphedTrainStep:
         # reducer.plan() is decided once, collectively, and is the same for captured and eager steps.
         self.native = reducer is not None and reducer.plan() == 'native'
         self.in_graph_step = reducer is None or self.native
+        self.metric_forward = bool(metric_forward)
+        if self.metric_forward and not self.in_graph_step:
+            raise RuntimeError('metric_forward needs the optimizer step inside the captured graph')
         views = reducer.ensure_bucket() if reducer is not None else None
         # with an averaging collective (RCCL) the captured step is the single-GPU one: unscaled loss, constant
         # unit gradient; otherwise (gloo) the loss is pre-scaled by 1/world and the bucket is summed
@@ -194,6 +202,15 @@ class GraphedTrainStep:
                 optimizer.step()
             if self.native:
                 reducer.reduced = False
+            if self.metric_forward:
+                # behind the Adam launch on the same stream: this forward's prologue reads the UPDATED architecture
+                # tensors; its criterion is the eager kernel (nothing follows that could evaluate a deferred one)
+                with torch.no_grad():
+                    mout = model(self.inputs)
+                    if isinstance(mout, tuple):
+                        mout = mout[-1]
+                    mloss = criterion(mout, self.labels)
+                return loss, logits, mloss, mout
             return loss, logits
 
         # The warm-up passes run WITHOUT the update (they settle allocations and lazy
@@ -234,7 +251,7 @@ class GraphedTrainStep:
             model.load_state_dict(state)        # also when the capture fails and the caller stays eager
 
     @staticmethod
-    def try_build(model, criterion, optimizer, inputs, labels, logger=None):
+    def try_build(model, criterion, optimizer, inputs, labels, logger=None, metric_forward=False):
         """-> a GraphedTrainStep, or False when this step cannot be captured (inputs that are not a
         flat list of tensors, a module that synchronises with the host, ...); callers then keep
         the eager path."""
@@ -243,7 +260,7 @@ class GraphedTrainStep:
             return False
         from .dist import all_ranks_agree
         try:
-            step = GraphedTrainStep(model, criterion, optimizer, inputs, labels)
+            step = GraphedTrainStep(model, criterion, optimizer, inputs, labels, metric_forward=metric_forward)
         except Exception as e:                       # noqa: BLE001 — capture errors are of many types
             torch.cuda.synchronize()
             from . import functions
@@ -280,14 +297,20 @@ class GraphedTrainStep:
         return (len(inputs) == len(self.inputs) and labels.shape == self.labels.shape and
                 all(a.shape == b.shape for a, b in zip(inputs, self.inputs)))
 
+    def static_batch(self):
+        """(inputs, labels) the captured step reads: a producer that writes the batch INTO these tensors (and then
+        passes them to `__call__`) saves the copy launch — 13 us for the 9.4 MB of an MM-IMDB b128 batch."""
+        return self.inputs, self.labels
+
     def __call__(self, inputs, labels):
         _copy_batch_in(self.inputs, self.labels, inputs, labels)
         opt = self.optimizer
         if self.in_graph_step:
             opt.activate(self.plan)          # an eager step in between must not leak into the replay
             opt.prepare_replay()
-            loss, logits = self._g.replay()
+            out = self._g.replay()
             opt.mark_launched()
+            return out                       # (loss, logits[, metric_loss, metric_logits])
         else:
             loss, logits = self._g.replay()
             # an eager step in between (ragged last batch) re-pointed .grad at its own tensors:

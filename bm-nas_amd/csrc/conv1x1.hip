@@ -1708,7 +1708,7 @@ long g_family_calls[F_COUNT] = {0};
 #define BMNAS_COUNT(f) (++g_family_calls[f])
 
 inline int conv_probe() {
-#if BMNAS_BODY_PROBES
+#if BMNAS_BODY_PROBES || defined(BMNAS_CLASS_PROBE)   // (-DBMNAS_CLASS_PROBE: the class-drop bits without the in-body stamps)
   static const int v = []() { const char* e = getenv("BMNAS_CONV_PROBE"); return e ? atoi(e) : 0; }();
   return v;
 #else

@@ -13,26 +13,43 @@ class Architect(object):
         self._graph = None
         self._attempts = 0
         self.graph_replays = 0
+        self._with_metric = False
 
     def log_learning_rate(self, logger):
         for group in self.optimizer.param_groups:
             logger.info("Architecture Learning Rate: {}".format(group['lr']))
             break
 
-    def step(self, input_valid, target_valid, logger):
+    def step(self, input_valid, target_valid, logger, metric=False):
+        """metric=True (the trainer loop's dev phase): the caller will evaluate `criterion(model(input_valid),
+        target_valid)` without gradients right after this step (train_searchable/mmimdb.py:66-84) — a captured step
+        then carries that forward at its end and this returns (loss, output) of it; None: evaluate it yourself."""
         if self.use_graph:
             if self._graph is None and self._attempts < 3:
                 from bmnas.graph import GraphedTrainStep
                 self._attempts += 1
-                self._graph = GraphedTrainStep.try_build(self.model, self.criterion, self.optimizer,
-                                                         input_valid, target_valid, logger) or None
+                self._with_metric = bool(metric)
+                g = False
+                if metric:
+                    g = GraphedTrainStep.try_build(self.model, self.criterion, self.optimizer, input_valid,
+                                                   target_valid, logger, metric_forward=True)
+                    self._with_metric = bool(g)
+                if not g:
+                    g = GraphedTrainStep.try_build(self.model, self.criterion, self.optimizer, input_valid,
+                                                   target_valid, logger)
+                self._graph = g or None
             if self._graph and self._graph.matches(input_valid, target_valid):
-                self._graph(input_valid, target_valid)
+                out = self._graph(input_valid, target_valid)
                 self.graph_replays += 1
-                return
+                if self._with_metric:
+                    # (the replay ran the metric forward whether or not this caller wants it: BatchNorm statistics and
+                    # the dropout stream advanced as they do when the caller runs it, which it then must not do again)
+                    return out[2], out[3]
+                return None
         self.optimizer.zero_grad()
         self._backward_step(input_valid, target_valid)
         self.optimizer.step()
+        return None
 
     def _backward_step(self, input_valid, target_valid):
         loss = self.criterion(self.model(input_valid), target_valid)

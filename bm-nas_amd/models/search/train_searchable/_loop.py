@@ -63,12 +63,24 @@ def _shard_batch(inputs, labels):
     per = labels.shape[0] // world
     if per == 0:
         raise ValueError(f'batch of {labels.shape[0]} samples cannot be split over {world} ranks')
+    if labels.shape[0] % world and not _shard_batch.warned:
+        # DEVIATION from nn.DataParallel ("Data parallelism"): its scatter gives the first n % world
+        # replicas one more sample and the gathered loss is the mean over all n; equal shards keep mean-of-means ==
+        # global mean with ONE unweighted all-reduce and one captured batch shape per rank.  Said once, never silent.
+        import warnings
+        warnings.warn(f'bmnas: a global batch of {labels.shape[0]} samples over {world} ranks drops '
+                      f'{labels.shape[0] % world} sample(s) per such batch (use a DistributedSampler, or a batch size '
+                      f'divisible by the world size, to train on every sample)', RuntimeWarning)
+        _shard_batch.warned = True
     cut = lambda t: t.narrow(0, rank * per, per) if torch.is_tensor(t) and t.dim() > 0 else t
     if isinstance(inputs, (tuple, list)):
         inputs = type(inputs)(cut(t) for t in inputs)
     else:
         inputs = cut(inputs)
     return inputs, cut(labels)
+
+
+_shard_batch.warned = False
 
 
 class AccuracyMeter:
@@ -133,9 +145,16 @@ class _ForwardGraphs:
         eager warm-ups, a rehearsal and a private pool — more than a short eval loader saves if every epoch's eval
         pass captured again.  (The graphs read the parameters in place: optimizer steps and load_state_dict are seen.)"""
         cache = model.__dict__.setdefault('_bmnas_forward_graphs', {})
-        fg = cache.get(id(criterion))
-        if fg is None:
-            fg = cache[id(criterion)] = _ForwardGraphs(args, logger)
+        # keyed by id(), but the entry HOLDS its criterion: an id can be re-used by a new object once the old one is
+        # freed (a criterion rebuilt per stage with another pos_weight), and a captured graph has its criterion baked
+        # in — an entry whose criterion is not this very object is dropped together with its graphs' pools (ADVICE r04)
+        entry = cache.get(id(criterion))
+        if entry is not None and entry[0] is not criterion:
+            del cache[id(criterion)]
+            entry = None
+        if entry is None:
+            entry = cache[id(criterion)] = (criterion, _ForwardGraphs(args, logger))
+        fg = entry[1]
         from bmnas.graph import GraphedTrainStep
         fg.on = GraphedTrainStep.enabled(args)
         fg.replays = 0
@@ -217,8 +236,11 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 # nothing of the previous batch's autograd graph may stay referenced while a step is
                 # being captured (see GraphedTrainStep._live_graph_tensors)
                 output = loss = None
+                got = None
                 if status == 'search' and phase in ('dev', 'test') and architect is not None:
-                    architect.step(inputs, labels, logger)
+                    # (captured: the metric forward below rides at the end of the architecture step's replay — one
+                    # batch copy and one hipGraph launch for both; None: it did not, evaluate it here)
+                    got = architect.step(inputs, labels, logger, metric=not learn and use_graph and f_graphs.on)
                 if learn and use_graph:
                     if w_graph is None and w_attempts < 3:
                         w_attempts += 1
@@ -238,7 +260,10 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 if not learn:
                     # the metric pass: no gradients, one replay (the step above — architect.step in the dev phase —
                     # has already happened: this forward sees the updated alphas, like the reference's)
-                    got = f_graphs(model, criterion, inputs, labels)
+                    if got is None:
+                        got = f_graphs(model, criterion, inputs, labels)
+                    else:
+                        stats['merged_metric_replays'] = stats.get('merged_metric_replays', 0) + 1
                     if got is not None:
                         loss, output = got
                         loss_sum += loss.detach().double() * labels.size(0)

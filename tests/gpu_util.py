@@ -145,10 +145,38 @@ def _allowed_flips(label):
     return None if n is None else int(n) + 1
 
 
+_DET_TABLE = None
+
+
+def _check_deterministic_kind(label, outcome):
+    """Labels that start with 'det: ' come from BMNAS_DETERMINISTIC runs (tests/test_deterministic_gpu.py): there the
+    result is bit-reproducible, so WHICH evaluation of the reference math it matches is reproducible too, and any
+    change against tests/golden/match_step_table_det.json (label -> 'fp32' | 'fp64' | 'fp64+Nflips', written by
+    tools/match_table.py from a GPU run) is a real change of the arithmetic — no '+1 flip' allowance as in the default
+    (atomics-order) mode.  Unknown labels are recorded, not judged."""
+    global _DET_TABLE
+    if not label.startswith('det: '):
+        return
+    if _DET_TABLE is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'match_step_table_det.json')
+        try:
+            with open(path) as f:
+                _DET_TABLE = json.load(f)
+        except OSError:
+            _DET_TABLE = {}
+    want = _DET_TABLE.get(label)
+    if want is not None and want != outcome:
+        raise AssertionError(f'[{label}] deterministic mode now matches the reference math as {outcome!r}; the committed '
+                             f'table (tests/golden/match_step_table_det.json) recorded {want!r}: the arithmetic changed')
+
+
 def _record(label, outcome):
     import json
     import os
     OUTCOMES.append((label, outcome))
+    _check_deterministic_kind(label, outcome)
     root = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:                                   # gpurun merges gpurun_out/ back: the outcomes of a GPU run can be read later
         os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)

@@ -38,6 +38,22 @@ def test_two_runs_are_bit_identical(deterministic, batch, mode):
     assert not diff, (len(diff), diff[:6])
 
 
+@pytest.mark.parametrize('head', ['fused', 'deferred'])
+@pytest.mark.parametrize('batch', [128, 100, 32])
+def test_deterministic_step_matches_the_oracle_the_recorded_way(deterministic, batch, head):
+    """in the default mode WHICH evaluation of the reference math a whole step matches (fp32,
+    float64, float64 with one ReLU decision flipped) moves between runs with the atomics' order, so the table can only
+    cap the flips.  In deterministic mode the outcome is reproducible: it is compared with the recorded kind exactly
+    (gpu_util._check_deterministic_kind, tests/golden/match_step_table_det.json)."""
+    from gpu_util import compare_search_step
+    from test_network_gpu import _run_search_case
+    cfg = fo.Cfg({**fo.CONFIGS['mmimdb'], 'drpt': 0.0})
+    meta = dict(cfg=dict(cfg), seed=31, batch=batch, num_outputs=23, loss='bce', mode='train_nodrop', has_grads=True)
+    net, cls, xs, feat, logits, loss = _run_search_case(meta, head)
+    compare_search_step(cfg, batch, 23, 'bce', net, cls, [x.grad for x in xs], logits, loss, masks=None, seed=31,
+                        label=f'det: mmimdb b{batch} head={head}', attn_drop=0.0)
+
+
 def test_small_cell_with_three_steps_is_bit_identical(deterministic):
     cfg = fo.make_cfg(N=3, C=64, L=16, S=3, M=2, ns=1, nm=1, drpt=0.1)
     a = _step(cfg, 10, 5, 7, True, 'ce', 'train')
@@ -68,6 +84,11 @@ def test_deterministic_mode_gives_the_same_numbers_as_the_default(deterministic)
 def test_configurations_outside_the_mode_are_refused(deterministic):
     from bmnas import lib
     cfg = fo.make_cfg(N=3, C=32, L=8, S=2, M=2, ns=2, nm=2, drpt=0.0)       # node_multiplier != 1
+    with pytest.raises(lib.BmnasError, match='BMNAS_DETERMINISTIC'):
+        _step(cfg, 6, 5, 7, True, 'ce', 'train_nodrop')
+    # node_steps == 2 with node_multiplier == 1 takes the lazy-LayerNorm path, but its inner step's mix backward
+    # accumulates with atomics from many workgroups: refused too, not silently non-reproducible
+    cfg = fo.make_cfg(N=3, C=64, L=16, S=2, M=2, ns=2, nm=1, drpt=0.0)
     with pytest.raises(lib.BmnasError, match='BMNAS_DETERMINISTIC'):
         _step(cfg, 6, 5, 7, True, 'ce', 'train_nodrop')
 

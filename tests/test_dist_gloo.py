@@ -127,6 +127,45 @@ def _worker(rank, world, port, tmp):
         assert torch.allclose(params[0].grad, torch.full_like(params[0], 0.5))      # (1 + 0) / 2
     else:
         assert params[0].grad is None
+    # the C-ABI communicator's rendezvous must not strand ranks.  (1) rank 0 cannot create the unique id:
+    # it still reaches the broadcast and ships an error sentinel; EVERY rank raises the same RuntimeError, nobody is
+    # left inside a collective.  (2) plan(): librccl binds on one rank only -> all ranks agree BEFORE any rendezvous and
+    # fall back to the host-issued plan together (gloo here, so the plan is 'presum' either way; what is checked is that
+    # the agreement precedes the rendezvous: comm_get_unique_id must never be called).
+    from bmnas import lib as blib
+
+    def boom():
+        raise OSError('librccl.so: cannot open shared object file (simulated)')
+    real_uid = blib.comm_get_unique_id
+    blib.comm_get_unique_id = boom
+    try:
+        with pytest.raises(RuntimeError, match='rank 0 could not create the RCCL unique id'):
+            bdist.NativeComm(None)
+    finally:
+        blib.comm_get_unique_id = real_uid
+    t = torch.ones(1)
+    dist.all_reduce(t)                 # both ranks are out of the rendezvous and still paired up
+    assert float(t) == world
+    calls = []
+    real_av, real_backend = blib.comm_available, dist.get_backend
+    blib.comm_available = lambda: rank == 0
+    blib.comm_get_unique_id = lambda: calls.append(1) or boom()
+
+    class _CudaLike:
+        type = 'cuda'
+    red2 = bdist.FlatGradAllReducer(list(model.parameters()))
+    real_all_agree = bdist.all_ranks_agree
+    bdist.all_ranks_agree = lambda ok, dev, group=None: real_all_agree(ok, torch.device('cpu'), group)
+    real_avg = bdist.avg_supported
+    bdist.avg_supported = lambda dev, group=None: False
+    dist.get_backend = lambda group=None: 'nccl'
+    try:
+        red2.tensors = [type('T', (), {'device': _CudaLike()})()]
+        assert red2.plan() == 'presum' and not calls
+    finally:
+        dist.get_backend = real_backend
+        blib.comm_available, blib.comm_get_unique_id = real_av, real_uid
+        bdist.all_ranks_agree, bdist.avg_supported = real_all_agree, real_avg
     dist.destroy_process_group()
     open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
 

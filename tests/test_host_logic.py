@@ -211,6 +211,27 @@ def test_trainer_loop_shards_unsharded_batches(monkeypatch):
         loop._shard_batch(x, y)
 
 
+def test_forward_graph_cache_holds_its_criterion():
+    """the captured-forward cache is keyed by id(criterion); an id re-used by a NEW criterion (the old one
+    freed, e.g. rebuilt per stage with another pos_weight) must not get the old graphs, whose criterion is baked in."""
+    import models.search.train_searchable._loop as loop
+
+    class M:
+        pass
+
+    class Args:
+        graph_step = False
+
+    model, c1 = M(), torch.nn.BCEWithLogitsLoss()
+    fg1 = loop._ForwardGraphs.of(model, c1, Args())
+    assert loop._ForwardGraphs.of(model, c1, Args()) is fg1                   # same object: same graphs
+    cache = model.__dict__['_bmnas_forward_graphs']
+    c2 = torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones(3))
+    cache[id(c2)] = cache.pop(id(c1))                                          # simulate the id collision
+    fg2 = loop._ForwardGraphs.of(model, c2, Args())
+    assert fg2 is not fg1 and cache[id(c2)][0] is c2
+
+
 def test_world_size_alone_requests_data_parallelism(monkeypatch):
     from models.search._common import data_parallel_world, parallel_flag
 

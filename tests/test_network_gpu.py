@@ -260,7 +260,7 @@ def test_edited_primitives_match_reference_golden(path):
         gt.PRIMITIVES[:] = saved
 
 
-@pytest.mark.parametrize('optim', ['torch', 'bmnas', 'graph'])
+@pytest.mark.parametrize('optim', ['torch', 'bmnas', 'graph', 'graph_metric'])
 @pytest.mark.parametrize('path', golden_files('traj_*.npz'), ids=case_id)
 def test_search_trajectory_matches_reference_golden(path, optim):
     """3 iterations of w-step + Architect.step on the product modules reproduce the reference's
@@ -308,15 +308,23 @@ def test_search_trajectory_matches_reference_golden(path, optim):
         y = synth.make_labels(meta['loss'], batch, nout, seed + 10 * it).to(dev())
         xv = [x.to(dev()) for x in synth.make_inputs(cfg, batch, seed + 10 * it + 5)]
         yv = synth.make_labels(meta['loss'], batch, nout, seed + 10 * it + 5).to(dev())
-        if optim == 'graph':
+        if optim in ('graph', 'graph_metric'):
             from bmnas.graph import GraphedTrainStep
             if w_graph is None:
                 w_graph = GraphedTrainStep(model, crit, opt, xs, y)
-                a_graph = GraphedTrainStep(model, crit, aopt, xv, yv)
+                # 'graph_metric' (round 5): the dev phase's gradient-free forward rides at the end of the architecture
+                # step's replay, behind the Adam launch — it must see the UPDATED alphas, like the reference's
+                a_graph = GraphedTrainStep(model, crit, aopt, xv, yv, metric_forward=optim == 'graph_metric')
             assert w_graph.matches(xs, y)
-            _, logits = w_graph(xs, y)
+            _, logits = w_graph(xs, y)[:2]
             assert_close_scaled(f'train_logits.{it}', logits, z[f'train_logits.{it}'], rel=5e-4)
-            a_graph(xv, yv)
+            got = a_graph(xv, yv)
+            if optim == 'graph_metric':
+                assert len(got) == 4
+                assert_close_scaled(f'dev_logits.{it}', got[3], z[f'dev_logits.{it}'], rel=5e-4)
+                assert_close_of_scale_loss = float(crit(got[3], yv))
+                assert abs(float(got[2]) - assert_close_of_scale_loss) <= 1e-5 * max(1.0, abs(assert_close_of_scale_loss))
+                continue
         else:
             opt.zero_grad()
             logits = model(xs)

@@ -130,3 +130,44 @@ def test_k7_layernorm_statistics_with_offset_node_outputs(offset, bound):
     err = _rel(logits, want)
     print(f'node LayerNorm bias + {offset}: logits off by {err:.1e} of scale')
     assert err <= bound, err
+
+
+@pytest.mark.parametrize('mu,rowsum,warns', [(1.0, 0.0, False), (4.0, 30.0, True)])
+def test_bn_ratio_debug_check_reports_offset_activations(mu, rowsum, warns):
+    """BMNAS_BN_RATIO_CHECK: nothing at run time noticed a BatchNorm input outside the range the
+    one-pass variance is pinned for.  With the switch on every training-mode BatchNorm of the path reports
+    r = |mean - bias| / std per layer (bmnas.cell.bn_ratio_report) and warns above 20."""
+    import warnings
+    import models.auxiliary.aux_models as aux
+    from bmnas import cell as K
+
+    class A:
+        drpt = 0.0
+
+    c_in, C, L, batch = 512, 64, 16, 32
+    rng = np.random.Generator(np.random.PCG64(5))
+    W = rng.standard_normal((C, c_in)) / np.sqrt(c_in)
+    W -= W.mean(1, keepdims=True)
+    W += rowsum / c_in
+    layer = aux._ReshapeBase(c_in, C, L, A())
+    with torch.no_grad():
+        layer.conv.weight.copy_(torch.from_numpy(W.astype(np.float32))[:, :, None])
+    layer.to(dev()).train()
+    x = torch.from_numpy((mu + rng.standard_normal((batch, c_in, L))).astype(np.float32)).to(dev())
+    u = torch.einsum('oc,bcl->bol', torch.from_numpy(W.astype(np.float32)).double(), x.double().cpu())
+    want = float((u.mean((0, 2)).abs() / u.var((0, 2), unbiased=False).sqrt()).max())
+    prev = K.BN_RATIO_CHECK
+    K.BN_RATIO_CHECK = True
+    K.BN_RATIOS.clear()
+    try:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            layer._tail(x)
+            got = K.bn_ratio_report()
+    finally:
+        K.BN_RATIO_CHECK = prev
+    assert len(got) == 1, got
+    r = next(iter(got.values()))
+    assert abs(r - want) <= 0.05 * want + 0.05, (r, want)
+    assert any('|mean| / std' in str(w.message) for w in rec) == warns, (r, [str(w.message) for w in rec])
+    assert (r > 20.0) == warns

@@ -138,6 +138,9 @@ def test_mmimdb_search_driver_with_hip_graph_steps(tmp_path, monkeypatch):
     assert loop.run.stats['graph_replays'] == 4, loop.run.stats
     # the metric pass of every dev batch (2 epochs x (1 full + 1 ragged): the ragged shape gets a graph of its own)
     assert loop.run.stats['forward_replays'] == 4, loop.run.stats
+    # round 5: the full dev batches' metric forward rides at the end of the architecture step's replay (one batch copy,
+    # one launch); the ragged ones run architect.step eagerly and replay a forward graph of their own
+    assert loop.run.stats.get('merged_metric_replays', 0) == 2, loop.run.stats
     sd = torch.load(os.path.join(a.save, 'best', 'best_model.pt'))
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
 

@@ -19,10 +19,21 @@ for path in paths:
         n = int(m.group(1)) if m else 0
         table[r['label']] = max(table.get(r['label'], 0), n)
         kinds.setdefault(r['label'], set()).add(r['outcome'])
+# 'det: ...' labels (BMNAS_DETERMINISTIC runs, bit-reproducible): the KIND of evaluation matched, compared exactly
+det = {k: sorted(v) for k, v in kinds.items() if k.startswith('det: ')}
+bad = {k: v for k, v in det.items() if len(v) != 1}
+if bad:
+    raise SystemExit(f'deterministic labels with more than one recorded outcome (not reproducible?): {bad}')
+table = {k: v for k, v in table.items() if not k.startswith('det: ')}
 out = os.path.join(ROOT, 'tests', 'golden', 'match_step_table.json')
 with open(out, 'w') as f:
     json.dump(dict(sorted(table.items())), f, indent=0)
 print(f'{len(table)} labels -> {out}')
+if det:
+    out = os.path.join(ROOT, 'tests', 'golden', 'match_step_table_det.json')
+    with open(out, 'w') as f:
+        json.dump({k: v[0] for k, v in sorted(det.items())}, f, indent=0)
+    print(f'{len(det)} deterministic labels -> {out}')
 for k, v in sorted(kinds.items()):
     if v != {'fp32'}:
         print(f'  {k}: {sorted(v)}')
