@@ -323,19 +323,22 @@ class GraphedTrainStep:
 
 
 def _copy_batch_in(static_inputs, static_labels, inputs, labels):
-    """The batch into a graph's static tensors: ONE multi-tensor copy launch for the modalities that are already on
-    the device, plain copies for anything else (host tensors: the copy IS the H2D transfer)."""
+    """The batch into a graph's static tensors: ONE launch (bmnas_copy_batch: features and labels of any dtypes
+    together) for everything that is already on the device, plain copies for anything else (host tensors: the copy IS
+    the H2D transfer; a dtype / layout change: torch's converting copy).  Tensors that already ARE the static ones
+    (GraphedTrainStep.static_batch()) cost nothing."""
+    from . import lib
     with torch.no_grad():
-        pairs = list(zip(static_inputs, inputs)) + [(static_labels, labels)]
-        # (the labels ride in the same launch when they have the features' dtype — BCE targets; class indices make
-        # a dtype group, i.e. a launch, of their own inside _foreach_copy_)
-        same = [(d, s_) for d, s_ in pairs
-                if s_.device == d.device and s_.dtype == d.dtype and s_.data_ptr() != d.data_ptr()]
-        batched = {id(d) for d, _ in same} if len(same) > 1 else set()
-        if batched:
-            torch._foreach_copy_([d for d, _ in same], [s_ for _, s_ in same])
+        pairs = [(d, s_) for d, s_ in list(zip(static_inputs, inputs)) + [(static_labels, labels)]
+                 if s_.data_ptr() != d.data_ptr() or s_.device != d.device]
+        fast = [(d, s_) for d, s_ in pairs
+                if s_.device == d.device and s_.dtype == d.dtype and s_.shape == d.shape
+                and s_.is_contiguous() and d.is_contiguous()]
+        if fast:
+            lib.copy_batch(fast)
+        done = {id(d) for d, _ in fast}
         for dst, src in pairs:
-            if id(dst) not in batched and src.data_ptr() != dst.data_ptr():
+            if id(dst) not in done:
                 dst.copy_(src, non_blocking=True)
 
 

@@ -190,6 +190,8 @@ SIGNATURES = {
     'bmnas_cross_entropy': ([_P, _P, _P, _P, _P, _I, _I, _P], _I),
     'bmnas_adam_chunk_elems': ([], _I),
     'bmnas_adam_multi': ([_P, _P, _I, _P, _P], _I),
+    'bmnas_copy_batch_max': ([], _I),
+    'bmnas_copy_batch': ([_PP, _PP, C.POINTER(C.c_longlong), _I, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
     'bmnas_backward_epilogue': ([_I, _PP, _PP, C.POINTER(_PP), C.POINTER(C.c_int), _PP, _PP, _PP, _PP, _PP,
@@ -935,6 +937,19 @@ def adam_multi(table, chunks, n_chunks, hyp):
     hyp: float32 device (rows, 8)."""
     _check(load().bmnas_adam_multi(table.data_ptr(), chunks.data_ptr(), n_chunks, hyp.data_ptr(), _stream()),
            'adam_multi')
+
+
+def copy_batch(pairs):
+    """pairs: [(dst, src)] device tensors of equal byte size, contiguous, any dtypes -> ONE launch (groups of
+    bmnas_copy_batch_max() tensors)."""
+    cap = load().bmnas_copy_batch_max()
+    for i in range(0, len(pairs), cap):
+        part = pairs[i:i + cap]
+        n = len(part)
+        ps = (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in part])
+        pd = (C.c_void_p * n)(*[d.data_ptr() for d, _ in part])
+        nb = (C.c_longlong * n)(*[d.numel() * d.element_size() for d, _ in part])
+        _check(load().bmnas_copy_batch(ps, pd, nb, n, _stream()), 'copy_batch')
 
 
 def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc, step=None, scrub=None):

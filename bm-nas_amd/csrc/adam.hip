@@ -80,3 +80,87 @@ extern "C" int bmnas_adam_multi(const bmnas_adam_tensor_t* tensors, const int32_
   BMNAS_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- the batch into a captured step's static tensors: ONE launch (round 5) -----------------------------------------
+// A replayed step reads its inputs from fixed addresses (bmnas.graph.GraphedTrainStep / GraphedForward): every call
+// copies the caller's batch there first.  torch._foreach_copy_ is one launch only for lists it can batch (one dtype,
+// and it fell back to a memcpy per tensor for the 8 + 1 small tensors of an NTU / Ego batch: 9 x 4.9 us in front of a
+// 0.2 ms step); class-index labels (int64) were a copy of their own in any case.  Here up to kCopyMax (src, dst, bytes)
+// triples of ANY dtype travel by value in the kernel arguments — no descriptor table to stage — and one grid of
+// 16-byte lanes moves them all.  Replaces the reference's `.to(device)` hand-over of a batch only in so far as the
+// batch is already on the device (train_searchable/mmimdb.py:60-63): host tensors keep torch's H2D copy.
+namespace {
+constexpr int kCopyMax = 16;
+struct CopyArgs {
+  const void* src[kCopyMax];
+  void* dst[kCopyMax];
+  long long bytes[kCopyMax];
+  int first[kCopyMax + 1];     // first workgroup of tensor i; first[n] = grid size
+  int n;
+};
+constexpr int kCopyChunk = 256 * 16 * 4;        // bytes per workgroup: four 16-byte pieces per lane
+
+__global__ __launch_bounds__(256) void copy_batch_k(CopyArgs a) {
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < kCopyMax; ++i) ti = (i < a.n && (int)blockIdx.x >= a.first[i]) ? i : ti;
+  const char* __restrict__ s = (const char*)a.src[0];
+  char* __restrict__ d = (char*)a.dst[0];
+  long long nb = a.bytes[0];
+  int f = a.first[0];
+#pragma unroll
+  for (int i = 1; i < kCopyMax; ++i) {        // selects over the by-value arrays: no indexed kernarg load
+    const bool hit = ti == i;
+    s = hit ? (const char*)a.src[i] : s;
+    d = hit ? (char*)a.dst[i] : d;
+    nb = hit ? a.bytes[i] : nb;
+    f = hit ? a.first[i] : f;
+  }
+  const long long base = (long long)((int)blockIdx.x - f) * kCopyChunk;
+  const long long full = nb & ~15ll;                            // bytes in whole 16-byte pieces
+  if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0 && nb >= 16) {
+    // four 16-byte pieces per lane, every load issued before the first store; scalars, not arrays (an indexed
+    // per-lane array here was promoted to 16 KB of LDS per workgroup and the launch took 18 us for 9.4 MB)
+    const long long o0 = base + (long long)threadIdx.x * 16, o1 = o0 + 4096, o2 = o0 + 8192, o3 = o0 + 12288;
+    const bool f0 = o0 < full, f1 = o1 < full, f2 = o2 < full, f3 = o3 < full;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(s + (f0 ? o0 : 0));     // clamped: no load under a branch
+    const uint4 v1 = *reinterpret_cast<const uint4*>(s + (f1 ? o1 : 0));
+    const uint4 v2 = *reinterpret_cast<const uint4*>(s + (f2 ? o2 : 0));
+    const uint4 v3 = *reinterpret_cast<const uint4*>(s + (f3 ? o3 : 0));
+    if (f0) *reinterpret_cast<uint4*>(d + o0) = v0;
+    if (f1) *reinterpret_cast<uint4*>(d + o1) = v1;
+    if (f2) *reinterpret_cast<uint4*>(d + o2) = v2;
+    if (f3) *reinterpret_cast<uint4*>(d + o3) = v3;
+    // the last nb % 16 bytes: the lane whose piece would have held them
+    if (full < nb && full >= base && full < base + kCopyChunk && (long long)threadIdx.x == ((full - base) >> 4) % 256)
+      for (long long o = full; o < nb; ++o) d[o] = s[o];
+  } else {
+    for (int r = 0; r < 4; ++r) {
+      const long long o0 = base + ((long long)r * 256 + threadIdx.x) * 16;
+      for (long long o = o0; o < nb && o < o0 + 16; ++o) d[o] = s[o];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int bmnas_copy_batch_max(void) { return kCopyMax; }
+
+extern "C" int bmnas_copy_batch(const void* const* srcs, void* const* dsts, const long long* bytes, int n,
+                                void* stream) {
+  if (n < 0 || n > kCopyMax || (n > 0 && (!srcs || !dsts || !bytes))) return BMNAS_E_ARG;
+  CopyArgs a{};
+  int g = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (bytes[i] < 0 || (bytes[i] > 0 && (!srcs[i] || !dsts[i]))) return BMNAS_E_ARG;
+    if (bytes[i] == 0) continue;
+    a.src[m] = srcs[i]; a.dst[m] = dsts[i]; a.bytes[m] = bytes[i]; a.first[m] = g;
+    g += (int)((bytes[i] + kCopyChunk - 1) / kCopyChunk);
+    ++m;
+  }
+  a.n = m;
+  for (int i = m; i <= kCopyMax; ++i) a.first[i] = g;
+  if (g == 0) return 0;
+  hipLaunchKernelGGL(copy_batch_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+  BMNAS_CHECK_LAUNCH();
+  return 0;
+}

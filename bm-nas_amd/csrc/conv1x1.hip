@@ -376,9 +376,10 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
                                  (p0.z + p1.z) + (p2.z + p3.z) + bj, (p0.w + p1.w) + (p2.w + p3.w) + bj);
     const int q = jj / a.Cj;
     const int cj = jj - q * a.Cj;
-    float* d = a.dst.p[0];
-#pragma unroll
-    for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
+    // (pick_ptr, not a hand-written select chain: LLVM folds select(load, load) of kernel-argument pointers back into ONE
+    // indexed load — a global_load_dwordx2 from the kernarg segment + s_waitcnt vmcnt(0) in front of the tile's store, and
+    // in the grouped kernels, whose descriptor is a local copy, 200 B of scratch per lane; round 5, by the ISA)
+    float* d = pick_ptr(a.dst.p, q);
     const int so = g * a.spw + ((4 * h) >> a.Lb);
     const bool vo = so < a.b;
     float4 ov = o;
@@ -935,9 +936,10 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     const int jj = jt + lo;
     const int q = jj / a.Cj;
     const int cj = jj - q * a.Cj;
-    float* d = a.dst.p[0];
-#pragma unroll
-    for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
+    // (pick_ptr, not a hand-written select chain: LLVM folds select(load, load) of kernel-argument pointers back into ONE
+    // indexed load — a global_load_dwordx2 from the kernarg segment + s_waitcnt vmcnt(0) in front of the tile's store, and
+    // in the grouped kernels, whose descriptor is a local copy, 200 B of scratch per lane; round 5, by the ISA)
+    float* d = pick_ptr(a.dst.p, q);
     const int so = g * a.spw + ((4 * h) >> a.Lb);
     if (so >= a.b || d == nullptr) continue;
     float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
@@ -1077,9 +1079,7 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
     const int i = i0 + k;
     const int ic = i < a.I ? i : a.I - 1;
     const int q = ic / a.Ci;
-    const float* sp = a.act.p[0];
-#pragma unroll
-    for (int qq = 1; qq < kConvPtrs; ++qq) sp = (q == qq) ? a.act.p[qq] : sp;
+    const float* sp = pick_ptr(a.act.p, q);
     const float4 t = ld4(sp + off + (int64_t)(ic - q * a.Ci) * a.L);
     return i < a.I ? t : z4;
   };
@@ -1188,9 +1188,10 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
     const float bj = (a.bias != nullptr) ? a.bias[jj] : 0.f;
     const int q = jj / a.Cj;
     const int cj = jj - q * a.Cj;
-    float* d = a.dst.p[0];
-#pragma unroll
-    for (int qq = 1; qq < kConvPtrs; ++qq) d = (q == qq) ? a.dst.p[qq] : d;
+    // (pick_ptr, not a hand-written select chain: LLVM folds select(load, load) of kernel-argument pointers back into ONE
+    // indexed load — a global_load_dwordx2 from the kernarg segment + s_waitcnt vmcnt(0) in front of the tile's store, and
+    // in the grouped kernels, whose descriptor is a local copy, 200 B of scratch per lane; round 5, by the ISA)
+    float* d = pick_ptr(a.dst.p, q);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int g = gbase + wn * TN + tn;
@@ -1254,9 +1255,7 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
     const int kt = k0 + 16 * t;
     const int k = (kt < a.K ? kt : a.K - 16) + lo;
     const int q = k / a.C_src;
-    sp = a.src.p[0];                                     // q differs per lane: selects, not an indexed load
-#pragma unroll
-    for (int qq = 1; qq < kConvPtrs; ++qq) sp = (q == qq) ? a.src.p[qq] : sp;
+    sp = pick_ptr(a.src.p, q);                           // q differs per lane: selects, not an indexed load
     return (int64_t)(k - q * a.C_src) * a.L;
   };
   const float *bsrc0, *bsrc1;

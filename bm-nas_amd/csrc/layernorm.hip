@@ -22,7 +22,7 @@ struct LnDst {
 __device__ __forceinline__ const float* src_ptr(const LnSrc& s, int i4, int cl4, int sample) {
   const int q = i4 / cl4;
   const int off = i4 - q * cl4;
-  return s.p[q] + ((int64_t)sample * cl4 + off) * 4;
+  return pick_ptr(s.p, q) + ((int64_t)sample * cl4 + off) * 4;      // (never s.p[q]: an indexed kernarg LOAD, common.hpp)
 }
 
 // BS = threads per workgroup: 512 when the batch leaves CUs idle (one workgroup per sample), so
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(BS) void cat_ln_bwd_k(const float* __restrict__ g, 
       dx.w = rstd * (dxh[k].w - m1 - xh[k].w * m2);
       const int q = i / cl4;
       const int off = i - q * cl4;
-      float* d = dsrcs.p[q];
+      float* d = pick_ptr(dsrcs.p, q);
       if (d != nullptr) {
         float* a = d + ((int64_t)s * cl4 + off) * 4;
         st4(a, (acc_mask & (1u << q)) ? f4_add(dx, ld4(a)) : dx);

@@ -747,6 +747,15 @@ int bmnas_adam_chunk_elems(void);
 int bmnas_adam_multi(const bmnas_adam_tensor_t* tensors, const int32_t* chunks, int n_chunks,
                      const float* hyp, void* stream);
 
+/* ---- a batch into a captured step's static tensors (bmnas.graph._copy_batch_in) -------------------
+ * The reference hands every batch over with `.to(device)` per tensor (train_searchable/mmimdb.py:60-63,
+ * ntu.py:60-66, ego.py:60-66); a replayed step reads its inputs from fixed addresses, so a batch that is
+ * already on the device is copied there first — n <= bmnas_copy_batch_max() device-to-device copies of ANY
+ * dtype (byte counts) as ONE launch, the (src, dst, bytes) triples by value in the kernel arguments.
+ * 16-byte lanes where both addresses are 16-byte aligned, bytes otherwise.  Overlapping src / dst: undefined. */
+int bmnas_copy_batch_max(void);
+int bmnas_copy_batch(const void* const* srcs, void* const* dsts, const long long* bytes, int n, void* stream);
+
 /* ---- data parallelism: RCCL behind the C ABI ---------------------------------------------------
  * One process per GPU; the data-path exchange of a search step is ONE in-place all-reduce of the flat
  * fp32 gradient bucket (w-grads, or the alpha/beta/gamma vector) over xGMI — what replaces

@@ -790,3 +790,28 @@ def test_conv1x1_bwd_data_large(b, C, L, M, n_dst, acc):
         if acc & (1 << q):
             want = want + prev[q].double()
         assert_close_scaled(f'dsrc{q}', dst[q], want.float(), rel=3e-5)
+
+
+def test_copy_batch_one_launch_any_dtypes():
+    """bmnas_copy_batch (the batch into a captured step's static tensors): features and labels of different dtypes,
+    byte counts that are no multiple of 16, a source whose address is not 16-byte aligned, more tensors than one
+    launch carries, an empty tensor — bit-equal to torch's copies, neighbours of the destinations untouched."""
+    from bmnas import lib
+    g = torch.Generator().manual_seed(3)
+    shapes = [((128, 192, 16), torch.float32), ((64, 128, 8), torch.float32), ((6,), torch.int64), ((7, 23), torch.float32),
+              ((0, 5), torch.float32), ((3,), torch.int32), ((1000003,), torch.uint8)] + [((5, 9, 4), torch.float32)] * 14
+    pairs, guards = [], []
+    for shp, dt in shapes:
+        n = 1
+        for s_ in shp:
+            n *= s_
+        src = (torch.randn(n + 8, generator=g) * 100).to(dt).to(dev())
+        buf = torch.full((n + 16,), 7, dtype=dt, device=dev())
+        pairs.append((buf[8:8 + n].view(shp), src[1:1 + n].view(shp)))      # src offset by ONE element: unaligned for most
+        guards.append(buf)
+    lib.copy_batch(pairs)
+    torch.cuda.synchronize()
+    for (d, s_), buf in zip(pairs, guards):
+        assert torch.equal(d, s_), (d.shape, d.dtype)
+        n = d.numel()
+        assert bool((buf[:8] == 7).all()) and bool((buf[8 + n:] == 7).all()), (d.shape, d.dtype)

@@ -1,6 +1,6 @@
 """Where the weight step's time beyond fwd + bwd goes: GraphedTrainStep (fwd + criterion + bwd + Adam) replayed
 with (a) the full optimizer launch, (b) the Adam kernel without the staging H2D copy node, (c) no optimizer work.
-    python tools/time_wstep.py [config] [batch]"""
+    python tools/time_wstep.py [config] [batch] [variant ...]     (one variant: a clean rocprofv3 --kernel-trace --stats)"""
 import os
 import sys
 import time
@@ -36,7 +36,7 @@ def build(variant):
     return g, xs, y
 
 
-for variant in ('full', 'nocopy', 'nostep'):
+for variant in (sys.argv[3:] or ('full', 'nocopy', 'nostep')):
     g, xs, y = build(variant)
     for _ in range(20):
         g(xs, y)
