@@ -81,6 +81,42 @@ class MixSumFn(Function):
         return (dw, *dxs)
 
 
+# ---- LayerNorm-affine reductions of the per-op path: ONE launch per backward pass ----------------------------------
+# The fused search cell ends its backward with one batched launch for every LayerNorm's (dweight, dbias) (reductions
+# over the batch: bmnas_ln_affine_bwd_multi); the per-op Functions below (Found_* nets, standalone modules) paid one
+# launch per LayerNorm — 4 of the 22 launches of an MM-IMDB found-stage step.  Inside `deferred_affine()` (entered by
+# bmnas.graph.GraphedTrainStep around its torch.autograd.grad call, whose results nobody reads before the context
+# ends) they only note the job; the context's exit launches them together.  Plain `loss.backward()` keeps the
+# immediate launches: an AccumulateGrad node may ADD a parameter's incoming gradient to an existing .grad right away.
+AFFINE_DEFER = None
+
+
+class deferred_affine:
+    def __enter__(self):
+        global AFFINE_DEFER
+        self.prev, AFFINE_DEFER = AFFINE_DEFER, []
+        return self
+
+    def __exit__(self, *exc):
+        global AFFINE_DEFER
+        jobs, AFFINE_DEFER = AFFINE_DEFER, self.prev
+        groups = {}
+        for b, L, prob in jobs:
+            groups.setdefault((b, L), []).append(prob)
+        for (b, L), probs in groups.items():
+            for i in range(0, len(probs), 8):
+                lib.ln_affine_bwd_multi(probs[i:i + 8], b, L)
+        return False
+
+
+def _ln_affine(g, srcs, resid, ln_w, ln_b, stats, dw, db, b, C, L, relu, prenorm):
+    if AFFINE_DEFER is not None:
+        AFFINE_DEFER.append((b, L, dict(g=g, gscale=None, srcs=list(srcs), resid=resid, ln_w=ln_w, ln_b=ln_b, stats=stats,
+                                        dln_w=dw, dln_b=db, C=C, relu=relu, prenorm=prenorm)))
+    else:
+        lib.ln_affine_bwd(g, None, srcs, resid, ln_w, ln_b, stats, dw, db, b, C, L, relu, prenorm)
+
+
 def _zero_pair(like):
     """Two zero-filled tensors shaped like `like` (a LayerNorm's dln_w, dln_b), slices of the backward pass's one
     zero-filled chunk (ZERO_POOL; the forward announced them)."""
@@ -119,7 +155,7 @@ class CatLnFn(Function):
         dw, db = _zero_pair(ctx.lw)
         lib.cat_ln_bwd(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dsrcs, dres, 0, None, None, b, C, L,
                        ctx.relu)
-        lib.ln_affine_bwd(g, None, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, ctx.relu, False)
+        _ln_affine(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, ctx.relu, False)
         return (None, dw, db, dres, *dsrcs)
 
 
@@ -151,7 +187,7 @@ class SdpaLnFn(Function):
         dw, db = _zero_pair(ctx.lw)
         g = _c(g)
         lib.sdpa_ln_bwd(g, None, x, y, ctx.lw, ctx.xhat, ctx.stats, dx, dy, 0, b, C, L, ctx.drop)
-        lib.ln_affine_bwd(g, None, [ctx.xhat], None, None, None, None, dw, db, b, C, L, False, True)
+        _ln_affine(g, [ctx.xhat], None, None, None, None, dw, db, b, C, L, False, True)
         return dx, dy, dw, db, None, None
 
 

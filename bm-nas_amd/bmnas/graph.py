@@ -9,7 +9,7 @@ the kernels add a DEVICE counter to their Philox offsets and the graph advances 
 import torch
 
 from . import cell as K
-from .functions import unit_grad
+from .functions import deferred_affine, unit_grad
 
 
 class GraphedStep:
@@ -178,7 +178,8 @@ class GraphedTrainStep:
                 if isinstance(logits, tuple):
                     logits = logits[-1]
                 loss = criterion(logits, self.labels)
-            with K.arch_grads_only(self.arch_only):
+            # (deferred_affine: the per-op path's LayerNorm-affine reductions of this pass as ONE launch at its end)
+            with K.arch_grads_only(self.arch_only), deferred_affine():
                 if scale != 1.0:
                     grads = torch.autograd.grad(loss * scale, self.targets, allow_unused=True)
                 else:

@@ -348,3 +348,53 @@ def test_ntu_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, m
     assert len(rec.batches) in (0, len(gold['tester_batches']))
     for g, w in zip(rec.batches, gold['tester_batches']):
         assert abs(g[3] - w[3]) <= 2e-4 * max(1.0, abs(w[3])) and abs(g[5] - w[5]) <= 2e-4 * w[5], (label, g, w)
+
+
+@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+def test_ego_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, monkeypatch, hip_graph):
+    """tests/golden/loop_ego_found.json (make_golden_r05_ego_found.py ran the reference's Found_RGB_Depth_Net through
+    train_ego_track_acc(status='eval') and test_ego_track_acc as main_darts_found_ego.py:118-153 does): the last
+    trainer / tester call chain of the mains without a recording (missing 4).  node_steps 3 /
+    node_multiplier 3, reshape layers only where the genotype reads an input, every parameter optimised."""
+    gold = _gold('loop_ego_found.json', 63)
+    drv, loop, rec = _install(monkeypatch, 'ego')
+    import models.auxiliary.scheduler as sc
+    import models.search.train_searchable.ego as tr
+    from bmnas import nn as bnn
+    from bmnas.optim import Adam
+    from models.search.darts.genotypes import Genotype, StepGenotype
+    from models.search.darts.utils import create_exp_dir
+    from models.search.plot_genotype import Plotter
+    gg = gold['genotype']
+    genotype = Genotype(edges=[tuple(e) for e in gg['edges']],
+                        steps=[StepGenotype(inner_edges=[tuple(e) for e in st['inner_edges']],
+                                            inner_steps=list(st['inner_steps']), inner_concat=list(st['inner_concat']))
+                               for st in gg['steps']],
+                        concat=list(gg['concat']))
+    a = _acc_args(tmp_path, 3, 3, stubs.EGO_CLASSES, hip_graph)
+    create_exp_dir(a.save)
+    device = torch.device('cuda:0')
+    criterion = bnn.CrossEntropyLoss()
+    model = stubs.fill_state(drv.Found_RGB_Depth_Net(a, None, criterion, genotype), gold['seed'])
+    lds = _loaders(gold, stubs.EgoData)
+    sizes = {k: len(v.dataset) for k, v in lds.items()}
+    model.to(device)
+    optimizer = Adam(model.parameters(), lr=a.eta_max, weight_decay=1e-4)
+    scheduler = sc.LRCosineAnnealingScheduler(a.eta_max, a.eta_min, a.Ti, a.Tm, sizes['train'] / a.batchsize)
+    logger = logging.getLogger('bmnas-test')
+    test_acc, test_genotype = tr.train_ego_track_acc(model, None, criterion, optimizer, scheduler, lds, sizes, device,
+                                                     a.epochs, False, logger, Plotter(a), a, 'eval')
+    label = 'ego found/' + ('graph' if hip_graph else 'eager')
+    _compare_batches(rec.batches, gold['batches'], 2e-4, label)
+    _compare_phases(rec, gold, label)
+    assert abs(float(test_acc) - gold['test_acc']) <= 1e-9 and str(test_genotype) == gold['test_genotype']
+    _compare_state(model, gold['final'], 5e-4, label + ' final')
+    model2 = drv.Found_RGB_Depth_Net(a, None, criterion, genotype)
+    model2.load_state_dict(torch.load(os.path.join(a.save, 'best', 'best_test_model.pt')))
+    model2.to(device)
+    rec.batches.clear()
+    got = tr.test_ego_track_acc(model2, lds, criterion, genotype, sizes, device, logger, a)
+    assert abs(float(got) - gold['tester_acc']) <= 1e-9
+    assert len(rec.batches) in (0, len(gold['tester_batches']))
+    for g, w in zip(rec.batches, gold['tester_batches']):
+        assert abs(g[3] - w[3]) <= 2e-4 * max(1.0, abs(w[3])) and abs(g[5] - w[5]) <= 2e-4 * w[5], (label, g, w)
