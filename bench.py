@@ -276,6 +276,14 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     # (GraphedTrainStep.static_batch(): a producer that writes the batch there skips the copy launch)
     sx, sy = gw.static_batch()
     ms_w_nocopy = timed(lambda: gw(sx, sy), pairs)
+    # host side of one replayed step: the time Python needs to ISSUE a call (no synchronisation inside the loop); a loop
+    # is host-bound once this exceeds the step's device time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        gw(xs, y)
+    host_us = (time.perf_counter() - t0) / 50 * 1e6
+    torch.cuda.synchronize()
     # the dev phase's metric pass (a gradient-free forward after every architect.step, train mode): one replay
     ms_f = None
     from bmnas.graph import GraphedForward
@@ -304,6 +312,7 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
             'loop_ms_per_train_dev_batch_pair': ms_loop,
             'w_step_without_input_copy_ms': round(ms_w_nocopy, 4),
             'input_copy_us': round((ms_w - ms_w_nocopy) * 1e3, 1),
+            'host_issue_us_per_w_step': round(host_us, 1),
             'pairs_per_s': round(world * 1e3 / ms_pair, 1), 'pairs_timed': pairs,
             'includes': 'w-step: fwd + criterion + bwd (weights, arch and input grads) + Adam(w, wd 1e-4); '
                         'alpha-step: the same with Adam(alpha/beta/gamma, betas (0.5, 0.999), wd 1e-3); '
@@ -1383,6 +1392,24 @@ def main():
             del g4
         except Exception as e:                       # noqa: BLE001 — diagnostics must not cost the headline
             result['four_steps_per_replay'] = {'error': f'{type(e).__name__}: {e}'[:200]}
+    if world == 1 and a.mode == 'graph' and a.tier == 'R' and not a.dp_selftest:
+        # The reference FREEZES its backbones (`p.requires_grad = False`: mmimdb_darts_searchable.py:68-71,
+        # ntu_darts_searchable.py:86-90, ego_darts_searchable.py:85-89): the features that enter the reshape layers never
+        # require a gradient, and autograd forms no data gradient for those layers.  The tier R line above keeps the input
+        # gradients (comparable with earlier rounds, and what SURVEY.md 8(d) literally lists); this is the same step as
+        # the reference's training loop runs it — no data-gradient tiles in the grouped backward launch.
+        try:
+            dpf = DPStep(model, c, crit, [x.detach() for x in xs], y, params, arch, device, None, 1.0, bucket=False)
+            dpf.leaves = dpf.shared
+            gF = GraphedStep(dpf.make_step('single'), warmup=1)
+            tF = measure(gF.replay, 3)
+            result['tier_R_frozen_backbones'] = {
+                'ms_per_step': round(statistics.median(tF) / a.steps * 1e3, 4),
+                'note': 'raw features without requires_grad (the reference freezes its backbones): no input gradient of '
+                        'the reshape layers is formed; every weight / arch gradient as in the headline'}
+            del gF
+        except Exception as e:                       # noqa: BLE001 — diagnostics must not cost the headline
+            result['tier_R_frozen_backbones'] = {'error': f'{type(e).__name__}: {e}'[:200]}
     if not a.no_full_step:
         # secondary figure: never allowed to take the headline line down with it — neither by raising nor (N > 1: it
         # contains collectives) by never returning: past the watchdog every rank leaves with the line as it stands

@@ -154,6 +154,7 @@ class GraphedTrainStep:
         self.reducer = reducer
         self.inputs = [x.detach().clone().requires_grad_(x.requires_grad) for x in inputs]
         self.labels = labels.detach().clone()
+        self._batch_in = _BatchIn(self.inputs, self.labels)
         # RCCL through the C ABI (bmnas.dist.NativeComm; BMNAS_NATIVE_RCCL=0 turns it off) is a plain launch
         # on the capture stream: the all-reduce and the Adam step then live INSIDE the graph.
         # reducer.plan() is decided once, collectively, and is the same for captured and eager steps.
@@ -242,7 +243,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         try:
             if self.in_graph_step:
-                optimizer.capture_safe()
+                optimizer.capture_safe(poke=True)        # no H2D node in the graph: the scalars ride with the batch copy
             armed[0] = True
             self._g = GraphedStep(fn, warmup=0)
             # the graph reads THIS plan's staging buffers and writes THESE gradient tensors for good
@@ -304,15 +305,17 @@ class GraphedTrainStep:
         return self.inputs, self.labels
 
     def __call__(self, inputs, labels):
-        _copy_batch_in(self.inputs, self.labels, inputs, labels)
         opt = self.optimizer
         if self.in_graph_step:
             opt.activate(self.plan)          # an eager step in between must not leak into the replay
             opt.prepare_replay()
+            # ONE launch in front of the replay: the batch into the static tensors + this step's Adam scalars (by value)
+            self._batch_in(inputs, labels, opt.replay_blob())
             out = self._g.replay()
             opt.mark_launched()
             return out                       # (loss, logits[, metric_loss, metric_logits])
         else:
+            self._batch_in(inputs, labels)
             loss, logits = self._g.replay()
             # an eager step in between (ragged last batch) re-pointed .grad at its own tensors:
             # the optimizer must read the bucket views the graph has just written
@@ -323,23 +326,19 @@ class GraphedTrainStep:
         return loss, logits
 
 
-def _copy_batch_in(static_inputs, static_labels, inputs, labels):
-    """The batch into a graph's static tensors: ONE launch (bmnas_copy_batch: features and labels of any dtypes
-    together) for everything that is already on the device, plain copies for anything else (host tensors: the copy IS
-    the H2D transfer; a dtype / layout change: torch's converting copy).  Tensors that already ARE the static ones
-    (GraphedTrainStep.static_batch()) cost nothing."""
-    from . import lib
-    with torch.no_grad():
-        pairs = [(d, s_) for d, s_ in list(zip(static_inputs, inputs)) + [(static_labels, labels)]
-                 if s_.data_ptr() != d.data_ptr() or s_.device != d.device]
-        fast = [(d, s_) for d, s_ in pairs
-                if s_.device == d.device and s_.dtype == d.dtype and s_.shape == d.shape
-                and s_.is_contiguous() and d.is_contiguous()]
-        if fast:
-            lib.copy_batch(fast)
-        done = {id(d) for d, _ in fast}
-        for dst, src in pairs:
-            if id(dst) not in done:
+class _BatchIn:
+    """The batch into a graph's static tensors: ONE launch (bmnas_copy_batch: features and labels of any dtypes together,
+    plus — `blob` — a captured optimizer step's per-replay scalars by value) for everything that is already on the
+    device, plain copies for anything else (host tensors: the copy IS the H2D transfer; a dtype / layout change:
+    torch's converting copy).  Tensors that already ARE the static ones (GraphedTrainStep.static_batch()) cost nothing."""
+
+    def __init__(self, static_inputs, static_labels):
+        from . import lib
+        self.copier = lib.BatchCopier(list(static_inputs) + [static_labels])
+
+    def __call__(self, inputs, labels, blob=None):
+        with torch.no_grad():
+            for dst, src in self.copier(list(inputs) + [labels], blob):
                 dst.copy_(src, non_blocking=True)
 
 
@@ -358,6 +357,7 @@ class GraphedForward:
         self.training = model.training
         self.inputs = [x.detach().clone() for x in inputs]
         self.labels = labels.detach().clone()
+        self._batch_in = _BatchIn(self.inputs, self.labels)
 
         def fn():
             with torch.no_grad():
@@ -416,5 +416,5 @@ class GraphedForward:
                         for a, b in zip(inputs, self.inputs)))
 
     def __call__(self, inputs, labels):
-        _copy_batch_in(self.inputs, self.labels, inputs, labels)
+        self._batch_in(inputs, labels)
         return self._g.replay()

@@ -191,7 +191,8 @@ SIGNATURES = {
     'bmnas_adam_chunk_elems': ([], _I),
     'bmnas_adam_multi': ([_P, _P, _I, _P, _P], _I),
     'bmnas_copy_batch_max': ([], _I),
-    'bmnas_copy_batch': ([_PP, _PP, C.POINTER(C.c_longlong), _I, _P], _I),
+    'bmnas_copy_blob_max': ([], _I),
+    'bmnas_copy_batch': ([_PP, _PP, C.POINTER(C.c_longlong), _I, _P, _P, _I, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
     'bmnas_backward_epilogue': ([_I, _PP, _PP, C.POINTER(_PP), C.POINTER(C.c_int), _PP, _PP, _PP, _PP, _PP,
@@ -939,17 +940,73 @@ def adam_multi(table, chunks, n_chunks, hyp):
            'adam_multi')
 
 
-def copy_batch(pairs):
+def copy_blob_max():
+    return load().bmnas_copy_blob_max()
+
+
+class BatchCopier:
+    """bmnas_copy_batch for a FIXED list of destinations (a captured step's static tensors), called once per batch: the
+    ctypes argument arrays are built once, a call only fills in the source addresses (the host side of a replayed step is
+    ~10 Python-level operations, not a list comprehension per tensor attribute)."""
+
+    def __init__(self, dsts):
+        self.dsts = list(dsts)
+        n = len(self.dsts)
+        assert n <= load().bmnas_copy_batch_max()
+        self.dptr = [d.data_ptr() for d in self.dsts]
+        self.nbytes = [d.numel() * d.element_size() for d in self.dsts]
+        self.ps = (C.c_void_p * max(n, 1))()
+        self.pd = (C.c_void_p * max(n, 1))()
+        self.nb = (C.c_longlong * max(n, 1))()
+        self.fn = load().bmnas_copy_batch
+
+    def __call__(self, srcs, blob=None):
+        """srcs[i] -> dsts[i] for every i whose source is not the destination itself; -> the (dst, src) pairs this
+        launch could NOT take (another device / dtype / shape, non-contiguous): the caller copies those with torch."""
+        n, slow = 0, []
+        for i, s_ in enumerate(srcs):
+            d = self.dsts[i]
+            if s_ is d:
+                continue
+            if s_.device == d.device and s_.dtype == d.dtype and s_.shape == d.shape and s_.is_contiguous():
+                sp = s_.data_ptr()
+                if sp == self.dptr[i]:
+                    continue
+                self.ps[n], self.pd[n], self.nb[n] = sp, self.dptr[i], self.nbytes[i]
+                n += 1
+            else:
+                slow.append((d, s_))
+        bd, bp, bn, keep = None, None, 0, None
+        if blob is not None:
+            raw = blob[1]
+            bd, bn = blob[0].data_ptr(), len(raw)
+            keep = C.create_string_buffer(raw, bn)
+            bp = C.cast(keep, C.c_void_p)
+        if n or bn:
+            _check(self.fn(self.ps, self.pd, self.nb, n, bd, bp, bn, _stream()), 'copy_batch')
+        return slow
+
+
+def copy_batch(pairs, blob=None):
     """pairs: [(dst, src)] device tensors of equal byte size, contiguous, any dtypes -> ONE launch (groups of
-    bmnas_copy_batch_max() tensors)."""
+    bmnas_copy_batch_max() tensors).  blob = (dst device tensor, host bytes-like of <= bmnas_copy_blob_max() bytes): stored
+    to dst by the same launch (it travels by value in the kernel arguments)."""
     cap = load().bmnas_copy_batch_max()
-    for i in range(0, len(pairs), cap):
-        part = pairs[i:i + cap]
+    groups = [pairs[i:i + cap] for i in range(0, len(pairs), cap)] or [[]]
+    for gi, part in enumerate(groups):
         n = len(part)
-        ps = (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in part])
-        pd = (C.c_void_p * n)(*[d.data_ptr() for d, _ in part])
-        nb = (C.c_longlong * n)(*[d.numel() * d.element_size() for d, _ in part])
-        _check(load().bmnas_copy_batch(ps, pd, nb, n, _stream()), 'copy_batch')
+        ps = (C.c_void_p * max(n, 1))(*[s_.data_ptr() for _, s_ in part])
+        pd = (C.c_void_p * max(n, 1))(*[d.data_ptr() for d, _ in part])
+        nb = (C.c_longlong * max(n, 1))(*[d.numel() * d.element_size() for d, _ in part])
+        bd, bp, bn, keep = None, None, 0, None
+        if blob is not None and gi == len(groups) - 1:
+            raw = bytes(blob[1])
+            bd, bn = blob[0].data_ptr(), len(raw)
+            keep = C.create_string_buffer(raw, bn)              # (alive until the call has copied it into the kernargs)
+            bp = C.cast(keep, C.c_void_p)
+        if n == 0 and bn == 0:
+            continue
+        _check(load().bmnas_copy_batch(ps, pd, nb, n, bd, bp, bn, _stream()), 'copy_batch')
 
 
 def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc, step=None, scrub=None):

@@ -31,6 +31,7 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False)
         self._plan = None
         self._gen = 0            # bumped whenever the state tensors are replaced (load_state_dict)
+        self._touch = 0          # bumped by everything that may re-point .grad or move the step counts outside a replay
 
     # ------------------------------------------------------------------ plan
     def _active(self):
@@ -103,7 +104,8 @@ class Adam(torch.optim.Adam):
 
     def _launch(self):
         pl = self._plan
-        pl['dev'].copy_(pl['pin'], non_blocking=True)
+        if not pl.get('poke'):
+            pl['dev'].copy_(pl['pin'], non_blocking=True)
         lib.adam_multi(pl['dev_tab'], pl['chunks'], pl['n_chunks'], pl['dev_hyp'])
 
     def wait_staging(self):
@@ -112,10 +114,13 @@ class Adam(torch.optim.Adam):
         if self._plan is not None and self._plan.get('event') is not None:
             self._plan['event'].synchronize()
 
-    def mark_launched(self):
+    def mark_launched(self, force=False):
         """Record, on the current stream, that everything queued so far (a step() or a graph
-        replay that contains one) has read the staging buffer."""
+        replay that contains one) has read the staging buffer.  (Poke-mode plans: their replays do not read it —
+        nothing to record, and nothing for the next call to wait for: the host may run ahead of the GPU.)"""
         pl = self._plan
+        if pl.get('poke') and not force:
+            return
         if pl.get('event') is None:
             pl['event'] = torch.cuda.Event()
         pl['event'].record()
@@ -130,6 +135,7 @@ class Adam(torch.optim.Adam):
         active = self._active()
         if not active:
             return loss
+        self._touch += 1
         if torch.cuda.is_current_stream_capturing():
             if self._plan is None or self._plan['ids'] != tuple(id(p) for p, _ in active):
                 raise lib.BmnasError('bmnas.optim.Adam: call capture_safe() before capturing step() in a graph')
@@ -154,6 +160,10 @@ class Adam(torch.optim.Adam):
         self.mark_launched()
         return loss
 
+    def zero_grad(self, set_to_none=True):
+        self._touch += 1         # .grad re-pointed / dropped: a captured plan re-attaches its static tensors next time
+        return super().zero_grad(set_to_none)
+
     def state_dict(self):
         self._flush_counts()
         return super().state_dict()
@@ -170,7 +180,7 @@ class Adam(torch.optim.Adam):
         self._gen += 1
 
     # ------------------------------------------------------------------ hipGraph support
-    def capture_safe(self):
+    def capture_safe(self, poke=False):
         """Build a plan OF ITS OWN from the gradients that exist NOW (static tensors of the step
         being captured) so that step() inside `torch.cuda.graph` issues only stream work: one
         pinned H2D copy and one launch.  The captured graph keeps reading this plan's staging
@@ -181,6 +191,11 @@ class Adam(torch.optim.Adam):
         self._build(active)
         self._write_ptrs(active)
         self._plan['captured'] = True
+        # "poke" mode (round 5): the captured step holds NO H2D copy node.  The descriptor table is uploaded once after the
+        # capture (and again whenever activate() / load_state_dict changed it); the per-step scalars — 32 bytes per row —
+        # travel by value in the launch that copies the batch into the step's static tensors (bmnas_copy_batch's blob,
+        # replay_blob()).  A captured copy node cost 4.7 us per optimizer step.
+        self._plan['poke'] = bool(poke) and self._plan['hyp'].nbytes <= lib.copy_blob_max()
 
     def captured_plan(self):
         """The plan a capture has just baked into a graph, with the pointer table as captured
@@ -191,7 +206,24 @@ class Adam(torch.optim.Adam):
         pl['snap_param'] = pl['tab']['param'].copy()
         pl['snap_grad'] = pl['tab']['grad'].copy()
         pl['static_grads'] = [p.grad for p, _ in pl['active']]       # keeps the static tensors alive
+        pl['tab_dirty'] = True                                       # poke mode: upload before the first replay
         return pl
+
+    def replay_blob(self):
+        """Poke mode, after prepare_replay(): -> (device tensor, host bytes) of this replay's scalar rows for
+        bmnas_copy_batch's blob; uploads the descriptor table first when it changed (eagerly, on the current stream, i.e.
+        in front of the replay).  None: the captured step carries its own H2D copy node."""
+        pl = self._plan
+        if not pl.get('poke'):
+            return None
+        if pl.get('tab_dirty'):
+            self.wait_staging()
+            pl['dev'].copy_(pl['pin'], non_blocking=True)
+            self.mark_launched(force=True)       # the pinned buffer must not be rewritten before this copy has read it
+            self.wait_staging()                  # (rare: once after a capture / load_state_dict)
+            pl['tab_dirty'] = False
+        h = pl['hyp']
+        return pl['dev_hyp'][:h.nbytes], h.tobytes()
 
     def _switch(self, plan):
         """Make `plan` current: step counts travel through the per-parameter `step` tensors, the
@@ -207,7 +239,8 @@ class Adam(torch.optim.Adam):
             for r, c in counts.items():
                 plan['count'][r] = c
             self._plan = plan
-        self.wait_staging()                  # the plan's last launch has consumed its pinned buffer
+        if not plan.get('poke'):
+            self.wait_staging()              # the plan's last launch has consumed its pinned buffer
         if plan['gen'] != self._gen:
             plan['tab']['exp_avg'] = [self._init_state(p)['exp_avg'].data_ptr() for p, _ in plan['active']]
             plan['tab']['exp_avg_sq'] = [self.state[p]['exp_avg_sq'].data_ptr() for p, _ in plan['active']]
@@ -219,11 +252,22 @@ class Adam(torch.optim.Adam):
         own, so the staging buffers the graph reads are intact; but they advanced the step counts
         and re-pointed `.grad`.  The counts are carried over, the capture-time parameter / gradient
         pointers are restored and `.grad` is re-attached to the static tensors the graph writes."""
+        # fast path (every replay of a training loop): this plan is current, no eager step / zero_grad / load_state_dict
+        # happened since its last activation — nothing to restore
+        if self._plan is plan and plan['gen'] == self._gen and plan.get('stamp') == self._touch:
+            return
+        gen = plan['gen']
         self._switch(plan)
+        if plan['gen'] != gen:
+            plan['tab_dirty'] = True             # load_state_dict replaced the moment tensors: new pointers in the table
+        if plan.get('poke') and ((plan['tab']['param'] != plan['snap_param']).any()
+                                 or (plan['tab']['grad'] != plan['snap_grad']).any()):
+            plan['tab_dirty'] = True
         plan['tab']['param'] = plan['snap_param']
         plan['tab']['grad'] = plan['snap_grad']
         for (p, _), gr in zip(plan['active'], plan['static_grads']):
             p.grad = gr
+        plan['stamp'] = self._touch
 
     def prepare_replay(self):
         """Advance the step count and publish the current learning rates for the next replay

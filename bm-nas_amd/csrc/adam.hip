@@ -15,6 +15,7 @@
 // counts without re-capture.
 // HBM-streaming: 4 reads + 3 writes per element = 28 B/param.
 #include "common.hpp"
+#include <cstring>
 #include "../../include/bmnas_hip.h"
 
 namespace {
@@ -91,16 +92,32 @@ extern "C" int bmnas_adam_multi(const bmnas_adam_tensor_t* tensors, const int32_
 // batch is already on the device (train_searchable/mmimdb.py:60-63): host tensors keep torch's H2D copy.
 namespace {
 constexpr int kCopyMax = 16;
+constexpr int kBlobWords = 64;                  // 256 bytes by value: eight rows of Adam scalars
 struct CopyArgs {
   const void* src[kCopyMax];
   void* dst[kCopyMax];
   long long bytes[kCopyMax];
-  int first[kCopyMax + 1];     // first workgroup of tensor i; first[n] = grid size
+  int first[kCopyMax + 1];     // first workgroup of tensor i; first[n] = number of copy workgroups
   int n;
+  // a few words that travel BY VALUE in the kernel arguments and are stored to device memory by one extra workgroup:
+  // the per-step scalars of a captured optimizer step (learning rate / bias corrections, bmnas.optim.Adam) ride in
+  // the launch that precedes the replay instead of an H2D copy node inside the graph (4.7 us per optimizer step)
+  unsigned int* blob_dst;
+  int blob_words;
+  unsigned int blob[kBlobWords];
 };
 constexpr int kCopyChunk = 256 * 16 * 4;        // bytes per workgroup: four 16-byte pieces per lane
 
 __global__ __launch_bounds__(256) void copy_batch_k(CopyArgs a) {
+  if ((int)blockIdx.x >= a.first[kCopyMax]) {                   // the blob's workgroup (last of the grid)
+    if ((int)threadIdx.x < kBlobWords) {
+      unsigned int v = a.blob[0];
+#pragma unroll
+      for (int i = 1; i < kBlobWords; ++i) v = ((int)threadIdx.x == i) ? a.blob[i] : v;   // selects: no indexed kernarg load
+      if ((int)threadIdx.x < a.blob_words) a.blob_dst[threadIdx.x] = v;
+    }
+    return;
+  }
   int ti = 0;
 #pragma unroll
   for (int i = 1; i < kCopyMax; ++i) ti = (i < a.n && (int)blockIdx.x >= a.first[i]) ? i : ti;
@@ -145,9 +162,13 @@ __global__ __launch_bounds__(256) void copy_batch_k(CopyArgs a) {
 
 extern "C" int bmnas_copy_batch_max(void) { return kCopyMax; }
 
+extern "C" int bmnas_copy_blob_max(void) { return kBlobWords * 4; }
+
 extern "C" int bmnas_copy_batch(const void* const* srcs, void* const* dsts, const long long* bytes, int n,
-                                void* stream) {
+                                void* blob_dst, const void* blob, int blob_bytes, void* stream) {
   if (n < 0 || n > kCopyMax || (n > 0 && (!srcs || !dsts || !bytes))) return BMNAS_E_ARG;
+  if (blob_bytes < 0 || blob_bytes > kBlobWords * 4 || blob_bytes % 4 || (blob_bytes > 0 && (!blob_dst || !blob)))
+    return BMNAS_E_ARG;
   CopyArgs a{};
   int g = 0, m = 0;
   for (int i = 0; i < n; ++i) {
@@ -159,6 +180,12 @@ extern "C" int bmnas_copy_batch(const void* const* srcs, void* const* dsts, cons
   }
   a.n = m;
   for (int i = m; i <= kCopyMax; ++i) a.first[i] = g;
+  if (blob_bytes > 0) {
+    a.blob_dst = static_cast<unsigned int*>(blob_dst);
+    a.blob_words = blob_bytes / 4;
+    memcpy(a.blob, blob, (size_t)blob_bytes);
+    ++g;                                                        // one more workgroup: it stores the blob
+  }
   if (g == 0) return 0;
   hipLaunchKernelGGL(copy_batch_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
   BMNAS_CHECK_LAUNCH();

@@ -754,7 +754,14 @@ int bmnas_adam_multi(const bmnas_adam_tensor_t* tensors, const int32_t* chunks, 
  * dtype (byte counts) as ONE launch, the (src, dst, bytes) triples by value in the kernel arguments.
  * 16-byte lanes where both addresses are 16-byte aligned, bytes otherwise.  Overlapping src / dst: undefined. */
 int bmnas_copy_batch_max(void);
-int bmnas_copy_batch(const void* const* srcs, void* const* dsts, const long long* bytes, int n, void* stream);
+/* blob (optional, blob_bytes % 4 == 0, <= bmnas_copy_blob_max() bytes of HOST memory): copied by value into the kernel
+ * arguments at the call and stored to the device address blob_dst by the same launch — the per-step scalars of a
+ * captured optimizer step (bmnas_adam_multi's `hyp` rows: the learning rate the reference's scheduler sets per batch,
+ * models/auxiliary/scheduler.py, and Adam's bias corrections) reach the device with the batch instead of through an
+ * H2D copy node inside the step's graph.  n may be 0 (the blob alone). */
+int bmnas_copy_blob_max(void);
+int bmnas_copy_batch(const void* const* srcs, void* const* dsts, const long long* bytes, int n,
+                     void* blob_dst, const void* blob, int blob_bytes, void* stream);
 
 /* ---- data parallelism: RCCL behind the C ABI ---------------------------------------------------
  * One process per GPU; the data-path exchange of a search step is ONE in-place all-reduce of the flat

@@ -815,3 +815,24 @@ def test_copy_batch_one_launch_any_dtypes():
         assert torch.equal(d, s_), (d.shape, d.dtype)
         n = d.numel()
         assert bool((buf[:8] == 7).all()) and bool((buf[8 + n:] == 7).all()), (d.shape, d.dtype)
+
+
+def test_copy_batch_blob_by_value():
+    """The by-value blob of bmnas_copy_batch (a captured optimizer step's per-replay scalars ride in the launch that
+    copies the batch: no H2D node in the graph): stored bit-exactly, with tensors and alone, neighbours untouched."""
+    import numpy as np
+    from bmnas import lib
+    src = torch.arange(1000, dtype=torch.float32, device=dev())
+    dst = torch.zeros(1000, dtype=torch.float32, device=dev())
+    for nbytes, with_tensors in ((32, True), (256, True), (64, False), (4, False)):
+        host = np.random.default_rng(nbytes).integers(0, 255, nbytes, dtype=np.uint8)
+        buf = torch.full((nbytes + 32,), 9, dtype=torch.uint8, device=dev())
+        dst.zero_()
+        lib.copy_batch([(dst, src)] if with_tensors else [], blob=(buf[16:16 + nbytes], host.tobytes()))
+        torch.cuda.synchronize()
+        assert bool((buf[16:16 + nbytes].cpu() == torch.from_numpy(host)).all()), nbytes
+        assert bool((buf[:16] == 9).all()) and bool((buf[16 + nbytes:] == 9).all()), nbytes
+        assert torch.equal(dst, src) == with_tensors
+    assert lib.copy_blob_max() == 256
+    with pytest.raises(lib.BmnasError):
+        lib.copy_batch([], blob=(torch.zeros(512, dtype=torch.uint8, device=dev()), bytes(260)))
