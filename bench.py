@@ -739,7 +739,7 @@ def roofline_report(a, c, step, ms_per_step, log):
                 ptr = q + 1
                 break
     unmatched = skipped + [cname for cname, _, _ in calls[ptr:]]
-    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f'r0{r}_traffic.json') for r in (4, 3, 2))
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f'r0{r}_traffic.json') for r in (5, 4, 3, 2))
                   if os.path.exists(q)), '')
     traffic = {}
     if a.config == 'mmimdb' and a.batch == 128 and a.tier == 'F' and os.path.exists(tpath):
@@ -770,6 +770,10 @@ def roofline_report(a, c, step, ms_per_step, log):
         else:
             row.update({'bound': 'latency', 'achieved': None, 'peak': None, 'unit': None, 'frac': None,
                         'algorithmic_units_per_launch': None, 'traffic': traffic.get(n)})
+        if traffic.get(n):
+            # the same launch priced by the bytes the PMC passes counted for it (profiles/*traffic.json): what an
+            # MFMA-priced launch of a few hundred MFLOP is really bound by (the head pair: VERDICT r04 item 2)
+            row['frac_of_hbm_by_traffic'] = round(traffic[n] / (g['us'] / g['n'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         rows.append(row)
     rows.sort(key=lambda r: -r['us_per_step'])
     out = {'roofline_kernels': rows,

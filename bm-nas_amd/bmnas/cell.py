@@ -488,6 +488,14 @@ LAZY_LN = os.environ.get('BMNAS_LAZY_LN', '1') != '0'
 WRITE_ONCE = os.environ.get('BMNAS_WRITE_ONCE', '1') != '0'
 
 
+# BMNAS_STRICT_ZERO=1 (debug): the reference's 'none' primitive is Zero(x) = x.mul(0.) (operations.py:18-20), so a NaN
+# or Inf in a cell input reaches EVERY step's mixed sum as NaN through w_none * (x * 0.) (model_search.py:58) — the
+# kernels drop that term (finite inputs: exactly 0).  With the switch the cell adds sum_j (x_j * 0.) of its inputs to every
+# step's sum (two extra torch launches per step): non-finite inputs then propagate element for element as in the
+# reference.  Forward only — for finite values the term and its gradient are zero.
+STRICT_ZERO = os.environ.get('BMNAS_STRICT_ZERO', '0') not in ('0', '', 'false', 'False')
+
+
 # Run-to-run bit-identical results (the reference's CPU path is deterministic; the default kernels sum batch reductions
 # with fp32 atomics in whatever order workgroups finish).  Covers the search step with node_multiplier == 1 under the
 # fused head (the lazy-LayerNorm path): BatchNorm statistics as per-n-group partials + bn_finalize, head logits and
@@ -904,6 +912,14 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
                 lib.mixsum_pair_fwd(states, alpha_w[offset:, 1], 2, beta_ws[i][:, 1], 2, sif, z0)
         else:
             sif, z0 = mixsum_fwd(states, alpha_w[offset:, 1]), None
+        if STRICT_ZERO:
+            if i == 0:
+                poison = xs[0] * 0.
+                for x_ in xs[1:]:
+                    poison = poison + x_ * 0.
+            sif.add_(poison)
+            if z0 is not None:
+                z0.add_(poison)
         # small batches: step i + 1's pair sum (its inputs = today's states + this node's output) rides in the
         # launch that ends this node (bmnas_bn_relu_ln_fwd_pair)
         next_pair = None

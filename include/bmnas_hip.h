@@ -68,7 +68,9 @@ int bmnas_dropout_mask(bmnas_dropout_t drop, int64_t n_elem, float* out, void* s
  * node_search.py:54 (FusionMixedOp.forward operations.py:104-105 with Zero :18-20 and
  * Identity :92-93).  w points at the 'skip' column of the softmaxed edge rows
  * (w_stride = 2).  The 'none' primitive contributes w0*(x*0) = 0 for finite x and is not
- * evaluated (differs from the reference only for non-finite inputs). */
+ * evaluated (differs from the reference only for non-finite inputs; the host mirror's debug switch
+ * BMNAS_STRICT_ZERO=1 adds sum_j (x_j * 0.) of the cell inputs back onto every step's sum, so that NaN / Inf
+ * inputs propagate element for element as in the reference — bmnas.cell.STRICT_ZERO). */
 int bmnas_mixsum_fwd(const float* const* xs, int n_in, const float* w, int w_stride,
                      float* out, int64_t n_elem, void* stream);
 /* dxs[j] (=|+=) w_j * g  (dxs[j] may be NULL to skip; bit j of accumulate_mask selects +=);

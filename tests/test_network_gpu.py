@@ -588,3 +588,34 @@ def test_architecture_step_backward_skips_the_weight_gradients(name, batch, nout
     net3, cls3, loss3 = forward()
     loss3.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net3.parameters())
+
+
+@pytest.mark.parametrize('ns,nm', [(1, 1), (2, 2)])
+def test_strict_zero_propagates_non_finite_inputs_like_the_reference(ns, nm):
+    """BMNAS_STRICT_ZERO (debug): the reference's Zero primitive is x.mul(0.) (operations.py:18-20), so a NaN / Inf in
+    a cell input reaches every step's mixed sum as NaN; the kernels drop the exactly-zero term.  With the switch the
+    non-finite PATTERN of the cell output equals the oracle's (which keeps the term), the finite samples agree to the
+    usual tolerance; without it the deviation documented in include/bmnas_hip.h shows (an Inf input stays Inf-scaled
+    instead of turning into NaN — still non-finite, but the affected samples are the same)."""
+    from bmnas import cell as K
+    cfg = fo.make_cfg(N=3, C=32, L=8, S=2, M=2, ns=ns, nm=nm, drpt=0.0)
+    seed, batch = 7, 6
+    xs_cpu = synth.make_inputs(cfg, batch, seed)
+    xs_cpu[1][2, 5, 3] = float('nan')
+    xs_cpu[2][4, 0, 0] = float('inf')
+    # eval mode: train-mode BatchNorm statistics would spread one sample's NaN over the whole batch (in the reference too)
+    want = fo.fusion_cell([x.clone() for x in xs_cpu], synth.make_arch(cfg, seed), synth.make_params(cfg, seed), cfg,
+                          False, attn_drop=0.0)
+    net = build_search_net(cfg, seed, 'eval')
+    prev = K.STRICT_ZERO
+    K.STRICT_ZERO = True
+    try:
+        with torch.no_grad():
+            got = net([x.to(dev()) for x in xs_cpu]).cpu()
+    finally:
+        K.STRICT_ZERO = prev
+    assert torch.equal(torch.isfinite(got), torch.isfinite(want)), (int((~torch.isfinite(got)).sum()),
+                                                                   int((~torch.isfinite(want)).sum()))
+    ok = torch.isfinite(want)
+    assert bool(ok.any()) and bool((~ok).any())
+    assert_close_scaled('finite part', got[ok], want[ok])
