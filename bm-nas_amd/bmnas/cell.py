@@ -491,8 +491,10 @@ WRITE_ONCE = os.environ.get('BMNAS_WRITE_ONCE', '1') != '0'
 # BMNAS_STRICT_ZERO=1 (debug): the reference's 'none' primitive is Zero(x) = x.mul(0.) (operations.py:18-20), so a NaN
 # or Inf in a cell input reaches EVERY step's mixed sum as NaN through w_none * (x * 0.) (model_search.py:58) — the
 # kernels drop that term (finite inputs: exactly 0).  With the switch the cell adds sum_j (x_j * 0.) of its inputs to every
-# step's sum (two extra torch launches per step): non-finite inputs then propagate element for element as in the
-# reference.  Forward only — for finite values the term and its gradient are zero.
+# step's sum (two extra torch launches per step) and restores the per-sample NaN that the kernels' ReLU (`v > 0 ? v : 0`)
+# would clear at the cell's output: the non-finite pattern of the cell output / logits then equals the reference's.
+# Forward only — for finite values the terms and their gradients are zero.  (L = 16: exact per sample.  L = 8 / 4: samples
+# that share a 16-column attention tile with a non-finite one turn NaN as well — the tile's block-diagonal mask multiplies.)
 STRICT_ZERO = os.environ.get('BMNAS_STRICT_ZERO', '0') not in ('0', '', 'false', 'False')
 
 
@@ -960,9 +962,16 @@ def fusion_cell_fwd(xs, alpha_w, beta_ws, gamma_ws, CP, training, S, M, ns, nm, 
         else:
             lib.head_fwd(states[-M:], head.sums, CP.ln_w, CP.ln_b, head.W, head.bias, head.hb, sv.stats, b, C, L,
                          head.W.shape[0])
+        if STRICT_ZERO and S > 0:
+            head.hb[0].add_(poison.sum(dim=(1, 2))[:, None])    # (see below)
         return head.hb[0], sv
     out = _empty(xs[0], b, M * C * L)
     lib.cat_ln_fwd(states[-M:], None, CP.ln_w, CP.ln_b, out, sv.stats, b, C, L, True)
+    if STRICT_ZERO and S > 0:
+        # The kernels' ReLU is `v > 0 ? v : 0`, which maps NaN to 0 where torch's relu keeps it: a sample with a non-finite
+        # cell input is NaN from its first step node on (the node's LayerNorm spreads it over the sample), and the
+        # reference's K7 LayerNorm + ReLU return NaN for that whole sample — restored here per sample.
+        out.add_(poison.sum(dim=(1, 2))[:, None])
     return out, sv
 
 

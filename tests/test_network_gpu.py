@@ -598,7 +598,9 @@ def test_strict_zero_propagates_non_finite_inputs_like_the_reference(ns, nm):
     usual tolerance; without it the deviation documented in include/bmnas_hip.h shows (an Inf input stays Inf-scaled
     instead of turning into NaN — still non-finite, but the affected samples are the same)."""
     from bmnas import cell as K
-    cfg = fo.make_cfg(N=3, C=32, L=8, S=2, M=2, ns=ns, nm=nm, drpt=0.0)
+    # (L = 16: one sample per 16-column MFMA n-group.  With L = 8 / 4 two / four samples share an attention tile whose
+    # block-diagonal mask is a multiplication, so a non-finite sample also takes its tile partners with it)
+    cfg = fo.make_cfg(N=3, C=32, L=16, S=2, M=2, ns=ns, nm=nm, drpt=0.0)
     seed, batch = 7, 6
     xs_cpu = synth.make_inputs(cfg, batch, seed)
     xs_cpu[1][2, 5, 3] = float('nan')
