@@ -616,7 +616,7 @@ KERNELS_OF = {
     'bn_glu_fwd': ('bn_glu_fwd_k',), 'bn_glu_bwd': ('bn_glu_bwd_k',),
     'bn_bwd_apply': ('bn_bwd_apply_k',), 'bn_finalize': ('bn_finalize_k',), 'fold_weight': ('fold_weight_k',),
     'linear_fwd': ('linear_fwd_k',), 'linear_bwd': ('linear_bwd_k',),
-    'bce_logits': ('bce_logits_k',), 'cross_entropy': ('ce_rows_k',),
+    'bce_logits': ('bce_logits_k',), 'cross_entropy': ('ce_rows_k', 'ce_small_k'),
     'head_fwd': ('head_fwd_k',), 'head_bwd': ('head_bwd_k',), 'head_loss_bwd': ('head_loss_bwd_k',),
     'cell_prologue': ('cell_prologue_k',), 'cell_prologue_pair': ('cell_prologue_pair_k',),
     'node_mix_pre_fwd': ('node_mix_pre_fwd_k',), 'node_mix_lnp_bwd': ('node_mix_lnp_bwd_k',),
@@ -807,7 +807,7 @@ def roofline_report(a, c, step, ms_per_step, log):
     if top is not None:
         top = dict(top)
         top['measured'] = (source + f'; mean over {len(replays)} replays of End - Start per dispatch; '
-                           'cross-check: profiles/r04_kernel_stats_<config>_b<batch>.csv (rocprofv3 --kernel-trace --stats of the same command)')
+                           'cross-check: profiles/r05_kernel_stats_<config>_b<batch>.csv (rocprofv3 --kernel-trace --stats of the same command)')
         out['roofline'] = top
     return out
 

@@ -303,8 +303,8 @@ class ConvBnActFn(Function):
         K_in = len(srcs) * C_src
         W = _c(conv_w).view(M, K_in)
         pool = None
-        if act != 'glu' and training and FUSE_STANDALONE_BN:
-            pool = FWD_STAT_POOL             # statistics finalised inside bn_relu_fwd (no bn_finalize launch)
+        if training and FUSE_STANDALONE_BN:
+            pool = FWD_STAT_POOL             # statistics finalised inside bn_relu_fwd / bn_glu_fwd (no bn_finalize launch)
             pool.device = srcs[0].device
         U, chan, sv = K.conv_bn_fwd(srcs, C_src, W, K_in, _c(conv_b), _c(bn_w), _c(bn_b), rm, rv, nbt,
                                     training, stats=pool)
@@ -312,7 +312,7 @@ class ConvBnActFn(Function):
             Cout = M // 2
             out = torch.empty((b, Cout, L), device=U.device, dtype=torch.float32)
             drop = K.DROP.make(p, out.numel(), training)
-            lib.bn_glu_fwd(U, chan, out, b, Cout, L, drop)
+            lib.bn_glu_fwd(U, chan, out, b, Cout, L, drop, sv.fin)
         else:
             out = torch.empty((b, M, L), device=U.device, dtype=torch.float32)
             drop = K.DROP.make(p, out.numel(), training)

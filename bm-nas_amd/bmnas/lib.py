@@ -165,7 +165,7 @@ SIGNATURES = {
     'bmnas_node_mix_ln_bwd_ok': ([_I, _I, _I], _I),
     'bmnas_node_mix_ln_bwd': ([_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P, _U32,
                                _P, _P, _I, _I, _I, Dropout, Dropout, _P], _I),
-    'bmnas_bn_glu_fwd': ([_P, _P, _P, _I, _I, _I, Dropout, _P], _I),
+    'bmnas_bn_glu_fwd': ([_P, _P, BnFin, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_glu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_fwd': ([_P, _P, BnFin, _P, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_relu_bwd': ([_P, _P, _P, _P, _P, _I, _I, _I, Dropout, _P], _I),
@@ -837,8 +837,8 @@ def node_mix_ln_bwd(g, pre, ln_w, stats, g_in, dresid, acc_resid, x, y, p1, U, c
                                         _ptr(bn_grad), b, Cc, L, dglu, dfc, _stream()), 'node_mix_ln_bwd')
 
 
-def bn_glu_fwd(U, chan, out, b, Cc, L, drop):
-    _check(load().bmnas_bn_glu_fwd(_ptr(U), _ptr(chan), _ptr(out), b, Cc, L, drop, _stream()), 'bn_glu_fwd')
+def bn_glu_fwd(U, chan, out, b, Cc, L, drop, fin=NO_FIN):
+    _check(load().bmnas_bn_glu_fwd(_ptr(U), _ptr(chan), fin, _ptr(out), b, Cc, L, drop, _stream()), 'bn_glu_fwd')
 
 
 def bn_glu_bwd(g, U, chan, dV, bn_grad, b, Cc, L, drop):

@@ -594,20 +594,26 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
 
 
 // standalone LinearGLU tail: out = drop(va * sigmoid(vg)), U is (b, 2C, L) = [a | gate]
+// (round 5: the BatchNorm statistics are finalised HERE when `fin` says so — as in bn_relu_fwd_k and every consumer of
+// the search path — instead of by a bn_finalize launch in front: one launch less per LinearGLU of a found network)
 __global__ __launch_bounds__(256) void bn_glu_fwd_k(const float* __restrict__ U,
-                                                    const float* __restrict__ chan,
+                                                    float* __restrict__ chan, BnFin fin,
                                                     float* __restrict__ out, int b, int C, int L,
                                                     DropCfg d) {
+  extern __shared__ float fin_lds[];
   const DropRt dr = drop_begin(d);
   const int cl4 = C * L / 4, l4n = L / 4, M = 2 * C;
+  float* sc = fin_lds;
+  float* sh = fin_lds + M;
+  bn_fin_fill<256>(fin, chan, M, b * L, sc, sh, blockIdx.x == 0);
   const int64_t total = (int64_t)b * cl4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int s = (int)(i / cl4);
     const int r = (int)(i - (int64_t)s * cl4);
     const int c = r / l4n;
     const int64_t ub = ((int64_t)s * M) * L + (int64_t)r * 4;
-    const float4 va = affine4(ld4(U + ub), chan[2 * M + c], chan[3 * M + c]);
-    const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), chan[2 * M + C + c], chan[3 * M + C + c]);
+    const float4 va = affine4(ld4(U + ub), sc[c], sh[c]);
+    const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), sc[C + c], sh[C + c]);
     const float4 m = drop_mult4(dr, (uint64_t)(i * 4));
     st4(out + i * 4, make_float4(va.x * sigmoidf(vg.x) * m.x, va.y * sigmoidf(vg.y) * m.y,
                                   va.z * sigmoidf(vg.z) * m.z, va.w * sigmoidf(vg.w) * m.w));
@@ -1536,14 +1542,18 @@ extern "C" int bmnas_node_mix_ln_bwd(const float* g, const float* pre, const flo
   return 0;
 }
 
-extern "C" int bmnas_bn_glu_fwd(const float* U, const float* chan, float* out, int b, int C, int L,
+extern "C" int bmnas_bn_glu_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, float* out, int b, int C, int L,
                                 bmnas_dropout_t drop, void* stream) {
   if (!U || !chan || !out || b < 0 || C < 1) return BMNAS_E_ARG;
   if (L % 4 || L > 16) return BMNAS_E_SHAPE;
+  if (2 * C > 4096) return BMNAS_E_LIMIT;                 // scale | shift of every channel sit in LDS
+  BnFin f;
+  if (int e = to_fin(fin, &f)) return e;
+  if (f.on && f.training && b * L < 2) return BMNAS_E_ARG;
   if (b == 0) return 0;
   const int64_t total = (int64_t)b * C * L / 4;
-  hipLaunchKernelGGL(bn_glu_fwd_k, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, U,
-                     chan, out, b, C, L, to_cfg(drop));
+  hipLaunchKernelGGL(bn_glu_fwd_k, dim3(stream_grid(total)), dim3(256), (size_t)4 * C * sizeof(float),
+                     (hipStream_t)stream, U, chan, f, out, b, C, L, to_cfg(drop));
   BMNAS_CHECK_LAUNCH();
   return 0;
 }

@@ -254,6 +254,38 @@ __global__ __launch_bounds__(256) void ce_rows_k(const float* __restrict__ z,
   }
 }
 
+// The same for batches of up to 256 samples as ONE workgroup: each wave walks its rows, the mean is formed behind one
+// barrier — the found-stage / evaluation criterion as one launch instead of ce_rows_k + mean_k (round 5).
+__global__ __launch_bounds__(256) void ce_small_k(const float* __restrict__ z, const int64_t* __restrict__ label,
+                                                  float* __restrict__ row_loss, float* __restrict__ dz,
+                                                  float* __restrict__ loss, int b, int O) {
+  __shared__ float red[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float inv = 1.f / (float)b;
+  float acc = 0.f;
+  for (int m = wave; m < b; m += 4) {
+    const float* zr = z + (int64_t)m * O;
+    float mx = -INFINITY;
+    for (int o = lane; o < O; o += 64) mx = fmaxf(mx, zr[o]);
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int o = lane; o < O; o += 64) den += expf(zr[o] - mx);
+    den = wave_sum(den);
+    const int lab = (int)label[m];
+    const float rl = (mx + logf(den)) - zr[lab];
+    if (lane == 0) {
+      row_loss[m] = rl;
+      acc += rl;
+    }
+    if (dz != nullptr)
+      for (int o = lane; o < O; o += 64)
+        dz[(int64_t)m * O + o] = (expf(zr[o] - mx) / den - (o == lab ? 1.f : 0.f)) * inv;
+  }
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv;
+}
+
 __global__ __launch_bounds__(256) void mean_k(const float* __restrict__ v, float* __restrict__ out, int n) {
   __shared__ float red[4];
   float s = 0.f;
@@ -330,6 +362,11 @@ extern "C" int bmnas_cross_entropy(const float* z, const int64_t* label, float* 
                                    float* row_loss, int b, int O, void* stream) {
   if (!z || !label || !loss || !row_loss || b < 1 || O < 1) return BMNAS_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (b <= 256) {
+    hipLaunchKernelGGL(ce_small_k, dim3(1), dim3(256), 0, st, z, label, row_loss, dz, loss, b, O);
+    BMNAS_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(ce_rows_k, dim3((b + 3) / 4), dim3(256), 0, st, z, label, row_loss, dz, b, O);
   BMNAS_CHECK_LAUNCH();
   hipLaunchKernelGGL(mean_k, dim3(1), dim3(256), 0, st, row_loss, loss, b);

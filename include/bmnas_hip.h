@@ -384,8 +384,11 @@ int bmnas_node_mix_bwd_next(const float* g, const float* x, const float* y, cons
                             const float* gz, const float* gz2, float* g_out, void* stream);
 
 /* ---- standalone LinearGLU tail (Found nets): out = drop(glu(BN(U))), U (b, 2C, L) --------
- * node_operations.py:34-38.  Backward phase A like bmnas_node_mix_bwd (M = 2C). */
-int bmnas_bn_glu_fwd(const float* U, const float* chan, float* out, int b, int C, int L,
+ * node_operations.py:34-38.  fin (as bmnas_bn_relu_fwd): when on, the BatchNorm batch sums that the conv's epilogue
+ * accumulated are finalised by this launch (every workgroup forms scale / shift in LDS, workgroup 0 writes `chan` and the
+ * running statistics) — no bmnas_bn_finalize launch in front; off: `chan` is read as given.
+ * Backward phase A like bmnas_node_mix_bwd (M = 2C). */
+int bmnas_bn_glu_fwd(const float* U, float* chan, bmnas_bn_fin_t fin, float* out, int b, int C, int L,
                      bmnas_dropout_t drop, void* stream);
 int bmnas_bn_glu_bwd(const float* g, const float* U, const float* chan, float* dV, float* bn_grad,
                      int b, int C, int L, bmnas_dropout_t drop, void* stream);

@@ -379,7 +379,7 @@ def test_bce_with_logits_loss(b, O):
     assert_close_scaled('dz', zd.grad, zo.grad)
 
 
-@pytest.mark.parametrize('b,O', [(64, 60), (48, 83), (5, 3), (1, 100)])
+@pytest.mark.parametrize('b,O', [(64, 60), (48, 83), (5, 3), (1, 100), (256, 60), (257, 83), (1000, 7)])   # <= 256: one launch
 def test_cross_entropy_loss(b, O):
     from bmnas import nn as bnn
     g = _gen(700 + b)
