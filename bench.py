@@ -221,7 +221,7 @@ def algo_table(C, L):
             ('mfma', sum((2.0 + 2.0 * (d is not None)) * M * x.shape[1] * b * L_ for x, d in zip(srcs, dsrcs))),
         'bn_relu_fwd_group': lambda Us, chans, outs, fins, drops, b, M, L_: ('hbm', sum(2 * T(U) for U in Us)),
         'bn_relu_bwd_group': lambda gs, Us, chans, dVs, bgs, drops, b, M, L_: ('hbm', sum(3 * T(U) for U in Us)),
-        'linear_fwd': lambda feat, W, bias, out, b, O, Kd: ('mfma', 2.0 * b * O * Kd),
+        'linear_fwd': lambda feat, W, bias, out, b, O, Kd, *_, **__: ('mfma', 2.0 * b * O * Kd),
         'linear_bwd': lambda g, gs, feat, W, df, dW, db, b, O, Kd: ('mfma', 4.0 * b * O * Kd),
     }
 

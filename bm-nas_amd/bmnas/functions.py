@@ -117,6 +117,75 @@ def _ln_affine(g, srcs, resid, ln_w, ln_b, stats, dw, db, b, C, L, relu, prenorm
         lib.ln_affine_bwd(g, None, srcs, resid, ln_w, ln_b, stats, dw, db, b, C, L, relu, prenorm)
 
 
+# ---- the zero-filled accumulators of a CAPTURED per-op step: one persistent arena, cleared in front of the replay --------
+# The per-op Functions (Found_* nets, standalone modules, the torch-side classifier) add into zero-filled buffers with
+# atomics: BatchNorm batch sums (_FwdStatPool), bn_grad | dW | dbias and the LayerNorm affine gradients (_ZeroPool), the
+# classifier's split-K output.  Each pool cost a torch.zeros fill launch inside the step (and LinearFn a zero_fill of its
+# own).  A captured step (bmnas.graph) now measures what a pass needs during its dress rehearsal (`arena_measure()`), owns
+# ONE persistent fp32 arena of that size, and the launch that copies the batch in front of every replay also clears it
+# (bmnas_copy_batch's zero-fill jobs): inside the capture (`arena_use(arena)`) the pools carve from it without any fill.
+# Anything beyond the measured size falls back to a fill of its own, as before.
+class _StepArena:
+    def __init__(self, buf):
+        self.buf, self.off = buf, 0
+
+    def take(self, n):
+        n = (n + 3) // 4 * 4
+        if self.off + n > self.buf.numel():
+            return None
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        return v
+
+
+_ARENA = None            # the arena of the capture in progress
+_ARENA_NEED = None       # [floats] while a rehearsal pass is being measured
+
+
+class arena_measure:
+    """with arena_measure() as m: one pass of the step -> m.need = floats of zero-filled scratch it took."""
+
+    def __enter__(self):
+        global _ARENA_NEED
+        self.prev, _ARENA_NEED = _ARENA_NEED, [0]
+        self.cell = _ARENA_NEED
+        return self
+
+    def __exit__(self, *exc):
+        global _ARENA_NEED
+        self.need, _ARENA_NEED = self.cell[0], self.prev
+        return False
+
+
+class arena_use:
+    def __init__(self, buf):
+        self.arena = _StepArena(buf) if buf is not None and buf.numel() else None
+
+    def __enter__(self):
+        global _ARENA
+        self.prev, _ARENA = _ARENA, self.arena
+        reset_pools()                     # nothing of an earlier (eager) pass may be handed out inside the capture
+        return self
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = self.prev
+        reset_pools()                     # ... nor arena slices to the eager passes that follow
+        return False
+
+
+def zeros_for_step(n, device):
+    """n zero-filled floats: a slice of the captured step's arena (cleared in front of every replay by the batch-copy
+    launch), else torch.zeros — one fill launch."""
+    if _ARENA_NEED is not None:
+        _ARENA_NEED[0] += (n + 3) // 4 * 4
+    if _ARENA is not None and _ARENA.buf.device == device:
+        v = _ARENA.take(n)
+        if v is not None:
+            return v
+    return torch.zeros(n, device=device, dtype=torch.float32)
+
+
 def _zero_pair(like):
     """Two zero-filled tensors shaped like `like` (a LayerNorm's dln_w, dln_b), slices of the backward pass's one
     zero-filled chunk (ZERO_POOL; the forward announced them)."""
@@ -225,10 +294,10 @@ class _ZeroPool:
             self.in_backward = True
             FWD_STAT_POOL.close()
             # (capped: forwards that were never followed by a backward must not inflate the fill)
-            self.chunk = torch.zeros(max(min(self.pending, 1 << 24), n), device=device, dtype=torch.float32)
+            self.chunk = zeros_for_step(max(min(self.pending, 1 << 24), n), device)
             self.off = 0
         if self.chunk is None or self.chunk.device != device or self.off + n > self.chunk.numel():
-            return torch.zeros(n, device=device, dtype=torch.float32)
+            return zeros_for_step(n, device)
         v = self.chunk[self.off:self.off + n]
         self.off += n
         return v
@@ -267,10 +336,10 @@ class _FwdStatPool:
         self.captured = cap
         if not self.open:
             self.open, self.off, self.total = True, 0, 0
-            self.chunk = torch.zeros(self.last_total, device=dev, dtype=torch.float32) if self.last_total else None
+            self.chunk = zeros_for_step(self.last_total, dev) if self.last_total else None
         self.total += n
         if self.chunk is None or self.chunk.device != dev or self.off + n > self.chunk.numel():
-            return torch.zeros(n, device=dev, dtype=torch.float32)
+            return zeros_for_step(n, dev)
         v = self.chunk[self.off:self.off + n]
         self.off += n
         return v
@@ -630,8 +699,12 @@ class LinearFn(Function):
         feat, W, bias = _c(_f32(feat)), _c(_f32(W)), _c(bias)
         b, Kd = feat.shape
         O = W.shape[0]
-        out = torch.empty((b, O), device=feat.device, dtype=torch.float32)
-        lib.linear_fwd(feat, W, bias, out, b, O, Kd)
+        # the k-slices add into `out`: zero-filled by the captured step's arena where there is one (no fill launch)
+        if _ARENA_NEED is not None:
+            _ARENA_NEED[0] += (b * O + 3) // 4 * 4
+        pre = _ARENA.take(b * O) if (_ARENA is not None and _ARENA.buf.device == feat.device) else None
+        out = pre.view(b, O) if pre is not None else torch.empty((b, O), device=feat.device, dtype=torch.float32)
+        lib.linear_fwd(feat, W, bias, out, b, O, Kd, out_is_zero=pre is not None)
         ctx.save_for_backward(feat, W)
         return out
 

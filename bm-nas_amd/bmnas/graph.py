@@ -9,7 +9,13 @@ the kernels add a DEVICE counter to their Philox offsets and the graph advances 
 import torch
 
 from . import cell as K
-from .functions import deferred_affine, unit_grad
+from .functions import arena_measure, deferred_affine, unit_grad
+
+
+def _step_arena_on():
+    """BMNAS_STEP_ARENA=0 (A/B runs): captured per-op steps keep their in-graph fill launches and counter add."""
+    import os
+    return os.environ.get('BMNAS_STEP_ARENA', '1') != '0'
 
 
 class GraphedStep:
@@ -25,7 +31,11 @@ class GraphedStep:
 
     _instances = 0
 
-    def __init__(self, fn, warmup=3):
+    def __init__(self, fn, warmup=3, external_advance=False, arena=None):
+        """external_advance: the caller advances the dropout step counter itself in front of every replay (the launch
+        that copies the batch in: `self.external = (counter, span)`), so a step without a fused cell prologue needs no
+        `counter.add_` node at its end.  arena: the zero-filled fp32 scratch the captured pass carves its accumulators
+        from (bmnas.functions.arena_use); the caller clears it in front of every replay."""
         quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
         if quiet is not None:
             quiet(False)         # leaves outside the differentiated set keep nodes from the warm-up stream
@@ -47,15 +57,22 @@ class GraphedStep:
         # if the step has none, an add at the end of the graph does
         K.DROP.pending_advance = (self.counter, self.span_dev)
         self.graph = torch.cuda.CUDAGraph()
+        self.external = None
+        from .functions import arena_use
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph), arena_use(arena):
                 out = fn()
                 self.span = K.DROP.offset
                 # True: a cell prologue advanced the counter in front of every dropout site of the step (they
                 # all read the advanced value); False: the sites read the old value and this add ends the graph
                 self.advanced_first = K.DROP.pending_advance is None
                 if self.span > 0 and not self.advanced_first:
-                    self.counter.add_(self.span)      # next replay draws new dropout masks
+                    if external_advance:
+                        # the caller's pre-replay launch adds the span: the sites then read the advanced value too
+                        self.external = (self.counter, self.span)
+                        self.advanced_first = True
+                    else:
+                        self.counter.add_(self.span)      # next replay draws new dropout masks
             self.span_dev.fill_(self.span)
             # keep the static storage, not the Python autograd graph that produced it (a retained
             # graph would get in the way of later captures: GraphedTrainStep._live_graph_tensors)
@@ -232,7 +249,8 @@ class GraphedTrainStep:
                 mode = torch.cuda.get_sync_debug_mode()
                 torch.cuda.set_sync_debug_mode('error')
                 try:
-                    fn()
+                    with arena_measure() as need:        # ... and what zero-filled scratch a pass of the step takes
+                        fn()
                 finally:
                     torch.cuda.set_sync_debug_mode(mode)
         except BaseException:
@@ -245,7 +263,12 @@ class GraphedTrainStep:
             if self.in_graph_step:
                 optimizer.capture_safe(poke=True)        # no H2D node in the graph: the scalars ride with the batch copy
             armed[0] = True
-            self._g = GraphedStep(fn, warmup=0)
+            # the step's accumulation arena: cleared, like the dropout step counter advanced, by the launch that copies
+            # the batch in front of every replay — no fill / add launches inside the step (bmnas.functions._StepArena)
+            self._arena = (torch.zeros(need.need, device=self.labels.device, dtype=torch.float32)
+                           if need.need and _step_arena_on() else None)
+            self._g = GraphedStep(fn, warmup=0, external_advance=_step_arena_on(), arena=self._arena)
+            self._batch_in = _BatchIn(self.inputs, self.labels, zero=[self._arena], advance=self._g.external)
             # the graph reads THIS plan's staging buffers and writes THESE gradient tensors for good
             self.plan = optimizer.captured_plan() if self.in_graph_step else None
             self.static_grads = [t.grad for t in self.targets]
@@ -332,9 +355,9 @@ class _BatchIn:
     device, plain copies for anything else (host tensors: the copy IS the H2D transfer; a dtype / layout change:
     torch's converting copy).  Tensors that already ARE the static ones (GraphedTrainStep.static_batch()) cost nothing."""
 
-    def __init__(self, static_inputs, static_labels):
+    def __init__(self, static_inputs, static_labels, zero=(), advance=None):
         from . import lib
-        self.copier = lib.BatchCopier(list(static_inputs) + [static_labels])
+        self.copier = lib.BatchCopier(list(static_inputs) + [static_labels], zero=zero, advance=advance)
 
     def __call__(self, inputs, labels, blob=None):
         with torch.no_grad():
@@ -378,12 +401,16 @@ class GraphedForward:
                 mode = torch.cuda.get_sync_debug_mode()      # dress rehearsal (see GraphedTrainStep)
                 torch.cuda.set_sync_debug_mode('error')
                 try:
-                    fn()
+                    with arena_measure() as need:
+                        fn()
                 finally:
                     torch.cuda.set_sync_debug_mode(mode)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self._g = GraphedStep(fn, warmup=0)
+            self._arena = (torch.zeros(need.need, device=self.labels.device, dtype=torch.float32)
+                           if need.need and _step_arena_on() else None)
+            self._g = GraphedStep(fn, warmup=0, external_advance=_step_arena_on(), arena=self._arena)
+            self._batch_in = _BatchIn(self.inputs, self.labels, zero=[self._arena], advance=self._g.external)
         finally:
             torch.cuda.synchronize()
             if state is not None:

@@ -184,7 +184,7 @@ SIGNATURES = {
                                    _U32, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I64, _P, _P], _I),
     'bmnas_bn_relu_ln_bwd': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, Dropout, _P], _I),
     'bmnas_bn_bwd_apply': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
-    'bmnas_linear_fwd': ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
+    'bmnas_linear_fwd': ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'bmnas_linear_bwd': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
     'bmnas_bce_logits': ([_P, _P, _P, _P, _I, _P], _I),
     'bmnas_cross_entropy': ([_P, _P, _P, _P, _P, _I, _I, _P], _I),
@@ -192,7 +192,7 @@ SIGNATURES = {
     'bmnas_adam_multi': ([_P, _P, _I, _P, _P], _I),
     'bmnas_copy_batch_max': ([], _I),
     'bmnas_copy_blob_max': ([], _I),
-    'bmnas_copy_batch': ([_PP, _PP, C.POINTER(C.c_longlong), _I, _P, _P, _I, _P], _I),
+    'bmnas_copy_batch': ([_PP, _PP, C.POINTER(C.c_longlong), _I, _P, _P, _I, _P, C.c_ulonglong, _P], _I),
     'bmnas_arch_softmax_fwd': ([_P, _P, _I, _I, _P], _I),
     'bmnas_arch_softmax_bwd': ([_P, _P, _P, _I, _I, _P], _I),
     'bmnas_backward_epilogue': ([_I, _PP, _PP, C.POINTER(_PP), C.POINTER(C.c_int), _PP, _PP, _PP, _PP, _PP,
@@ -908,8 +908,8 @@ def arch_softmax_bwd(w, dw, dlogits, rows, cols):
                                          _stream()), 'arch_softmax_bwd')
 
 
-def linear_fwd(feat, W, bias, out, b, O, Kd):
-    _check(load().bmnas_linear_fwd(_ptr(feat), _ptr(W), _ptr(bias), _ptr(out), b, O, Kd, _stream()),
+def linear_fwd(feat, W, bias, out, b, O, Kd, out_is_zero=False):
+    _check(load().bmnas_linear_fwd(_ptr(feat), _ptr(W), _ptr(bias), _ptr(out), b, O, Kd, int(out_is_zero), _stream()),
            'linear_fwd')
 
 
@@ -947,11 +947,14 @@ def copy_blob_max():
 class BatchCopier:
     """bmnas_copy_batch for a FIXED list of destinations (a captured step's static tensors), called once per batch: the
     ctypes argument arrays are built once, a call only fills in the source addresses (the host side of a replayed step is
-    ~10 Python-level operations, not a list comprehension per tensor attribute)."""
+    ~10 Python-level operations, not a list comprehension per tensor attribute).
+    zero: tensors the same launch ZERO-FILLS on every call (the step's accumulation arena); advance = (int64 device
+    tensor, value): a counter the launch advances by `value` on every call."""
 
-    def __init__(self, dsts):
+    def __init__(self, dsts, zero=(), advance=None):
         self.dsts = list(dsts)
-        n = len(self.dsts)
+        self.zero = [z for z in zero if z is not None and z.numel()]
+        n = len(self.dsts) + len(self.zero)
         assert n <= load().bmnas_copy_batch_max()
         self.dptr = [d.data_ptr() for d in self.dsts]
         self.nbytes = [d.numel() * d.element_size() for d in self.dsts]
@@ -959,6 +962,9 @@ class BatchCopier:
         self.pd = (C.c_void_p * max(n, 1))()
         self.nb = (C.c_longlong * max(n, 1))()
         self.fn = load().bmnas_copy_batch
+        self.add_dst = None if advance is None else advance[0].data_ptr()
+        self.add_val = 0 if advance is None else int(advance[1])
+        self._keep = (self.zero, advance)
 
     def __call__(self, srcs, blob=None):
         """srcs[i] -> dsts[i] for every i whose source is not the destination itself; -> the (dst, src) pairs this
@@ -976,14 +982,18 @@ class BatchCopier:
                 n += 1
             else:
                 slow.append((d, s_))
+        for z in self.zero:                                  # zero-fill jobs: a NULL source
+            self.ps[n], self.pd[n], self.nb[n] = None, z.data_ptr(), z.numel() * z.element_size()
+            n += 1
         bd, bp, bn, keep = None, None, 0, None
         if blob is not None:
             raw = blob[1]
             bd, bn = blob[0].data_ptr(), len(raw)
             keep = C.create_string_buffer(raw, bn)
             bp = C.cast(keep, C.c_void_p)
-        if n or bn:
-            _check(self.fn(self.ps, self.pd, self.nb, n, bd, bp, bn, _stream()), 'copy_batch')
+        if n or bn or self.add_dst:
+            _check(self.fn(self.ps, self.pd, self.nb, n, bd, bp, bn, self.add_dst, self.add_val, _stream()),
+                   'copy_batch')
         return slow
 
 
@@ -995,7 +1005,7 @@ def copy_batch(pairs, blob=None):
     groups = [pairs[i:i + cap] for i in range(0, len(pairs), cap)] or [[]]
     for gi, part in enumerate(groups):
         n = len(part)
-        ps = (C.c_void_p * max(n, 1))(*[s_.data_ptr() for _, s_ in part])
+        ps = (C.c_void_p * max(n, 1))(*[None if s_ is None else s_.data_ptr() for _, s_ in part])   # None: zero-fill
         pd = (C.c_void_p * max(n, 1))(*[d.data_ptr() for d, _ in part])
         nb = (C.c_longlong * max(n, 1))(*[d.numel() * d.element_size() for d, _ in part])
         bd, bp, bn, keep = None, None, 0, None
@@ -1006,7 +1016,7 @@ def copy_batch(pairs, blob=None):
             bp = C.cast(keep, C.c_void_p)
         if n == 0 and bn == 0:
             continue
-        _check(load().bmnas_copy_batch(ps, pd, nb, n, bd, bp, bn, _stream()), 'copy_batch')
+        _check(load().bmnas_copy_batch(ps, pd, nb, n, bd, bp, bn, None, 0, _stream()), 'copy_batch')
 
 
 def cell_prologue(a_list, out_list, Ws, Weffs, M, Cc, step=None, scrub=None):

@@ -105,6 +105,10 @@ struct CopyArgs {
   unsigned int* blob_dst;
   int blob_words;
   unsigned int blob[kBlobWords];
+  // ... and one 64-bit device counter it advances: the dropout step counter of a captured step without a fused cell
+  // prologue (found networks, evaluation forwards) — torch's `counter.add_(span)` node at the end of such a graph
+  unsigned long long* add_dst;
+  unsigned long long add_val;
 };
 constexpr int kCopyChunk = 256 * 16 * 4;        // bytes per workgroup: four 16-byte pieces per lane
 
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(256) void copy_batch_k(CopyArgs a) {
       for (int i = 1; i < kBlobWords; ++i) v = ((int)threadIdx.x == i) ? a.blob[i] : v;   // selects: no indexed kernarg load
       if ((int)threadIdx.x < a.blob_words) a.blob_dst[threadIdx.x] = v;
     }
+    if (threadIdx.x == 0 && a.add_dst != nullptr) a.add_dst[0] += a.add_val;
     return;
   }
   int ti = 0;
@@ -135,6 +140,27 @@ __global__ __launch_bounds__(256) void copy_batch_k(CopyArgs a) {
   }
   const long long base = (long long)((int)blockIdx.x - f) * kCopyChunk;
   const long long full = nb & ~15ll;                            // bytes in whole 16-byte pieces
+  if (s == nullptr) {
+    // zero-fill job (workgroup-uniform): the accumulators a captured per-op step adds into with atomics (BatchNorm batch
+    // sums, weight / affine gradients, the classifier's split-K output) are cleared by THIS launch, in front of the
+    // replay, instead of by torch.zeros / zero_fill launches inside it (bmnas.functions.STEP_ARENA)
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    if (((uintptr_t)d & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long o = base + ((long long)r * 256 + threadIdx.x) * 16;
+        if (o < full) *reinterpret_cast<uint4*>(d + o) = z4;
+      }
+      if (full < nb && full >= base && full < base + kCopyChunk && (long long)threadIdx.x == ((full - base) >> 4) % 256)
+        for (long long o = full; o < nb; ++o) d[o] = 0;
+    } else {
+      for (int r = 0; r < 4; ++r) {
+        const long long o0 = base + ((long long)r * 256 + threadIdx.x) * 16;
+        for (long long o = o0; o < nb && o < o0 + 16; ++o) d[o] = 0;
+      }
+    }
+    return;
+  }
   if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0 && nb >= 16) {
     // four 16-byte pieces per lane, every load issued before the first store; scalars, not arrays (an indexed
     // per-lane array here was promoted to 16 KB of LDS per workgroup and the launch took 18 us for 9.4 MB)
@@ -165,14 +191,15 @@ extern "C" int bmnas_copy_batch_max(void) { return kCopyMax; }
 extern "C" int bmnas_copy_blob_max(void) { return kBlobWords * 4; }
 
 extern "C" int bmnas_copy_batch(const void* const* srcs, void* const* dsts, const long long* bytes, int n,
-                                void* blob_dst, const void* blob, int blob_bytes, void* stream) {
+                                void* blob_dst, const void* blob, int blob_bytes, unsigned long long* add_dst,
+                                unsigned long long add_val, void* stream) {
   if (n < 0 || n > kCopyMax || (n > 0 && (!srcs || !dsts || !bytes))) return BMNAS_E_ARG;
   if (blob_bytes < 0 || blob_bytes > kBlobWords * 4 || blob_bytes % 4 || (blob_bytes > 0 && (!blob_dst || !blob)))
     return BMNAS_E_ARG;
   CopyArgs a{};
   int g = 0, m = 0;
   for (int i = 0; i < n; ++i) {
-    if (bytes[i] < 0 || (bytes[i] > 0 && (!srcs[i] || !dsts[i]))) return BMNAS_E_ARG;
+    if (bytes[i] < 0 || (bytes[i] > 0 && !dsts[i])) return BMNAS_E_ARG;      // (srcs[i] == NULL: zero-fill dsts[i])
     if (bytes[i] == 0) continue;
     a.src[m] = srcs[i]; a.dst[m] = dsts[i]; a.bytes[m] = bytes[i]; a.first[m] = g;
     g += (int)((bytes[i] + kCopyChunk - 1) / kCopyChunk);
@@ -184,8 +211,10 @@ extern "C" int bmnas_copy_batch(const void* const* srcs, void* const* dsts, cons
     a.blob_dst = static_cast<unsigned int*>(blob_dst);
     a.blob_words = blob_bytes / 4;
     memcpy(a.blob, blob, (size_t)blob_bytes);
-    ++g;                                                        // one more workgroup: it stores the blob
   }
+  a.add_dst = add_dst;
+  a.add_val = add_val;
+  if (blob_bytes > 0 || add_dst != nullptr) ++g;                // one more workgroup: it stores the blob / advances the counter
   if (g == 0) return 0;
   hipLaunchKernelGGL(copy_batch_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
   BMNAS_CHECK_LAUNCH();

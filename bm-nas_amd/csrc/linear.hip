@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void mean_k(const float* __restrict__ v, float
   }
 
 extern "C" int bmnas_linear_fwd(const float* feat, const float* W, const float* bias, float* out,
-                                int b, int O, int K, void* stream) {
+                                int b, int O, int K, int out_is_zero, void* stream) {
   if (!feat || !W || !bias || !out || b < 0 || O < 1 || K < 1) return BMNAS_E_ARG;
   if (K % 16 != 0) return BMNAS_E_SHAPE;
   if (b == 0) return 0;
@@ -314,7 +314,7 @@ extern "C" int bmnas_linear_fwd(const float* feat, const float* W, const float* 
   if (tj > kMaxTJ) return BMNAS_E_LIMIT;
   hipStream_t st = (hipStream_t)stream;
   if ((int64_t)b * O > (int64_t)1 << 30) return BMNAS_E_LIMIT;
-  hipLaunchKernelGGL(zero_fill_k, dim3((b * O + 255) / 256), dim3(256), 0, st, out, b * O);
+  if (!out_is_zero) hipLaunchKernelGGL(zero_fill_k, dim3((b * O + 255) / 256), dim3(256), 0, st, out, b * O);
   const int nblk = K / 16;
   const int splits = (nblk + 15) / 16;                       // <= 4 blocks per wave, 4 waves
   const int bpw = (nblk + splits * 4 - 1) / (splits * 4);

@@ -713,9 +713,10 @@ int bmnas_debug_stamps_conv(void* buf, int slots);   /* csrc/conv1x1.hip: slot 6
 
 /* ---- central_classifier + criterion epilogue (the callers' side of the path) ---------------
  * out[m, o] = bias[o] + sum_k feat[m, k] * W[o, k]  — nn.Linear(M*C*L, classes) at
- * mmimdb_darts_searchable.py:82-83,114 (O <= 128, K % 16 == 0). */
+ * mmimdb_darts_searchable.py:82-83,114 (O <= 128, K % 16 == 0).  The k-slices ADD into `out`: out_is_zero != 0 says the
+ * caller hands it over zero-filled (a captured step's arena, cleared by bmnas_copy_batch); 0: this call clears it. */
 int bmnas_linear_fwd(const float* feat, const float* W, const float* bias, float* out, int b, int O,
-                     int K, void* stream);
+                     int K, int out_is_zero, void* stream);
 /* g: gradient of out, times *gscale if gscale != NULL.  dfeat (b, K), dW (O, K), dbias (O) are
  * OVERWRITTEN; any of them may be NULL. */
 int bmnas_linear_bwd(const float* g, const float* gscale, const float* feat, const float* W,
@@ -763,10 +764,14 @@ int bmnas_copy_batch_max(void);
  * arguments at the call and stored to the device address blob_dst by the same launch — the per-step scalars of a
  * captured optimizer step (bmnas_adam_multi's `hyp` rows: the learning rate the reference's scheduler sets per batch,
  * models/auxiliary/scheduler.py, and Adam's bias corrections) reach the device with the batch instead of through an
- * H2D copy node inside the step's graph.  n may be 0 (the blob alone). */
+ * H2D copy node inside the step's graph.  n may be 0 (the blob alone).
+ * srcs[i] == NULL: dsts[i] is ZERO-FILLED instead (the accumulators a captured per-op step adds into: cleared in front of
+ * the replay by this launch, not by fill launches inside it).  add_dst (nullable): a 64-bit device counter advanced by
+ * add_val by the same launch (the dropout step counter of a captured step that has no fused cell prologue to do it). */
 int bmnas_copy_blob_max(void);
 int bmnas_copy_batch(const void* const* srcs, void* const* dsts, const long long* bytes, int n,
-                     void* blob_dst, const void* blob, int blob_bytes, void* stream);
+                     void* blob_dst, const void* blob, int blob_bytes, unsigned long long* add_dst,
+                     unsigned long long add_val, void* stream);
 
 /* ---- data parallelism: RCCL behind the C ABI ---------------------------------------------------
  * One process per GPU; the data-path exchange of a search step is ONE in-place all-reduce of the flat

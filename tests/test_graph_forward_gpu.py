@@ -96,3 +96,39 @@ def test_graphed_forward_declines_what_it_cannot_capture():
         assert torch.equal(v, before[k]), k
     with torch.no_grad():
         assert torch.isfinite(model(xs)).all()
+
+
+@pytest.mark.parametrize('cname,batch,foreign_allowed', [('mmimdb', 32, 0), ('ntu', 16, 2)])
+def test_captured_found_stage_step_holds_only_this_repos_launches(cname, batch, foreign_allowed):
+    """no aten / runtime launches inside the captured found-stage step.  Its zero-filled accumulators
+    come from ONE persistent arena that the batch-copy launch in front of every replay clears (bmnas.functions
+    _StepArena), the dropout step counter is advanced by that launch too, Adam's scalars ride in its arguments: a replay
+    of the MM-IMDB found network contains this repository's kernels only; the NTU genotype keeps autograd's two
+    gradient-accumulation adds (a state read by two consumers)."""
+    import bench as B
+    from bmnas import nn as bnn
+    from bmnas.graph import GraphedTrainStep
+    from bmnas.optim import Adam
+    from torch.profiler import ProfilerActivity, profile
+    c = B.CONFIGS[cname]
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    model = B.FoundNet(c, cname).to(dev).train()
+    crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
+    xs, y = B.synth_batch(c, batch, dev, 0)
+    xs = [x.detach() for x in xs]
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    g = GraphedTrainStep(model, crit, opt, xs, y)
+    ref = [p.detach().clone() for p in model.parameters()]
+    for _ in range(3):
+        g(xs, y)
+    torch.cuda.synchronize()
+    assert any(not torch.equal(a, b) for a, b in zip(ref, model.parameters()))     # the replays do train
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        loss, _ = g(xs, y)[:2]
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    foreign = [n for n in names if 'at::native' in n or 'Memcpy' in n or 'Memset' in n or 'rocclr' in n]
+    assert len(foreign) <= foreign_allowed, foreign
+    assert any('copy_batch_k' in n for n in names), names
+    assert torch.isfinite(loss).all()

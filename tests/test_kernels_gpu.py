@@ -836,3 +836,27 @@ def test_copy_batch_blob_by_value():
     assert lib.copy_blob_max() == 256
     with pytest.raises(lib.BmnasError):
         lib.copy_batch([], blob=(torch.zeros(512, dtype=torch.uint8, device=dev()), bytes(260)))
+
+
+def test_batch_copier_zero_jobs_and_counter_advance():
+    """What rides in front of a captured per-op step's replay (bmnas.lib.BatchCopier): the batch copies, the zero-fill of
+    the step's accumulation arena (a NULL source) and the advance of its dropout step counter — one launch."""
+    from bmnas import lib
+    srcs = [torch.randn(64, 32, 8, device=dev()), torch.arange(64, device=dev())]
+    dsts = [torch.zeros_like(t) for t in srcs]
+    arena = torch.full((1003,), 7.0, device=dev())          # no multiple of 4 floats: the byte tail is cleared too
+    guard = torch.full((8,), 5.0, device=dev())
+    counter = torch.full((1,), (1 << 60) + 5, dtype=torch.int64, device=dev())
+    cp = lib.BatchCopier(dsts, zero=[arena], advance=(counter, 1234))
+    for k in range(3):
+        arena.fill_(7.0)
+        assert cp(srcs) == []
+        torch.cuda.synchronize()
+        assert all(torch.equal(d, s_) for d, s_ in zip(dsts, srcs))
+        assert float(arena.abs().max()) == 0.0 and bool((guard == 5.0).all())
+        assert int(counter.item()) == (1 << 60) + 5 + 1234 * (k + 1)
+    # the static tensors themselves as sources (nothing to copy): the zero-fill and the advance still happen
+    arena.fill_(3.0)
+    cp(dsts)
+    torch.cuda.synchronize()
+    assert float(arena.abs().max()) == 0.0 and int(counter.item()) == (1 << 60) + 5 + 1234 * 4
