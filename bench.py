@@ -438,7 +438,7 @@ class FoundNet(torch.nn.Module):
         self.central_classifier = bnn.Linear(c['M'] * c['C'] * c['L'], c['nout'])
 
     def forward(self, xs):
-        return self.central_classifier(self.fusion_net(list(xs)))
+        return self.fusion_net.forward_classified(list(xs), self.central_classifier)      # as models/search/_common.py
 
 
 def found_cpu_baseline(cname, c, batch, max_seconds=15.0):

@@ -100,12 +100,21 @@ class deferred_affine:
     def __exit__(self, *exc):
         global AFFINE_DEFER
         jobs, AFFINE_DEFER = AFFINE_DEFER, self.prev
-        groups = {}
+        groups, sums = {}, []
         for b, L, prob in jobs:
-            groups.setdefault((b, L), []).append(prob)
+            if b is None:
+                sums.append(prob)                 # (part, out, n_chunk): the fused found head's per-chunk partials
+            else:
+                groups.setdefault((b, L), []).append(prob)
         for (b, L), probs in groups.items():
             for i in range(0, len(probs), 8):
-                lib.ln_affine_bwd_multi(probs[i:i + 8], b, L)
+                if sums:                          # ride in the same launch (bmnas_backward_epilogue: affine + sums)
+                    lib.backward_epilogue(probs[i:i + 8], b, L, [], [], [], 1, 0, sums=tuple(sums[:2]))
+                    sums = sums[2:]
+                else:
+                    lib.ln_affine_bwd_multi(probs[i:i + 8], b, L)
+        for part, out, n_chunk in sums:
+            lib.sum_chunks(part, out, n_chunk)
         return False
 
 
@@ -226,6 +235,97 @@ class CatLnFn(Function):
                        ctx.relu)
         _ln_affine(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, ctx.relu, False)
         return (None, dw, db, dres, *dsrcs)
+
+
+class CatLnSumsFn(Function):
+    """CatLnFn (no ReLU) that also hands out each sample's (sum, sum of squares) of its output — what the fused head
+    (FoundHeadFn, csrc/head.hip) takes the K7 LayerNorm statistics from.  -> (out, sums (b, 2))."""
+
+    @staticmethod
+    def forward(ctx, ln_w, ln_b, resid, *srcs):
+        _require_gpu(srcs[0], 'concat + LayerNorm')
+        srcs = [_c(_f32(s)) for s in srcs]
+        resid = None if resid is None else _c(resid)
+        b, C, L = srcs[0].shape
+        n = len(srcs)
+        out = torch.empty((b, n * C, L), device=srcs[0].device, dtype=torch.float32)
+        stats = torch.empty(b * 2, device=srcs[0].device, dtype=torch.float32)
+        sums = torch.empty((b, 2), device=srcs[0].device, dtype=torch.float32)
+        lw, lb = _c(ln_w), _c(ln_b)
+        lib.cat_ln_fwd(srcs, resid, lw, lb, out, stats, b, C, L, False, sums)
+        ctx.relu, ctx.srcs, ctx.resid, ctx.lw, ctx.lb, ctx.stats = False, srcs, resid, lw, lb, stats
+        if any(ctx.needs_input_grad):
+            ZERO_POOL.announce(2 * lw.numel())
+        ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)          # (else autograd fills a zero tensor for `sums`' absent gradient: a launch)
+        return out, sums
+
+    @staticmethod
+    def backward(ctx, g, _g_sums):
+        srcs, resid = ctx.srcs, ctx.resid
+        b, C, L = srcs[0].shape
+        if g is None:                             # nobody differentiated the output (materialisation is off)
+            return (None,) * (3 + len(srcs))
+        g = _c(g)
+        dsrcs = [torch.empty_like(s) if ctx.needs_input_grad[3 + q] else None for q, s in enumerate(srcs)]
+        dres = torch.empty_like(resid) if (resid is not None and ctx.needs_input_grad[2]) else None
+        dw, db = _zero_pair(ctx.lw)
+        lib.cat_ln_bwd(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dsrcs, dres, 0, None, None, b, C, L, False)
+        _ln_affine(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, False, False)
+        return (dw, db, dres, *dsrcs)
+
+
+class FoundHeadFn(Function):
+    """The found cell's tail + central classifier (+ criterion) as the two launches of csrc/head.hip — K7
+    `relu(LayerNorm(cat(states[-M:])))` (model.py:157-160), `central_classifier` (mmimdb_darts_searchable.py:185-188) and,
+    inside bmnas.nn.fused_criterion(), the criterion evaluated by the backward launch — instead of cat_ln + linear +
+    criterion and their three backward launches.  states: the M concatenated step-node outputs with their per-sample
+    sums (CatLnSumsFn).  Returns the logits; the caller attaches K.LAST_HEAD.pop() to them as `_bmnas_head`."""
+
+    @staticmethod
+    def forward(ctx, ln_w, ln_b, W, bias, M, *tensors):
+        states = [_c(_f32(t)) for t in tensors[:M]]
+        sums = [_c(t) for t in tensors[M:2 * M]]
+        _require_gpu(states[0], 'found cell head')
+        dev = states[0].device
+        b, C, L = states[0].shape
+        Wc, bc = _c(_f32(W)), _c(_f32(bias))
+        O = Wc.shape[0]
+        hb_n = (3 * b * O + 3) // 4 * 4
+        buf = zeros_for_step(hb_n + 4, dev)                   # logits | A | B accumulate with atomics; + the loss scalar
+        head = K.HeadState(W=Wc, bias=bc, hb=buf[:3 * b * O].view(3, b, O), loss=buf[hb_n:hb_n + 1],
+                           marker=torch.empty((b, O), device=dev, dtype=torch.float32))
+        stats = torch.empty(b * 2, device=dev, dtype=torch.float32)
+        lw, lb = _c(ln_w), _c(ln_b)
+        lib.head_fwd(states, sums, lw, lb, Wc, bc, head.hb, stats, b, C, L, O)
+        ctx.states, ctx.sums, ctx.lw, ctx.lb, ctx.stats, ctx.head, ctx.M = states, sums, lw, lb, stats, head, M
+        K.LAST_HEAD.append(head)
+        return head.hb[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        states, sums, head, M = ctx.states, ctx.sums, ctx.head, ctx.M
+        b, C, L = states[0].shape
+        O, D = head.W.shape[0], M * C * L
+        mode, gten, gscale, labels = head.resolve(g)
+        want = any(ctx.needs_input_grad[:4])
+        n_chunk = lib.head_chunks(b)
+        part = torch.empty(n_chunk * (O + 3) * D, device=states[0].device, dtype=torch.float32) if want else None
+        dstates = [torch.empty_like(s) if ctx.needs_input_grad[5 + i] else None for i, s in enumerate(states)]
+        lib.head_bwd(states, sums, dstates, 0, ctx.lw, ctx.lb, head.W, head.hb, ctx.stats, mode, gten, gscale, labels,
+                     head.loss, part, b, C, L, O, None)
+        dlw = dlb = dW = dbias = None
+        if want:
+            hsum = torch.empty((O + 3) * D, device=states[0].device, dtype=torch.float32)
+            if AFFINE_DEFER is not None:
+                AFFINE_DEFER.append((None, None, (part, hsum, n_chunk)))      # summed with the pass's affine reductions
+            else:
+                lib.sum_chunks(part, hsum, n_chunk)
+            dW = hsum[:O * D].view(O, D)
+            dlw = hsum[O * D:(O + 1) * D].view_as(ctx.lw)
+            dlb = hsum[(O + 1) * D:(O + 2) * D].view_as(ctx.lb)
+            dbias = hsum[(O + 2) * D:(O + 2) * D + O]
+        return (dlw, dlb, dW, dbias, None, *dstates, *([None] * M))
 
 
 # ----------------------------------------------------------------------------- K3

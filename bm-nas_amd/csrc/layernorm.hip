@@ -531,8 +531,10 @@ extern "C" int bmnas_backward_epilogue(int n_prob, const float* const* g, const 
                           stats ? stats[i] : nullptr, dln_w[i], dln_b[i], C[i], L, relu[i], prenorm[i]))
       return e;
   ArchPack A{};
-  const int total = fill_arch_pack(A, arch_w, arch_dw, arch_out, arch_rows, arch_cols, n_arch, 1, n_shards,
-                                   shard_stride);
+  // (n_arch == 0: no architecture tensors — the per-op path's end-of-backward launch: affine reductions + chunk sums)
+  const int total = n_arch > 0 ? fill_arch_pack(A, arch_w, arch_dw, arch_out, arch_rows, arch_cols, n_arch, 1, n_shards,
+                                                shard_stride)
+                               : 0;
   if (total < 0) return total;
   B.n = n_prob;
   B.b = b;

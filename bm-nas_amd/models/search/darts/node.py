@@ -6,7 +6,7 @@ names that are not in STEP_STEP_OPS and cannot be constructed; they are not mirr
 """
 import torch.nn as nn
 
-from bmnas.functions import CatLnFn, ConvBnActFn
+from bmnas.functions import CatLnFn, CatLnSumsFn, ConvBnActFn
 
 from .node_operations import STEP_STEP_OPS
 from .operations import OPS
@@ -32,6 +32,9 @@ class Found_NodeCell(nn.Module):
             self.out_dropout = nn.Dropout(args.drpt)
         self.ln = nn.LayerNorm([self.C, self.L])
         self.dropout = nn.Dropout(args.drpt)
+        # set by Found_FusionCell on the nodes whose output its tail concatenates: the node then also hands out each
+        # sample's (sum, sum of squares) of its output, from which the fused head takes the K7 LayerNorm statistics
+        self.want_sums = False
 
     def compile(self, edge_op_names, edge_indices, inner_steps):
         for name in edge_op_names:
@@ -54,6 +57,10 @@ class Found_NodeCell(nn.Module):
                                     self.out_conv.bias, bn.weight, bn.bias, *tail)
         else:
             out = tail[0]
+        if self.want_sums and out.is_cuda:
+            o, sums = CatLnSumsFn.apply(self.ln.weight, self.ln.bias, x, out)
+            o._bmnas_sums = sums
+            return o
         return CatLnFn.apply(False, self.ln.weight, self.ln.bias, x, out)
 
 
