@@ -764,6 +764,11 @@ class FusedCellFn(Function):
             dws += [dbeta_ws[i], dgamma_ws[i]]
         if ctx.alpha_is_logits:
             ws, dws = [sv.alpha_w] + ws, [dalpha_w] + dws
+        # does anybody differentiate alpha / beta / gamma?  (a captured weight step does not: its optimizer holds the
+        # network weights only, and the pass then ends without the arch-softmax backward)
+        need_arch = bool(ctx.needs_input_grad[3]) or any(ctx.needs_input_grad[5 + N:5 + N + 2 * S])
+        if not need_arch:
+            ws, dws = [], []
         darch = [torch.empty_like(w) for w in ws]
         # does ANY parameter of the cell / the fused classifier need its gradient?  (a captured architecture step
         # says no: K.arch_grads_only)
@@ -775,9 +780,11 @@ class FusedCellFn(Function):
                                     CG, (ws, dws, darch))
         finally:
             K.WANT_PARAM_GRADS = saved
-        if not sv.epilogue_done:
+        if not sv.epilogue_done and need_arch:
             lib.arch_softmax_multi(ws, dws, darch, True, CG.shards, CG.shard_stride)
-        if ctx.alpha_is_logits:
+        if not need_arch:
+            dalpha, darch = None, [None] * (2 * S)
+        elif ctx.alpha_is_logits:
             dalpha, darch = darch[0], darch[1:]
         else:
             # the caller owns the alpha softmax: hand back the sum of the atomic shards
