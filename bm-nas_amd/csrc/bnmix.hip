@@ -1223,8 +1223,11 @@ inline int pick_chunk(int b, int slots4) {
   // 4 sample lanes walk the chunk.  Measured (MM-IMDB b = 128, dgamma atomics sharded):
   // chunk 4: 10.2 us, 8: 10.2 us, 16: 12.8 us, 32: 16.5 us.  (Before the dgamma adds were
   // sharded, small chunks were much WORSE: every extra workgroup queued on the same 4 scalars.)
-  (void)slots4;
-  return b >= 32 ? 8 : 4;
+  // Narrow samples (NTU / Ego: C L / 4 = 256 slots = 4 column blocks): eight-sample chunks leave 32 / 24 workgroups at
+  // b = 64 / 48, each lane walking two samples in turn.  Four-sample chunks there: node_mix_bwd_k<2> 8.7 -> 6.6 us
+  // (NTU b64), <3> 8.9 -> 6.8 (Ego b48); step 0.1905 -> 0.1878 ms and 0.2449 -> 0.2357 (profiles/r05_knob_sweep.txt).
+  const int cols = (slots4 + 63) / 64;
+  return (b >= 32 && cols * ((b + 7) / 8) >= 128) ? 8 : 4;
 }
 
 // ---- cell prologue: everything a FusionCell forward needs before its first data kernel, in
