@@ -1001,12 +1001,40 @@ class arch_grads_only:
         _ARCH_ONLY[0] = self.prev
         return False
 
+
+# The mirror image: the WEIGHT step of the search loop (train_searchable/*.py: its optimizer holds model.parameters(),
+# none of alpha / beta / gamma).  The reference's loss.backward() forms the architecture gradients there as well and
+# zeroes them before the next architecture step; a captured weight step says `weight_grads_only()` and the fused cell
+# then runs no arch-softmax backward and its cell-level K1 pair backward launches neither form the edge-weight dot
+# products nor load the operands read only for them (WANT_ARCH_GRADS below).
+_NO_ARCH = [False]
+
+
+class weight_grads_only:
+    """with weight_grads_only(on): a backward that runs inside asks for no gradient of an architecture tensor."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _NO_ARCH[0] = _NO_ARCH[0], self.on
+        return self
+
+    def __exit__(self, *exc):
+        _NO_ARCH[0] = self.prev
+        return False
+
 # Data-parallel overlap (bench.py's 'overlap' shape): a callable (i, NG) invoked right after the launches of
 # step node i's backward have been issued.  From that point the node's conv / BatchNorm gradients in NG
 # (stack_dW, stack_dbias, stack_bn_grad, out_conv_dW / _db, bn_grad) are final — its LayerNorm-affine gradients
 # are not (the epilogue launch sums them) — so an all-reduce of them can run on a forked stream while the
 # remaining nodes' backward continues.
 NODE_DONE_HOOK = None
+
+# Does anybody differentiate alpha / beta / gamma in the backward that is running?  (set by FusedCellFn.backward: no
+# when none of them requires a gradient or inside weight_grads_only().)  False: the cell-level K1 pair backward launches skip
+# their dot products and the N + 1 operand streams read only for them (dw = dw2 = NULL at the C ABI).
+WANT_ARCH_GRADS = True
 
 
 def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, epilogue=None):
@@ -1093,25 +1121,25 @@ def fusion_cell_bwd(sv, g, need_input_grads, dalpha_w, dbeta_ws, dgamma_ws, CG, 
                 bufs, mask = _write_group([None] * N + slots[N:n_in])
             else:
                 bufs, mask = _write_group(slots[:n_in])
+            da_w, db_w = (dalpha_w[off:, 1], dbeta_ws[i][:, 1]) if WANT_ARCH_GRADS else (None, None)
             if sv.lazy_on and i >= 1:
                 # its last i inputs are step-node outputs with a streaming LayerNorm backward: leave their partials
                 P = sv.nodes[0].lazy.P
                 lzs = [sv.nodes[t].lazy for t in range(i)]
                 views = [lz.lnp_k1[(i - 1 - t) * P * 2:] for t, lz in enumerate(lzs)]
                 lib.mixsum_pair_bwd_lazy(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
-                                         sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1], mask,
+                                         sv.sifs[i], sif_slot.get(), gz, da_w, db_w, mask,
                                          [lz.desc for lz in lzs], views, [lz.k1_n * P for lz in lzs], b, C, L,
                                          CG.shards, CG.shard_stride, gz2, g_fulls.get(i))
             elif g_fulls:
                 ts = sorted(g_fulls)
                 lib.mixsum_pair_bwd_x(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
-                                      sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1], mask,
+                                      sv.sifs[i], sif_slot.get(), gz, da_w, db_w, mask,
                                       [g_fulls[t] for t in ts], [sv.alpha_w[sv.offsets[t]:, 1] for t in ts],
                                       CG.shards, CG.shard_stride, gz2)
             else:
                 lib.mixsum_pair_bwd(sv.states[:n_in], bufs, sv.alpha_w[off:, 1], 2, nsv.beta_w[:, 1], 2,
-                                    sv.sifs[i], sif_slot.get(), gz, dalpha_w[off:, 1], dbeta_ws[i][:, 1],
-                                    mask, CG.shards, CG.shard_stride, gz2)
+                                    sv.sifs[i], sif_slot.get(), gz, da_w, db_w, mask, CG.shards, CG.shard_stride, gz2)
         else:
             mixsum_bwd(sv.states[:n_in], slots[:n_in], sv.alpha_w[off:, 1], sif_slot.buf(),
                        dalpha_w[off:, 1], 2, CG.shards, CG.shard_stride)

@@ -764,9 +764,10 @@ class FusedCellFn(Function):
             dws += [dbeta_ws[i], dgamma_ws[i]]
         if ctx.alpha_is_logits:
             ws, dws = [sv.alpha_w] + ws, [dalpha_w] + dws
-        # does anybody differentiate alpha / beta / gamma?  (a captured weight step does not: its optimizer holds the
-        # network weights only, and the pass then ends without the arch-softmax backward)
-        need_arch = bool(ctx.needs_input_grad[3]) or any(ctx.needs_input_grad[5 + N:5 + N + 2 * S])
+        # does anybody differentiate alpha / beta / gamma?  (a captured weight step does not — its optimizer holds the
+        # network weights only, K.weight_grads_only — and the pass then ends without the arch-softmax backward)
+        need_arch = ((bool(ctx.needs_input_grad[3]) or any(ctx.needs_input_grad[5 + N:5 + N + 2 * S]))
+                     and not K._NO_ARCH[0])
         if not need_arch:
             ws, dws = [], []
         darch = [torch.empty_like(w) for w in ws]
@@ -775,11 +776,13 @@ class FusedCellFn(Function):
         first_param = 5 + N + 2 * S
         want = any(ctx.needs_input_grad[first_param:]) and not K._ARCH_ONLY[0]
         saved, K.WANT_PARAM_GRADS = K.WANT_PARAM_GRADS, want
+        saved_arch, K.WANT_ARCH_GRADS = K.WANT_ARCH_GRADS, need_arch
         try:
             dxs = K.fusion_cell_bwd(sv, g if sv.head is not None else _c(g), need_in, dalpha_w, dbeta_ws, dgamma_ws,
                                     CG, (ws, dws, darch))
         finally:
             K.WANT_PARAM_GRADS = saved
+            K.WANT_ARCH_GRADS = saved_arch
         if not sv.epilogue_done and need_arch:
             lib.arch_softmax_multi(ws, dws, darch, True, CG.shards, CG.shard_stride)
         if not need_arch:

@@ -165,6 +165,9 @@ class GraphedTrainStep:
         arch_fn = getattr(model, 'arch_parameters', None)
         aids = {id(t) for t in arch_fn()} if callable(arch_fn) else set()
         self.arch_only = bool(self.targets) and bool(aids) and all(id(t) in aids for t in self.targets)
+        # ... and the weight step none of them: no arch-softmax backward, no edge-weight dot products in the cell-level
+        # K1 backward launches (bmnas.cell.weight_grads_only)
+        self.no_arch = bool(self.targets) and bool(aids) and not any(id(t) in aids for t in self.targets)
         reducer = getattr(optimizer, '_bmnas_reducer', None)
         if reducer is not None and reducer.world <= 1:
             reducer = None
@@ -197,7 +200,7 @@ class GraphedTrainStep:
                     logits = logits[-1]
                 loss = criterion(logits, self.labels)
             # (deferred_affine: the per-op path's LayerNorm-affine reductions of this pass as ONE launch at its end)
-            with K.arch_grads_only(self.arch_only), deferred_affine():
+            with K.arch_grads_only(self.arch_only), K.weight_grads_only(self.no_arch), deferred_affine():
                 if scale != 1.0:
                     grads = torch.autograd.grad(loss * scale, self.targets, allow_unused=True)
                 else:

@@ -279,6 +279,11 @@ def _ptr(t):
     return t.data_ptr()
 
 
+def _opt(t):
+    """data_ptr of a (possibly strided) tensor, or NULL."""
+    return None if t is None else t.data_ptr()
+
+
 def _ptrs(ts):
     arr = (C.c_void_p * len(ts))()
     for i, t in enumerate(ts):
@@ -339,7 +344,7 @@ def mixsum_pair_bwd(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, acc
                     dw_shard_stride=0, gz2=None):
     _check(load().bmnas_mixsum_pair_bwd(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride,
                                         w2.data_ptr(), w2_stride, _ptr(h), _ptr(gh), _ptr(gz), _ptr(gz2),
-                                        dw.data_ptr(), dw2.data_ptr(), dw_shards, dw_shard_stride, acc_mask,
+                                        _opt(dw), _opt(dw2), dw_shards, dw_shard_stride, acc_mask,
                                         gz.numel(), _stream()), 'mixsum_pair_bwd')
 
 
@@ -474,8 +479,8 @@ def mixsum_pair_bwd_lazy(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2
     arr = (LazyLn * n)(*lazies)
     st = (C.c_int * n)(*strides)
     _check(load().bmnas_mixsum_pair_bwd_lazy(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, w2.data_ptr(),
-                                             w2_stride, _ptr(h), _ptr(gh), _ptr(gz), _ptr(gz2), dw.data_ptr(),
-                                             dw2.data_ptr(), dw_shards, dw_shard_stride, acc_mask, arr,
+                                             w2_stride, _ptr(h), _ptr(gh), _ptr(gz), _ptr(gz2), _opt(dw),
+                                             _opt(dw2), dw_shards, dw_shard_stride, acc_mask, arr,
                                              (C.c_void_p * n)(*[t.data_ptr() for t in lnparts]), st, n,
                                              _ptr(g_full), b, Cc, L, _stream()),
            'mixsum_pair_bwd_lazy')
@@ -486,8 +491,8 @@ def mixsum_pair_bwd_x(xs, dxs, w, w_stride, w2, w2_stride, h, gh, gz, dw, dw2, a
     """g_more[t]: the stored G of a later cell step, w_more[t]: that step's softmaxed edge-weight column (first edge)."""
     n = len(g_more)
     _check(load().bmnas_mixsum_pair_bwd_x(_ptrs(xs), _ptrs(dxs), len(xs), w.data_ptr(), w_stride, w2.data_ptr(),
-                                          w2_stride, _ptr(h), _ptr(gh), _ptr(gz), _ptr(gz2), dw.data_ptr(),
-                                          dw2.data_ptr(), dw_shards, dw_shard_stride, acc_mask, _ptrs(g_more),
+                                          w2_stride, _ptr(h), _ptr(gh), _ptr(gz), _ptr(gz2), _opt(dw),
+                                          _opt(dw2), dw_shards, dw_shard_stride, acc_mask, _ptrs(g_more),
                                           (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in w_more]), n, gz.numel(),
                                           _stream()), 'mixsum_pair_bwd_x')
 

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void mixsum_pair_fwd_k(PtrsIn xs, const float*
 // backward of the pair: G = gh + (w2_0 + w2_1) * gz is the full gradient of h (gh: what the other
 // consumers of h already accumulated, may be null); dx_j (+)= w_j G, dw_j += <G, x_j>,
 // dw2_0 += <gz, h>, dw2_1 += <gz, h>.
-template <int NIN>
+// DOTS = false (dw == dw2 == NULL at the C ABI): nobody differentiates the edge weights — the weight step of the search
+// loop — so the NIN inputs and h, read only for the dot products, are not loaded: dx_j needs G alone.
+template <int NIN, bool DOTS = true>
 __global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
                                                          const float* __restrict__ w, int w_stride,
                                                          const float* __restrict__ w2, int w2_stride,
@@ -150,11 +152,15 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 z4 = reinterpret_cast<const float4*>(gz)[i];
     const float4 z2v = reinterpret_cast<const float4*>(gz2 != nullptr ? gz2 : gz)[i];
-    const float4 h4 = reinterpret_cast<const float4*>(h)[i];
+    float4 h4 = zero4;
+    if constexpr (DOTS) h4 = reinterpret_cast<const float4*>(h)[i];
     const float4 ghv = reinterpret_cast<const float4*>(gh != nullptr ? gh : gz)[i];
     float4 v[NIN];
 #pragma unroll
-    for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+    for (int j = 0; j < NIN; ++j) {
+      if constexpr (DOTS) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+      else v[j] = zero4;
+    }
     z4 = f4_add(z4, gz2 != nullptr ? z2v : zero4);
     const float4 g4 = f4_add(f4_scale(z4, s2), gh != nullptr ? ghv : zero4);
 #pragma unroll
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
       reinterpret_cast<float4*>(d)[i] = r;
     }
   }
+  if constexpr (!DOTS) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j <= NIN; ++j) {
@@ -195,7 +202,7 @@ struct MoreG {
   const float* w[kMaxMoreG];     // softmaxed edge weights of step t's sum: w[t][j * w_stride], j < NIN
 };
 
-template <int NIN, int NX>
+template <int NIN, int NX, bool DOTS = true>
 __global__ __launch_bounds__(256) void mixsum_pair_bwd_x_k(PtrsIn xs, PtrsOut dxs,
                                                            const float* __restrict__ w, int w_stride,
                                                            const float* __restrict__ w2, int w2_stride,
@@ -224,14 +231,18 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_x_k(PtrsIn xs, PtrsOut dx
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 z4 = reinterpret_cast<const float4*>(gz)[i];
     const float4 z2v = reinterpret_cast<const float4*>(gz2 != nullptr ? gz2 : gz)[i];
-    const float4 h4 = reinterpret_cast<const float4*>(h)[i];
+    float4 h4 = zero4;
+    if constexpr (DOTS) h4 = reinterpret_cast<const float4*>(h)[i];
     const float4 ghv = reinterpret_cast<const float4*>(gh != nullptr ? gh : gz)[i];
     float4 gx[NX];
 #pragma unroll
     for (int t = 0; t < NX; ++t) gx[t] = reinterpret_cast<const float4*>(X.g[t])[i];
     float4 v[NIN];
 #pragma unroll
-    for (int j = 0; j < NIN; ++j) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+    for (int j = 0; j < NIN; ++j) {
+      if constexpr (DOTS) v[j] = reinterpret_cast<const float4*>(xs.p[j])[i];
+      else v[j] = zero4;
+    }
     z4 = f4_add(z4, gz2 != nullptr ? z2v : zero4);
     const float4 g4 = f4_add(f4_scale(z4, s2), gh != nullptr ? ghv : zero4);
 #pragma unroll
@@ -253,6 +264,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_x_k(PtrsIn xs, PtrsOut dx
       reinterpret_cast<float4*>(d)[i] = r;
     }
   }
+  if constexpr (!DOTS) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j <= NIN; ++j) {
@@ -372,9 +384,11 @@ extern "C" int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, 
                                      const float* gz2, float* dw, float* dw2, int dw_shards,
                                      int64_t dw_shard_stride,
                                      uint32_t accumulate_mask, int64_t n_elem, void* stream) {
-  if (!xs || !dxs || !w || !w2 || !h || !gz || !dw || !dw2 || n_in < 1 || n_elem < 0 || w_stride < 1 ||
-      w2_stride < 1 || dw_shards < 1)
+  if (!xs || !dxs || !w || !w2 || !h || !gz || n_in < 1 || n_elem < 0 || w_stride < 1 || w2_stride < 1 ||
+      dw_shards < 1)
     return BMNAS_E_ARG;
+  if ((dw == nullptr) != (dw2 == nullptr)) return BMNAS_E_ARG;      // both (the dot products wanted) or neither
+  const bool dots = dw != nullptr;
   if (n_in > BMNAS_MAX_PTRS - 1) return BMNAS_E_LIMIT;
   if (n_elem % 4 != 0) return BMNAS_E_SHAPE;
   if (n_elem == 0) return 0;
@@ -387,7 +401,15 @@ extern "C" int bmnas_mixsum_pair_bwd(const float* const* xs, float* const* dxs, 
   }
   const int64_t n4 = n_elem / 4;
   hipStream_t st = (hipStream_t)stream;
-#define CALL(N) hipLaunchKernelGGL(mixsum_pair_bwd_k<N>, dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards, dw_shard_stride, accumulate_mask, n4)
+#define CALL(N)                                                                                                    \
+  do {                                                                                                             \
+    if (dots)                                                                                                      \
+      hipLaunchKernelGGL((mixsum_pair_bwd_k<N, true>), dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride,    \
+                         w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards, dw_shard_stride, accumulate_mask, n4); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((mixsum_pair_bwd_k<N, false>), dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride,   \
+                         w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards, dw_shard_stride, accumulate_mask, n4); \
+  } while (0)
   switch (n_in) {
     case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;
     case 4: CALL(4); break;   case 5: CALL(5); break;   case 6: CALL(6); break;
@@ -411,9 +433,11 @@ extern "C" int bmnas_mixsum_pair_bwd_x(const float* const* xs, float* const* dxs
   if (n_more == 0)
     return bmnas_mixsum_pair_bwd(xs, dxs, n_in, w, w_stride, w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards,
                                  dw_shard_stride, accumulate_mask, n_elem, stream);
-  if (!xs || !dxs || !w || !w2 || !h || !gz || !dw || !dw2 || !g_more || !w_more || n_in < 1 || n_elem < 0 ||
-      w_stride < 1 || w2_stride < 1 || dw_shards < 1)
+  if (!xs || !dxs || !w || !w2 || !h || !gz || !g_more || !w_more || n_in < 1 || n_elem < 0 || w_stride < 1 ||
+      w2_stride < 1 || dw_shards < 1)
     return BMNAS_E_ARG;
+  if ((dw == nullptr) != (dw2 == nullptr)) return BMNAS_E_ARG;      // both (the dot products wanted) or neither
+  const bool dots = dw != nullptr;
   if (n_more < 0 || n_more > kMaxMoreG || n_in > BMNAS_MAX_PTRS - 1) return BMNAS_E_LIMIT;
   if (n_elem % 4 != 0) return BMNAS_E_SHAPE;
   if (n_elem == 0) return 0;
@@ -432,9 +456,17 @@ extern "C" int bmnas_mixsum_pair_bwd_x(const float* const* xs, float* const* dxs
   }
   const int64_t n4 = n_elem / 4;
   hipStream_t st = (hipStream_t)stream;
-#define CALL2(N, X_)                                                                                             \
-  hipLaunchKernelGGL((mixsum_pair_bwd_x_k<N, X_>), dim3(grid_for(n4)), dim3(256), 0, st, p, d, w, w_stride, w2,   \
-                     w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards, dw_shard_stride, accumulate_mask, X, n4)
+#define CALL2(N, X_)                                                                                                \
+  do {                                                                                                              \
+    if (dots)                                                                                                       \
+      hipLaunchKernelGGL((mixsum_pair_bwd_x_k<N, X_, true>), dim3(grid_for(n4)), dim3(256), 0, st, p, d, w,         \
+                         w_stride, w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards, dw_shard_stride,              \
+                         accumulate_mask, X, n4);                                                                   \
+    else                                                                                                            \
+      hipLaunchKernelGGL((mixsum_pair_bwd_x_k<N, X_, false>), dim3(grid_for(n4)), dim3(256), 0, st, p, d, w,        \
+                         w_stride, w2, w2_stride, h, gh, gz, gz2, dw, dw2, dw_shards, dw_shard_stride,              \
+                         accumulate_mask, X, n4);                                                                   \
+  } while (0)
 #define CALL(N)                   \
   do {                            \
     if (n_more == 1) CALL2(N, 1); \

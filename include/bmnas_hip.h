@@ -661,7 +661,10 @@ int bmnas_mixsum_pair_bwd_lazy(const float* const* xs, float* const* dxs, int n_
  * of read-modify-writing the N cell-input gradients (g_full of bmnas_mixsum_pair_bwd_lazy): every step's mixed sum
  * reads the same cell inputs (reference model_search.py:58), so
  *   dxs[j] (=|+=) w[j*w_stride] G + sum_{t < n_more} w_more[t][j*w_stride] g_more[t]        written ONCE.
- * n_more <= 2; n_more == 0 is bmnas_mixsum_pair_bwd. */
+ * n_more <= 2; n_more == 0 is bmnas_mixsum_pair_bwd.
+ * dw == dw2 == NULL (both or neither; also bmnas_mixsum_pair_bwd and bmnas_mixsum_pair_bwd_lazy): nobody differentiates
+ * the edge weights — the weight step of the search loop, whose optimizer holds the network weights only — and the launch
+ * neither forms the dot products nor loads the n_in inputs and h, which it reads for nothing else. */
 int bmnas_mixsum_pair_bwd_x(const float* const* xs, float* const* dxs, int n_in, const float* w, int w_stride,
                             const float* w2, int w2_stride, const float* h, const float* gh, const float* gz,
                             const float* gz2, float* dw, float* dw2, int dw_shards, int64_t dw_shard_stride,

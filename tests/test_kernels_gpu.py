@@ -860,3 +860,40 @@ def test_batch_copier_zero_jobs_and_counter_advance():
     cp(dsts)
     torch.cuda.synchronize()
     assert float(arena.abs().max()) == 0.0 and int(counter.item()) == (1 << 60) + 5 + 1234 * 4
+
+
+@pytest.mark.parametrize('n_in,n_more,shape,have_gh,have_gz2', [(6, 1, (16, 192, 16), True, True), (8, 0, (8, 128, 8), False, False),
+                                                               (3, 2, (5, 16, 4), True, False), (15, 0, (2, 32, 8), False, True)])
+def test_mixsum_pair_bwd_without_dot_products(n_in, n_more, shape, have_gh, have_gz2):
+    """dw = dw2 = NULL (the weight step: nobody differentiates the edge weights): the input gradients are bit-equal to
+    the launch that also forms the dot products; one of the two without the other is refused."""
+    from bmnas import lib
+    g = _gen(n_in * 7 + n_more)
+    d = dev()
+    xs = [_rand(g, *shape).to(d) for _ in range(n_in)]
+    h, gz = _rand(g, *shape).to(d), _rand(g, *shape).to(d)
+    gh = _rand(g, *shape).to(d) if have_gh else None
+    gz2 = _rand(g, *shape).to(d) if have_gz2 else None
+    aw = torch.softmax(_rand(g, n_in, 2), -1).to(d)
+    bw = torch.softmax(_rand(g, 2, 2), -1).to(d)
+    g_more = [_rand(g, *shape).to(d) for _ in range(n_more)]
+    w_more = [torch.softmax(_rand(g, n_in, 2), -1).to(d) for _ in range(n_more)]
+
+    def run(dots):
+        dxs = [torch.full(shape, float('nan'), device=d) if j % 4 != 3 else None for j in range(n_in)]
+        dxs[0] = torch.ones(shape, device=d)
+        da, db = torch.zeros(n_in, 2, device=d), torch.zeros(2, 2, device=d)
+        lib.mixsum_pair_bwd_x(xs, dxs, aw[:, 1], 2, bw[:, 1], 2, h, gh, gz, da[:, 1] if dots else None,
+                              db[:, 1] if dots else None, 1, g_more, [w[:, 1] for w in w_more], 1, 0, gz2)
+        torch.cuda.synchronize()
+        return dxs, da, db
+
+    (want, da, db), (got, _, _) = run(True), run(False)
+    assert float(da.abs().sum()) > 0 and float(db.abs().sum()) > 0
+    for j, (a, e) in enumerate(zip(got, want)):
+        assert (a is None) == (e is None)
+        if a is not None:
+            assert torch.isfinite(a).all() and torch.equal(a, e), j
+    with pytest.raises(lib.BmnasError):
+        lib.mixsum_pair_bwd_x(xs, [None] * n_in, aw[:, 1], 2, bw[:, 1], 2, h, gh, gz, torch.zeros(n_in, 2, device=d)[:, 1],
+                              None, 0, g_more, [w[:, 1] for w in w_more], 1, 0, gz2)

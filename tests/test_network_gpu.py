@@ -590,6 +590,67 @@ def test_architecture_step_backward_skips_the_weight_gradients(name, batch, nout
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net3.parameters())
 
 
+@pytest.mark.parametrize('name,batch,nout,loss_kind', [('mmimdb', 32, 23, 'bce'), ('mmimdb', 128, 23, 'bce'),
+                                                       ('ntu', 8, 60, 'ce'), ('ego', 6, 83, 'ce')])
+@pytest.mark.parametrize('head', [None, 'deferred'])
+def test_weight_step_backward_skips_the_architecture_gradients(name, batch, nout, loss_kind, head, monkeypatch):
+    """The weight step of the search loop differentiates the network weights only (train_searchable/*.py: its optimizer
+    holds model.parameters(); the captured step calls torch.autograd.grad(loss, those) inside
+    bmnas.cell.weight_grads_only()).  The cell backward then runs no
+    arch-softmax backward, its cell-level K1 pair launches get dw = dw2 = NULL (no dot products, inputs not loaded) —
+    and the weight / input gradients are the ones a full backward gives (the streams that are still read are the same,
+    so are the additions: equal up to the order of the batch-reduction atomics)."""
+    from bmnas import lib, nn as bnn
+    cfg = fo.Cfg({**fo.CONFIGS[name], 'drpt': 0.0})
+
+    def forward():
+        net = build_search_net(cfg, 17, 'train_nodrop')
+        cls = (torch.nn.Linear if head is None else bnn.Linear)(cfg.M * cfg.C * cfg.L, nout).to(dev())
+        cw, cb = synth.make_classifier(cfg, nout, 17)
+        cls.weight.data.copy_(cw)
+        cls.bias.data.copy_(cb)
+        xs = [x.to(dev()).requires_grad_(True) for x in synth.make_inputs(cfg, batch, 17)]
+        y = synth.make_labels(loss_kind, batch, nout, 17).to(dev())
+        if head is None:
+            crit = torch.nn.BCEWithLogitsLoss() if loss_kind == 'bce' else torch.nn.CrossEntropyLoss()
+            return net, cls, xs, crit(cls(net(xs)), y)
+        crit = bnn.BCEWithLogitsLoss() if loss_kind == 'bce' else bnn.CrossEntropyLoss()
+        with bnn.fused_criterion(True):
+            return net, cls, xs, crit(net.forward_classified(xs, cls), y)
+
+    net, cls, xs, loss = forward()
+    leaves = list(net.parameters()) + list(cls.parameters()) + xs
+    want = torch.autograd.grad(loss, leaves + list(net.arch_parameters()))[:len(leaves)]
+    seen = {'pair': 0, 'pair_null': 0, 'softmax_bwd': 0}
+
+    def spy_pair(real):
+        def f(*a, **k):
+            seen['pair'] += 1
+            seen['pair_null'] += a[9] is None and a[10] is None
+            return real(*a, **k)
+        return f
+
+    for fn in ('mixsum_pair_bwd', 'mixsum_pair_bwd_x', 'mixsum_pair_bwd_lazy'):
+        monkeypatch.setattr(lib, fn, spy_pair(getattr(lib, fn)))
+    real_sm, real_ep = lib.arch_softmax_multi, lib.backward_epilogue
+    monkeypatch.setattr(lib, 'arch_softmax_multi',
+                        lambda ws, dws, outs, bwd, *a, **k: (seen.__setitem__('softmax_bwd', seen['softmax_bwd'] + bool(bwd)),
+                                                             real_sm(ws, dws, outs, bwd, *a, **k))[1])
+    monkeypatch.setattr(lib, 'backward_epilogue',
+                        lambda probs, b, L, ws, *a, **k: (seen.__setitem__('softmax_bwd', seen['softmax_bwd'] + bool(ws)),
+                                                          real_ep(probs, b, L, ws, *a, **k))[1])
+    from bmnas import cell as K
+    net2, cls2, xs2, loss2 = forward()
+    with K.weight_grads_only():                          # what GraphedTrainStep does for the weight optimizer
+        got = torch.autograd.grad(loss2, list(net2.parameters()) + list(cls2.parameters()) + xs2)
+    assert seen['softmax_bwd'] == 0, seen
+    assert seen['pair'] == seen['pair_null'], seen           # every stand-alone K1 pair backward went without dots
+    if cfg.nm == 1:
+        assert seen['pair'] == cfg.S, seen                    # (node_multiplier != 1: all but step 0's ride in tail launches)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert_close_scaled(f'grad {i}', g, w, rel=1e-5)
+
+
 @pytest.mark.parametrize('ns,nm', [(1, 1), (2, 2)])
 def test_strict_zero_propagates_non_finite_inputs_like_the_reference(ns, nm):
     """BMNAS_STRICT_ZERO (debug): the reference's Zero primitive is x.mul(0.) (operations.py:18-20), so a NaN / Inf in
