@@ -314,8 +314,10 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
             'input_copy_us': round((ms_w - ms_w_nocopy) * 1e3, 1),
             'host_issue_us_per_w_step': round(host_us, 1),
             'pairs_per_s': round(world * 1e3 / ms_pair, 1), 'pairs_timed': pairs,
-            'includes': 'w-step: fwd + criterion + bwd (weights, arch and input grads) + Adam(w, wd 1e-4); '
-                        'alpha-step: the same with Adam(alpha/beta/gamma, betas (0.5, 0.999), wd 1e-3); '
+            'includes': 'w-step: fwd + criterion + bwd w.r.t. the weight optimizer\'s tensors (the network and classifier '
+                        'weights; input-feature gradients as far as the model asks for them; no alpha/beta/gamma '
+                        'gradient: nothing reads it in this phase) + Adam(w, wd 1e-4); '
+                        'alpha-step: fwd + criterion + bwd w.r.t. alpha/beta/gamma only + Adam(betas (0.5, 0.999), wd 1e-3); '
                         + ('each step = one hipGraph replay' if world == 1 else
                            'hipGraph replay + one flat RCCL all-reduce + one-launch Adam per step')}
 
