@@ -308,6 +308,7 @@ struct SumPack {
   long long n4[kMaxSums];
   int n_chunk[kMaxSums];
   int n;
+  int reps;                      // z-slices (of gridDim.x * gridDim.y workgroups) per sum
 };
 
 // The two launches that end a fused cell's backward, as one: blockIdx.z < B.n are the LayerNorm
@@ -315,11 +316,13 @@ struct SumPack {
 // per workgroup, one wavefront each) for the row-softmax backward.  Independent work.
 __global__ __launch_bounds__(256) void backward_epilogue_k(LnAffineBatch B, ArchPack A, int arch_rows, SumPack S) {
   __shared__ float4 red[2][3][64];
-  if ((int)blockIdx.z > B.n) {                                   // z = B.n + 1 + i: the i-th partial sum
-    const int i = (int)blockIdx.z - B.n - 1;
-    const long long n4 = S.n4[i], wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  if ((int)blockIdx.z > B.n) {                                   // z = B.n + 1 + i * reps + r: slice r of the i-th partial sum
+    const int k = (int)blockIdx.z - B.n - 1;
+    const int i = k / S.reps, rep = k - i * S.reps;
+    const long long per = (long long)gridDim.x * gridDim.y;
+    const long long n4 = S.n4[i], wg = rep * per + (long long)blockIdx.y * gridDim.x + blockIdx.x;
     const float* __restrict__ part = S.part[i];
-    for (long long e = wg * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * gridDim.y * 256) {
+    for (long long e = wg * 256 + threadIdx.x; e < n4; e += (long long)S.reps * per * 256) {
       float4 t = ld4(part + 4 * e);
       for (int c = 1; c < S.n_chunk[i]; ++c) t = f4_add(t, ld4(part + 4 * (e + (long long)c * n4)));
       st4(S.out[i] + 4 * e, t);
@@ -546,6 +549,19 @@ extern "C" int bmnas_backward_epilogue(int n_prob, const float* const* g, const 
   // problem's width return at once, so widening the grid for tiny shapes costs nothing)
   const unsigned need_x = (unsigned)((total + 4 * (int)grid.y - 1) / (4 * (int)grid.y));
   if (grid.x < need_x) grid.x = need_x;
+  // ... and a partial sum gets one workgroup per 256 float4 of its output, up to 256 workgroups: on NTU / Ego's narrow
+  // LayerNorm grids (4 column blocks x 3-4 sample chunks) the head's (O + 3) x D partials were walked by 12-16
+  // workgroups, 8-14 rounds of n_chunk dependent loads each — the longest chain of the launch (Ego b48: 11.3 us)
+  // (as S.reps z-slices per sum rather than a wider grid.x: that would multiply the LayerNorm slices' idle workgroups
+  // too — measured +0.9 us at NTU b64)
+  long long max_n4 = 0;
+  for (int i = 0; i < n_sums; ++i) max_n4 = S.n4[i] > max_n4 ? S.n4[i] : max_n4;
+  long long want_wg = (max_n4 + 255) / 256;
+  if (want_wg > 256) want_wg = 256;
+  const long long per = (long long)grid.x * grid.y;
+  S.reps = (int)((want_wg + per - 1) / per);
+  if (S.reps < 1) S.reps = 1;
+  grid.z = (unsigned)(B.n + 1 + n_sums * S.reps);
   hipLaunchKernelGGL(backward_epilogue_k, grid, dim3(256), 0, (hipStream_t)stream, B, A, total, S);
   BMNAS_CHECK_LAUNCH();
   return 0;
