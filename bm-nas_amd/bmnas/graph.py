@@ -97,6 +97,19 @@ class GraphedStep:
         return now if self.advanced_first else now - self.span
 
 
+def classify_targets(model, targets):
+    """(arch_only, no_arch) of an optimizer's tensors against model.arch_parameters(): every target IS an architecture
+    tensor of the model / none of them is.  Both False when the model has no architecture tensors or no targets (a
+    found-stage net, an empty optimizer): nothing is identified, the backward stays the full one."""
+    arch_fn = getattr(model, 'arch_parameters', None)
+    aids = {id(t) for t in arch_fn()} if callable(arch_fn) else set()
+    targets = list(targets)
+    if not targets or not aids:
+        return False, False
+    hits = sum(id(t) in aids for t in targets)
+    return hits == len(targets), hits == 0
+
+
 class GraphedTrainStep:
     """One optimisation step of the search loop — forward, criterion, backward and the Adam
     update — as ONE hipGraph replay ("HIP-graph capture of the whole
@@ -162,12 +175,9 @@ class GraphedTrainStep:
         # product of its backward (bmnas.cell.arch_grads_only).  Only on POSITIVE identification: every target IS one
         # of the model's architecture tensors.  (An optimizer over anything else that is not a module parameter —
         # learnable inputs, criterion parameters, a wrapper's own tensors — keeps the full backward.)
-        arch_fn = getattr(model, 'arch_parameters', None)
-        aids = {id(t) for t in arch_fn()} if callable(arch_fn) else set()
-        self.arch_only = bool(self.targets) and bool(aids) and all(id(t) in aids for t in self.targets)
         # ... and the weight step none of them: no arch-softmax backward, no edge-weight dot products in the cell-level
         # K1 backward launches (bmnas.cell.weight_grads_only)
-        self.no_arch = bool(self.targets) and bool(aids) and not any(id(t) in aids for t in self.targets)
+        self.arch_only, self.no_arch = classify_targets(model, self.targets)
         reducer = getattr(optimizer, '_bmnas_reducer', None)
         if reducer is not None and reducer.world <= 1:
             reducer = None

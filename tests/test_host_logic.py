@@ -408,3 +408,32 @@ def test_bench_line_is_the_median_region_of_the_fastest_shape():
     assert d['rccl'] == {'ranks': 8} and d['vs_baseline'] is None and d['dtype'] == 'f32'
     single = B.headline(A(), c, 1, {'single': [0.0033] * 5}, 'single', None, None)
     assert 'step_shapes' not in single and 'rccl' not in single and single['config']['parallelism'] == 'dp1'
+
+
+def test_captured_step_identifies_the_phase_by_its_optimizer_tensors():
+    """bmnas.graph.classify_targets: the architecture step (every optimizer tensor is one of model.arch_parameters():
+    architect.py:14-18) skips the weight gradients, the weight step (none is: train_searchable/*.py build their optimizer
+    over model.parameters()) skips the architecture gradients; anything mixed, or a model without architecture tensors
+    (the found stage), keeps the full backward."""
+    import torch
+    from bmnas.graph import classify_targets
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+            self.v = torch.nn.Parameter(torch.zeros(2))
+            self._arch = [torch.zeros(4, 2, requires_grad=True), torch.zeros(2, 2, requires_grad=True)]
+
+        def arch_parameters(self):
+            return self._arch
+
+    net = Net()
+    assert classify_targets(net, net.arch_parameters()) == (True, False)
+    assert classify_targets(net, net.parameters()) == (False, True)
+    assert classify_targets(net, [net.w, net.arch_parameters()[0]]) == (False, False)
+    assert classify_targets(net, []) == (False, False)
+    # an equal-valued copy is not the model's tensor: identity decides
+    assert classify_targets(net, [net.arch_parameters()[0].clone()]) == (False, True)
+    found = torch.nn.Linear(2, 2)                               # no arch_parameters(): nothing identified
+    assert classify_targets(found, found.parameters()) == (False, False)
