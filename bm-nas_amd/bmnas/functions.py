@@ -88,20 +88,31 @@ class MixSumFn(Function):
 # bmnas.graph.GraphedTrainStep around its torch.autograd.grad call, whose results nobody reads before the context
 # ends) they only note the job; the context's exit launches them together.  Plain `loss.backward()` keeps the
 # immediate launches: an AccumulateGrad node may ADD a parameter's incoming gradient to an existing .grad right away.
+# Constraint: a deferred job's (dweight, dbias) are handed to autograd BEFORE the launch that fills them has run,
+# so nothing may read them inside the torch.autograd.grad call.  That holds when the LayerNorm's weight / bias are leaf
+# tensors used by ONE Function of the pass (the engine passes a single incoming gradient through untouched).  A parameter
+# that reaches the Function through an op (a cast, a view, a parametrization: not a leaf) or that is used twice (the engine
+# adds the two gradients out of place as soon as the second arrives) gets its launches immediately instead — `_ln_affine`
+# checks both.
 AFFINE_DEFER = None
+_DEFER_KEYS = {}          # id(ln_w storage) -> its pending job, for the pass in progress
 
 
 class deferred_affine:
     def __enter__(self):
-        global AFFINE_DEFER
+        global AFFINE_DEFER, _DEFER_KEYS
         self.prev, AFFINE_DEFER = AFFINE_DEFER, []
+        self.prev_keys, _DEFER_KEYS = _DEFER_KEYS, {}
         return self
 
     def __exit__(self, *exc):
-        global AFFINE_DEFER
+        global AFFINE_DEFER, _DEFER_KEYS
         jobs, AFFINE_DEFER = AFFINE_DEFER, self.prev
+        _DEFER_KEYS = self.prev_keys
         groups, sums = {}, []
         for b, L, prob in jobs:
+            if prob is None:
+                continue                          # launched early (its parameter came up a second time)
             if b is None:
                 sums.append(prob)                 # (part, out, n_chunk): the fused found head's per-chunk partials
             else:
@@ -118,12 +129,23 @@ class deferred_affine:
         return False
 
 
-def _ln_affine(g, srcs, resid, ln_w, ln_b, stats, dw, db, b, C, L, relu, prenorm):
-    if AFFINE_DEFER is not None:
+def _ln_affine(g, srcs, resid, ln_w, ln_b, stats, dw, db, b, C, L, relu, prenorm, key=None, leaf=True):
+    """key: identifies the LayerNorm's weight (its data pointer) — a second job for the same key inside one deferral, or a
+    weight that is not a leaf (`leaf=False`), is launched at once, and so is the earlier job of that key."""
+    if AFFINE_DEFER is not None and leaf and (key is None or key not in _DEFER_KEYS):
         AFFINE_DEFER.append((b, L, dict(g=g, gscale=None, srcs=list(srcs), resid=resid, ln_w=ln_w, ln_b=ln_b, stats=stats,
                                         dln_w=dw, dln_b=db, C=C, relu=relu, prenorm=prenorm)))
-    else:
-        lib.ln_affine_bwd(g, None, srcs, resid, ln_w, ln_b, stats, dw, db, b, C, L, relu, prenorm)
+        if key is not None:
+            _DEFER_KEYS[key] = len(AFFINE_DEFER) - 1
+        return
+    if AFFINE_DEFER is not None and key is not None and _DEFER_KEYS.get(key) is not None:
+        i = _DEFER_KEYS[key]                      # the first use's job: its gradient is about to be added to this one
+        b0, L0, p0 = AFFINE_DEFER[i]
+        AFFINE_DEFER[i] = (b0, L0, None)
+        _DEFER_KEYS[key] = None
+        lib.ln_affine_bwd(p0['g'], None, p0['srcs'], p0['resid'], p0['ln_w'], p0['ln_b'], p0['stats'], p0['dln_w'],
+                          p0['dln_b'], b0, p0['C'], L0, p0['relu'], p0['prenorm'])
+    lib.ln_affine_bwd(g, None, srcs, resid, ln_w, ln_b, stats, dw, db, b, C, L, relu, prenorm)
 
 
 # ---- the zero-filled accumulators of a CAPTURED per-op step: one persistent arena, cleared in front of the replay --------
@@ -139,11 +161,13 @@ class _StepArena:
         self.buf, self.off = buf, 0
 
     def take(self, n):
-        n = (n + 3) // 4 * 4
-        if self.off + n > self.buf.numel():
+        """n floats (exactly n: callers view the slice by shape); the cursor advances by n rounded up to a multiple of
+        four so that every slice stays 16-byte aligned."""
+        step = (n + 3) // 4 * 4
+        if self.off + step > self.buf.numel():
             return None
         v = self.buf[self.off:self.off + n]
-        self.off += n
+        self.off += step
         return v
 
 
@@ -219,6 +243,7 @@ class CatLnFn(Function):
         lw, lb = _c(ln_w), _c(ln_b)
         lib.cat_ln_fwd(srcs, resid, lw, lb, out, stats, b, C, L, relu)
         ctx.relu, ctx.srcs, ctx.resid, ctx.lw, ctx.lb, ctx.stats = relu, srcs, resid, lw, lb, stats
+        ctx.leaf = ln_w.is_leaf and ln_b.is_leaf
         if any(ctx.needs_input_grad):
             ZERO_POOL.announce(2 * lw.numel())      # dln_w | dln_b of the backward: one fill per pass for all modules
         return out
@@ -233,7 +258,8 @@ class CatLnFn(Function):
         dw, db = _zero_pair(ctx.lw)
         lib.cat_ln_bwd(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dsrcs, dres, 0, None, None, b, C, L,
                        ctx.relu)
-        _ln_affine(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, ctx.relu, False)
+        _ln_affine(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, ctx.relu, False,
+                   key=ctx.lw.data_ptr(), leaf=ctx.leaf)
         return (None, dw, db, dres, *dsrcs)
 
 
@@ -254,6 +280,7 @@ class CatLnSumsFn(Function):
         lw, lb = _c(ln_w), _c(ln_b)
         lib.cat_ln_fwd(srcs, resid, lw, lb, out, stats, b, C, L, False, sums)
         ctx.relu, ctx.srcs, ctx.resid, ctx.lw, ctx.lb, ctx.stats = False, srcs, resid, lw, lb, stats
+        ctx.leaf = ln_w.is_leaf and ln_b.is_leaf
         if any(ctx.needs_input_grad):
             ZERO_POOL.announce(2 * lw.numel())
         ctx.mark_non_differentiable(sums)
@@ -271,7 +298,8 @@ class CatLnSumsFn(Function):
         dres = torch.empty_like(resid) if (resid is not None and ctx.needs_input_grad[2]) else None
         dw, db = _zero_pair(ctx.lw)
         lib.cat_ln_bwd(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dsrcs, dres, 0, None, None, b, C, L, False)
-        _ln_affine(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, False, False)
+        _ln_affine(g, srcs, resid, ctx.lw, ctx.lb, ctx.stats, dw, db, b, C, L, False, False,
+                   key=ctx.lw.data_ptr(), leaf=ctx.leaf)
         return (dw, db, dres, *dsrcs)
 
 
@@ -299,6 +327,7 @@ class FoundHeadFn(Function):
         lw, lb = _c(ln_w), _c(ln_b)
         lib.head_fwd(states, sums, lw, lb, Wc, bc, head.hb, stats, b, C, L, O)
         ctx.states, ctx.sums, ctx.lw, ctx.lb, ctx.stats, ctx.head, ctx.M = states, sums, lw, lb, stats, head, M
+        ctx.leaf = all(t.is_leaf for t in (ln_w, ln_b, W, bias))      # (see deferred_affine: only leaves may be deferred)
         K.LAST_HEAD.append(head)
         return head.hb[0]
 
@@ -317,7 +346,7 @@ class FoundHeadFn(Function):
         dlw = dlb = dW = dbias = None
         if want:
             hsum = torch.empty((O + 3) * D, device=states[0].device, dtype=torch.float32)
-            if AFFINE_DEFER is not None:
+            if AFFINE_DEFER is not None and ctx.leaf:
                 AFFINE_DEFER.append((None, None, (part, hsum, n_chunk)))      # summed with the pass's affine reductions
             else:
                 lib.sum_chunks(part, hsum, n_chunk)
@@ -344,6 +373,7 @@ class SdpaLnFn(Function):
         xhat = torch.empty_like(x)
         lib.sdpa_ln_fwd(x, y, lw, lb, out, xhat, stats, b, C, L, drop)
         ctx.x, ctx.y, ctx.lw, ctx.stats, ctx.drop, ctx.xhat = x, y, lw, stats, drop, xhat
+        ctx.leaf = ln_w.is_leaf and ln_b.is_leaf
         if any(ctx.needs_input_grad):
             ZERO_POOL.announce(2 * lw.numel())
         return out
@@ -356,7 +386,8 @@ class SdpaLnFn(Function):
         dw, db = _zero_pair(ctx.lw)
         g = _c(g)
         lib.sdpa_ln_bwd(g, None, x, y, ctx.lw, ctx.xhat, ctx.stats, dx, dy, 0, b, C, L, ctx.drop)
-        _ln_affine(g, [ctx.xhat], None, None, None, None, dw, db, b, C, L, False, True)
+        _ln_affine(g, [ctx.xhat], None, None, None, None, dw, db, b, C, L, False, True,
+                   key=ctx.lw.data_ptr(), leaf=ctx.leaf)
         return dx, dy, dw, db, None, None
 
 

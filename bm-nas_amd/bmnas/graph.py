@@ -123,12 +123,20 @@ class GraphedTrainStep:
       arch_parameters for the alpha phase); their gradients come from torch.autograd.grad, so no
       other leaf's .grad is touched — the stepped tensors end up exactly as after
       zero_grad + backward + step.
-    * `optimizer`: a bmnas.optim.Adam (its step is capturable: the scalars travel through a pinned
-      staging buffer, so per-batch learning rates and bias corrections stay exact).
+    * `optimizer`: a bmnas.optim.Adam (its step is capturable; per-batch learning rates and bias
+      corrections stay exact: the scalars of a replay, 32 bytes per row, travel BY VALUE in the
+      kernel arguments of the launch that copies the batch into the step's static tensors —
+      `Adam.replay_blob()`, bmnas_copy_batch — so the captured step holds no H2D copy node and the
+      host never waits for the previous replay.  Optimizers with more scalar rows than that blob
+      holds (> 8) fall back to a copy node fed from a pinned staging buffer, guarded by
+      `wait_staging()`).
     * Data parallel (optimizer passed through bmnas.dist.attach, world size > 1): the captured step
-      writes the gradients straight into the reducer's flat bucket with the loss pre-scaled by
-      1/world; the replay is followed by one RCCL all-reduce(sum) of the bucket and the one-launch
-      Adam step (outside the graph: collectives are not captured).
+      writes the gradients straight into the reducer's flat bucket.  Under an RCCL process group the
+      all-reduce(avg) of the bucket is a launch INSIDE the captured step (`bmnas_allreduce_f32`
+      through the C-ABI communicator, `FlatGradAllReducer.plan() == 'native'`), followed by the
+      one-launch Adam step in the same replay; under gloo, or when the communicator could not be
+      created on every rank, the replay ends after the backward and the host issues the same
+      collective (`reduce_bucket()`) and the Adam step.
     * The batch shape is fixed at capture: check `matches(inputs, labels)` and run a ragged last
       batch through the eager path.
     Returned `loss` / `logits` are static tensors that the next call overwrites."""

@@ -960,7 +960,7 @@ class BatchCopier:
         self.dsts = list(dsts)
         self.zero = [z for z in zero if z is not None and z.numel()]
         n = len(self.dsts) + len(self.zero)
-        assert n <= load().bmnas_copy_batch_max()
+        self.cap = load().bmnas_copy_batch_max()     # tensors per launch; longer lists go out in groups of `cap`
         self.dptr = [d.data_ptr() for d in self.dsts]
         self.nbytes = [d.numel() * d.element_size() for d in self.dsts]
         self.ps = (C.c_void_p * max(n, 1))()
@@ -996,9 +996,21 @@ class BatchCopier:
             bd, bn = blob[0].data_ptr(), len(raw)
             keep = C.create_string_buffer(raw, bn)
             bp = C.cast(keep, C.c_void_p)
-        if n or bn or self.add_dst:
-            _check(self.fn(self.ps, self.pd, self.nb, n, bd, bp, bn, self.add_dst, self.add_val, _stream()),
-                   'copy_batch')
+        if n <= self.cap:
+            if n or bn or self.add_dst:
+                _check(self.fn(self.ps, self.pd, self.nb, n, bd, bp, bn, self.add_dst, self.add_val, _stream()),
+                       'copy_batch')
+            return slow
+        # more tensors than one launch takes (a model with >= 15 inputs): groups of `cap`, the blob and the counter
+        # advance riding in the LAST one (they must happen once)
+        esz = C.sizeof(C.c_void_p)
+        for o in range(0, n, self.cap):
+            m = min(self.cap, n - o)
+            last = o + m >= n
+            _check(self.fn((C.c_void_p * m).from_buffer(self.ps, o * esz), (C.c_void_p * m).from_buffer(self.pd, o * esz),
+                           (C.c_longlong * m).from_buffer(self.nb, o * C.sizeof(C.c_longlong)), m,
+                           bd if last else None, bp if last else None, bn if last else 0,
+                           self.add_dst if last else None, self.add_val if last else 0, _stream()), 'copy_batch')
         return slow
 
 

@@ -255,6 +255,11 @@ class Adam(torch.optim.Adam):
         # fast path (every replay of a training loop): this plan is current, no eager step / zero_grad / load_state_dict
         # happened since its last activation — nothing to restore
         if self._plan is plan and plan['gen'] == self._gen and plan.get('stamp') == self._touch:
+            if not plan.get('poke'):
+                # the captured step carries an H2D copy node that reads this plan's pinned staging buffer (capture_safe()
+                # without poke, or more scalar rows than the blob holds): prepare_replay() is about to rewrite that
+                # buffer, so the previous replay's copy must have read it first
+                self.wait_staging()
             return
         gen = plan['gen']
         self._switch(plan)

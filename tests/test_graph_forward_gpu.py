@@ -132,3 +132,41 @@ def test_captured_found_stage_step_holds_only_this_repos_launches(cname, batch, 
     assert len(foreign) <= foreign_allowed, foreign
     assert any('copy_batch_k' in n for n in names), names
     assert torch.isfinite(loss).all()
+
+
+def test_captured_step_with_an_unfused_classifier_whose_output_is_not_a_multiple_of_four(monkeypatch):
+    """with the classifier outside the fused head (BMNAS_FUSE_HEAD=0) LinearFn carves its (b, O) output from
+    the captured step's arena; Ego's per-GPU shard is 6 x 83 = 498 floats — not a multiple of four, which the arena's
+    rounding turned into a 500-float slice that `view(6, 83)` refused INSIDE the capture.  The step must capture and its
+    replays must train like the eager step."""
+    import bench as B
+    from bmnas import cell as K
+    from bmnas import nn as bnn
+    from bmnas.graph import GraphedTrainStep
+    from bmnas.optim import Adam
+    monkeypatch.setattr(K, 'FUSE_HEAD', False)
+    c = dict(B.CONFIGS['ego'], drpt=0.0)
+    dev = torch.device('cuda:0')
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        m = B.HyperNet(c, 'F', 'ego').to(dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        nets.append(m)
+    crit = bnn.CrossEntropyLoss()
+    xs, y = B.synth_batch(c, 6, dev, 0)
+    xs = [x.detach() for x in xs]
+    assert (6 * c['nout']) % 4 != 0
+    opts = [Adam(m.parameters(), lr=1e-3, weight_decay=1e-4) for m in nets]
+    g = GraphedTrainStep(nets[0], crit, opts[0], xs, y)
+    for _ in range(2):
+        loss_g = g(xs, y)[0].clone()
+        opts[1].zero_grad()
+        loss_e = crit(nets[1](xs), y)
+        loss_e.backward()
+        opts[1].step()
+        assert abs(float(loss_g) - float(loss_e)) <= 1e-4 * max(1.0, abs(float(loss_e)))
+    for a, b in zip(nets[0].parameters(), nets[1].parameters()):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-5)

@@ -211,6 +211,81 @@ def test_trainer_loop_shards_unsharded_batches(monkeypatch):
         loop._shard_batch(x, y)
 
 
+def test_uneven_global_batch_is_a_stated_deviation_from_dataparallel(monkeypatch):
+    """nn.DataParallel's scatter (mmimdb_darts_searchable.py:36-37) hands a global batch of 10 to 3 replicas as chunks of
+    4 / 4 / 2 and averages the loss over all 10; this loop keeps EQUAL shards (one captured batch shape per rank, one
+    unweighted all-reduce, mean of shard means == mean over what was processed) and drops the n % world remainder.  The
+    deviation is deliberate ("Data parallelism") and never silent: pinned here as what it is — the first
+    such batch warns, names the count, and the samples every rank keeps are disjoint and cover exactly world * (n // world)."""
+    import warnings
+    import torch
+    import models.search.train_searchable._loop as loop
+    x, y = torch.arange(10).float().view(10, 1), torch.arange(10)
+    monkeypatch.setattr(loop, '_world', lambda: 3)
+    monkeypatch.setattr(loop._shard_batch, 'warned', False)
+    kept = []
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        for rank in range(3):
+            monkeypatch.setattr(loop, '_rank', lambda r=rank: r)
+            _, lab = loop._shard_batch(x, y)
+            kept += lab.tolist()
+    assert kept == list(range(9))                                  # sample 9 — the remainder — is dropped
+    msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]
+    assert len(msgs) == 1 and 'drops 1 sample' in msgs[0]          # said once, with the count
+    # the epoch metrics divide by what the ranks processed together, not by the dataset size (run(): n = all-reduced `seen`)
+    import inspect
+    assert '_all_sum(torch.tensor(float(seen)' in inspect.getsource(loop.run)
+
+
+def test_step_arena_slices_have_the_requested_length():
+    """LinearFn views its arena slice as (b, O); 6 x 83 = 498 floats must come back as 498 (the cursor still
+    advances by 500 so that the next slice stays 16-byte aligned)."""
+    from bmnas.functions import _StepArena
+    a = _StepArena(torch.zeros(1024))
+    v = a.take(6 * 83)
+    assert v.numel() == 498 and v.view(6, 83).shape == (6, 83) and a.off == 500
+    w = a.take(8)
+    assert w.data_ptr() == a.buf.data_ptr() + 500 * 4 and w.data_ptr() % 16 == 0
+    assert a.take(1024) is None and a.off == 508                   # too large: nothing handed out, cursor unchanged
+
+
+def test_adam_fast_activate_waits_for_the_staging_buffer_of_copy_node_plans(monkeypatch):
+    """the no-op fast path of Adam.activate() must still wait for the previous replay's H2D copy node when the
+    captured plan is NOT in poke mode (capture_safe() without poke, or more than 8 scalar rows): prepare_replay() rewrites
+    the pinned staging buffer that node reads."""
+    from bmnas.optim import Adam
+    opt = Adam([torch.nn.Parameter(torch.zeros(2))], lr=1e-3)
+    waits = []
+    monkeypatch.setattr(opt, 'wait_staging', lambda: waits.append(1))
+    for poke, want in ((False, 1), (True, 0)):
+        del waits[:]
+        plan = dict(gen=opt._gen, stamp=opt._touch, poke=poke)
+        opt._plan = plan
+        opt.activate(plan)
+        assert len(waits) == want
+
+
+def test_deferred_affine_launches_a_repeated_or_non_leaf_layernorm_at_once(monkeypatch):
+    """a deferred LayerNorm-affine job hands unfilled (dweight, dbias) to autograd; that is only safe for a
+    leaf weight seen once per pass.  A second job for the same weight launches both at once; a non-leaf weight is never
+    deferred."""
+    from bmnas import functions as F
+    launched = []
+    monkeypatch.setattr(F.lib, 'ln_affine_bwd', lambda *a: launched.append(a[7]))      # a[7] = dln_w
+    monkeypatch.setattr(F.lib, 'ln_affine_bwd_multi', lambda probs, b, L: launched.extend(p['dln_w'] for p in probs))
+    t = torch.zeros(1)
+    with F.deferred_affine():
+        F._ln_affine(t, [t], None, t, t, t, 'dw_a', 'db', 2, 4, 8, False, False, key=11, leaf=True)
+        assert launched == []                                          # first use of a leaf: deferred
+        F._ln_affine(t, [t], None, t, t, t, 'dw_b', 'db', 2, 4, 8, False, False, key=22, leaf=False)
+        assert launched == ['dw_b']                                    # not a leaf: at once
+        F._ln_affine(t, [t], None, t, t, t, 'dw_a2', 'db', 2, 4, 8, False, False, key=11, leaf=True)
+        assert launched == ['dw_b', 'dw_a', 'dw_a2']                   # repeated: the pending job first, then this one
+        F._ln_affine(t, [t], None, t, t, t, 'dw_c', 'db', 2, 4, 8, False, False, key=33, leaf=True)
+    assert launched == ['dw_b', 'dw_a', 'dw_a2', 'dw_c']               # the one still pending goes out at the exit
+
+
 def test_forward_graph_cache_holds_its_criterion():
     """the captured-forward cache is keyed by id(criterion); an id re-used by a NEW criterion (the old one
     freed, e.g. rebuilt per stage with another pos_weight) must not get the old graphs, whose criterion is baked in."""

@@ -1,5 +1,5 @@
 """Where the weight step's time beyond fwd + bwd goes: GraphedTrainStep (fwd + criterion + bwd + Adam) replayed
-with (a) the full optimizer launch, (b) the Adam kernel without the staging H2D copy node, (c) no optimizer work.
+with (a) the full optimizer launch, (b) the Adam kernel alone (poke-mode plans hold no H2D copy node any more: same as (a)), (c) no optimizer work.
     python tools/time_wstep.py [config] [batch] [variant ...]     (one variant: a clean rocprofv3 --kernel-trace --stats)"""
 import os
 import sys
@@ -48,13 +48,16 @@ for variant in (sys.argv[3:] or ('full', 'nocopy', 'nostep')):
             g(xs, y)
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / 100 * 1e3)
-    # replay only (no input copies, no host-side staging)
+    # no input copy: the step called on its own static tensors.  (Not `g._g.replay()`: a captured step depends on the launch
+    # in front of every replay — it clears the accumulation arena, advances the dropout counter and delivers Adam's
+    # scalars; raw replays accumulate into an arena nobody clears and reach Inf / NaN.)
+    sb = g.static_batch()
     for _ in range(20):
-        g._g.replay()
+        g(*sb)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(200):
-        g._g.replay()
+        g(*sb)
     torch.cuda.synchronize()
     rep = (time.perf_counter() - t0) / 200 * 1e3
-    print(f'{cname} b{batch} {variant:7s}: call {best:.4f} ms   replay only {rep:.4f} ms', flush=True)
+    print(f'{cname} b{batch} {variant:7s}: call {best:.4f} ms   without input copy {rep:.4f} ms', flush=True)
