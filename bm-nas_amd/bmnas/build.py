@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(HERE), 'csrc')
 OBJ = os.path.join(CSRC, '.obj')
 LIB = os.path.join(HERE, 'libbmnas_hip.so')
 SOURCES = ['mixsum.hip', 'layernorm.hip', 'sdpa.hip', 'conv1x1.hip', 'bnmix.hip', 'linear.hip', 'adam.hip',
-           'head.hip', 'comm.hip', 'probe.hip', 'dropout.hip', 'pool.hip', 'mixconv.hip', 'lazyln.hip', 'chanown.hip']
+           'head.hip', 'comm.hip', 'probe.hip', 'dropout.hip', 'pool.hip', 'mixconv.hip', 'lazyln.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-pass-failed']
 # timing builds only (e.g. BMNAS_HIPCC_EXTRA=-DBMNAS_BODY_PROBES=1 python -m bmnas.build --force)
 FLAGS += os.environ.get('BMNAS_HIPCC_EXTRA', '').split()

@@ -278,25 +278,11 @@ class StatArena:
     per-channel sums into them with atomics and the kernels that apply the BatchNorm finalise them
     in place of a bmnas_bn_finalize launch per conv."""
 
-    def __init__(self, like, channel_counts, buf=None, zero=None):
-        """zero: a further zero-filled region (same scrub) that `take_zero_like` carves (b, C, L) tensors from — the
-        outputs that the channel-owner launches ADD into (bmnas_co_inner_fwd: s, z_next)."""
+    def __init__(self, like, channel_counts, buf=None):
         self.sizes = [STAT_SHARDS * M * 2 for M in channel_counts]
         self.buf = torch.empty(sum(self.sizes), device=like.device, dtype=torch.float32) if buf is None else buf
         assert self.buf.numel() >= sum(self.sizes)
         self.off = 0
-        self.zero, self.zoff = zero, 0
-
-    def zero_left(self):
-        return 0 if self.zero is None else self.zero.numel() - self.zoff
-
-    def take_zero_like(self, x):
-        n = x.numel()
-        if self.zero is None or self.zoff + n > self.zero.numel():
-            raise lib.BmnasError('StatArena: more zero-filled outputs in the forward than were planned')
-        v = self.zero[self.zoff:self.zoff + n].view(x.shape)
-        self.zoff += (n + 3) // 4 * 4
-        return v
 
     @staticmethod
     def numel_for(channel_counts):
@@ -410,8 +396,7 @@ class MixedSaved:
     pass
 
 
-def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None, nxt=None, launch_mix=True,
-                   co=False):
+def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None, nxt=None, launch_mix=True):
     """NodeMixedOp.forward (node_operations.py:118-120).  P: parameter pack of one NodeMixedOp
     (see models.search.darts.node_operations.NodeMixedOp.pack()).  x may be y (search).
     ln = (resid, ln_w, ln_b, stats): fuse the NodeCell tail `out += x; ln(out)` (node_search.py:67-68)
@@ -429,29 +414,6 @@ def node_mixed_fwd(x, y, gamma_row, P, training, ln=None, Weff=None, stats=None,
     sv.d_glu = DROP.make(P.glu_p, x.numel(), training)
     sv.d_fc = DROP.make(P.fc_p, x.numel(), training)
     sv.merged = same and FUSE_ATTN_GEMM
-    sv.co = False
-    if co:
-        # ONE launch for the whole inner step (bmnas_co_inner_fwd): the workgroup that owns 16 channels of the stacked
-        # conv holds all b L columns, so the BatchNorm statistics are local; s and z_next are ADDED into zero-filled
-        # slices of the forward arena by the channel owners and the attention workgroups
-        assert same and sv.merged and ln is None and launch_mix and nxt is not None and Weff is not None
-        M = 3 * C
-        if training and b * L < 2:
-            raise ValueError('Expected more than 1 value per channel when training, got input size '
-                             f'{[b, M, L]}')
-        U, chan = _empty(x, b, M, L), _empty(x, 4 * M)
-        out = stats.take_zero_like(x)
-        bnd = lib.make_bn_fin(None, 0, P.stack_bias, P.stack_bn_w, P.stack_bn_b, P.stack_rm, P.stack_rv,
-                              P.stack_nbt, training)
-        lib.co_inner_fwd(x, Weff, bnd, gamma_row, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, U, chan, out, b, C, L,
-                         sv.d_attn, sv.d_glu, sv.d_fc, nxt)
-        cs = ConvBnSaved()
-        cs.fin = lib.NO_FIN
-        cs.srcs, cs.C_src, cs.W, cs.ldw, cs.U, cs.chan, cs.M = [x], C, Weff, C, U, chan, M
-        cs.training, cs.dup, cs.fold = training, C, 0
-        sv.conv, sv.co = cs, True
-        bn_ratio_note(chan, P.stack_bias, M, f'conv 1x{C}->{M}', training)
-        return out, sv
     if sv.merged:
         U, chan = _mixed_conv_fwd(sv, x, y, same, P, training, C,
                                   attn=(x, y, P.ln_w, P.ln_b, p1, sv.xhat1, sv.stats1, C, sv.d_attn), Weff=Weff,
@@ -516,20 +478,6 @@ FUSE_NEXT_PAIR = os.environ.get('BMNAS_FUSE_NEXT_PAIR', '1') != '0'
 # small grids, node_multiplier != 1: the last inner step's mix backward as the epilogue of the out_conv
 # data-gradient tiles (needs the one-launch out_conv backward, FUSE_BWD_PAIR)
 FUSE_MIX_EPILOGUE = os.environ.get('BMNAS_FUSE_MIX_EPILOGUE', '1') != '0'
-# small per-GPU shards (b L <= 64 columns: NTU b8, Ego b6): the inner steps t < node_steps - 1 of a NodeCell as ONE
-# channel-owner launch per direction (csrc/chanown.hip) instead of conv + attention | mix (+ next inner sum)
-CO_INNER = os.environ.get('BMNAS_CO_INNER', '1') != '0'
-
-
-def co_inner_steps(b, C, L, ns, is_cuda=True):
-    """How many inner steps of ONE NodeCell run as channel-owner launches (each needs two zero-filled (b, C, L)
-    outputs from the forward arena: its s and the next step's mixed sum)."""
-    if not (CO_INNER and FUSE_INNER_SUM and FUSE_ATTN_GEMM and FUSE_BN_FINALIZE and not DETERMINISTIC and ns >= 2
-            and is_cuda and lib.co_inner_ok(b, C, L)):
-        return 0
-    return sum(1 for t in range(ns - 1) if 2 + t <= MIX_PREV_MAX)
-
-
 # the cell's K7 tail + central classifier (+ criterion) as two launches (csrc/head.hip)
 FUSE_HEAD = os.environ.get('BMNAS_FUSE_HEAD', '1') != '0'
 # node_multiplier == 1 under the fused head: the step node's LayerNorm is applied by its consumers (the next step's K1
@@ -772,11 +720,8 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
             z = z0 if (t == 0 and z0 is not None) else mixsum_fwd(states, beta_w[offset:, 1])
         last = sv.fused_tail and t == ns - 1
         nxt, z_next = None, None
-        co = False
         if FUSE_INNER_SUM and t + 1 < ns and len(states) <= MIX_PREV_MAX:
-            co = (weffs is not None and stats is not None and stats.zero_left() >= 2 * x.numel()
-                  and co_inner_steps(b, C, L, ns, x.is_cuda) > 0)
-            z_next = stats.take_zero_like(x) if co else torch.empty_like(x)
+            z_next = torch.empty_like(x)
             nxt = (list(states), beta_w[offset + len(states):, 1], 2, z_next)
         sv.next_fused.append(nxt is not None)
         # the last inner step's mix rides in the out_conv launch below (small grids)
@@ -784,7 +729,7 @@ def node_cell_fwd(x, y, beta_w, gamma_w, NP, training, ns, nm, z0=None, weffs=No
                  and lib.node_mix_conv_fwd_ok(b, C, L, nm - 1))
         s, msv = node_mixed_fwd(z, z, gamma_w[t], NP.mixed[t], training,
                                 (x, NP.ln_w, NP.ln_b, sv.stats, sv.osum, lazy) if last else None,
-                                None if weffs is None else weffs[t], stats, nxt, launch_mix=not defer, co=co)
+                                None if weffs is None else weffs[t], stats, nxt, launch_mix=not defer)
         sv.zs.append(z)
         sv.mixed.append(msv)
         sv.offsets.append(offset)

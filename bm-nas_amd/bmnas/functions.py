@@ -736,15 +736,8 @@ class FusedCellFn(Function):
             O = Wc.shape[0]
             hb_n = (3 * b * O + 3) // 4 * 4
             head_n = hb_n + 4
-        # ... and the (b, C, L) outputs that the channel-owner launches of small shards add into (csrc/chanown.hip)
-        co_n = 0
-        if stat_n and K.FUSE_PROLOGUE and 0 < len(mixed) <= 8:
-            per = (xs[0].numel() + 3) // 4 * 4
-            co_n = 2 * per * len(CP.nodes) * K.co_inner_steps(b, C_, xs[0].shape[2], cell.args.node_steps, True)
-        arena = (torch.empty(stat_n + head_n + co_n, device=dev, dtype=torch.float32)
-                 if stat_n + head_n + co_n else None)
-        stats = (K.StatArena(xs[0], counts, arena[:stat_n], arena[stat_n + head_n:] if co_n else None)
-                 if stat_n else None)
+        arena = torch.empty(stat_n + head_n, device=dev, dtype=torch.float32) if stat_n + head_n else None
+        stats = K.StatArena(xs[0], counts, arena[:stat_n]) if stat_n else None
         if n_head:
             head = K.HeadState(W=Wc, bias=bc, hb=arena[stat_n:stat_n + 3 * b * O].view(3, b, O),
                                loss=arena[stat_n + hb_n:stat_n + hb_n + 1],

@@ -205,9 +205,6 @@ SIGNATURES = {
     'bmnas_debug_stamps_head': ([_P, _I], _I),
     'bmnas_debug_stamps_conv': ([_P, _I], _I),
     'bmnas_lazy_ln_ok': ([_I, _I], _I),
-    'bmnas_co_inner_fwd_ok': ([_I, _I, _I], _I),
-    'bmnas_co_inner_fwd': ([_P, _P, BnFin, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout, Dropout,
-                            _PP, _I, _P, _I, _P, _P], _I),
     'bmnas_lazy_ln_parts': ([_I, _I], _I),
     'bmnas_node_mix_pre_fwd': ([_P, _P, _P, _P, _P, BnFin, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, Dropout, Dropout,
                                 _P], _I),
@@ -443,22 +440,6 @@ def head_bwd(srcs, sums, dsrcs, acc_mask, ln_w, ln_b, W, hb, stats, mode, g, gsc
                                  None if labels is None else labels.data_ptr(), _ptr(loss), _ptr(part),
                                  b, Cc, L, O, _ptr(scrub),
                                  0 if scrub is None else scrub.numel(), _stream()), 'head_bwd')
-
-
-# ------------------------------------------------- channel-owner kernels for small per-GPU shards (csrc/chanown.hip)
-def co_inner_ok(b, Cc, L):
-    return bool(load().bmnas_co_inner_fwd_ok(b, Cc, L))
-
-
-def co_inner_fwd(z, Weff, bn, gamma, ln_w, ln_b, p1, xhat, stats1, U, chan, s, b, Cc, L, d_attn, d_glu, d_fc, nxt=None):
-    """One inner step of a search-mode NodeCell in one launch.  bn: make_bn_fin(None, 0, bias, bn_w, bn_b, rm, rv, nbt,
-    training); s (and nxt's z_next) zero-filled; nxt = (prev states, w_row0, w_stride, z_next)."""
-    prev, w, ws, zn = ([], None, 1, None) if nxt is None else nxt
-    _check(load().bmnas_co_inner_fwd(_ptr(z), _ptr(Weff), bn, gamma.data_ptr(), _ptr(ln_w), _ptr(ln_b), _ptr(p1),
-                                     _ptr(xhat), _ptr(stats1), _ptr(U), _ptr(chan), _ptr(s), b, Cc, L, d_attn, d_glu,
-                                     d_fc, _ptrs(prev) if prev else None, len(prev), None if w is None else w.data_ptr(), ws, _ptr(zn),
-                                     _stream()),
-           'co_inner_fwd')
 
 
 # ------------------------------------------------- the step node's LayerNorm applied by its consumers (csrc/lazyln.hip)

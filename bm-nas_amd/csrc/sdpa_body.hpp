@@ -107,17 +107,6 @@ __device__ __forceinline__ void attn_probs(const float* __restrict__ x, const fl
   for (int r = 0; r < 4; ++r) p[r] *= rden;
 }
 
-// The attention branch as one ADDEND of a NodeMixedOp whose other three primitives are formed by other workgroups of
-// the same launch (csrc/chanown.hip): s += gamma[1] * p1 and z_next += w_n * gamma[1] * p1 with fp32 atomics onto
-// buffers that a launch in front zero-filled.  Two addends per address (this one and the channel owner's), so the
-// result does not depend on their order.
-struct SdpaMixAdd {
-  float* s;              // (b, C, L) the NodeMixedOp output; nullptr: no epilogue
-  float* z;              // (b, C, L) the next inner step's mixed sum, nullable
-  const float* gamma;    // the 4 softmaxed primitive weights
-  const float* wn;       // weight of s in z_next (nullable with z)
-};
-
 // g = tile group (one workgroup of 256 threads each)
 template <int KCH>
 __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restrict__ x,
@@ -125,14 +114,8 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
                                               const float* __restrict__ ln_w,
                                               const float* __restrict__ ln_b, float* __restrict__ out,
                                               float* __restrict__ xhat, float* __restrict__ stats,
-                                              const SdpaGeom& G, const DropCfg& drop, char* lds,
-                                              const SdpaMixAdd ma = SdpaMixAdd{nullptr, nullptr, nullptr, nullptr}) {
+                                              const SdpaGeom& G, const DropCfg& drop, char* lds) {
   const DropRt drop_rt = drop_begin(drop);          // the step counter's load goes out first
-  float ma_g1 = 0.f, ma_wn = 0.f;
-  if (ma.s != nullptr) {
-    ma_g1 = ma.gamma[1];
-    if (ma.z != nullptr) ma_wn = ma.wn[0] * ma_g1;
-  }
   // LDS comes from the caller (kSdpaFwdLds bytes, 16-byte aligned) so that a launch that merges
   // this body with others pays max(), not sum(), of their footprints
   float4* ldsS = reinterpret_cast<float4*>(lds);                 // [4 * 64]
@@ -203,41 +186,18 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
       const float4 hh = make_float4((od[k].x - mean) * rstd, (od[k].y - mean) * rstd,
                                     (od[k].z - mean) * rstd, (od[k].w - mean) * rstd);
       st4(xhat + e, hh);
-      const float4 o4 = make_float4(hh.x * w.x + bb.x, hh.y * w.y + bb.y, hh.z * w.z + bb.z, hh.w * w.w + bb.w);
-      st4(out + e, o4);
-      if (ma.s != nullptr) {
-        atomicAdd(ma.s + e, ma_g1 * o4.x);
-        atomicAdd(ma.s + e + 1, ma_g1 * o4.y);
-        atomicAdd(ma.s + e + 2, ma_g1 * o4.z);
-        atomicAdd(ma.s + e + 3, ma_g1 * o4.w);
-        if (ma.z != nullptr) {
-          atomicAdd(ma.z + e, ma_wn * o4.x);
-          atomicAdd(ma.z + e + 1, ma_wn * o4.y);
-          atomicAdd(ma.z + e + 2, ma_wn * o4.z);
-          atomicAdd(ma.z + e + 3, ma_wn * o4.w);
-        }
-      }
+      st4(out + e, make_float4(hh.x * w.x + bb.x, hh.y * w.y + bb.y, hh.z * w.z + bb.z, hh.w * w.w + bb.w));
     }
   }
 }
-
-// The incoming gradient completed while it is loaded: g = gout (nullable) + wn * (gz + gz2 (nullable)) — the gradient
-// of a state that the NEXT inner step's mixed sum also read, before any launch has added that share (csrc/chanown.hip).
-struct SdpaGNext {
-  const float* gz;       // nullptr: gout is the complete gradient
-  const float* gz2;
-  const float* wn;
-};
 
 template <int KCH>
 __device__ __forceinline__ void sdpa_bwd_body(
     const int g, const float* __restrict__ gout, const float* __restrict__ gscale,
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ ln_w,
     const float* __restrict__ xhat, const float* __restrict__ stats, float* dx, float* dy,
-    uint32_t acc_mask, const SdpaGeom& G, const DropCfg& drop, char* lds,
-    const SdpaGNext gn = SdpaGNext{nullptr, nullptr, nullptr}) {
+    uint32_t acc_mask, const SdpaGeom& G, const DropCfg& drop, char* lds) {
   const DropRt drop_rt = drop_begin(drop);          // the step counter's load goes out first
-  const float gn_w = gn.gz != nullptr ? gn.wn[0] : 0.f;
   // LDS from the caller: sdpa_bwd_lds(C) bytes, 16-byte aligned (see sdpa_fwd_body)
   float4* ldsS = reinterpret_cast<float4*>(lds);                                  // [4 * 64]
   float (*tP)[16 * 17] = reinterpret_cast<float (*)[16 * 17]>(lds + 4096);        // [4][272]
@@ -261,16 +221,7 @@ __device__ __forceinline__ void sdpa_bwd_body(
     const int64_t pe = (int64_t)(chc * 16 + lo) * G.L + l0;
     const int64_t e = (int64_t)shc * G.C * G.L + pe;
     xh[k] = ld4(xhat + e);
-    float4 gv;
-    if (gn.gz != nullptr) {
-      float4 G4 = ld4(gn.gz + e);
-      if (gn.gz2 != nullptr) G4 = f4_add(G4, ld4(gn.gz2 + e));
-      gv = f4_scale(G4, gn_w);
-      if (gout != nullptr) gv = f4_add(gv, ld4(gout + e));
-    } else {
-      gv = ld4(gout + e);
-    }
-    dv[k] = f4_mul(gv, ld4(ln_w + pe));                          // g * w (the gamma scale comes later)
+    dv[k] = f4_mul(ld4(gout + e), ld4(ln_w + pe));               // g * w (the gamma scale comes later)
     yv[k] = ld4(y + e);
     xv[k] = ld4(x + e);
   }

@@ -707,30 +707,6 @@ int bmnas_node_mix_lnp_bwd_rows(int b);
 int bmnas_conv1x1_set_deterministic(int on);
 int bmnas_ln_set_deterministic(int on);
 
-/* ---- channel-owner kernels: one launch per inner step at small per-GPU shards (csrc/chanown.hip) -----------
- * An inner step of a search-mode NodeCell (reference models/search/darts/node_search.py:52-57:
- * `z = sum(edge_ops[...])`, `s = node_ops[i](z, z, gammas[i])` with NodeMixedOp.forward node_operations.py:118-120 over
- * Sum :19-20, ScaledDotAttn :92-108, LinearGLU :30-39, ConcatFC :49-56) whose b * L <= 64 columns fit ONE workgroup per
- * 16 output channels: that workgroup owns rows {cb, C + cb, 2C + cb} of the stacked conv over ALL columns, so the
- * train-mode BatchNorm statistics (node_operations.py:34, :53) are sums inside it and conv + BatchNorm + GLU / ReLU +
- * dropout + Sum + the gamma-mix are one launch, the attention branch riding in the same grid on b L / 16 workgroups of
- * its own.  x is y (FusionNode(x, x), model_search.py:59); Weff: the folded weight of bmnas_fold_weight.
- * bmnas_co_inner_fwd_ok: L in {4, 8, 16}, C in {64, 128, 192}, 2 <= b L <= 64.
- *
- * Forward.  bn: conv_bias, bn_w, bn_b, running_mean / running_var (updated in training mode when present, read in eval
- * mode), num_batches_tracked / n_nbt, training — `stat`, `shards`, `on` are ignored (nothing is accumulated across
- * workgroups).  Outputs exactly what bmnas_conv1x1_fwd_sdpa + bmnas_node_mix_fwd_next leave: U (b, 3C, L), chan
- * (mean | rstd | scale | shift, 4 x 3C), p1 / xhat / stats1 of the attention branch, s and — z_next != NULL —
- * z_next = sum_{j < n_prev} w[j * w_stride] prev[j] + w[n_prev * w_stride] s (n_prev <= 5).  `s` and `z_next` must be
- * ZERO-FILLED by the caller: the channel owners and the attention workgroups each ADD their share (fp32 atomics, two
- * addends per address: the sum does not depend on their order). */
-int bmnas_co_inner_fwd_ok(int b, int C, int L);
-int bmnas_co_inner_fwd(const float* z, const float* Weff, bmnas_bn_fin_t bn, const float* gamma, const float* ln_w,
-                       const float* ln_b, float* p1, float* xhat, float* stats1, float* U, float* chan, float* s,
-                       int b, int C, int L, bmnas_dropout_t drop_attn, bmnas_dropout_t drop_glu,
-                       bmnas_dropout_t drop_fc, const float* const* prev, int n_prev, const float* w, int w_stride,
-                       float* z_next, void* stream);
-
 /* Diagnostics (timing builds with -DBMNAS_BODY_PROBES=1 only; BMNAS_E_LIMIT otherwise): thread 0 of every workgroup
  * of the instrumented kernels records the shader clock at up to six points and the 100 MHz wall clock at entry / exit
  * into buf[kernel slot][workgroup][8] (uint64; slots workgroups per kernel, 8 kernel slots).  tools/stamp_probe.py. */
