@@ -747,6 +747,13 @@ def roofline_report(a, c, step, ms_per_step, log):
     if a.config == 'mmimdb' and a.batch == 128 and a.tier == 'F' and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = {k: v.get('traffic_bytes') for k, v in json.load(f).items()}
+    # MFMA utilisation and cache behaviour of the GEMM launches from the hardware counters:
+    # profiles/r06_pmc_gemm.json = tools/pmc_summary.py over four rocprofv3 --pmc passes of this same step
+    pmc = {}
+    ppath = os.path.join(ROOT, 'profiles', 'r06_pmc_gemm.json')
+    if a.config == 'mmimdb' and a.batch == 128 and a.tier == 'F' and os.path.exists(ppath):
+        with open(ppath) as f:
+            pmc = json.load(f)
     agg = {}
     for i, n in enumerate(names):
         g = agg.setdefault(n, {'us': 0.0, 'n': 0, 'units': 0.0, 'bound': None, 'wrapper': None})
@@ -776,6 +783,17 @@ def roofline_report(a, c, step, ms_per_step, log):
             # the same launch priced by the bytes the PMC passes counted for it (profiles/*traffic.json): what an
             # MFMA-priced launch of a few hundred MFLOP is really bound by (the head pair: VERDICT r04 item 2)
             row['frac_of_hbm_by_traffic'] = round(traffic[n] / (g['us'] / g['n'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        if n in pmc:
+            # SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipes were busy, summed over the 1024 SIMDs) against the launch
+            # duration measured HERE at the 2.4 GHz engine clock; hit rates and the wave-time split as collected
+            d, cnt = pmc[n]['derived'], pmc[n]['counters']
+            row['pmc'] = {'source': 'profiles/r06_pmc_gemm.json (rocprofv3 --pmc, separate passes)',
+                          'mfma_util': round(cnt['SQ_VALU_MFMA_BUSY_CYCLES'] /
+                                             (1024 * g['us'] / g['n'] * 1e-6 * 2.4e9), 4),
+                          'mfma_gflop_executed': d['mfma_gflop'], 'l2_hit_rate': d['l2_hit_rate'],
+                          'l1_hit_rate': d['l1_hit_rate'],
+                          'wave_time_waiting_for_any_instruction': d['wave_time_waiting_for_any_instruction'],
+                          'lds_bank_conflict_share': d['lds_bank_conflict_share']}
         rows.append(row)
     rows.sort(key=lambda r: -r['us_per_step'])
     out = {'roofline_kernels': rows,
