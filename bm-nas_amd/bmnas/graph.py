@@ -164,8 +164,14 @@ class GraphedTrainStep:
                     pass
         return n
 
-    def __init__(self, model, criterion, optimizer, inputs, labels, warmup=2, metric_forward=False):
-        """metric_forward: the replay ENDS with a gradient-free `criterion(model(inputs), labels)` over the same static
+    def __init__(self, model, criterion, optimizer, inputs, labels, warmup=2, metric_forward=False, k=1):
+        """k: optimisation steps per replay.  k > 1 captures k CONSECUTIVE steps — each over a static batch of its own,
+        each with its own Adam scalars (learning rate, bias corrections: `stage(i, inputs, labels)` per batch, then
+        `replay_staged()`) — into one graph: what separates two replays (~4 us of launch gap and ~30 us of host work)
+        is then paid once per k batches.  The reference's loop takes its batches one by one
+        (train_searchable/mmimdb.py:73-113); the k batches of a replay are processed in the same order with the same
+        arithmetic.  Needs the update inside the graph.
+        metric_forward: the replay ENDS with a gradient-free `criterion(model(inputs), labels)` over the same static
         batch, evaluated after the update — the dev phase of a search does exactly this after every `architect.step`
         (train_searchable/mmimdb.py:66-84: Architect.step, then the metric forward on the same batch, which sees the
         updated alphas).  One batch copy and one replay instead of two of each; `__call__` then returns
@@ -190,8 +196,14 @@ class GraphedTrainStep:
         if reducer is not None and reducer.world <= 1:
             reducer = None
         self.reducer = reducer
-        self.inputs = [x.detach().clone().requires_grad_(x.requires_grad) for x in inputs]
-        self.labels = labels.detach().clone()
+        self.k = int(k)
+        if self.k < 1:
+            raise ValueError('k >= 1')
+        # one static batch per captured step; slot 0 doubles as `static_batch()`
+        self.slots = [([x.detach().clone().requires_grad_(x.requires_grad) for x in inputs], labels.detach().clone())
+                      for _ in range(self.k)]
+        self.inputs, self.labels = self.slots[0]
+        self._staged = []
         self._batch_in = _BatchIn(self.inputs, self.labels)
         # RCCL through the C ABI (bmnas.dist.NativeComm; BMNAS_NATIVE_RCCL=0 turns it off) is a plain launch
         # on the capture stream: the all-reduce and the Adam step then live INSIDE the graph.
@@ -201,6 +213,9 @@ class GraphedTrainStep:
         self.metric_forward = bool(metric_forward)
         if self.metric_forward and not self.in_graph_step:
             raise RuntimeError('metric_forward needs the optimizer step inside the captured graph')
+        if self.k > 1 and (not self.in_graph_step or self.metric_forward):
+            raise RuntimeError('k steps per replay need the optimizer step inside the captured graph (and no metric '
+                               'forward riding along)')
         views = reducer.ensure_bucket() if reducer is not None else None
         # with an averaging collective (RCCL) the captured step is the single-GPU one: unscaled loss, constant
         # unit gradient; otherwise (gloo) the loss is pre-scaled by 1/world and the bucket is summed
@@ -210,13 +225,21 @@ class GraphedTrainStep:
         from . import nn as bnn
 
         def fn():
+            if self.k == 1:
+                return one(self.inputs, self.labels)
+            out = ()
+            for xs_i, y_i in self.slots:             # (loss_0, logits_0, loss_1, logits_1, ...)
+                out += one(xs_i, y_i)
+            return out
+
+        def one(xs_, y_):
             # the criterion of a fused head is evaluated by the head's backward launch: the static
             # `loss` output is complete when the replay is (bmnas.nn.fused_criterion)
             with bnn.fused_criterion():
-                logits = model(self.inputs)
+                logits = model(xs_)
                 if isinstance(logits, tuple):
                     logits = logits[-1]
-                loss = criterion(logits, self.labels)
+                loss = criterion(logits, y_)
             # (deferred_affine: the per-op path's LayerNorm-affine reductions of this pass as ONE launch at its end)
             with K.arch_grads_only(self.arch_only), K.weight_grads_only(self.no_arch), deferred_affine():
                 if scale != 1.0:
@@ -246,10 +269,10 @@ class GraphedTrainStep:
                 # behind the Adam launch on the same stream: this forward's prologue reads the UPDATED architecture
                 # tensors; its criterion is the eager kernel (nothing follows that could evaluate a deferred one)
                 with torch.no_grad():
-                    mout = model(self.inputs)
+                    mout = model(xs_)
                     if isinstance(mout, tuple):
                         mout = mout[-1]
-                    mloss = criterion(mout, self.labels)
+                    mloss = criterion(mout, y_)
                 return loss, logits, mloss, mout
             return loss, logits
 
@@ -282,14 +305,16 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         try:
             if self.in_graph_step:
-                optimizer.capture_safe(poke=True)        # no H2D node in the graph: the scalars ride with the batch copy
+                # no H2D node in the graph: the scalars (of every one of the k steps) ride with the batch copy
+                optimizer.capture_safe(poke=True, slots=self.k)
             armed[0] = True
             # the step's accumulation arena: cleared, like the dropout step counter advanced, by the launch that copies
             # the batch in front of every replay — no fill / add launches inside the step (bmnas.functions._StepArena)
             self._arena = (torch.zeros(need.need, device=self.labels.device, dtype=torch.float32)
                            if need.need and _step_arena_on() else None)
             self._g = GraphedStep(fn, warmup=0, external_advance=_step_arena_on(), arena=self._arena)
-            self._batch_in = _BatchIn(self.inputs, self.labels, zero=[self._arena], advance=self._g.external)
+            flat = [t for xs_i, y_i in self.slots for t in list(xs_i) + [y_i]]
+            self._batch_in = _BatchIn(flat[:-1], flat[-1], zero=[self._arena], advance=self._g.external)
             # the graph reads THIS plan's staging buffers and writes THESE gradient tensors for good
             self.plan = optimizer.captured_plan() if self.in_graph_step else None
             self.static_grads = [t.grad for t in self.targets]
@@ -297,7 +322,7 @@ class GraphedTrainStep:
             model.load_state_dict(state)        # also when the capture fails and the caller stays eager
 
     @staticmethod
-    def try_build(model, criterion, optimizer, inputs, labels, logger=None, metric_forward=False):
+    def try_build(model, criterion, optimizer, inputs, labels, logger=None, metric_forward=False, k=1):
         """-> a GraphedTrainStep, or False when this step cannot be captured (inputs that are not a
         flat list of tensors, a module that synchronises with the host, ...); callers then keep
         the eager path."""
@@ -306,7 +331,7 @@ class GraphedTrainStep:
             return False
         from .dist import all_ranks_agree
         try:
-            step = GraphedTrainStep(model, criterion, optimizer, inputs, labels, metric_forward=metric_forward)
+            step = GraphedTrainStep(model, criterion, optimizer, inputs, labels, metric_forward=metric_forward, k=k)
         except Exception as e:                       # noqa: BLE001 — capture errors are of many types
             torch.cuda.synchronize()
             from . import functions
@@ -349,8 +374,34 @@ class GraphedTrainStep:
         it overlaps the gap between two replays (bench.py `input_copy_us`)."""
         return self.inputs, self.labels
 
+    def stage(self, i, inputs, labels):
+        """k > 1: hand over batch i (0 ... k - 1, in order) of the next replay.  Call it AFTER the scheduler has set the
+        learning rates this batch's step runs with: the step's Adam scalars are fixed here."""
+        opt = self.optimizer
+        if i == 0:
+            opt.activate(self.plan)          # an eager step in between must not leak into the replay
+            self._staged = []
+        if i != len(self._staged) // (len(self.inputs) + 1):
+            raise RuntimeError('GraphedTrainStep.stage: batches must be staged in order, one call per slot')
+        opt.prepare_replay(slot=i)
+        self._staged += list(inputs) + [labels]
+
+    def replay_staged(self):
+        """-> [(loss, logits)] * k of the k staged batches (static tensors, overwritten by the next replay)."""
+        opt = self.optimizer
+        if len(self._staged) != self.k * (len(self.inputs) + 1):
+            raise RuntimeError(f'GraphedTrainStep.replay_staged: {self.k} batches must be staged first')
+        # ONE launch in front of the replay: the k batches into the static tensors + the k steps' Adam scalars
+        self._batch_in(self._staged[:-1], self._staged[-1], opt.replay_blob())
+        self._staged = []
+        out = self._g.replay()
+        opt.mark_launched()
+        return [(out[2 * i], out[2 * i + 1]) for i in range(self.k)]
+
     def __call__(self, inputs, labels):
         opt = self.optimizer
+        if self.k != 1:
+            raise RuntimeError('a k-step GraphedTrainStep is driven by stage() / replay_staged()')
         if self.in_graph_step:
             opt.activate(self.plan)          # an eager step in between must not leak into the replay
             opt.prepare_replay()

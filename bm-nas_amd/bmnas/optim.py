@@ -52,7 +52,10 @@ class Adam(torch.optim.Adam):
             for (p, _), r in zip(pl['active'], pl['row_of']):
                 self.state[p]['step'].fill_(pl['count'][r])
 
-    def _build(self, active):
+    def _build(self, active, slots=1):
+        """slots > 1: a captured graph that holds `slots` consecutive optimizer steps (bmnas.graph.GraphedTrainStep(k=...)):
+        every step has its own scalar rows and its own descriptor table (each step's backward leaves its gradients in
+        tensors of its own), all in the ONE staging buffer."""
         self._flush_counts()
         dev = active[0][0].device
         E = lib.adam_chunk_elems()
@@ -71,42 +74,51 @@ class Adam(torch.optim.Adam):
                 rows.append(key)
             row_of.append(row_idx[key])
             chunks += [(i, c) for c in range((p.numel() + E - 1) // E)]
-        hyp_bytes = (len(rows) * 32 + 63) // 64 * 64
-        nbytes = hyp_bytes + len(active) * _DESC.itemsize
+        # (scalar slots packed back to back — 32 bytes per row —: the whole region travels by value in poke mode)
+        hyp_slot = len(rows) * 32
+        hyp_bytes = (slots * hyp_slot + 63) // 64 * 64
+        tab_slot = len(active) * _DESC.itemsize
+        nbytes = hyp_bytes + slots * tab_slot
         pin = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
         host = pin.numpy()
-        tab = host[hyp_bytes:].view(_DESC)
-        tab['exp_avg'] = [self.state[p]['exp_avg'].data_ptr() for p, _ in active]
-        tab['exp_avg_sq'] = [self.state[p]['exp_avg_sq'].data_ptr() for p, _ in active]
-        tab['numel'] = [p.numel() for p, _ in active]
-        tab['hyp_row'] = row_of
+        tabs = [host[hyp_bytes + i * tab_slot:hyp_bytes + (i + 1) * tab_slot].view(_DESC) for i in range(slots)]
+        for tab in tabs:
+            tab['exp_avg'] = [self.state[p]['exp_avg'].data_ptr() for p, _ in active]
+            tab['exp_avg_sq'] = [self.state[p]['exp_avg_sq'].data_ptr() for p, _ in active]
+            tab['numel'] = [p.numel() for p, _ in active]
+            tab['hyp_row'] = row_of
         devbuf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        hyps = [host[i * hyp_slot:(i + 1) * hyp_slot].view(np.float32).reshape(len(rows), 8) for i in range(slots)]
         self._plan = dict(ids=tuple(id(p) for p, _ in active), active=active, row_of=row_of, gen=self._gen,
                           groups=[gi for gi, _ in rows], count=[t for _, t in rows],
-                          pin=pin, hyp=host[:len(rows) * 32].view(np.float32).reshape(len(rows), 8), tab=tab,
-                          dev=devbuf, dev_hyp=devbuf[:hyp_bytes], dev_tab=devbuf[hyp_bytes:],
+                          pin=pin, hyp=hyps[0], hyps=hyps, hyp_all=host[:slots * hyp_slot], tab=tabs[0], tabs=tabs,
+                          dev=devbuf, dev_hyp=devbuf[:hyp_bytes],
+                          dev_hyps=[devbuf[i * hyp_slot:(i + 1) * hyp_slot] for i in range(slots)],
+                          dev_tab=devbuf[hyp_bytes:hyp_bytes + tab_slot],
+                          dev_tabs=[devbuf[hyp_bytes + i * tab_slot:hyp_bytes + (i + 1) * tab_slot]
+                                    for i in range(slots)],
                           chunks=torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev),
-                          n_chunks=len(chunks))
+                          n_chunks=len(chunks), slots=slots, cap_slot=0)
 
     def _stage(self, active):
         """Advance the step counts; write this step's scalars and pointers into the staging buffer."""
         self.prepare_replay()
         self._write_ptrs(active)
 
-    def _write_ptrs(self, active):
+    def _write_ptrs(self, active, slot=0):
         grads = [p.grad for p, _ in active]
         for gr, (p, _) in zip(grads, active):
             if gr.dtype != torch.float32 or not gr.is_contiguous() or gr.device != p.device:
                 raise lib.BmnasError('bmnas.optim.Adam: gradients must be contiguous fp32 on the parameter device')
-        pl = self._plan
-        pl['tab']['param'] = [p.data_ptr() for p, _ in active]
-        pl['tab']['grad'] = [gr.data_ptr() for gr in grads]
+        tab = self._plan['tabs'][slot]
+        tab['param'] = [p.data_ptr() for p, _ in active]
+        tab['grad'] = [gr.data_ptr() for gr in grads]
 
-    def _launch(self):
+    def _launch(self, slot=0):
         pl = self._plan
-        if not pl.get('poke'):
-            pl['dev'].copy_(pl['pin'], non_blocking=True)
-        lib.adam_multi(pl['dev_tab'], pl['chunks'], pl['n_chunks'], pl['dev_hyp'])
+        if not pl.get('poke') and slot == 0:
+            pl['dev'].copy_(pl['pin'], non_blocking=True)       # (one copy node serves every slot of the graph)
+        lib.adam_multi(pl['dev_tabs'][slot], pl['chunks'], pl['n_chunks'], pl['dev_hyps'][slot])
 
     def wait_staging(self):
         """Block until the last launch has consumed the pinned staging buffer (the host may run
@@ -139,9 +151,14 @@ class Adam(torch.optim.Adam):
         if torch.cuda.is_current_stream_capturing():
             if self._plan is None or self._plan['ids'] != tuple(id(p) for p, _ in active):
                 raise lib.BmnasError('bmnas.optim.Adam: call capture_safe() before capturing step() in a graph')
-            self._write_ptrs(active)            # the capture's static gradient tensors
+            slot = self._plan['cap_slot']
+            if slot >= self._plan['slots']:
+                raise lib.BmnasError('bmnas.optim.Adam: more captured steps than capture_safe(slots=...) planned')
+            self._write_ptrs(active, slot)      # the capture's static gradient tensors (of THIS step of the graph)
             self._plan['active'] = active
-            self._launch()                      # scalars are refreshed by prepare_replay()
+            self._plan.setdefault('slot_grads', {})[slot] = [p.grad for p, _ in active]
+            self._launch(slot)                  # scalars are refreshed by prepare_replay()
+            self._plan['cap_slot'] = slot + 1
             return loss
         ids = tuple(id(p) for p, _ in active)
         if self._plan is None or self._plan.get('captured') or self._plan['ids'] != ids:
@@ -180,7 +197,7 @@ class Adam(torch.optim.Adam):
         self._gen += 1
 
     # ------------------------------------------------------------------ hipGraph support
-    def capture_safe(self, poke=False):
+    def capture_safe(self, poke=False, slots=1):
         """Build a plan OF ITS OWN from the gradients that exist NOW (static tensors of the step
         being captured) so that step() inside `torch.cuda.graph` issues only stream work: one
         pinned H2D copy and one launch.  The captured graph keeps reading this plan's staging
@@ -188,14 +205,17 @@ class Adam(torch.optim.Adam):
         the capture and call `activate(plan)` + `prepare_replay()` before every replay."""
         active = self._active()
         self.wait_staging()
-        self._build(active)
+        self._build(active, slots)
         self._write_ptrs(active)
         self._plan['captured'] = True
         # "poke" mode (round 5): the captured step holds NO H2D copy node.  The descriptor table is uploaded once after the
         # capture (and again whenever activate() / load_state_dict changed it); the per-step scalars — 32 bytes per row —
         # travel by value in the launch that copies the batch into the step's static tensors (bmnas_copy_batch's blob,
         # replay_blob()).  A captured copy node cost 4.7 us per optimizer step.
-        self._plan['poke'] = bool(poke) and self._plan['hyp'].nbytes <= lib.copy_blob_max()
+        self._plan['poke'] = bool(poke) and self._plan['hyp_all'].nbytes <= lib.copy_blob_max()
+        if slots > 1 and not self._plan['poke']:
+            raise lib.BmnasError(f'bmnas.optim.Adam: {slots} captured steps x {len(self._plan["groups"])} scalar rows do not '
+                                 'fit the by-value blob of the batch-copy launch')
 
     def captured_plan(self):
         """The plan a capture has just baked into a graph, with the pointer table as captured
@@ -203,9 +223,14 @@ class Adam(torch.optim.Adam):
         pl = self._plan
         if pl is None or not pl.get('captured'):
             raise lib.BmnasError('bmnas.optim.Adam: no captured plan (capture_safe() + a captured step() first)')
-        pl['snap_param'] = pl['tab']['param'].copy()
-        pl['snap_grad'] = pl['tab']['grad'].copy()
-        pl['static_grads'] = [p.grad for p, _ in pl['active']]       # keeps the static tensors alive
+        if pl['cap_slot'] != pl['slots']:
+            raise lib.BmnasError(f'bmnas.optim.Adam: the capture holds {pl["cap_slot"]} step(s), the plan was built for '
+                                 f'{pl["slots"]}')
+        pl['snap_param'] = [t['param'].copy() for t in pl['tabs']]
+        pl['snap_grad'] = [t['grad'].copy() for t in pl['tabs']]
+        # keeps every slot's static gradient tensors alive; .grad is re-attached to the LAST step's (what a sequence of
+        # eager steps leaves behind)
+        pl['static_grads'] = pl['slot_grads'][pl['slots'] - 1]
         pl['tab_dirty'] = True                                       # poke mode: upload before the first replay
         return pl
 
@@ -222,7 +247,7 @@ class Adam(torch.optim.Adam):
             self.mark_launched(force=True)       # the pinned buffer must not be rewritten before this copy has read it
             self.wait_staging()                  # (rare: once after a capture / load_state_dict)
             pl['tab_dirty'] = False
-        h = pl['hyp']
+        h = pl['hyp_all']
         return pl['dev_hyp'][:h.nbytes], h.tobytes()
 
     def _switch(self, plan):
@@ -242,8 +267,9 @@ class Adam(torch.optim.Adam):
         if not plan.get('poke'):
             self.wait_staging()              # the plan's last launch has consumed its pinned buffer
         if plan['gen'] != self._gen:
-            plan['tab']['exp_avg'] = [self._init_state(p)['exp_avg'].data_ptr() for p, _ in plan['active']]
-            plan['tab']['exp_avg_sq'] = [self.state[p]['exp_avg_sq'].data_ptr() for p, _ in plan['active']]
+            for tab in plan['tabs']:
+                tab['exp_avg'] = [self._init_state(p)['exp_avg'].data_ptr() for p, _ in plan['active']]
+                tab['exp_avg_sq'] = [self.state[p]['exp_avg_sq'].data_ptr() for p, _ in plan['active']]
             plan['gen'] = self._gen
 
     def activate(self, plan):
@@ -265,20 +291,22 @@ class Adam(torch.optim.Adam):
         self._switch(plan)
         if plan['gen'] != gen:
             plan['tab_dirty'] = True             # load_state_dict replaced the moment tensors: new pointers in the table
-        if plan.get('poke') and ((plan['tab']['param'] != plan['snap_param']).any()
-                                 or (plan['tab']['grad'] != plan['snap_grad']).any()):
-            plan['tab_dirty'] = True
-        plan['tab']['param'] = plan['snap_param']
-        plan['tab']['grad'] = plan['snap_grad']
+        for tab, sp, sg in zip(plan['tabs'], plan['snap_param'], plan['snap_grad']):
+            if plan.get('poke') and ((tab['param'] != sp).any() or (tab['grad'] != sg).any()):
+                plan['tab_dirty'] = True
+            tab['param'] = sp
+            tab['grad'] = sg
         for (p, _), gr in zip(plan['active'], plan['static_grads']):
             p.grad = gr
         plan['stamp'] = self._touch
 
-    def prepare_replay(self):
+    def prepare_replay(self, slot=0):
         """Advance the step count and publish the current learning rates for the next replay
-        (call wait_staging() first and mark_launched() after the replay; GraphedTrainStep does)."""
+        (call wait_staging() first and mark_launched() after the replay; GraphedTrainStep does).
+        slot: which of the graph's consecutive steps these scalars are for — a graph of k steps takes k calls, slot 0
+        first, each with the learning rates its step runs with (the scheduler moves them between two calls)."""
         pl = self._plan
-        h = pl['hyp']
+        h = pl['hyps'][slot]
         for r, gi in enumerate(pl['groups']):
             g = self.param_groups[gi]
             pl['count'][r] += 1.0

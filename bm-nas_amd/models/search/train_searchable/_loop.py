@@ -180,6 +180,21 @@ class _ForwardGraphs:
         return g(inputs, labels)
 
 
+def steps_per_replay(args):
+    """How many weight steps the trainer captures into ONE hipGraph replay (`args.steps_per_replay`, else the environment
+    variable BMNAS_STEPS_PER_REPLAY, else 1; at most 8).  With k > 1 the loop keeps k batches resident and replays a
+    k-step graph — same batches, same order, same per-batch learning rates as the reference's one-by-one loop
+    (train_searchable/mmimdb.py:73-113) —; a ragged tail of fewer than k batches runs as single steps."""
+    v = getattr(args, 'steps_per_replay', None)
+    if v is None:
+        v = os.environ.get('BMNAS_STEPS_PER_REPLAY')
+    try:
+        k = int(v) if v is not None else 1
+    except (TypeError, ValueError):
+        k = 1
+    return max(1, min(k, 8))
+
+
 def _observe(event, **info):
     """tests/test_outer_loop_golden_gpu.py pins the loop against the reference's trainers through this hook
     (run.observer = callable(event, **info)); None in production: no host synchronisation is added."""
@@ -199,8 +214,10 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
     from bmnas.graph import GraphedTrainStep
     use_graph = GraphedTrainStep.enabled(args)
     w_graph, w_attempts = None, 0
+    k_steps = steps_per_replay(args) if use_graph else 1
+    wk_graph, wk_attempts = None, 0
     f_graphs = _ForwardGraphs.of(model, criterion, args, logger)
-    stats = run.stats = dict(graph_replays=0, eager_steps=0, forward_replays=0)
+    stats = run.stats = dict(graph_replays=0, eager_steps=0, forward_replays=0, k_step_replays=0)
     best = dict(best_dev=None, best_dev_genotype=None, best_dev_epoch=0, best_test=None,
                 best_test_genotype=None, best_test_epoch=0, last_genotype=None, nan_abort=False)
     for epoch in range(num_epochs):
@@ -228,11 +245,8 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
             split = _world() > 1 and not _is_sharded(loader)
             if _world() > 1 and _is_sharded(loader):
                 loader.sampler.set_epoch(epoch)          # a new shuffle per epoch, the same on every rank
-            for data in loader:
-                inputs, labels = unpack(data, device)
-                if split:
-                    inputs, labels = _shard_batch(inputs, labels)
-                seen += labels.size(0)
+            def one_batch(inputs, labels):
+                nonlocal w_graph, w_attempts, loss_sum
                 # nothing of the previous batch's autograd graph may stay referenced while a step is
                 # being captured (see GraphedTrainStep._live_graph_tensors)
                 output = loss = None
@@ -256,7 +270,7 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                         stats['graph_replays'] += 1
                         _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
                                  learn=True, how='graph')
-                        continue
+                        return
                 if not learn:
                     # the metric pass: no gradients, one replay (the step above — architect.step in the dev phase —
                     # has already happened: this forward sees the updated alphas, like the reference's)
@@ -271,7 +285,7 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                         stats['forward_replays'] += 1
                         _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
                                  learn=False, how='graph')
-                        continue
+                        return
                 stats['eager_steps'] += 1
                 optimizer.zero_grad()
                 with torch.set_grad_enabled(learn):
@@ -289,6 +303,48 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 meter.update(output.detach(), labels)
                 _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
                          learn=learn, how='eager')
+
+            def k_batches(batches):
+                """k resident batches as ONE replay of a k-step graph (each step with the learning rate the scheduler gives
+                its batch); anything that does not fit — no capture, another batch shape — runs batch by batch."""
+                nonlocal wk_graph, wk_attempts, loss_sum
+                x0, y0 = batches[0]
+                if wk_graph is None and wk_attempts < 3:
+                    wk_attempts += 1
+                    wk_graph = GraphedTrainStep.try_build(model, criterion, optimizer, x0, y0, logger, k=k_steps) or None
+                if not (wk_graph and all(wk_graph.matches(x_, y_) for x_, y_ in batches)):
+                    for x_, y_ in batches:
+                        one_batch(x_, y_)
+                    return
+                for j, (x_, y_) in enumerate(batches):
+                    if cosine:
+                        scheduler.step()
+                        scheduler.update_optimizer(optimizer)
+                    wk_graph.stage(j, x_, y_)
+                stats['k_step_replays'] += 1
+                for (loss, output), (x_, y_) in zip(wk_graph.replay_staged(), batches):
+                    loss_sum += loss.detach().double() * y_.size(0)
+                    meter.update(output.detach(), y_)
+                    stats['graph_replays'] += 1
+                    _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
+                             learn=True, how='graph')
+
+            held = []                                   # batches waiting for their k-step replay
+            for data in loader:
+                inputs, labels = unpack(data, device)
+                if split:
+                    inputs, labels = _shard_batch(inputs, labels)
+                seen += labels.size(0)
+                if learn and k_steps > 1 and isinstance(inputs, (list, tuple)):
+                    held.append((inputs, labels))
+                    if len(held) == k_steps:
+                        k_batches(held)
+                        held = []
+                    continue
+                one_batch(inputs, labels)
+            for x_, y_ in held:                         # the ragged tail of a phase: single steps
+                one_batch(x_, y_)
+            held = []
             n = dataset_sizes[phase]
             if _world() > 1:
                 # what the ranks processed together (a DistributedSampler pads, a split drops a remainder)

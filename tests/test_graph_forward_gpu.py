@@ -172,3 +172,54 @@ def test_captured_step_with_an_unfused_classifier_whose_output_is_not_a_multiple
         assert abs(loss_g - loss_e) <= 2e-4 * max(1.0, abs(loss_e)), (loss_g, loss_e)
         first = loss_e if first is None else first
     assert loss_e < first                      # and the replays do train
+
+
+@pytest.mark.parametrize('cname,batch', [('mmimdb', 32), ('ntu', 8)])
+def test_k_steps_per_replay_train_like_single_steps(cname, batch):
+    """GraphedTrainStep(k=4): four consecutive optimisation steps — each over a batch of its own, each with the learning
+    rate of ITS step — as one hipGraph replay.  Against the same eight batches taken one by one by a
+    single-step graph on an identically initialised copy: every step's loss agrees (later losses depend on the earlier
+    updates, so the per-step Adam scalars and gradient tensors of all four slots are pinned), and so do the step counts."""
+    import bench as B
+    from bmnas import nn as bnn
+    from bmnas.graph import GraphedTrainStep
+    from bmnas.optim import Adam
+    c = dict(B.CONFIGS[cname], drpt=0.0)
+    dev = torch.device('cuda:0')
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        m = B.HyperNet(c, 'F', cname).to(dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        nets.append(m)
+    crit = bnn.BCEWithLogitsLoss() if c['loss'] == 'bce' else bnn.CrossEntropyLoss()
+    batches = []
+    for i in range(8):
+        xs, y = B.synth_batch(c, batch, dev, 10 + i)
+        batches.append(([x.detach() for x in xs], y))
+    lrs = [2e-3 * (0.8 ** i) for i in range(8)]                  # a schedule that moves every step
+    opts = [Adam(m.parameters(), lr=lrs[0], weight_decay=1e-4) for m in nets]
+    g4 = GraphedTrainStep(nets[0], crit, opts[0], *batches[0], k=4)
+    g1 = GraphedTrainStep(nets[1], crit, opts[1], *batches[0])
+    got, want = [], []
+    for r in range(2):
+        for j in range(4):
+            i = 4 * r + j
+            for g in opts[0].param_groups:
+                g['lr'] = lrs[i]
+            g4.stage(j, *batches[i])
+        got += [float(l) for l, _ in g4.replay_staged()]
+    for i in range(8):
+        for g in opts[1].param_groups:
+            g['lr'] = lrs[i]
+        want.append(float(g1(*batches[i])[0]))
+    for i, (a, b_) in enumerate(zip(got, want)):
+        assert abs(a - b_) <= 3e-4 * max(1.0, abs(b_)), (i, got, want)
+    assert want[-1] != want[0]
+    s0 = {float(st['step']) for st in opts[0].state_dict()['state'].values()}
+    s1 = {float(st['step']) for st in opts[1].state_dict()['state'].values()}
+    assert s0 == s1 == {8.0}
+    with pytest.raises(RuntimeError):
+        g4(*batches[0])                                          # a k-step graph is driven by stage() / replay_staged()

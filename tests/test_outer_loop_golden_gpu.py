@@ -43,7 +43,11 @@ def _args(save, found=False, hip_graph=False):
     a.arch_learning_rate, a.arch_weight_decay, a.weight_decay = 3e-3, 1e-3, 1e-4
     a.f1_type = 'weighted'
     a.use_dataparallel = False
-    a.hip_graph = hip_graph
+    a.hip_graph = bool(hip_graph)
+    if hip_graph == 'k2':
+        # two weight steps per hipGraph replay (models/search/train_searchable/_loop.py steps_per_replay): the recordings
+        # hold phases of 3 / 2 batches with a ragged last one, so k = 2 is what gives every phase a k-step replay AND a tail
+        a.steps_per_replay = 2
     a.save = save
     return a
 
@@ -133,7 +137,7 @@ def _gold(name, seed_data=21):
     return g
 
 
-@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+@pytest.mark.parametrize('hip_graph', [False, True, 'k2'], ids=['eager', 'graph', 'graph-k2'])
 def test_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip_graph):
     gold = _gold('loop_mmimdb_search.json')
     drv, loop, rec = _install(monkeypatch)
@@ -153,6 +157,8 @@ def test_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip
     label = 'search/' + ('graph' if hip_graph else 'eager')
     if hip_graph:
         assert loop.run.stats['graph_replays'] == 4 and loop.run.stats['forward_replays'] >= 2, loop.run.stats
+        if hip_graph == 'k2':                  # both full batches of each epoch's train phase went out as ONE replay
+            assert loop.run.stats['k_step_replays'] == 2, loop.run.stats
     else:
         assert loop.run.stats['graph_replays'] == 0, loop.run.stats
     _compare_batches(rec.batches, gold['batches'], 2e-4, label)
@@ -172,7 +178,7 @@ def test_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip
         assert abs(g[1] - w[1]) <= 5e-4 * max(abs(w[1]), 1e-12) + 1e-7, (label, 'best checkpoint', k, g[1], w[1])
 
 
-@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+@pytest.mark.parametrize('hip_graph', [False, True, 'k2'], ids=['eager', 'graph', 'graph-k2'])
 def test_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, monkeypatch, hip_graph):
     gold = _gold('loop_mmimdb_found.json')
     drv, loop, rec = _install(monkeypatch)
@@ -241,6 +247,8 @@ def _acc_args(tmp_path, ns, nm, nout, hip_graph):
 def _check_search(gold, a, rec, loop, made, best_acc, genotype, label, hip_graph, arch_rel=2e-4):
     if hip_graph:
         assert loop.run.stats['graph_replays'] == 4 and loop.run.stats['forward_replays'] >= 2, loop.run.stats
+        if hip_graph == 'k2':                  # both full batches of each epoch's train phase went out as ONE replay
+            assert loop.run.stats['k_step_replays'] == 2, loop.run.stats
     else:
         assert loop.run.stats['graph_replays'] == 0, loop.run.stats
     _compare_batches(rec.batches, gold['batches'], 2e-4, label)
@@ -274,7 +282,7 @@ def _pin(monkeypatch, drv, cls_name, seed):
     return made
 
 
-@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+@pytest.mark.parametrize('hip_graph', [False, True, 'k2'], ids=['eager', 'graph', 'graph-k2'])
 def test_ntu_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip_graph):
     gold = _gold('loop_ntu_search.json', 33)
     drv, loop, rec = _install(monkeypatch, 'ntu')
@@ -288,7 +296,7 @@ def test_ntu_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch,
                   hip_graph)
 
 
-@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+@pytest.mark.parametrize('hip_graph', [False, True, 'k2'], ids=['eager', 'graph', 'graph-k2'])
 def test_ego_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip_graph):
     gold = _gold('loop_ego_search.json', 43)
     drv, loop, rec = _install(monkeypatch, 'ego')
@@ -302,7 +310,7 @@ def test_ego_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch,
                   hip_graph)
 
 
-@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+@pytest.mark.parametrize('hip_graph', [False, True, 'k2'], ids=['eager', 'graph', 'graph-k2'])
 def test_ntu_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, monkeypatch, hip_graph):
     gold = _gold('loop_ntu_found.json', 33)
     drv, loop, rec = _install(monkeypatch, 'ntu')
@@ -350,7 +358,7 @@ def test_ntu_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, m
         assert abs(g[3] - w[3]) <= 2e-4 * max(1.0, abs(w[3])) and abs(g[5] - w[5]) <= 2e-4 * w[5], (label, g, w)
 
 
-@pytest.mark.parametrize('hip_graph', [False, True], ids=['eager', 'graph'])
+@pytest.mark.parametrize('hip_graph', [False, True, 'k2'], ids=['eager', 'graph', 'graph-k2'])
 def test_ego_found_stage_reproduces_the_reference_trainer_and_tester(tmp_path, monkeypatch, hip_graph):
     """tests/golden/loop_ego_found.json (make_golden_r05_ego_found.py ran the reference's Found_RGB_Depth_Net through
     train_ego_track_acc(status='eval') and test_ego_track_acc as main_darts_found_ego.py:118-153 does): the last
