@@ -306,10 +306,33 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
             ms_loop = round(timed(loop_pair, pairs), 4)
         except Exception as e:                                   # noqa: BLE001
             log(f'merged alpha + metric step not captured: {type(e).__name__}: {e}')
+    # round 6: the trainer's steps_per_replay = 4 — four weight steps (four resident batches, per-step learning rates) as
+    # ONE replay; the phases of the search loop are sequential (a whole train phase, then a whole dev phase), so the
+    # cost per (train batch, dev batch) is w4 / 4 + (alpha step with metric forward)
+    ms_w4 = ms_loop4 = None
+    if world == 1:
+        try:
+            gw4 = GraphedTrainStep(model, crit, w_opt, xs, y, k=4)
+            more = [synth_batch(c, a.batch, device, 2000 + i, a.tier, a.config) for i in range(3)]
+            b4 = [([t.detach() for t in xs], y)] + [([t.detach() for t in xi], yi) for xi, yi in more]
+
+            def w4():
+                for j, (xj, yj) in enumerate(b4):
+                    for g in w_opt.param_groups:
+                        g['lr'] *= 0.999
+                    gw4.stage(j, xj, yj)
+                gw4.replay_staged()
+            ms_w4 = round(timed(w4, max(1, pairs // 4)) / 4, 4)
+            if ms_am is not None:
+                ms_loop4 = round(ms_w4 + ms_am, 4)
+        except Exception as e:                                   # noqa: BLE001
+            log(f'k = 4 weight step not captured: {type(e).__name__}: {e}')
     log(f'full search step: {ms_pair:.4f} ms per (w-step + alpha-step) pair')
     return {'ms_per_pair': round(ms_pair, 4), 'w_step_ms': round(ms_w, 4), 'alpha_step_ms': round(ms_a, 4),
             'metric_forward_ms': ms_f, 'alpha_step_with_metric_forward_ms': ms_am,
             'loop_ms_per_train_dev_batch_pair': ms_loop,
+            'w_step_ms_at_4_steps_per_replay': ms_w4,
+            'loop_ms_per_train_dev_batch_pair_at_4_steps_per_replay': ms_loop4,
             'w_step_without_input_copy_ms': round(ms_w_nocopy, 4),
             'input_copy_us': round((ms_w - ms_w_nocopy) * 1e3, 1),
             'host_issue_us_per_w_step': round(host_us, 1),
@@ -1034,6 +1057,8 @@ def headline(a, c, world, shapes, best, eager_ms, rccl, note=None):
     bracketed by barrier + synchronize, max over ranks; the headline is the MEDIAN region of the best shape."""
     dt = statistics.median(shapes[best])
     step_desc = {'single': 'fwd+bwd, one hipGraph replay',
+                 'k4': 'fwd+bwd, FOUR consecutive steps (each over a resident batch of its own, fresh dropout masks) per '
+                       'hipGraph replay: K steps = K / 4 replays',
                  'eager': 'fwd+bwd issued from Python, then flatten + RCCL all-reduce + copy back',
                  'host': 'fwd+bwd as one hipGraph replay writing every w- and arch-gradient into one flat bucket, '
                          'then ONE host-issued RCCL all-reduce(avg) of the bucket',
@@ -1370,6 +1395,37 @@ def main():
             torch.distributed.barrier()
         guard.cancel()
 
+    if (world == 1 and a.mode == 'graph' and not a.dp_selftest and a.steps % 4 == 0 and a.steps >= 4
+            and not os.environ.get('BMNAS_BENCH_CHILD') and os.environ.get('BMNAS_BENCH_K4', '1') != '0'):
+        # The same K steps with FOUR consecutive steps per hipGraph replay (K / 4 replays): each step is the full fwd + bwd
+        # over a synthetic batch of its OWN (four resident batches), fresh dropout masks per step — what a trainer that
+        # keeps k batches resident runs (models/search/train_searchable/_loop.py `steps_per_replay`,
+        # bmnas.graph.GraphedTrainStep(k=...)).  What separates two replays is paid once per four steps.
+        try:
+            ones = [make_step('single')]
+            for i in range(1, 4):
+                xs_i, y_i = synth_batch(c, a.batch, device, 100 + i, a.tier, a.config)
+                ones.append(DPStep(model, c, crit, xs_i, y_i, params, arch, device, None, 1.0,
+                                   bucket=False).make_step('single'))
+
+            def four():
+                out = None
+                for f in ones:
+                    out = f()
+                return out
+            g4 = GraphedStep(four, warmup=1)
+            saved_steps, a.steps = a.steps, a.steps // 4
+            try:
+                shapes['k4'] = measure(g4.replay, a.regions)        # (each region: K / 4 replays = K steps)
+            finally:
+                a.steps = saved_steps
+            log('k4: ' + ', '.join(f'{t / a.steps * 1e3:.4f}' for t in shapes['k4']) + ' ms/step')
+            if statistics.median(shapes['k4']) < statistics.median(shapes[best]):
+                best = 'k4'
+        except Exception as e:                       # noqa: BLE001 — a secondary shape must not cost the line
+            shapes.pop('k4', None)
+            log(f'k4 shape not measured: {type(e).__name__}: {e}')
+
     result = headline(a, c, world, shapes, best, eager_ms, rccl)
     dt = statistics.median(shapes[best])
     log(f'timed region done: {dt / a.steps * 1e3:.4f} ms/step')
@@ -1393,29 +1449,6 @@ def main():
             'weak_scaling_efficiency_vs_compute_only': round(compute_only / step_ms, 3),
             'speedup_bound_over_one_gpu': round(world * compute_only / step_ms, 2),
             'exposed_us_allowed_for_6x_at_8_gpus': round((8.0 / 6.0 - 1.0) * compute_only * 1e3, 1)}
-    if world == 1 and a.mode == 'graph' and not a.no_full_step and not a.dp_selftest:
-        # NOT the headline (one step per replay, above): what the ~8 us between two replays of a graph are worth,
-        # measured by capturing FOUR consecutive steps into one graph (same kernels, same batch, fresh dropout masks
-        # per step) — what a trainer that keeps several batches resident per replay would see
-        try:
-            one = make_step('single')
-
-            def four():
-                out = None
-                for _ in range(4):
-                    out = one()
-                return out
-            g4 = GraphedStep(four, warmup=1)
-            saved_steps, a.steps = a.steps, max(1, a.steps // 4)
-            t4 = measure(g4.replay, 3)
-            a.steps = saved_steps
-            result['four_steps_per_replay'] = {
-                'ms_per_step': round(statistics.median(t4) / (max(1, a.steps // 4) * 4) * 1e3, 4),
-                'note': 'secondary: four consecutive steps captured into ONE hipGraph; the headline replays one step '
-                        'per graph launch'}
-            del g4
-        except Exception as e:                       # noqa: BLE001 — diagnostics must not cost the headline
-            result['four_steps_per_replay'] = {'error': f'{type(e).__name__}: {e}'[:200]}
     if world == 1 and a.mode == 'graph' and a.tier == 'R' and not a.dp_selftest:
         # The reference FREEZES its backbones (`p.requires_grad = False`: mmimdb_darts_searchable.py:68-71,
         # ntu_darts_searchable.py:86-90, ego_darts_searchable.py:85-89): the features that enter the reshape layers never

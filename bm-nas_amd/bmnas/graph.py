@@ -376,7 +376,8 @@ class GraphedTrainStep:
 
     def stage(self, i, inputs, labels):
         """k > 1: hand over batch i (0 ... k - 1, in order) of the next replay.  Call it AFTER the scheduler has set the
-        learning rates this batch's step runs with: the step's Adam scalars are fixed here."""
+        learning rates this batch's step runs with: the step's Adam scalars are fixed here.  -> those learning rates, as
+        staged (one per scalar row)."""
         opt = self.optimizer
         if i == 0:
             opt.activate(self.plan)          # an eager step in between must not leak into the replay
@@ -385,6 +386,8 @@ class GraphedTrainStep:
             raise RuntimeError('GraphedTrainStep.stage: batches must be staged in order, one call per slot')
         opt.prepare_replay(slot=i)
         self._staged += list(inputs) + [labels]
+        # (decoded here, right after this slot's rows were written: `count` still is this step's)
+        return opt.staged_lrs(slot=i)
 
     def replay_staged(self):
         """-> [(loss, logits)] * k of the k staged batches (static tensors, overwritten by the next replay)."""

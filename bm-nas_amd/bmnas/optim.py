@@ -314,3 +314,10 @@ class Adam(torch.optim.Adam):
             b1, b2 = g['betas']
             h[r] = (-(g['lr'] / (1 - b1 ** t)), math.sqrt(1 - b2 ** t), b1, b2, g['eps'], g['weight_decay'],
                     1 - b1, 1 - b2)
+
+    def staged_lrs(self, slot=0):
+        """The learning rate of every scalar row of `slot`, decoded from what prepare_replay() STAGED there (the fp32 value
+        the Adam launch of that step reads) — for loops that report the rate a batch's step ran with."""
+        pl = self._plan
+        return [float(-pl['hyps'][slot][r][0]) * (1 - self.param_groups[gi]['betas'][0] ** pl['count'][r])
+                for r, gi in enumerate(pl['groups'])]

@@ -316,18 +316,21 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                     for x_, y_ in batches:
                         one_batch(x_, y_)
                     return
+                lrs = []
                 for j, (x_, y_) in enumerate(batches):
                     if cosine:
                         scheduler.step()
                         scheduler.update_optimizer(optimizer)
-                    wk_graph.stage(j, x_, y_)
+                    lrs.append(wk_graph.stage(j, x_, y_))
                 stats['k_step_replays'] += 1
-                for (loss, output), (x_, y_) in zip(wk_graph.replay_staged(), batches):
+                for (loss, output), (x_, y_), lr in zip(wk_graph.replay_staged(), batches, lrs):
                     loss_sum += loss.detach().double() * y_.size(0)
                     meter.update(output.detach(), y_)
                     stats['graph_replays'] += 1
+                    # (lr: the rates THIS batch's step was staged with — the optimizer's own have moved on to the last
+                    # batch of the group by now)
                     _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
-                             learn=True, how='graph')
+                             learn=True, how='graph', lr=lr)
 
             held = []                                   # batches waiting for their k-step replay
             for data in loader:

@@ -77,8 +77,9 @@ def _install(monkeypatch, task='mmimdb'):
 
     def observer(event, **k):
         if event == 'batch':
-            rec.batch(k['epoch'], k['phase'], k['learn'], k['loss'].detach(), k['output'],
-                      float(k['optimizer'].param_groups[0]['lr']))
+            # (a k-step replay reports the rates each of its batches was STAGED with, decoded from the Adam scalars)
+            lr = k['lr'][0] if k.get('lr') is not None else float(k['optimizer'].param_groups[0]['lr'])
+            rec.batch(k['epoch'], k['phase'], k['learn'], k['loss'].detach(), k['output'], lr)
         else:
             rec.phase(k['epoch'], k['phase'], k['loss'], k['metric'], k['genotype'])
 
@@ -96,7 +97,7 @@ def _compare_batches(got, want, rel, label):
         assert abs(g[5] - w[5]) <= rel * w[5], (label, 'logits l2', i, g[5], w[5])
         assert abs(g[4] - w[4]) <= rel * w[5] * 14.0, (label, 'logits sum', i, g[4], w[4])
         if w[2] and w[6] >= 0:
-            assert abs(g[6] - w[6]) <= 1e-9 + 1e-6 * w[6], (label, 'lr', i, g[6], w[6])
+            assert abs(g[6] - w[6]) <= 1e-9 + 2e-6 * w[6], (label, 'lr', i, g[6], w[6])   # (k-step: decoded from fp32)
         worst = max(worst, abs(g[3] - w[3]) / max(1.0, abs(w[3])), abs(g[5] - w[5]) / w[5])
     print(f'{label}: {len(got)} batches, worst relative deviation {worst:.2e}')
 
@@ -156,8 +157,11 @@ def test_search_loop_reproduces_the_reference_trainer(tmp_path, monkeypatch, hip
     best_f1, genotype = drv.train_darts_model(_loaders(gold), a, torch.device('cuda:0'), logging.getLogger('bmnas-test'))
     label = 'search/' + ('graph' if hip_graph else 'eager')
     if hip_graph:
-        assert loop.run.stats['graph_replays'] == 4 and loop.run.stats['forward_replays'] >= 2, loop.run.stats
-        if hip_graph == 'k2':                  # both full batches of each epoch's train phase went out as ONE replay
+        # (k2: the two full batches of each epoch's train phase go out as ONE replay, and the first batch the single-step
+        # path then sees is the ragged one — it captures THAT shape, so the tails replay too instead of running eagerly)
+        want_replays = 6 if hip_graph == 'k2' else 4
+        assert loop.run.stats['graph_replays'] == want_replays and loop.run.stats['forward_replays'] >= 2, loop.run.stats
+        if hip_graph == 'k2':
             assert loop.run.stats['k_step_replays'] == 2, loop.run.stats
     else:
         assert loop.run.stats['graph_replays'] == 0, loop.run.stats
@@ -246,8 +250,11 @@ def _acc_args(tmp_path, ns, nm, nout, hip_graph):
 
 def _check_search(gold, a, rec, loop, made, best_acc, genotype, label, hip_graph, arch_rel=2e-4):
     if hip_graph:
-        assert loop.run.stats['graph_replays'] == 4 and loop.run.stats['forward_replays'] >= 2, loop.run.stats
-        if hip_graph == 'k2':                  # both full batches of each epoch's train phase went out as ONE replay
+        # (k2: the two full batches of each epoch's train phase go out as ONE replay, and the first batch the single-step
+        # path then sees is the ragged one — it captures THAT shape, so the tails replay too instead of running eagerly)
+        want_replays = 6 if hip_graph == 'k2' else 4
+        assert loop.run.stats['graph_replays'] == want_replays and loop.run.stats['forward_replays'] >= 2, loop.run.stats
+        if hip_graph == 'k2':
             assert loop.run.stats['k_step_replays'] == 2, loop.run.stats
     else:
         assert loop.run.stats['graph_replays'] == 0, loop.run.stats
