@@ -308,8 +308,8 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
             log(f'merged alpha + metric step not captured: {type(e).__name__}: {e}')
     # round 6: the trainer's steps_per_replay = 4 — four weight steps (four resident batches, per-step learning rates) as
     # ONE replay; the phases of the search loop are sequential (a whole train phase, then a whole dev phase), so the
-    # cost per (train batch, dev batch) is w4 / 4 + (alpha step with metric forward)
-    ms_w4 = ms_loop4 = None
+    # cost per (train batch, dev batch) is (w4 + alpha4-with-metric-forward) / 4
+    ms_w4 = ms_am4 = ms_loop4 = None
     if world == 1:
         try:
             gw4 = GraphedTrainStep(model, crit, w_opt, xs, y, k=4)
@@ -323,8 +323,16 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
                     gw4.stage(j, xj, yj)
                 gw4.replay_staged()
             ms_w4 = round(timed(w4, max(1, pairs // 4)) / 4, 4)
-            if ms_am is not None:
-                ms_loop4 = round(ms_w4 + ms_am, 4)
+            gam4 = GraphedTrainStep(model, crit, a_opt, xv, yv, metric_forward=True, k=4)
+            moreb = [synth_batch(c, a.batch, device, 3000 + i, a.tier, a.config) for i in range(3)]
+            bv4 = [([t.detach() for t in xv], yv)] + [([t.detach() for t in xi], yi) for xi, yi in moreb]
+
+            def am4():
+                for j, (xj, yj) in enumerate(bv4):
+                    gam4.stage(j, xj, yj)
+                gam4.replay_staged()
+            ms_am4 = round(timed(am4, max(1, pairs // 4)) / 4, 4)
+            ms_loop4 = round(ms_w4 + ms_am4, 4)
         except Exception as e:                                   # noqa: BLE001
             log(f'k = 4 weight step not captured: {type(e).__name__}: {e}')
     log(f'full search step: {ms_pair:.4f} ms per (w-step + alpha-step) pair')
@@ -332,6 +340,7 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
             'metric_forward_ms': ms_f, 'alpha_step_with_metric_forward_ms': ms_am,
             'loop_ms_per_train_dev_batch_pair': ms_loop,
             'w_step_ms_at_4_steps_per_replay': ms_w4,
+            'alpha_step_with_metric_forward_ms_at_4_steps_per_replay': ms_am4,
             'loop_ms_per_train_dev_batch_pair_at_4_steps_per_replay': ms_loop4,
             'w_step_without_input_copy_ms': round(ms_w_nocopy, 4),
             'input_copy_us': round((ms_w - ms_w_nocopy) * 1e3, 1),

@@ -213,9 +213,8 @@ class GraphedTrainStep:
         self.metric_forward = bool(metric_forward)
         if self.metric_forward and not self.in_graph_step:
             raise RuntimeError('metric_forward needs the optimizer step inside the captured graph')
-        if self.k > 1 and (not self.in_graph_step or self.metric_forward):
-            raise RuntimeError('k steps per replay need the optimizer step inside the captured graph (and no metric '
-                               'forward riding along)')
+        if self.k > 1 and not self.in_graph_step:
+            raise RuntimeError('k steps per replay need the optimizer step inside the captured graph')
         views = reducer.ensure_bucket() if reducer is not None else None
         # with an averaging collective (RCCL) the captured step is the single-GPU one: unscaled loss, constant
         # unit gradient; otherwise (gloo) the loss is pre-scaled by 1/world and the bucket is summed
@@ -228,7 +227,7 @@ class GraphedTrainStep:
             if self.k == 1:
                 return one(self.inputs, self.labels)
             out = ()
-            for xs_i, y_i in self.slots:             # (loss_0, logits_0, loss_1, logits_1, ...)
+            for xs_i, y_i in self.slots:             # (loss_0, logits_0[, metric_loss_0, metric_logits_0], loss_1, ...)
                 out += one(xs_i, y_i)
             return out
 
@@ -390,7 +389,8 @@ class GraphedTrainStep:
         return opt.staged_lrs(slot=i)
 
     def replay_staged(self):
-        """-> [(loss, logits)] * k of the k staged batches (static tensors, overwritten by the next replay)."""
+        """-> [(loss, logits[, metric_loss, metric_logits])] * k of the k staged batches (static tensors, overwritten by
+        the next replay)."""
         opt = self.optimizer
         if len(self._staged) != self.k * (len(self.inputs) + 1):
             raise RuntimeError(f'GraphedTrainStep.replay_staged: {self.k} batches must be staged first')
@@ -399,7 +399,8 @@ class GraphedTrainStep:
         self._staged = []
         out = self._g.replay()
         opt.mark_launched()
-        return [(out[2 * i], out[2 * i + 1]) for i in range(self.k)]
+        n = 4 if self.metric_forward else 2
+        return [tuple(out[n * i:n * (i + 1)]) for i in range(self.k)]
 
     def __call__(self, inputs, labels):
         opt = self.optimizer

@@ -51,6 +51,26 @@ class Architect(object):
         self.optimizer.step()
         return None
 
+    def step_k(self, batches, logger):
+        """k architecture steps, each followed by its metric forward (`step(..., metric=True)` k times), as ONE hipGraph
+        replay over k resident batches — the dev phase of a search with the trainer's `steps_per_replay` = k.
+        -> [(loss, output)] of the k metric forwards, or None: the caller takes the batches one by one."""
+        if not self.use_graph:
+            return None
+        k = len(batches)
+        from bmnas.graph import GraphedTrainStep
+        gk = getattr(self, '_graph_k', None)
+        if gk is None and getattr(self, '_attempts_k', 0) < 3:
+            self._attempts_k = getattr(self, '_attempts_k', 0) + 1
+            gk = self._graph_k = GraphedTrainStep.try_build(self.model, self.criterion, self.optimizer, batches[0][0],
+                                                            batches[0][1], logger, metric_forward=True, k=k) or None
+        if not gk or gk.k != k or not all(gk.matches(x, y) for x, y in batches):
+            return None
+        for j, (x, y) in enumerate(batches):
+            gk.stage(j, x, y)
+        self.graph_replays += k
+        return [(o[2], o[3]) for o in gk.replay_staged()]
+
     def _backward_step(self, input_valid, target_valid):
         loss = self.criterion(self.model(input_valid), target_valid)
         loss.backward()

@@ -332,16 +332,38 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                     _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
                              learn=True, how='graph', lr=lr)
 
+            def k_arch_batches(batches):
+                """The dev phase of a search: k (architecture step + metric forward) pairs as ONE replay."""
+                nonlocal loss_sum
+                outs = architect.step_k(batches, logger)
+                if outs is None:
+                    for x_, y_ in batches:
+                        one_batch(x_, y_)
+                    return
+                stats['k_step_replays'] += 1
+                for (loss, output), (x_, y_) in zip(outs, batches):
+                    loss_sum += loss.detach().double() * y_.size(0)
+                    meter.update(output.detach(), y_)
+                    stats['forward_replays'] += 1
+                    stats['merged_metric_replays'] = stats.get('merged_metric_replays', 0) + 1
+                    _observe('batch', epoch=epoch, phase=phase, loss=loss, output=output, optimizer=optimizer,
+                             learn=False, how='graph')
+
+            # which batches wait for a k-step replay: the weight steps of a learning phase; the (architecture step +
+            # metric forward) pairs of a search's dev phase
+            arch_phase = (status == 'search' and phase in ('dev', 'test') and architect is not None and not learn
+                          and f_graphs.on and hasattr(architect, 'step_k'))
+            group = k_batches if learn else (k_arch_batches if arch_phase else None)
             held = []                                   # batches waiting for their k-step replay
             for data in loader:
                 inputs, labels = unpack(data, device)
                 if split:
                     inputs, labels = _shard_batch(inputs, labels)
                 seen += labels.size(0)
-                if learn and k_steps > 1 and isinstance(inputs, (list, tuple)):
+                if group is not None and k_steps > 1 and isinstance(inputs, (list, tuple)):
                     held.append((inputs, labels))
                     if len(held) == k_steps:
-                        k_batches(held)
+                        group(held)
                         held = []
                     continue
                 one_batch(inputs, labels)

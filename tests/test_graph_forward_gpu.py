@@ -223,3 +223,46 @@ def test_k_steps_per_replay_train_like_single_steps(cname, batch):
     assert s0 == s1 == {8.0}
     with pytest.raises(RuntimeError):
         g4(*batches[0])                                          # a k-step graph is driven by stage() / replay_staged()
+
+
+def test_k_architecture_steps_with_metric_forward_per_replay():
+    """Architect.step_k: k x (architecture step + the dev phase's metric forward) as one replay — against Architect.step
+    (..., metric=True) batch by batch on an identically initialised copy: the metric losses (each seen AFTER its own alpha
+    update) and the final alphas agree."""
+    import types
+    import bench as B
+    from bmnas import nn as bnn
+    from bmnas.optim import Adam
+    from models.search.darts.architect import Architect
+    c = dict(B.CONFIGS['mmimdb'], drpt=0.0)
+    dev = torch.device('cuda:0')
+    args = types.SimpleNamespace(weight_decay=1e-4, hip_graph=True)
+    crit = bnn.BCEWithLogitsLoss()
+    runs = []
+    batches = []
+    for i in range(4):
+        xs, y = B.synth_batch(c, 16, dev, 30 + i)
+        batches.append(([x.detach() for x in xs], y))
+    for mode in ('k', 'one'):
+        torch.manual_seed(9)
+        m = B.HyperNet(c, 'F', 'mmimdb').to(dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        opt = Adam(m.arch_parameters(), lr=3e-2, betas=(0.5, 0.999), weight_decay=1e-3)
+        arch = Architect(m, args, crit, opt)
+        if mode == 'k':
+            outs = arch.step_k(batches, None)
+            assert outs is not None and len(outs) == 4
+            losses = [float(l) for l, _ in outs]
+        else:
+            losses = []
+            for x, y in batches:
+                got = arch.step(x, y, None, metric=True)
+                assert got is not None
+                losses.append(float(got[0]))
+        runs.append((losses, [p.detach().clone() for p in m.arch_parameters()]))
+    for a, b_ in zip(*[r[0] for r in runs]):
+        assert abs(a - b_) <= 2e-4 * max(1.0, abs(b_)), runs
+    for pa, pb in zip(runs[0][1], runs[1][1]):
+        assert torch.allclose(pa, pb, rtol=1e-3, atol=1e-5)
