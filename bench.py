@@ -237,9 +237,35 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     from bmnas.optim import Adam
     w_opt = Adam(params, lr=1e-3, weight_decay=1e-4)
     a_opt = Adam(arch, lr=3e-4, betas=(0.5, 0.999), weight_decay=1e-3)
-    if world > 1:
-        bdist.attach(w_opt)
-        bdist.attach(a_opt)
+    selftest = bool(getattr(a, 'dp_selftest', False)) and world == 1
+    dp_phase = None
+    if world > 1 or selftest:
+        # The TRAINERS' buckets, phase by phase: the weight step reduces its optimizer's tensors only
+        # (no alpha / beta / gamma), the architecture step the 42-94 architecture floats alone.  Each phase's step is
+        # timed first WITHOUT any collective (optimizers that nobody attached a reducer to: compute only — the replicas
+        # drift apart for these few steps, which no later figure depends on), then with the step the trainers run.
+        # One GPU (--dp-selftest): the same through a world-size-1 communicator — the collective is in the graph, it
+        # just has nobody to talk to.
+        try:
+            dp_phase = {}
+            w0 = Adam(params, lr=1e-3, weight_decay=1e-4)
+            a0 = Adam(arch, lr=3e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+            for name, opt0 in (('w_step', w0), ('alpha_step', a0)):
+                g0 = GraphedTrainStep(model, crit, opt0, xs, y)
+                for _ in range(200):
+                    g0(xs, y)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(pairs):
+                    g0(xs, y)
+                torch.cuda.synchronize()
+                dp_phase[name] = {'compute_only_ms': round((time.perf_counter() - t0) / pairs * 1e3, 4)}
+                del g0
+            del w0, a0
+        except Exception as e:                                   # noqa: BLE001
+            dp_phase = {'error': f'{type(e).__name__}: {e}'[:200]}
+        rw, _ = bdist.attach(w_opt, selftest=selftest)
+        ra, _ = bdist.attach(a_opt, selftest=selftest)
     xv, yv = synth_batch(c, a.batch, device, 1000 + (torch.distributed.get_rank() if world > 1 else 0), a.tier,
                          a.config)
     gw = GraphedTrainStep(model, crit, w_opt, xs, y)
@@ -272,6 +298,27 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     ms_pair = timed(pair, pairs)
     ms_w = timed(lambda: gw(xs, y), pairs)
     ms_a = timed(lambda: ga(xv, yv), pairs)
+    if dp_phase is not None and 'error' not in dp_phase:
+        for name, ms, red in (('w_step', ms_w, rw), ('alpha_step', ms_a, ra)):
+            d = dp_phase[name]
+            d['with_allreduce_ms'] = round(ms, 4)
+            d['exposed_us_per_step'] = round(max(0.0, ms - d['compute_only_ms']) * 1e3, 1)
+            d['bucket_bytes'] = int(red.flat.numel() * 4) if red.flat is not None else None
+            d['plan'] = red.plan()
+            try:                                                  # the bucket's all-reduce alone, on this communicator
+                for _ in range(20):
+                    red.reduce_bucket()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    red.reduce_bucket()
+                torch.cuda.synchronize()
+                d['allreduce_alone_us'] = round((time.perf_counter() - t0) / 100 * 1e6, 1)
+            except Exception as e:                                # noqa: BLE001
+                d['allreduce_alone_error'] = f'{type(e).__name__}: {e}'[:120]
+        dp_phase['in_graph'] = bool(gw.native and ga.native)
+        dp_phase['note'] = ('exposed = (step with its collective) - (the same step with no reducer attached), both '
+                            'hipGraph replays timed in this run; the all-reduce alone is host-issued back to back')
     # what the batch copy into the graph's static tensors costs: the same replay handed its own static tensors
     # (GraphedTrainStep.static_batch(): a producer that writes the batch there skips the copy launch)
     sx, sy = gw.static_batch()
@@ -293,7 +340,7 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     # round 5: the architecture step and that metric forward as ONE replay over one copy of the batch (what the trainer
     # loop runs in the dev phase, models/search/darts/architect.py) -> the loop's cost per (train batch, dev batch)
     ms_am = ms_loop = None
-    if world == 1:
+    if world == 1 and not selftest:
         try:
             gam = GraphedTrainStep(model, crit, a_opt, xv, yv, metric_forward=True)
             ms_am = round(timed(lambda: gam(xv, yv), pairs), 4)
@@ -310,7 +357,7 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
     # ONE replay; the phases of the search loop are sequential (a whole train phase, then a whole dev phase), so the
     # cost per (train batch, dev batch) is (w4 + alpha4-with-metric-forward) / 4
     ms_w4 = ms_am4 = ms_loop4 = None
-    if world == 1:
+    if world == 1 and not selftest:
         try:
             gw4 = GraphedTrainStep(model, crit, w_opt, xs, y, k=4)
             more = [synth_batch(c, a.batch, device, 2000 + i, a.tier, a.config) for i in range(3)]
@@ -346,6 +393,7 @@ def full_search_step(model, crit, params, arch, xs, y, c, a, world, device, log,
             'input_copy_us': round((ms_w - ms_w_nocopy) * 1e3, 1),
             'host_issue_us_per_w_step': round(host_us, 1),
             'pairs_per_s': round(world * 1e3 / ms_pair, 1), 'pairs_timed': pairs,
+            'dp_cost_trainer_buckets': dp_phase,
             'includes': 'w-step: fwd + criterion + bwd w.r.t. the weight optimizer\'s tensors (the network and classifier '
                         'weights; input-feature gradients as far as the model asks for them; no alpha/beta/gamma '
                         'gradient: nothing reads it in this phase) + Adam(w, wd 1e-4); '

@@ -202,10 +202,14 @@ class FlatGradAllReducer:
     same communicator, same reduction, same scaling (`plan()`, decided once, collectively).  A rank that could
     not capture its step and a rank replaying its graph therefore still pair up."""
 
-    def __init__(self, tensors, group=None):
+    def __init__(self, tensors, group=None, selftest=False):
+        """selftest: on ONE GPU, go through everything an N > 1 step goes through — the flat bucket, the C-ABI
+        communicator (of world size 1) and its all-reduce captured inside the step's hipGraph — so that the trainers'
+        per-phase buckets can be exercised and timed without a second GPU (bench.py --dp-selftest)."""
         self.tensors = [t for t in tensors]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.selftest = bool(selftest) and self.world <= 1
         self._plan = None
         self.flat = None
         self.reduced = False
@@ -219,6 +223,11 @@ class FlatGradAllReducer:
             dev = self.tensors[0].device
             if self.world <= 1:
                 self._plan = 'single'
+                if self.selftest and dev.type == 'cuda':
+                    from . import lib
+                    if lib.comm_available():
+                        NativeComm.get(self.group)
+                        self._plan = 'native'
             elif native_rccl_enabled() and dev.type == 'cuda' and dist.get_backend(self.group) == 'nccl':
                 # collective init, here rather than inside a capture; a rank that cannot bind librccl / create the
                 # communicator takes every rank back to the host-issued plan (all ranks agree, or none goes native)
@@ -288,7 +297,7 @@ class FlatGradAllReducer:
         if self.reduced:
             self.reduced = False
             return
-        if self.world <= 1:
+        if self.world <= 1 and not self.selftest:
             return
         views = self.ensure_bucket()
         have = [(v, t.grad) for v, t in zip(views, self.tensors) if t.grad is not None]
@@ -313,12 +322,12 @@ def all_ranks_agree(ok, device, group=None):
     return bool(t.item() > 0.5)
 
 
-def attach(optimizer, tensors=None, group=None):
+def attach(optimizer, tensors=None, group=None, selftest=False):
     """Average gradients across ranks right before ``optimizer.step()``.  tensors defaults
-    to every tensor in the optimizer's param groups."""
+    to every tensor in the optimizer's param groups.  selftest: see FlatGradAllReducer."""
     if tensors is None:
         tensors = [p for g in optimizer.param_groups for p in g['params']]
-    reducer = FlatGradAllReducer(tensors, group)
+    reducer = FlatGradAllReducer(tensors, group, selftest=selftest)
     handle = optimizer.register_step_pre_hook(lambda opt, args, kwargs: reducer())
     optimizer._bmnas_reducer = reducer           # GraphedTrainStep writes gradients into its bucket
     return reducer, handle

@@ -1638,7 +1638,10 @@ __global__ __launch_bounds__(256 * NQ) void conv_fwd_group_q_k(ConvFwdGroup G) {
   const ConvArgs a = uni(pick_uniform(G.a, p));
   const int t = blockIdx.x - uni(pick_uniform(G.start, p)), gx = uni(pick_uniform(G.gx, p));
   const int kind = uni(pick_uniform(G.kind, p));               // here: 0 / 2 / 3 = tiles 96 / 64 / 32 columns wide
-  if (kind == 0) conv_pipe_fwd_body<32, 2, NQ, 3>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
+  // (the 96-column body needs 141 VGPRs; a 1024-thread workgroup has 128 per lane: four quads take the narrow tiles
+  // only — the launcher falls back to two quads when a layer of the group wants 96-column tiles — instead of spilling
+  // 44 B / lane in every instantiation of the kernel)
+  if (NQ <= 2 && kind == 0) conv_pipe_fwd_body<32, 2, (NQ <= 2 ? NQ : 2), 3>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
   else if (kind == 2) conv_pipe_fwd_body<32, 2, NQ, 2>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
   else conv_pipe_fwd_body<32, 2, NQ, 1>(a, t % gx, t / gx, reinterpret_cast<float*>(group_smem));
 }
@@ -2376,6 +2379,8 @@ extern "C" int bmnas_conv1x1_fwd_group(const bmnas_conv_fwd_prob_t* probs, int n
                                               : (jt == 2 ? conv_pipe_lds<32, 2, 2>(L) : conv_pipe_lds<32, 2, 1>(L)));
       }
       Gq.start[n] = qblocks;
+      for (int q = 0; q < n; ++q)
+        if (Gq.kind[q] == 0 && quads == 4) quads = 2;            // (96-column tiles: two quads, see conv_fwd_group_q_k)
       // (a stale error of an earlier call must not read as a refused launch: the plain kernel would then run ON TOP
       // of this one and add the BatchNorm sums twice)
       hipError_t err = hipGetLastError();
