@@ -193,6 +193,33 @@ def shard(t, rank, world, dim=0):
     return t.narrow(dim, rank * per, per)
 
 
+def uneven_bounds(n, rank, world):
+    """(start, length) of rank's slice when n samples are scattered the way nn.DataParallel does it
+    (mmimdb_darts_searchable.py:36-37 -> torch.nn.parallel.scatter -> comm.scatter -> Tensor.chunk(world)):
+    contiguous slices of ceil(n / world) samples until the batch is used up — 100 over 8 is 13 x 7 + 9, 9 over 8 is
+    2, 2, 2, 2, 1 and three idle replicas (length 0).  Which samples share a replica matters beyond bookkeeping:
+    train-mode BatchNorm takes its batch statistics per replica."""
+    c = -(-n // world)
+    start = min(rank * c, n)
+    return start, max(0, min(c, n - start))
+
+
+# The weight of THIS rank's shard in the current global batch: n_rank * world / n (1.0 for equal shards).  The
+# reference's criterion sees the gathered output of all replicas and takes ONE mean over the n samples
+# (mmimdb_darts_searchable.py:114 after DataParallel's gather); a rank here takes the mean over its own n_rank
+# samples, so its gradient enters the average over ranks with this weight.  Set per batch by the trainer loop
+# (`_loop._shard_batch`), read by every reducer.
+_SHARD_WEIGHT = [1.0]
+
+
+def set_shard_weight(w):
+    _SHARD_WEIGHT[0] = float(w)
+
+
+def shard_weight():
+    return _SHARD_WEIGHT[0]
+
+
 class FlatGradAllReducer:
     """Averages the .grad of a fixed tensor list across ranks with ONE all-reduce on a flat
     fp32 bucket (4.2 / 6.3 / 9.3 MB of weights, or the 42 / 70 / 94-float arch vector).
@@ -259,8 +286,9 @@ class FlatGradAllReducer:
 
     @property
     def loss_scale(self):
-        """What a step that writes its gradients straight into the bucket multiplies its loss by."""
-        return 1.0 / self.world if self.plan() == 'presum' else 1.0
+        """What a step that writes its gradients straight into the bucket multiplies its loss by: 1 / world under a
+        summing collective, times the weight of this rank's shard in the global batch (uneven scatter)."""
+        return (1.0 / self.world if self.plan() == 'presum' else 1.0) * shard_weight()
 
     # -- persistent bucket: gradients are PRODUCED in the flat buffer (GraphedTrainStep writes them
     # there inside the captured step), so a step's communication is one all-reduce and nothing else:
@@ -305,8 +333,8 @@ class FlatGradAllReducer:
             self.flat.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        if self.plan() == 'presum':
-            self.flat.mul_(1.0 / self.world)
+        if self.loss_scale != 1.0:                # 1 / world of a summing collective x this rank's shard weight
+            self.flat.mul_(self.loss_scale)
         self.reduce_bucket()
         if have:
             torch._foreach_copy_([g for _, g in have], [v for v, _ in have])

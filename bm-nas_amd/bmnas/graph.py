@@ -219,6 +219,9 @@ class GraphedTrainStep:
         # with an averaging collective (RCCL) the captured step is the single-GPU one: unscaled loss, constant
         # unit gradient; otherwise (gloo) the loss is pre-scaled by 1/world and the bucket is summed
         scale = reducer.loss_scale if reducer is not None else 1.0
+        # (the scale is a constant of the capture: `matches` refuses a batch whose shard weight differs — an uneven
+        # scatter of another global batch size that happens to give this rank the captured shape)
+        self.loss_scale = scale
         armed = [False]
 
         from . import nn as bnn
@@ -364,6 +367,8 @@ class GraphedTrainStep:
         return bool(v) and torch.cuda.is_available()
 
     def matches(self, inputs, labels):
+        if self.reducer is not None and abs(self.reducer.loss_scale - self.loss_scale) > 1e-12:
+            return False
         return (len(inputs) == len(self.inputs) and labels.shape == self.labels.shape and
                 all(a.shape == b.shape for a, b in zip(inputs, self.inputs)))
 

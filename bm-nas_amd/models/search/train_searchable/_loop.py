@@ -56,23 +56,20 @@ def _is_sharded(loader):
 
 
 def _shard_batch(inputs, labels):
-    """A loader without a DistributedSampler yields the GLOBAL batch on every rank: keep this
-    rank's contiguous slice (what DataParallel's scatter does; equal slices, so the mean of the
-    per-rank mean losses is the global mean — a remainder of n % world samples is dropped)."""
+    """A loader without a DistributedSampler yields the GLOBAL batch on every rank: keep this rank's contiguous slice,
+    cut the way nn.DataParallel's scatter cuts it (mmimdb_darts_searchable.py:36-37; `bmnas.dist.uneven_bounds`:
+    Tensor.chunk — ceil(n / world) samples per replica until the batch is used up, so the last replicas may get fewer
+    or none).  The reference's loss is ONE mean over the n gathered outputs; a rank's mean over its own n_rank samples
+    enters the gradient average with weight n_rank * world / n (`bmnas.dist.set_shard_weight`, applied by the reducer:
+    eager steps scale the bucket, captured steps their loss — and are replayed only for the weight they were captured
+    with).  A rank left without samples idles through the batch (`_idle_step`): zero gradients into the same
+    collective, the same averaged update."""
+    from bmnas import dist as bdist
     world, rank = _world(), _rank()
-    per = labels.shape[0] // world
-    if per == 0:
-        raise ValueError(f'batch of {labels.shape[0]} samples cannot be split over {world} ranks')
-    if labels.shape[0] % world and not _shard_batch.warned:
-        # DEVIATION from nn.DataParallel (INTEGRATION.md, "Data parallelism"): its scatter gives the first n % world
-        # replicas one more sample and the gathered loss is the mean over all n; equal shards keep mean-of-means ==
-        # global mean with ONE unweighted all-reduce and one captured batch shape per rank.  Said once, never silent.
-        import warnings
-        warnings.warn(f'bmnas: a global batch of {labels.shape[0]} samples over {world} ranks drops '
-                      f'{labels.shape[0] % world} sample(s) per such batch (use a DistributedSampler, or a batch size '
-                      f'divisible by the world size, to train on every sample)', RuntimeWarning)
-        _shard_batch.warned = True
-    cut = lambda t: t.narrow(0, rank * per, per) if torch.is_tensor(t) and t.dim() > 0 else t
+    n = labels.shape[0]
+    start, length = bdist.uneven_bounds(n, rank, world)
+    bdist.set_shard_weight(length * world / n if n else 1.0)
+    cut = lambda t: t.narrow(0, start, length) if torch.is_tensor(t) and t.dim() > 0 else t
     if isinstance(inputs, (tuple, list)):
         inputs = type(inputs)(cut(t) for t in inputs)
     else:
@@ -80,7 +77,23 @@ def _shard_batch(inputs, labels):
     return inputs, cut(labels)
 
 
-_shard_batch.warned = False
+def _weight():
+    from bmnas import dist as bdist
+    return bdist.shard_weight()
+
+
+def _set_weight(w):
+    from bmnas import dist as bdist
+    bdist.set_shard_weight(w)
+
+
+def _idle_step(optimizer):
+    """This rank got no sample of the batch (uneven scatter): it still joins the step's ONE collective — with zero
+    gradients, its shard weight is 0 — and applies the averaged gradients like every other rank."""
+    for group in optimizer.param_groups:
+        for p in group['params']:
+            p.grad = torch.zeros_like(p)
+    optimizer.step()
 
 
 class AccuracyMeter:
@@ -251,6 +264,17 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 # being captured (see GraphedTrainStep._live_graph_tensors)
                 output = loss = None
                 got = None
+                if labels.size(0) == 0:
+                    # an idle replica of an uneven scatter: no forward, the collectives of the batch only
+                    if status == 'search' and phase in ('dev', 'test') and architect is not None:
+                        _idle_step(architect.optimizer)
+                    if learn:
+                        if cosine:
+                            scheduler.step()
+                            scheduler.update_optimizer(optimizer)
+                        _idle_step(optimizer)
+                    stats['idle_steps'] = stats.get('idle_steps', 0) + 1
+                    return
                 if status == 'search' and phase in ('dev', 'test') and architect is not None:
                     # (captured: the metric forward below rides at the end of the architecture step's replay — one
                     # batch copy and one hipGraph launch for both; None: it did not, evaluate it here)
@@ -354,25 +378,39 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
             arch_phase = (status == 'search' and phase in ('dev', 'test') and architect is not None and not learn
                           and f_graphs.on and hasattr(architect, 'step_k'))
             group = k_batches if learn else (k_arch_batches if arch_phase else None)
-            held = []                                   # batches waiting for their k-step replay
+            held, held_w = [], []                       # batches waiting for their k-step replay (+ their shard weights)
+
+            def flush():
+                # (a shard weight belongs to ITS batch: uneven scatters of different global sizes must not share a replay)
+                nonlocal held, held_w
+                if len(held) == k_steps and len(set(held_w)) == 1:
+                    _set_weight(held_w[0])
+                    group(held)
+                else:                                   # the ragged tail of a phase: single steps
+                    for (x_, y_), w_ in zip(held, held_w):
+                        _set_weight(w_)
+                        one_batch(x_, y_)
+                held, held_w = [], []
+
             for data in loader:
                 inputs, labels = unpack(data, device)
                 if split:
                     inputs, labels = _shard_batch(inputs, labels)
                 seen += labels.size(0)
-                if group is not None and k_steps > 1 and isinstance(inputs, (list, tuple)):
+                if group is not None and k_steps > 1 and isinstance(inputs, (list, tuple)) and labels.size(0):
                     held.append((inputs, labels))
+                    held_w.append(_weight())
                     if len(held) == k_steps:
-                        group(held)
-                        held = []
+                        flush()
                     continue
+                w_now = _weight()
+                flush()                                 # keep the batch order
+                _set_weight(w_now)
                 one_batch(inputs, labels)
-            for x_, y_ in held:                         # the ragged tail of a phase: single steps
-                one_batch(x_, y_)
-            held = []
+            flush()
             n = dataset_sizes[phase]
             if _world() > 1:
-                # what the ranks processed together (a DistributedSampler pads, a split drops a remainder)
+                # what the ranks processed together (a DistributedSampler pads; a split covers every sample)
                 n = int(_all_sum(torch.tensor(float(seen), device=device, dtype=torch.float64)))
             epoch_loss = float(_all_sum(loss_sum)) / n
             epoch_metric = meter.compute(n)

@@ -127,6 +127,30 @@ def _worker(rank, world, port, tmp):
         assert torch.allclose(params[0].grad, torch.full_like(params[0], 0.5))      # (1 + 0) / 2
     else:
         assert params[0].grad is None
+    # uneven scatter (DataParallel / Tensor.chunk: 7 samples over 2 ranks = 4 + 3; 1 sample over 2 = 1 + an idle replica):
+    # each rank's shard-mean gradient is weighted by n_rank * world / n inside the reducer, the result is the gradient of
+    # ONE mean over all n samples; a rank without samples joins with zeros and ends with the same averaged gradient
+    torch.manual_seed(7)
+    for n in (7, 1):
+        Xu, Yu = torch.randn(n, 6), torch.randn(n, 3)
+        start, length = bdist.uneven_bounds(n, rank, world)
+        assert (start, length) == ((0, (n + 1) // 2) if rank == 0 else ((n + 1) // 2, n // 2))
+        bdist.set_shard_weight(length * world / n)
+        red.reduced = False
+        for p_ in params:
+            p_.grad = None
+        if length:
+            crit(model(Xu.narrow(0, start, length)), Yu.narrow(0, start, length)).backward()
+        else:
+            for p_ in params:
+                p_.grad = torch.zeros_like(p_)
+        assert abs(red.loss_scale - (length * world / n) / world) < 1e-12
+        red()
+        # (the replicas are identical; `ref` has not followed the last opt.step above: the full-batch gradient of `model`)
+        want = torch.autograd.grad(crit(model(Xu), Yu), params)
+        for a, b in zip(params, want):
+            assert torch.allclose(a.grad, b, rtol=1e-5, atol=1e-6), (n, (a.grad - b).abs().max())
+    bdist.set_shard_weight(1.0)
     # the C-ABI communicator's rendezvous must not strand ranks.  (1) rank 0 cannot create the unique id:
     # it still reaches the broadcast and ships an error sentinel; EVERY rank raises the same RuntimeError, nobody is
     # left inside a collective.  (2) plan(): librccl binds on one rank only -> all ranks agree BEFORE any rendezvous and

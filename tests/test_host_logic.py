@@ -194,45 +194,59 @@ def test_live_autograd_graph_detector():
 
 def test_trainer_loop_shards_unsharded_batches(monkeypatch):
     """Data parallelism through the reference's call chain: a loader without a DistributedSampler yields
-    the GLOBAL batch on every rank; the trainer loop keeps this rank's contiguous slice (what
-    DataParallel's scatter does), equal slices, remainder dropped."""
+    the GLOBAL batch on every rank; the trainer loop keeps this rank's contiguous slice, cut the way
+    DataParallel's scatter (Tensor.chunk) cuts it."""
     import torch
     import models.search.train_searchable._loop as loop
-    x = (torch.arange(10).float().view(10, 1), torch.arange(20).float().view(10, 2))
-    y = torch.arange(10)
-    for rank in range(3):
-        monkeypatch.setattr(loop, '_world', lambda: 3)
-        monkeypatch.setattr(loop, '_rank', lambda r=rank: r)
-        (a, b), lab = loop._shard_batch(x, y)
-        assert lab.tolist() == [3 * rank, 3 * rank + 1, 3 * rank + 2]
-        assert a.shape == (3, 1) and b.shape == (3, 2) and float(a[0, 0]) == 3 * rank
-    monkeypatch.setattr(loop, '_world', lambda: 16)
-    with pytest.raises(ValueError):
-        loop._shard_batch(x, y)
-
-
-def test_uneven_global_batch_is_a_stated_deviation_from_dataparallel(monkeypatch):
-    """nn.DataParallel's scatter (mmimdb_darts_searchable.py:36-37) hands a global batch of 10 to 3 replicas as chunks of
-    4 / 4 / 2 and averages the loss over all 10; this loop keeps EQUAL shards (one captured batch shape per rank, one
-    unweighted all-reduce, mean of shard means == mean over what was processed) and drops the n % world remainder.  The
-    deviation is deliberate ("Data parallelism") and never silent: pinned here as what it is — the first
-    such batch warns, names the count, and the samples every rank keeps are disjoint and cover exactly world * (n // world)."""
-    import warnings
-    import torch
-    import models.search.train_searchable._loop as loop
-    x, y = torch.arange(10).float().view(10, 1), torch.arange(10)
-    monkeypatch.setattr(loop, '_world', lambda: 3)
-    monkeypatch.setattr(loop._shard_batch, 'warned', False)
-    kept = []
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter('always')
+    from bmnas import dist as bdist
+    x = (torch.arange(9).float().view(9, 1), torch.arange(18).float().view(9, 2))
+    y = torch.arange(9)
+    try:
         for rank in range(3):
+            monkeypatch.setattr(loop, '_world', lambda: 3)
             monkeypatch.setattr(loop, '_rank', lambda r=rank: r)
-            _, lab = loop._shard_batch(x, y)
-            kept += lab.tolist()
-    assert kept == list(range(9))                                  # sample 9 — the remainder — is dropped
-    msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]
-    assert len(msgs) == 1 and 'drops 1 sample' in msgs[0]          # said once, with the count
+            (a, b), lab = loop._shard_batch(x, y)
+            assert lab.tolist() == [3 * rank, 3 * rank + 1, 3 * rank + 2]
+            assert a.shape == (3, 1) and b.shape == (3, 2) and float(a[0, 0]) == 3 * rank
+            assert bdist.shard_weight() == 1.0                     # equal shards: plain mean of means
+    finally:
+        bdist.set_shard_weight(1.0)
+
+
+def test_uneven_global_batch_is_scattered_like_dataparallel(monkeypatch):
+    """nn.DataParallel's scatter (mmimdb_darts_searchable.py:36-37 -> comm.scatter -> Tensor.chunk) hands a global batch
+    of 10 to 3 replicas as chunks of 4 / 4 / 2, 100 over 8 as 13 x 7 + 9, 9 over 8 as 2, 2, 2, 2, 1 + three idle replicas,
+    and the criterion takes ONE mean over all n gathered outputs.  The loop cuts the same slices — checked against
+    torch.chunk itself — and weights each rank's shard mean by n_rank * world / n, so that the average over ranks IS that
+    mean; no sample is dropped."""
+    import torch
+    import models.search.train_searchable._loop as loop
+    from bmnas import dist as bdist
+    try:
+        for n, world in ((10, 3), (100, 8), (9, 8), (128, 8), (7, 2), (1, 4)):
+            x, y = torch.arange(n).float().view(n, 1), torch.arange(n)
+            want = [c.tolist() for c in y.chunk(world)]
+            want += [[] for _ in range(world - len(want))]
+            monkeypatch.setattr(loop, '_world', lambda w=world: w)
+            kept, wsum = [], 0.0
+            vals = torch.randn(n, dtype=torch.float64)
+            mean_of_weighted = 0.0
+            for rank in range(world):
+                monkeypatch.setattr(loop, '_rank', lambda r=rank: r)
+                xs, lab = loop._shard_batch(x, y)
+                assert lab.tolist() == want[rank] and xs.shape[0] == len(want[rank])
+                assert bdist.uneven_bounds(n, rank, world)[1] == len(want[rank])
+                w = bdist.shard_weight()
+                assert abs(w - len(want[rank]) * world / n) < 1e-12
+                kept += lab.tolist()
+                wsum += w
+                if len(want[rank]):
+                    mean_of_weighted += w * float(vals[lab].mean()) / world
+            assert kept == list(range(n))                          # every sample, once, in order
+            assert abs(wsum - world) < 1e-9
+            assert abs(mean_of_weighted - float(vals.mean())) < 1e-12
+    finally:
+        bdist.set_shard_weight(1.0)
     # the epoch metrics divide by what the ranks processed together, not by the dataset size (run(): n = all-reduced `seen`)
     import inspect
     assert '_all_sum(torch.tensor(float(seen)' in inspect.getsource(loop.run)
