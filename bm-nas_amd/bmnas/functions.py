@@ -546,6 +546,76 @@ class ConvBnActFn(Function):
                 *dsrcs)
 
 
+class ConvBnReluLnFn(Function):
+    """The tail of a discrete step node with node_multiplier != 1 (Found_NodeCell.forward, node.py:62-76):
+        out = LayerNorm_[C, L]( dropout(relu(bn(out_conv(cat(tail))))) + x )
+    as the conv GEMM + ONE tail launch per direction (bmnas_bn_relu_ln_fwd / _bwd: the kernels the search path's
+    NodeCell ends in) instead of ConvBnActFn + CatLnFn (conv, BatchNorm tail, LayerNorm: one launch more each way).
+    -> (out, sums): sums (b, 2) = each sample's (sum, sum of squares) of `out` when want_sums (the fused head's K7
+    statistics), else an empty tensor.  Callers check `usable(b, C)` first."""
+
+    @staticmethod
+    def usable(b, C):
+        return K.FUSE_BN_TAIL and b <= K.BN_TAIL_MAX_B and C <= 1024
+
+    @staticmethod
+    def forward(ctx, p, training, want_sums, rm, rv, nbt, conv_w, conv_b, bn_w, bn_b, ln_w, ln_b, x, *srcs):
+        _require_gpu(srcs[0], 'conv1x1 + BatchNorm + LayerNorm tail')
+        srcs = [_c(_f32(s)) for s in srcs]
+        x = _c(_f32(x))
+        b, C_src, L = srcs[0].shape
+        M = conv_w.shape[0]
+        K_in = len(srcs) * C_src
+        W = _c(conv_w).view(M, K_in)
+        pool = None
+        if training and FUSE_STANDALONE_BN:
+            pool = FWD_STAT_POOL
+            pool.device = srcs[0].device
+        U, chan, sv = K.conv_bn_fwd(srcs, C_src, W, K_in, _c(conv_b), _c(bn_w), _c(bn_b), rm, rv, nbt,
+                                    training, stats=pool)
+        o = torch.empty_like(x)                  # dropout(relu(bn(U))), saved for the backward
+        out = torch.empty_like(x)
+        stats = torch.empty(b * 2, device=x.device, dtype=torch.float32)
+        sums = torch.empty((b, 2) if want_sums else (0,), device=x.device, dtype=torch.float32)
+        drop = K.DROP.make(p, out.numel(), training)
+        lw, lb = _c(ln_w), _c(ln_b)
+        lib.bn_relu_ln_fwd(U, chan, x, lw, lb, o, out, stats, b, M, L, drop, sv.fin, sums if want_sums else None)
+        ctx.sv, ctx.drop, ctx.wshape, ctx.x, ctx.o, ctx.stats, ctx.lw, ctx.lb = sv, drop, tuple(conv_w.shape), x, o, stats, lw, lb
+        ctx.leaf = ln_w.is_leaf and ln_b.is_leaf
+        if any(ctx.needs_input_grad):
+            ZERO_POOL.announce(2 * M + M * sv.ldw + M)
+            ZERO_POOL.announce(2 * lw.numel())
+        ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)
+        return out, sums
+
+    @staticmethod
+    def backward(ctx, g, _g_sums):
+        sv = ctx.sv
+        n_in = 13 + len(sv.srcs)
+        if g is None:
+            return (None,) * n_in
+        U, x = sv.U, ctx.x
+        b, M, L = U.shape
+        g = _c(g)
+        dV = torch.empty_like(U)
+        zero = ZERO_POOL.take(2 * M + M * sv.ldw + M, U.device)
+        bn_grad = zero[:2 * M]
+        dW = zero[2 * M:2 * M + M * sv.ldw].view(M, sv.ldw)
+        dbias = zero[2 * M + M * sv.ldw:]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[12] else None
+        dlw, dlb = _zero_pair(ctx.lw)
+        # LayerNorm input gradient, ReLU / dropout mask, BatchNorm reductions and the residual's gradient: one launch
+        lib.bn_relu_ln_bwd(g, ctx.o, x, ctx.lw, ctx.stats, U, sv.chan, dV, bn_grad, dx, 0, b, M, L, ctx.drop)
+        slots = [K.GradSlot(s) if ctx.needs_input_grad[13 + q] else None for q, s in enumerate(sv.srcs)]
+        K.conv_bn_bwd(sv, dV, bn_grad, slots, dW, dbias)
+        _ln_affine(g, [ctx.o], x, ctx.lw, ctx.lb, ctx.stats, dlw, dlb, b, M, L, False, False,
+                   key=ctx.lw.data_ptr(), leaf=ctx.leaf)
+        dsrcs = [s.get() if s is not None else None for s in slots]
+        return (None, None, None, None, None, None, dW.view(ctx.wshape), dbias, bn_grad[:M], bn_grad[M:], dlw, dlb, dx,
+                *dsrcs)
+
+
 class PoolGroupFn(Function):
     """The AdaptiveMaxPool2d in front of every reshape conv (aux_models.py:62-70, 101-108), all modalities in ONE
     launch per direction (csrc/pool.hip), output in the (b, C_in, L) layout the grouped GEMM reads.

@@ -222,6 +222,28 @@ constexpr size_t conv_ksplit_lds();
 #endif
 #define KS_PROBE(a, bit) (BMNAS_BODY_PROBES && ((a).probe & (bit)))
 
+// Wave priorities of the tile classes that share a merged launch (s_setprio: the SIMD's issue arbiter prefers the
+// higher-priority wave when several are ready).  0 = leave the wave at its launch priority.
+#ifndef BMNAS_PRIO_BWD_A
+#define BMNAS_PRIO_BWD_A 0
+#endif
+#ifndef BMNAS_PRIO_BWD_W
+#define BMNAS_PRIO_BWD_W 0
+#endif
+#ifndef BMNAS_PRIO_BWD_D
+#define BMNAS_PRIO_BWD_D 0
+#endif
+#ifndef BMNAS_PRIO_FWD_A
+#define BMNAS_PRIO_FWD_A 0
+#endif
+#ifndef BMNAS_PRIO_FWD_G
+#define BMNAS_PRIO_FWD_G 0
+#endif
+#define BMNAS_SETPRIO(p)                                  \
+  do {                                                    \
+    if constexpr ((p) != 0) __builtin_amdgcn_s_setprio(p); \
+  } while (0)
+
 // MULTI: contractions longer than the 4 * KPW blocks a workgroup holds in registers at once (the K = 2048
 // reshape layers) run as several rounds of [all loads, then all MFMAs] into the same accumulators.
 template <bool TRANS, int TN, int TJ, int KPW, bool MULTI = false, bool MIXEP = false>
@@ -1012,8 +1034,10 @@ __global__ __launch_bounds__(256) void conv_pipe_fwd_sdpa_k(ConvArgs a, SdpaFwdA
   if ((a.probe & 16) && (int)blockIdx.x < s.groups) return;
   if ((a.probe & 64) && (int)blockIdx.x >= s.groups) return;
   if ((int)blockIdx.x < s.groups) {
+    BMNAS_SETPRIO(BMNAS_PRIO_FWD_A);
     sdpa_fwd_body<KCH>(blockIdx.x, s.x, s.y, s.ln_w, s.ln_b, s.out, s.xhat, s.stats, s.G, s.drop, merged_smem);
   } else {
+    BMNAS_SETPRIO(BMNAS_PRIO_FWD_G);
     const int t = blockIdx.x - s.groups;
     conv_pipe_fwd_body<KC, NG>(a, t % gx, t / gx, reinterpret_cast<float*>(merged_smem));
   }
@@ -1392,6 +1416,12 @@ __device__ __forceinline__ void conv_w_body(const ConvWArgs& a, const int bx, co
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += tile[w][mm * 33 + kk];
       float* pp = a.dW + (int64_t)m * a.ldw + k;
+#if defined(BMNAS_PROBE_W_STORE)   // timing only (variant builds): what the weight-gradient class costs WITHOUT its atomics
+      if (a.use_atomic) {
+        pp[((int64_t)bz * a.M * a.ldw) & 0] = v;
+        continue;
+      }
+#endif
       if (a.use_atomic) {
         atomicAdd(pp, v);
         if (a.dup_cols > 0) atomicAdd(pp + a.dup_cols, v);
@@ -1512,9 +1542,11 @@ __global__ __launch_bounds__(256, BMNAS_MERGED_OCC) void conv_bwd_all_pipe_k(Con
   if ((a.probe & 32) && blk >= s.groups && blk < s.groups + n_w) return;
   if ((a.probe & 64) && blk >= s.groups + n_w) return;
   if (blk < s.groups) {
+    BMNAS_SETPRIO(BMNAS_PRIO_BWD_A);
     sdpa_bwd_body<KCH>(blk, s.g, s.gscale, s.x, s.y, s.ln_w, s.xhat, s.stats, s.dx, s.dy, s.acc_mask, s.G,
                        s.drop, merged_smem);
   } else if (blk < s.groups + n_w) {
+    BMNAS_SETPRIO(BMNAS_PRIO_BWD_W);
     const int t = blk - s.groups;
     int bx, by, bz;
     if (wx < 0) {
@@ -1545,6 +1577,7 @@ __global__ __launch_bounds__(256, BMNAS_MERGED_OCC) void conv_bwd_all_pipe_k(Con
       bx = x * hw + i % hw;
       by = i / hw;
     }
+    BMNAS_SETPRIO(BMNAS_PRIO_BWD_D);
     if (a.bn_U != nullptr) conv_pipe_bwd_body<KC, NG, true, kLa2>(a, bx, by, reinterpret_cast<float*>(merged_smem));
     else conv_pipe_bwd_body<KC, NG, false>(a, bx, by, reinterpret_cast<float*>(merged_smem));
   }

@@ -558,7 +558,8 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = 16 * t + 4 * h + r;
-        if (o < a.O) part[(int64_t)o * a.D + k0 + lo] = acc2[r];
+        // (probe bit 4, timing builds: one store per address — the volume of a design without per-chunk partials)
+        if (o < a.O && (!(a.probe & 4) || chunk == 0)) part[(int64_t)o * a.D + k0 + lo] = acc2[r];
       }
     }
   }
@@ -719,7 +720,7 @@ static int head_bwd_impl(const float* const* srcs, const float* const* sums, flo
   a.labels_i = mode == 2 ? (const long long*)labels : nullptr;
   a.loss = loss; a.loss_part = loss_part; a.part = part; a.scrub = scrub; a.scrub4 = scrub_n / 4;
   a.b = b; a.O = O; a.CL = C * L; a.D = n_src * C * L; a.n_src = n_src;
-#if defined(BMNAS_BODY_PROBES) && BMNAS_BODY_PROBES
+#if (defined(BMNAS_BODY_PROBES) && BMNAS_BODY_PROBES) || defined(BMNAS_CLASS_PROBE)
   static const int probe = []() { const char* e = getenv("BMNAS_HEAD_PROBE"); return e ? atoi(e) : 0; }();
   a.probe = probe;
 #else

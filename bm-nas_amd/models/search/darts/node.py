@@ -4,12 +4,17 @@ Mirror of the reference's models/search/darts/node.py (Found_NodeCell :8-76,
 Found_FusionNode :78-91).  The reference's ablation nodes (:94-184) look up primitive
 names that are not in STEP_STEP_OPS and cannot be constructed; they are not mirrored.
 """
+import os
+
 import torch.nn as nn
 
-from bmnas.functions import CatLnFn, CatLnSumsFn, ConvBnActFn
+from bmnas.functions import CatLnFn, CatLnSumsFn, ConvBnActFn, ConvBnReluLnFn
 
 from .node_operations import STEP_STEP_OPS
 from .operations import OPS
+
+# BMNAS_FOUND_FUSE_TAIL=0: the node tail as ConvBnActFn + CatLnFn (A/B runs)
+FOUND_FUSE_TAIL = os.environ.get('BMNAS_FOUND_FUSE_TAIL', '1') != '0'
 
 
 class Found_NodeCell(nn.Module):
@@ -50,6 +55,17 @@ class Found_NodeCell(nn.Module):
             in_y = self.edge_ops[2 * i + 1](states[self.edge_indices[2 * i + 1]])
             states.append(self.node_ops[i](in_x, in_y))
         tail = states[-self.node_multiplier:]
+        if (self.node_multiplier != 1 and x.is_cuda and FOUND_FUSE_TAIL
+                and ConvBnReluLnFn.usable(x.shape[0], self.C)):
+            # out_conv's BatchNorm / ReLU / dropout tail, the residual and the node's LayerNorm as ONE launch each way
+            bn = self.bn
+            o, sums = ConvBnReluLnFn.apply(self.out_dropout.p, self.training, self.want_sums, bn.running_mean,
+                                           bn.running_var, bn.num_batches_tracked, self.out_conv.weight,
+                                           self.out_conv.bias, bn.weight, bn.bias, self.ln.weight, self.ln.bias, x,
+                                           *tail)
+            if self.want_sums:
+                o._bmnas_sums = sums
+            return o
         if self.node_multiplier != 1:
             bn = self.bn
             out = ConvBnActFn.apply('relu', self.out_dropout.p, self.training, bn.running_mean,
