@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void adam_multi_k(const bmnas_adam_tensor_t* _
     adam1(p.y, g.y, m.y, v.y, h);
     adam1(p.z, g.z, m.z, v.z, h);
     adam1(p.w, g.w, m.w, v.w, h);
-    st4(t.param + e, p);
-    st4(t.exp_avg + e, m);
-    st4(t.exp_avg_sq + e, v);
+    st4_wtg<5>(t.param + e, p);
+    st4_wtg<5>(t.exp_avg + e, m);
+    st4_wtg<5>(t.exp_avg_sq + e, v);
   } else {
     const int64_t end = (e + 4 < t.numel) ? e + 4 : t.numel;
     for (int64_t i = e; i < end; ++i) {
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void copy_batch_k(CopyArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long o = base + ((long long)r * 256 + threadIdx.x) * 16;
-        if (o < full) *reinterpret_cast<uint4*>(d + o) = z4;
+        if (o < full) st16_wt(d + o, z4);
       }
       if (full < nb && full >= base && full < base + kCopyChunk && (long long)threadIdx.x == ((full - base) >> 4) % 256)
         for (long long o = full; o < nb; ++o) d[o] = 0;
@@ -170,10 +170,10 @@ __global__ __launch_bounds__(256) void copy_batch_k(CopyArgs a) {
     const uint4 v1 = *reinterpret_cast<const uint4*>(s + (f1 ? o1 : 0));
     const uint4 v2 = *reinterpret_cast<const uint4*>(s + (f2 ? o2 : 0));
     const uint4 v3 = *reinterpret_cast<const uint4*>(s + (f3 ? o3 : 0));
-    if (f0) *reinterpret_cast<uint4*>(d + o0) = v0;
-    if (f1) *reinterpret_cast<uint4*>(d + o1) = v1;
-    if (f2) *reinterpret_cast<uint4*>(d + o2) = v2;
-    if (f3) *reinterpret_cast<uint4*>(d + o3) = v3;
+    if (f0) st16_wt(d + o0, v0);
+    if (f1) st16_wt(d + o1, v1);
+    if (f2) st16_wt(d + o2, v2);
+    if (f3) st16_wt(d + o3, v3);
     // the last nb % 16 bytes: the lane whose piece would have held them
     if (full < nb && full >= base && full < base + kCopyChunk && (long long)threadIdx.x == ((full - base) >> 4) % 256)
       for (long long o = full; o < nb; ++o) d[o] = s[o];

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
     o.y = g0 * (xv.y + yv.y) + g1 * pv.y + g2 * (va.y * sigmoidf(vg.y) * m2.y) + g3 * (fmaxf(vf.y, 0.f) * m3.y);
     o.z = g0 * (xv.z + yv.z) + g1 * pv.z + g2 * (va.z * sigmoidf(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
     o.w = g0 * (xv.w + yv.w) + g1 * pv.w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
-    st4(out + e, o);
+    st4_wtg<2>(out + e, o);
     if (NP > 0) {
       float4 z = f4_scale(o, N.w[NP * N.ws]);
 #pragma unroll
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void node_mix_fwd_k(
         const float4 pj = ld4(N.prev[j] + e);
         z.x = fmaf(wj, pj.x, z.x); z.y = fmaf(wj, pj.y, z.y); z.z = fmaf(wj, pj.z, z.z); z.w = fmaf(wj, pj.w, z.w);
       }
-      st4(N.z + e, z);
+      st4_wtg<2>(N.z + e, z);
     }
   }
 }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
       o.z = g0 * (xv[k].z + yv[k].z) + g1 * pv[k].z + g2 * (va.z * sigmoidf(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
       o.w = g0 * (xv[k].w + yv[k].w) + g1 * pv[k].w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
       v[k] = f4_add(o, rv[k]);
-      st4(pre + e, v[k]);
+      st4_wtg<2>(pre + e, v[k]);
       sum += f4_hsum(v[k]);
     }
   }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(BS) void node_mix_ln_fwd_k(
     const int r = threadIdx.x + k * BS;
     if (r < cl4) {
       const float4 w = lw[k], bb = lb[k];
-      st4(out + ((int64_t)smp * cl4 + r) * 4,
+      st4_wtg<2>(out + ((int64_t)smp * cl4 + r) * 4,
           make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
                       (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w));
     }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
         if (N.gz2 != nullptr) G = f4_add(G, ld4(N.gz2 + e));
         gv = f4_scale(G, wn[NP]);
         if (N.g_in != nullptr) gv = f4_add(gv, ld4(N.g_in + e));
-        st4(N.g_out + e, gv);
+        st4_wtg<2>(N.g_out + e, gv);
         part[NP] += f4_dot(G, ld4(N.s + e));
 #pragma unroll
         for (int j = 0; j < NP; ++j) {                     // in order: destinations may alias each other
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
           if (d == nullptr) continue;
           float4 rr = f4_scale(G, wn[j]);
           if (N.acc & (1u << j)) rr = f4_add(rr, ld4(d + e));
-          st4(d + e, rr);
+          st4_wtg<2>(d + e, rr);
         }
       } else {
         gv = ld4(g + e);
@@ -366,19 +366,19 @@ __global__ __launch_bounds__(256) void node_mix_bwd_k(
         sw[2] += df[t] * (ufq[t] - mu[2]) * rs[2];
         sb[0] += da[t]; sb[1] += dg[t]; sb[2] += df[t];
       }
-      st4(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
-      st4(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
-      st4(dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
+      st4_wtg<2>(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
+      st4_wtg<2>(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
+      st4_wtg<2>(dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
       const float4 d0 = f4_scale(gv, g0);
       if (dx != nullptr) {
         float4 v = (dy == nullptr) ? f4_scale(d0, 2.f) : d0;
         if (acc_mask & 1u) v = f4_add(v, ld4(dx + e));
-        st4(dx + e, v);
+        st4_wtg<2>(dx + e, v);
       }
       if (dy != nullptr) {
         float4 v = d0;
         if (acc_mask & 2u) v = f4_add(v, ld4(dy + e));
-        st4(dy + e, v);
+        st4_wtg<2>(dy + e, v);
       }
     }
   }
@@ -536,8 +536,8 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
       gv.y = rstd * (dxh[k].y - m1 - xh[k].y * m2);
       gv.z = rstd * (dxh[k].z - m1 - xh[k].z * m2);
       gv.w = rstd * (dxh[k].w - m1 - xh[k].w * m2);
-      if (gbuf != nullptr) st4(gbuf + e, gv);
-      if (dresid != nullptr) st4(dresid + e, f4_add(gv, oldr[k]));
+      if (gbuf != nullptr) st4_wtg<2>(gbuf + e, gv);
+      if (dresid != nullptr) st4_wtg<2>(dresid + e, f4_add(gv, oldr[k]));
       const float4 m2d = drop_mult4(rglu, (uint64_t)e), m3d = drop_mult4(rfc, (uint64_t)e);
       const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
       const float uaq[4] = {ua[k].x, ua[k].y, ua[k].z, ua[k].w}, ugq[4] = {ug[k].x, ug[k].y, ug[k].z, ug[k].w},
@@ -564,12 +564,12 @@ __global__ __launch_bounds__(BS) void node_mix_ln_bwd_k(
         sw[2] += df[t] * (ufq[t] - cmu[k][2]) * crs[k][2];
         sb[0] += da[t]; sb[1] += dg[t]; sb[2] += df[t];
       }
-      st4(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
-      st4(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
-      st4(dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
+      st4_wtg<2>(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
+      st4_wtg<2>(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
+      st4_wtg<2>(dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
       const float4 d0 = f4_scale(gv, g0);
-      if (dx != nullptr) st4(dx + e, f4_add((dy == nullptr) ? f4_scale(d0, 2.f) : d0, oldx[k]));
-      if (dy != nullptr) st4(dy + e, f4_add(d0, oldy[k]));
+      if (dx != nullptr) st4_wtg<2>(dx + e, f4_add((dy == nullptr) ? f4_scale(d0, 2.f) : d0, oldx[k]));
+      if (dy != nullptr) st4_wtg<2>(dy + e, f4_add(d0, oldy[k]));
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void bn_glu_fwd_k(const float* __restrict__ U,
     const float4 va = affine4(ld4(U + ub), sc[c], sh[c]);
     const float4 vg = affine4(ld4(U + ub + (int64_t)C * L), sc[C + c], sh[C + c]);
     const float4 m = drop_mult4(dr, (uint64_t)(i * 4));
-    st4(out + i * 4, make_float4(va.x * sigmoidf(vg.x) * m.x, va.y * sigmoidf(vg.y) * m.y,
+    st4_wtg<2>(out + i * 4, make_float4(va.x * sigmoidf(vg.x) * m.x, va.y * sigmoidf(vg.y) * m.y,
                                   va.z * sigmoidf(vg.z) * m.z, va.w * sigmoidf(vg.w) * m.w));
   }
 }
@@ -664,8 +664,8 @@ __global__ __launch_bounds__(256) void bn_glu_bwd_k(const float* __restrict__ g,
         sw[1] += dg[t] * (ugq[t] - mu[1]) * rs[1];
         sb[0] += da[t]; sb[1] += dg[t];
       }
-      st4(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
-      st4(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
+      st4_wtg<2>(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
+      st4_wtg<2>(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
     }
   }
   float cs[4];
@@ -704,7 +704,7 @@ __device__ __forceinline__ void bn_relu_fwd_body(const float* __restrict__ U, fl
     const int c = r / l4n;
     const float4 v = affine4(ld4(U + i * 4), sc[c], sh[c]);
     const float4 m = drop_mult4(dr, (uint64_t)(i * 4));
-    st4(out + i * 4, make_float4(fmaxf(v.x, 0.f) * m.x, fmaxf(v.y, 0.f) * m.y,
+    st4_wtg<2>(out + i * 4, make_float4(fmaxf(v.x, 0.f) * m.x, fmaxf(v.y, 0.f) * m.y,
                                   fmaxf(v.z, 0.f) * m.z, fmaxf(v.w, 0.f) * m.w));
   }
 }
@@ -773,7 +773,7 @@ __device__ __forceinline__ void bn_relu_bwd_body(const float* __restrict__ g, co
         sw += dv[t] * (uq[t] - mu) * rs;
         sb += dv[t];
       }
-      st4(dV + e, make_float4(dv[0], dv[1], dv[2], dv[3]));
+      st4_wtg<2>(dV + e, make_float4(dv[0], dv[1], dv[2], dv[3]));
     }
   }
   float w = row_sum(sw, l4n), bb = row_sum(sb, l4n);
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
       const float4 m = drop_mult4(dr, (uint64_t)e);
       const float4 o = make_float4(fmaxf(a.x, 0.f) * m.x, fmaxf(a.y, 0.f) * m.y, fmaxf(a.z, 0.f) * m.z,
                                    fmaxf(a.w, 0.f) * m.w);
-      st4(o_out + e, o);
+      st4_wtg<2>(o_out + e, o);
       v[k] = f4_add(o, rv[k]);
       sum += f4_hsum(v[k]);
     }
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
       const float4 y = make_float4((v[k].x - mean) * rstd * w.x + bb.x, (v[k].y - mean) * rstd * w.y + bb.y,
                                    (v[k].z - mean) * rstd * w.z + bb.z, (v[k].w - mean) * rstd * w.w + bb.w);
       const int64_t e = ((int64_t)smp * cl4 + r) * 4;
-      st4(out + e, y);
+      st4_wtg<2>(out + e, y);
       if (NP > 0) {
         // the arithmetic of mixsum_pair_fwd_k, in its order: inputs 0 .. NP-1, then this output
         float4 acc = f4_scale(pn[k][0], pw[0]);
@@ -953,8 +953,8 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_fwd_k(
         acc.y = fmaf(pw[NP], y.y, acc.y);
         acc.z = fmaf(pw[NP], y.z, acc.z);
         acc.w = fmaf(pw[NP], y.w, acc.w);
-        st4(P.h + e, acc);
-        st4(P.z + e, f4_scale(acc, ps2));
+        st4_wtg<2>(P.h + e, acc);
+        st4_wtg<2>(P.z + e, f4_scale(acc, ps2));
       }
     }
   }
@@ -1036,12 +1036,12 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
           part[j] += f4_dot(G, xv[j]);
-          if (P.dxs.p[j] != nullptr) st4(P.dxs.p[j] + e, f4_add(f4_scale(G, P.w[j * P.ws]), od[j]));
+          if (P.dxs.p[j] != nullptr) st4_wtg<2>(P.dxs.p[j] + e, f4_add(f4_scale(G, P.w[j * P.ws]), od[j]));
         }
         part[NP] += f4_dot(G, ov);
         part[NP + 1] += f4_dot(z4, h4);
         gy = f4_add(gy, f4_scale(G, P.w[NP * P.ws]));
-        st4(P.g_full + e, gy);
+        st4_wtg<2>(P.g_full + e, gy);
       }
       xh[k] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
       dxh[k] = f4_mul(gy, w);
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
       dx.y = rstd * (dxh[k].y - m1 - xh[k].y * m2);
       dx.z = rstd * (dxh[k].z - m1 - xh[k].z * m2);
       dx.w = rstd * (dxh[k].w - m1 - xh[k].w * m2);
-      if (dresid != nullptr) st4(dresid + e, f4_add(dx, old[k]));
+      if (dresid != nullptr) st4_wtg<2>(dresid + e, f4_add(dx, old[k]));
       const float mu = chan[c], rs = chan[C + c], scv = chan[2 * C + c], shv = chan[3 * C + c];
       const float4 m = drop_mult4(dr, (uint64_t)e);
       const float uq[4] = {u[k].x, u[k].y, u[k].z, u[k].w}, gq[4] = {dx.x, dx.y, dx.z, dx.w},
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(BS) void bn_relu_ln_bwd_k(
         sw += dv[t] * (uq[t] - mu) * rs;
         sb += dv[t];
       }
-      st4(dV + e, make_float4(dv[0], dv[1], dv[2], dv[3]));
+      st4_wtg<2>(dV + e, make_float4(dv[0], dv[1], dv[2], dv[3]));
     }
     sw = row_sum(sw, l4n);
     sb = row_sum(sb, l4n);
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(float* __restrict__ dV,
     } else {
       d = f4_scale(d, sc);
     }
-    st4(dV + i * 4, d);
+    st4_wtg<2>(dV + i * 4, d);
   }
 }
 
@@ -1251,7 +1251,7 @@ __device__ __forceinline__ void cell_prologue_body(const ArchPack& P, const Fold
   // side job: zero-fill the caller's forward accumulation buffers (BatchNorm batch sums that the GEMM
   // epilogues add into with atomics, the head's logits) — instead of a memset launch
   for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < scrub4; i += (int64_t)nblocks * 256)
-    st4(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    st4_wtg<2>(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   // hipGraph replays: advance the dropout step counter once, here, before any kernel of this replay
   // reads it (one thread of the last workgroup; every later kernel is ordered after this launch)
   if (step_counter != nullptr && bid == nblocks - 1 && threadIdx.x == 0)
@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void cell_prologue_body(const ArchPack& P, const Fold
     for (int i = bi * 256 + threadIdx.x; i < total; i += F.blocks_per * 256) {
       const int m = i / c4n, c4 = i - m * c4n;
       const float* r = W + (int64_t)m * 2 * F.C + 4 * c4;
-      st4(We + (int64_t)m * F.C + 4 * c4, f4_add(ld4(r), ld4(r + F.C)));
+      st4_wtg<2>(We + (int64_t)m * F.C + 4 * c4, f4_add(ld4(r), ld4(r + F.C)));
     }
     return;
   }
@@ -1341,8 +1341,8 @@ __global__ __launch_bounds__(256) void cell_prologue_pair_k(ArchPack P, FoldPack
       acc.z = fmaf(wj[j], v[j].z, acc.z);
       acc.w = fmaf(wj[j], v[j].w, acc.w);
     }
-    reinterpret_cast<float4*>(A.out)[i] = acc;
-    reinterpret_cast<float4*>(A.out2)[i] = f4_scale(acc, s2);
+    st4_wt(A.out + 4 * i, acc);
+    st4_wt(A.out2 + 4 * i, f4_scale(acc, s2));
   }
 }
 

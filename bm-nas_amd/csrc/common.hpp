@@ -309,6 +309,43 @@ __device__ __forceinline__ T* pick_ptr(T* const (&arr)[N], int q) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Write-through (sc1) 16-byte store: the bytes go to memory when the store is issued instead of staying dirty in the
+// XCD's L2 until the kernel's end-of-launch write-back (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s for B dirty
+// bytes) — for tensors the NEXT launch reads, mostly from other XCDs anyway.  hipcc does not count an asm store in its
+// waits: only for data this wave never loads again, and ONLY for pointers into global memory (an LDS or scratch address
+// in a global_store faults).  (`s_nop 1`: the store reads its data registers after issue.)
+__device__ __forceinline__ void st4_wt(float* p, float4 v) {
+#if defined(BMNAS_NO_WT)
+  *reinterpret_cast<float4*>(p) = v;
+#else
+  const f32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
+#endif
+}
+
+// Store-policy groups (which launches write through is a measured choice, profiles/r06_write_through.txt): bit G of
+// BMNAS_WT_MASK turns group G on.  0: the streaming / GEMM launches of the lazy-LayerNorm search path (st4_wt direct);
+// 2: bnmix.hip's mix / BatchNorm-tail kernels; 3: layernorm.hip; 4: split-K conv epilogues + mixconv; 5: adam / linear.
+// Default 0x29: groups 2 and 4 stay plain — NTU / Ego's per-sample workgroups read what the SAME XCD wrote one launch
+// earlier (sample s -> workgroup s in producer and consumer), and a write-through store drops the line from that L2.
+#ifndef BMNAS_WT_MASK
+#define BMNAS_WT_MASK 0x29
+#endif
+template <int G>
+__device__ __forceinline__ void st4_wtg(float* p, float4 v) {
+  if constexpr ((BMNAS_WT_MASK >> G) & 1) st4_wt(p, v);
+  else *reinterpret_cast<float4*>(p) = v;
+}
+
+__device__ __forceinline__ void st16_wt(void* p, uint4 v) {     // the same for 16 raw bytes
+#if defined(BMNAS_NO_WT) || !((BMNAS_WT_MASK >> 5) & 1)
+  *reinterpret_cast<uint4*>(p) = v;
+#else
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+  const u32x4_ d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
+#endif
+}
 
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);

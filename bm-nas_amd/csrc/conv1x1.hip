@@ -408,7 +408,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvArgs& a, const int bx
     if (vo && d != nullptr && (!KS_PROBE(a, 4) || o.x == 12345.f)) {
       float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
       if (a.acc_mask & (1u << q)) ov = f4_add(o, ld4(pp));
-      st4(pp, ov);
+      st4_wtg<4>(pp, ov);
     }
     if (MIXEP && q == mix->q)                                  // wave-uniform: a 16-channel tile lies in one source
       mix_ep_tile(*mix, vo ? ov : make_float4(0.f, 0.f, 0.f, 0.f), so, cj, l0, vo, a.Cj, a.L,
@@ -662,7 +662,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
                                    acc[tn][tj][3] + bj);
       const int so = g * a.spw + ((4 * h) >> a.Lb);
       const bool vo = so < a.b;
-      if (vo) st4(a.dst.p[0] + ((int64_t)so * a.Cj + jj) * a.L + l0, o);
+      if (vo) st4_wt(a.dst.p[0] + ((int64_t)so * a.Cj + jj) * a.L + l0, o);
       if (a.stat == nullptr) {
         bn_tile_stats(a, o, bj, vo, g, jj, h);
       } else if (vo) {                                         // d = u - bias = the bare accumulator
@@ -966,7 +966,7 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     if (so >= a.b || d == nullptr) continue;
     float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
     const float4 o = make_float4(acc[tj][0], acc[tj][1], acc[tj][2], acc[tj][3]);
-    st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
+    st4_wt(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
   }
 }
 
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(256) void conv_lds_k(ConvArgs a) {
                                    acc[tn][tj][3] + bj);
       if (vo && d != nullptr) {
         float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
-        st4(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
+        st4_wtg<4>(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
       }
       bn_tile_stats(a, o, bj, vo, g, jj, h);
     }
@@ -1730,7 +1730,7 @@ __global__ __launch_bounds__(256) void fold_weight_k(const float* __restrict__ W
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int m = (int)(i / c4n), c4 = (int)(i - (int64_t)m * c4n);
     const float* r = W + (int64_t)m * 2 * C + 4 * c4;
-    st4(Weff + (int64_t)m * C + 4 * c4, f4_add(ld4(r), ld4(r + C)));
+    st4_wt(Weff + (int64_t)m * C + 4 * c4, f4_add(ld4(r), ld4(r + C)));
   }
 }
 

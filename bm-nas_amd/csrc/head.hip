@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
     __builtin_amdgcn_sched_barrier(0);
     for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < a.scrub4;
          i += (long long)gridDim.x * gridDim.y * 256)
-      st4(a.scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+      st4_wt(a.scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
     __builtin_amdgcn_sched_barrier(0);
     float loss_acc = 0.f;
 #pragma unroll
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
       float* pp = d + (int64_t)s * a.CL + kin + 4 * h;
       float4 o4 = make_float4(dx[0], dx[1], dx[2], dx[3]);
       if (a.acc_mask & (1u << q)) o4 = f4_add(o4, ld4(pp));
-      st4(pp, o4);
+      st4_wt(pp, o4);
     }
     // feat in (s = 4h + r, k = lo) layout for GEMM 2, recomputed from the state (never stored)
 #pragma unroll
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
   STAMP(5, blockIdx.y * gridDim.x + blockIdx.x, 3);
   if (a.part == nullptr) return;
   if (lo == 0) {
-    st4(part + (int64_t)a.O * a.D + k0 + 4 * h, make_float4(gw[0], gw[1], gw[2], gw[3]));
-    st4(part + (int64_t)(a.O + 1) * a.D + k0 + 4 * h, make_float4(gb[0], gb[1], gb[2], gb[3]));
+    st4_wt(part + (int64_t)a.O * a.D + k0 + 4 * h, make_float4(gw[0], gw[1], gw[2], gw[3]));
+    st4_wt(part + (int64_t)(a.O + 1) * a.D + k0 + 4 * h, make_float4(gb[0], gb[1], gb[2], gb[3]));
   }
   // GEMM 2: dW[o = 16 t + 4h + r][k0 + lo] = sum_s dl[s][o] feat[s][k0 + lo]
 #pragma unroll
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void sum_chunks_k(const float* __restrict__ pa
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 t = ld4(part + 4 * i);
     for (int c = 1; c < n_chunk; ++c) t = f4_add(t, ld4(part + 4 * (i + (long long)c * n4)));
-    st4(out + 4 * i, t);
+    st4_wt(out + 4 * i, t);
   }
 }
 
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void sum_chunks_strided_k(const float* __restr
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 t = ld4(part + 4 * i);
     for (int c = 1; c < n_chunk; ++c) t = f4_add(t, ld4(part + (long long)c * stride + 4 * i));
-    st4(out + 4 * i, t);
+    st4_wt(out + 4 * i, t);
   }
   if (blockIdx.x == 0 && (long long)threadIdx.x < tail) {
     const long long e = 4 * n4 + threadIdx.x;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(BS) void cat_ln_fwd_k(LnSrc srcs, const float* __re
       if (relu) {
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
       }
-      st4(out + ((int64_t)s * d4 + i) * 4, o);
+      st4_wtg<3>(out + ((int64_t)s * d4 + i) * 4, o);
       os += f4_hsum(o);
       oq += f4_dot(o, o);
     }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BS) void cat_ln_bwd_k(const float* __restrict__ g, 
   const int s = blockIdx.x;
   // side job: clear the caller's accumulation arena (saves a memset launch per backward)
   for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < scrub4; i += (int64_t)gridDim.x * BS)
-    st4(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    st4_wtg<3>(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   const float mean = stats[2 * s], rstd = stats[2 * s + 1];
   float4 xh[VPT], dxh[VPT];
   float s1 = 0.f, s2 = 0.f;
@@ -204,11 +204,11 @@ __global__ __launch_bounds__(BS) void cat_ln_bwd_k(const float* __restrict__ g, 
       float* d = pick_ptr(dsrcs.p, q);
       if (d != nullptr) {
         float* a = d + ((int64_t)s * cl4 + off) * 4;
-        st4(a, (acc_mask & (1u << q)) ? f4_add(dx, ld4(a)) : dx);
+        st4_wtg<3>(a, (acc_mask & (1u << q)) ? f4_add(dx, ld4(a)) : dx);
       }
       if (dresid != nullptr) {
         float* a = dresid + ((int64_t)s * d4 + i) * 4;
-        st4(a, (acc_mask & (1u << 31)) ? f4_add(dx, ld4(a)) : dx);
+        st4_wtg<3>(a, (acc_mask & (1u << 31)) ? f4_add(dx, ld4(a)) : dx);
       }
     }
   }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void backward_epilogue_k(LnAffineBatch B, Arch
     for (long long e = wg * 256 + threadIdx.x; e < n4; e += (long long)S.reps * per * 256) {
       float4 t = ld4(part + 4 * e);
       for (int c = 1; c < S.n_chunk[i]; ++c) t = f4_add(t, ld4(part + 4 * (e + (long long)c * n4)));
-      st4(S.out[i] + 4 * e, t);
+      st4_wtg<3>(S.out[i] + 4 * e, t);
     }
     return;
   }

@@ -122,7 +122,7 @@ __device__ __forceinline__ void linear_dfeat_body(const int bx, const int by, co
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, g[(int64_t)mc * O + oc], acc, 0, 0, 0);
   }
   if (m0 + lo < b)                                             // acc[r] = D[k = 4h + r][m = lo]
-    st4(dfeat + (int64_t)(m0 + lo) * K + k0 + 4 * h,
+    st4_wtg<5>(dfeat + (int64_t)(m0 + lo) * K + k0 + 4 * h,
         make_float4(acc[0] * gs, acc[1] * gs, acc[2] * gs, acc[3] * gs));
 }
 
@@ -170,7 +170,7 @@ __device__ __forceinline__ void linear_dw_body(const int bx, const float* __rest
     const float4 s4 = f4_add(f4_add(part[0][tj][lane], part[1][tj][lane]),
                              f4_add(part[2][tj][lane], part[3][tj][lane]));
     const int o = 16 * tj + lo;
-    if (o < O) st4(dW + (int64_t)o * K + k0 + 4 * h, f4_scale(s4, gs));   // D[k = 4h + r][o = lo]
+    if (o < O) st4_wtg<5>(dW + (int64_t)o * K + k0 + 4 * h, f4_scale(s4, gs));   // D[k = 4h + r][o = lo]
   }
 }
 

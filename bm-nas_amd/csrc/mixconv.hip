@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void mix_conv_fwd_k(MixConvArgs a) {
       o.z = g0 * (xv[k].z + yv[k].z) + g1 * pv[k].z + g2 * (va.z * sigm(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
       o.w = g0 * (xv[k].w + yv[k].w) + g1 * pv[k].w + g2 * (va.w * sigm(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
       st4(Af + c * kLd + sl * L + 4 * l4, valid ? o : make_float4(0.f, 0.f, 0.f, 0.f));
-      if (by == 0 && valid) st4(a.mix_out + e, o);
+      if (by == 0 && valid) st4_wtg<4>(a.mix_out + e, o);
     }
   }
   __syncthreads();
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void mix_conv_fwd_k(MixConvArgs a) {
                                (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
   const int so = bx * a.spw + ((4 * h) >> a.Lb), l0 = (4 * h) & (L - 1);
   const bool vo = so < a.b;
-  if (vo) st4(a.V + ((int64_t)so * C + jj) * L + l0, make_float4(d.x + bj, d.y + bj, d.z + bj, d.w + bj));
+  if (vo) st4_wtg<4>(a.V + ((int64_t)so * C + jj) * L + l0, make_float4(d.x + bj, d.y + bj, d.z + bj, d.w + bj));
   if (a.stat != nullptr) {                                      // batch sums of d = v - bias (bn_tile_stats, conv1x1.hip)
     float sum = vo ? f4_hsum(d) : 0.f, sq = vo ? f4_dot(d, d) : 0.f;
     sum = xor16_sum(sum);

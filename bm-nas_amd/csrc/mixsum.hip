@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void mixsum_fwd_k(PtrsIn xs, const float* __re
       acc.z = fmaf(wj[j], v[j].z, acc.z);
       acc.w = fmaf(wj[j], v[j].w, acc.w);
     }
-    reinterpret_cast<float4*>(out)[i] = acc;
+    st4_wt(out + 4 * i, acc);
   }
 }
 
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void mixsum_bwd_k(PtrsIn xs, PtrsOut dxs,
       if (d == nullptr) continue;
       float4 r = f4_scale(g4, wj[j]);
       if (acc_mask & (1u << j)) r = f4_add(r, reinterpret_cast<float4*>(d)[i]);
-      reinterpret_cast<float4*>(d)[i] = r;
+      st4_wt(d + 4 * i, r);
     }
   }
   if (dw == nullptr) return;
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void mixsum_pair_fwd_k(PtrsIn xs, const float*
       acc.z = fmaf(wj[j], v[j].z, acc.z);
       acc.w = fmaf(wj[j], v[j].w, acc.w);
     }
-    reinterpret_cast<float4*>(out)[i] = acc;
-    reinterpret_cast<float4*>(out2)[i] = f4_scale(acc, s2);
+    st4_wt(out + 4 * i, acc);
+    st4_wt(out2 + 4 * i, f4_scale(acc, s2));
   }
 }
 
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_k(PtrsIn xs, PtrsOut dxs,
       if (d == nullptr) continue;
       float4 r = f4_scale(g4, wj[j]);
       if (acc_mask & (1u << j)) r = f4_add(r, reinterpret_cast<float4*>(d)[i]);
-      reinterpret_cast<float4*>(d)[i] = r;
+      st4_wt(d + 4 * i, r);
     }
   }
   if constexpr (!DOTS) return;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_x_k(PtrsIn xs, PtrsOut dx
         r.w = fmaf(wx[t][j], gx[t].w, r.w);
       }
       if (acc_mask & (1u << j)) r = f4_add(r, reinterpret_cast<float4*>(d)[i]);
-      reinterpret_cast<float4*>(d)[i] = r;
+      st4_wt(d + 4 * i, r);
     }
   }
   if constexpr (!DOTS) return;
