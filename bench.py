@@ -821,7 +821,7 @@ def roofline_report(a, c, step, ms_per_step, log):
                 ptr = q + 1
                 break
     unmatched = skipped + [cname for cname, _, _ in calls[ptr:]]
-    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f'r0{r}_traffic.json') for r in (5, 4, 3, 2))
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f'r0{r}_traffic.json') for r in (6, 5, 4, 3, 2))
                   if os.path.exists(q)), '')
     traffic = {}
     if a.config == 'mmimdb' and a.batch == 128 and a.tier == 'F' and os.path.exists(tpath):
@@ -907,7 +907,7 @@ def roofline_report(a, c, step, ms_per_step, log):
     if top is not None:
         top = dict(top)
         top['measured'] = (source + f'; mean over {len(replays)} replays of End - Start per dispatch; '
-                           'cross-check: profiles/r05_kernel_stats_<config>_b<batch>.csv (rocprofv3 --kernel-trace --stats of the same command)')
+                           'cross-check: profiles/r06_kernel_stats_<config>_b<batch>.csv (rocprofv3 --kernel-trace --stats of the same command)')
         out['roofline'] = top
     return out
 
