@@ -546,6 +546,60 @@ class ConvBnActFn(Function):
                 *dsrcs)
 
 
+class ConvBnActThruFn(Function):
+    """ConvBnActFn whose sources are ALSO handed back as outputs: -> (out, *srcs).  A discrete step node reads an inner
+    state more than once (Found_NodeCell.forward, node.py:45-76: a later inner step, the out_conv tail, the residual); as
+    separate autograd nodes every extra reader costs an `at::add` launch when the engine sums the gradients.  Here the
+    later readers take the handed-back alias instead, so their gradient arrives as this node's grad_output for it — and
+    the data-gradient launch ACCUMULATES onto that tensor in place (the kernels' accumulate mask) instead of writing a
+    fresh one for the engine to add.  (The arriving gradient is written in place: it is the fresh result of the later
+    reader's backward, which nothing else holds — no retain_grad / hooks on these inner tensors.)"""
+
+    @staticmethod
+    def forward(ctx, act, p, training, rm, rv, nbt, conv_w, conv_b, bn_w, bn_b, *srcs):
+        out = ConvBnActFn.forward(ctx, act, p, training, rm, rv, nbt, conv_w, conv_b, bn_w, bn_b, *srcs)
+        ctx.set_materialize_grads(False)
+        return (out, *[s.view_as(s) for s in srcs])
+
+    @staticmethod
+    def backward(ctx, g, *g_thru):
+        sv, act = ctx.sv, ctx.act
+        n = len(sv.srcs)
+        if g is None:                       # only the handed-back sources were differentiated: identity
+            return (None,) * 10 + tuple(g_thru)
+        U = sv.U
+        b, M, L = U.shape
+        g = _c(g)
+        dV = torch.empty_like(U)
+        zero = ZERO_POOL.take(2 * M + M * sv.ldw + M, U.device)
+        bn_grad = zero[:2 * M]
+        dW = zero[2 * M:2 * M + M * sv.ldw].view(M, sv.ldw)
+        dbias = zero[2 * M + M * sv.ldw:]
+        if act == 'glu':
+            lib.bn_glu_bwd(g, U, sv.chan, dV, bn_grad, b, M // 2, L, ctx.drop)
+        else:
+            lib.bn_relu_bwd(g, U, sv.chan, dV, bn_grad, b, M, L, ctx.drop)
+        slots = []
+        for q, s in enumerate(sv.srcs):
+            gt = g_thru[q] if q < len(g_thru) else None
+            if not ctx.needs_input_grad[10 + q]:
+                slots.append(None)
+                continue
+            slot = K.GradSlot(s)
+            if gt is not None and gt.is_contiguous() and gt.dtype == torch.float32:
+                slot.t, slot.written = gt, True          # the later readers' gradient: accumulated onto, in place
+            slots.append(slot)
+        K.conv_bn_bwd(sv, dV, bn_grad, slots, dW, dbias)
+        dsrcs = []
+        for q, slot in enumerate(slots):
+            gt = g_thru[q] if q < len(g_thru) else None
+            d = slot.get() if slot is not None else None
+            if slot is not None and gt is not None and d is not gt:
+                d = gt if d is None else d + gt          # (a non-contiguous arrival: the engine's way)
+            dsrcs.append(d)
+        return (None, None, None, None, None, None, dW.view(ctx.wshape), dbias, bn_grad[:M], bn_grad[M:], *dsrcs)
+
+
 class ConvBnReluLnFn(Function):
     """The tail of a discrete step node with node_multiplier != 1 (Found_NodeCell.forward, node.py:62-76):
         out = LayerNorm_[C, L]( dropout(relu(bn(out_conv(cat(tail))))) + x )

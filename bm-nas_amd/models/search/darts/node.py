@@ -6,6 +6,7 @@ names that are not in STEP_STEP_OPS and cannot be constructed; they are not mirr
 """
 import os
 
+import torch
 import torch.nn as nn
 
 from bmnas.functions import CatLnFn, CatLnSumsFn, ConvBnActFn, ConvBnReluLnFn
@@ -15,6 +16,8 @@ from .operations import OPS
 
 # BMNAS_FOUND_FUSE_TAIL=0: the node tail as ConvBnActFn + CatLnFn (A/B runs)
 FOUND_FUSE_TAIL = os.environ.get('BMNAS_FOUND_FUSE_TAIL', '1') != '0'
+# BMNAS_FOUND_THRU=0: every reader of an inner state as an autograd node of its own (gradients summed by the engine)
+FOUND_THRU = os.environ.get('BMNAS_FOUND_THRU', '1') != '0'
 
 
 class Found_NodeCell(nn.Module):
@@ -50,10 +53,25 @@ class Found_NodeCell(nn.Module):
 
     def forward(self, x, y):
         states = [x, y]
+        thru = FOUND_THRU and x.is_cuda and torch.is_grad_enabled()
         for i in range(self.node_steps):
-            in_x = self.edge_ops[2 * i](states[self.edge_indices[2 * i]])
-            in_y = self.edge_ops[2 * i + 1](states[self.edge_indices[2 * i + 1]])
-            states.append(self.node_ops[i](in_x, in_y))
+            ix, iy = self.edge_indices[2 * i], self.edge_indices[2 * i + 1]
+            in_x = self.edge_ops[2 * i](states[ix])
+            in_y = self.edge_ops[2 * i + 1](states[iy])
+            op = self.node_ops[i]
+            if thru and hasattr(op, 'forward_thru') and in_x is not in_y:
+                # a state that is read again later (another inner step, the out_conv tail, the residual) travels THROUGH
+                # this op: the later readers take the alias, and their gradients are accumulated by this op's
+                # data-gradient launch instead of by autograd `add` launches (bmnas.functions.ConvBnActThruFn)
+                s, ax, ay = op.forward_thru(in_x, in_y)
+                if in_x is states[ix]:
+                    states[ix] = ax
+                if in_y is states[iy]:
+                    states[iy] = ay
+                states.append(s)
+            else:
+                states.append(op(in_x, in_y))
+        x = states[0]                       # (the residual reads the end of x's chain)
         tail = states[-self.node_multiplier:]
         if (self.node_multiplier != 1 and x.is_cuda and FOUND_FUSE_TAIL
                 and ConvBnReluLnFn.usable(x.shape[0], self.C)):

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from bmnas.cell import Arena, Pack
-from bmnas.functions import ConvBnActFn, MixSumFn, NodeMixedFn, SdpaLnFn
+from bmnas.functions import ConvBnActFn, ConvBnActThruFn, MixSumFn, NodeMixedFn, SdpaLnFn
 
 from .genotypes import *  # noqa: F401,F403
 from .genotypes import STEP_STEP_PRIMITIVES
@@ -55,6 +55,15 @@ class _CatConvBn(nn.Module):
         return ConvBnActFn.apply(self._act, self.dropout.p, self.training, bn.running_mean,
                                  bn.running_var, bn.num_batches_tracked, self.conv.weight,
                                  self.conv.bias, bn.weight, bn.bias, x, y)
+
+    def forward_thru(self, x, y):
+        """-> (out, x', y'): the same, with the two inputs handed back for their LATER readers (bmnas.functions
+        ConvBnActThruFn: those readers' gradients are then accumulated by this op's data-gradient launch, not by
+        autograd `add` launches)."""
+        bn = self.bn
+        return ConvBnActThruFn.apply(self._act, self.dropout.p, self.training, bn.running_mean,
+                                     bn.running_var, bn.num_batches_tracked, self.conv.weight,
+                                     self.conv.bias, bn.weight, bn.bias, x, y)
 
 
 class LinearGLU(_CatConvBn):
