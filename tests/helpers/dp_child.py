@@ -5,6 +5,7 @@ GPU-initialised process); reads RANK / WORLD_SIZE / MASTER_* from the environmen
 
     python dp_child.py grads  <outdir>     all-reduced w- and arch-gradients of one captured step
     python dp_child.py driver <outdir>     train_darts_model end to end (synthetic loaders)
+    python dp_child.py uneven <outdir>     an uneven global batch (7 = 4 + 3) through the loop's scatter
 """
 import logging
 import os
@@ -21,6 +22,7 @@ import torch
 import torch.nn as nn
 
 GLOBAL_BATCH, NOUT, SEED = 8, 23, 6
+UNEVEN_BATCH = 7
 
 
 def cfg_small():
@@ -125,6 +127,77 @@ def run_grads(out):
     torch.distributed.destroy_process_group()
 
 
+def run_uneven(out):
+    """An UNEVEN global batch (7 samples over 2 ranks = 4 + 3, nn.DataParallel's Tensor.chunk scatter) through the trainer
+    loop's own `_shard_batch`: captured weight step and Architect step with lr = 0; the all-reduced buckets must hold the
+    gradient of ONE mean over all 7 samples (per-replica BatchNorm statistics) — each shard's mean weighted n_rank * 2 / 7."""
+    from gpu_util import set_mode
+    from oracle import synth
+    from bmnas import dist as bdist
+    from bmnas import nn as bnn
+    from bmnas.graph import GraphedTrainStep
+    from models.search._common import HyperNetBase, search_setup
+    import models.search.train_searchable._loop as loop
+    cfg = cfg_small()
+    args = make_args(cfg)
+
+    class Net(HyperNetBase):
+        def __init__(self, criterion):
+            super().__init__()
+            self._build_head(args, criterion, nn.ModuleList([nn.Identity() for _ in range(cfg.N)]), cfg.N, 2)
+
+        def forward(self, feats):
+            return self.fuse(feats)
+
+    crit = bnn.BCEWithLogitsLoss()
+    model = Net(crit)
+    model.fusion_net.load_state_dict(synth.make_params(cfg, SEED))
+    for dst, src in zip(model.arch_parameters(), synth.make_arch(cfg, SEED, 0.5)):
+        dst.data.copy_(src)
+    cw, cb = synth.make_classifier(cfg, NOUT, SEED)
+    model.central_classifier.weight.data.copy_(cw)
+    model.central_classifier.bias.data.copy_(cb)
+    optimizer, scheduler, architect, _ = search_setup(model, args, crit, torch.device('cuda:0'),
+                                                      1.0, args.weight_decay)
+    rank = torch.distributed.get_rank()
+    device = next(model.parameters()).device
+    set_mode(model, 'train_nodrop')
+    X = [x[:UNEVEN_BATCH].to(device) for x in synth.make_inputs(cfg, GLOBAL_BATCH, SEED)]
+    Y = synth.make_labels('bce', GLOBAL_BATCH, NOUT, SEED)[:UNEVEN_BATCH].to(device)
+    xs, y = loop._shard_batch(X, Y)
+    xs, y = [x.contiguous() for x in xs], y.contiguous()
+    assert y.shape[0] == (4 if rank == 0 else 3) and abs(bdist.shard_weight() - y.shape[0] * 2 / 7) < 1e-12
+    for o in (optimizer, architect.optimizer):
+        for g in o.param_groups:
+            g['lr'] = 0.0
+    wg = GraphedTrainStep(model, crit, optimizer, xs, y)
+    assert wg.matches(xs, y)
+    wg(xs, y)
+    names = [n for grp in ('reshape_layers', 'fusion_net', 'central_classifier')
+             for n, _ in getattr(model, grp).named_parameters(prefix=grp)]
+    dump = {'wgrad:' + n: v.detach().cpu().clone() for n, v in zip(names, wg.reducer.views)}
+    architect.step(xs, y, None)
+    assert architect.graph_replays == 1
+    for i, v in enumerate(architect.optimizer._bmnas_reducer.views):
+        dump[f'agrad:{i}'] = v.detach().cpu().clone()
+    # another global batch size that gives this rank the SAME shard shape must not replay the captured step
+    bdist.set_shard_weight(1.0)
+    assert not wg.matches(xs, y)
+    # ... and the eager path weights its bucket the same way: same reduced gradients
+    bdist.set_shard_weight(y.shape[0] * 2 / 7)
+    optimizer.zero_grad()
+    crit(model(xs), y).backward()
+    optimizer.step()                       # lr = 0: the pre-hook reduces, nothing moves
+    for n, p_ in zip(names, [p for grp in ('reshape_layers', 'fusion_net', 'central_classifier')
+                             for p in getattr(model, grp).parameters()]):
+        if p_.grad is not None:
+            dump['egrad:' + n] = p_.grad.detach().cpu().clone()
+    torch.cuda.synchronize()
+    torch.save(dump, os.path.join(out, f'uneven_rank{rank}.pt'))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 class _VGG(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -193,4 +266,4 @@ def run_driver(out):
 
 
 if __name__ == '__main__':
-    {'grads': run_grads, 'driver': run_driver}[sys.argv[1]](sys.argv[2])
+    {'grads': run_grads, 'driver': run_driver, 'uneven': run_uneven}[sys.argv[1]](sys.argv[2])

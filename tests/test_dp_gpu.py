@@ -99,6 +99,46 @@ def test_two_ranks_allreduced_grads_match_oracle_shard_by_shard(tmp_path):
         assert torch.equal(d0[k], d1[k]), k
 
 
+def test_two_ranks_uneven_global_batch_matches_one_mean_over_all_samples(tmp_path):
+    """nn.DataParallel scatters 7 samples over 2 replicas as 4 + 3 (Tensor.chunk) and its criterion takes ONE mean over the
+    7 gathered outputs (mmimdb_darts_searchable.py:36-37, :114).  The loop's `_shard_batch` cuts the same slices and the
+    reducer weights each rank's shard mean by n_rank * world / n: the all-reduced weight and architecture gradients equal
+    the CPU oracle's shard gradients (per-replica BatchNorm statistics) combined with weights 4/7 and 3/7 — captured and
+    eager steps alike."""
+    sys.path.insert(0, os.path.dirname(CHILD))
+    import dp_child as ch
+    _launch('uneven', tmp_path)
+    d0 = torch.load(tmp_path / 'uneven_rank0.pt')
+    d1 = torch.load(tmp_path / 'uneven_rank1.pt')
+    cfg = ch.cfg_small()
+    n = ch.UNEVEN_BATCH
+    X = [x[:n] for x in synth.make_inputs(cfg, ch.GLOBAL_BATCH, ch.SEED)]
+    Y = synth.make_labels('bce', ch.GLOBAL_BATCH, ch.NOUT, ch.SEED)[:n]
+    cw, cb = synth.make_classifier(cfg, ch.NOUT, ch.SEED)
+    want = None
+    for lo, hi in ((0, 4), (4, 7)):
+        _, _, g = fo.search_step([x[lo:hi] for x in X], Y[lo:hi], synth.make_arch(cfg, ch.SEED, 0.5),
+                                 synth.make_params(cfg, ch.SEED), cw, cb, cfg, 'bce', training=True, attn_drop=0.0)
+        w = (hi - lo) / n
+        g = {k: v for k, v in g.items() if not k.startswith('input.')}       # (per-sample gradients: a shard's own)
+        want = {k: w * v for k, v in g.items()} if want is None else {k: want[k] + w * v for k, v in g.items()}
+    checked = 0
+    for k, v in d0.items():
+        if k.startswith(('wgrad:', 'egrad:')):
+            name = k.split(':', 1)[1]
+            key = name[len('fusion_net.'):] if name.startswith('fusion_net.') else name
+            if key.endswith('conv.bias') or key.endswith('out_conv.bias'):
+                assert float(v.abs().max()) < 1e-4
+            else:
+                assert_close_scaled(k, v, want[key], rel=5e-4)
+            checked += 1
+        elif k.startswith('agrad:'):
+            assert_close_scaled(k, v, want['arch.' + k.split(':')[1]], rel=5e-4)
+            checked += 1
+        assert torch.equal(v, d1[k]), k          # both ranks hold the same reduced gradients
+    assert checked > 40
+
+
 def test_two_ranks_run_the_reference_call_chain(tmp_path):
     _launch('driver', tmp_path)
     r0 = torch.load(tmp_path / 'driver_rank0.pt')

@@ -9,7 +9,7 @@
 # reducer.plan() on the eager path).
 # Usage (via gpurun; one call may run 20 minutes — pass a subset):  bash tools/test_matrix.sh "TOGGLE=0 TOGGLE=0 ..."
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-ALL="BMNAS_DEFAULT=1 BMNAS_HIP_GRAPH=0 BMNAS_LAZY_LN=0 BMNAS_WRITE_ONCE=0 BMNAS_CONV_PIPE=0 BMNAS_FUSE_ATTN_GEMM=0 BMNAS_FUSE_PROLOGUE=0 BMNAS_FUSE_EPILOGUE=0 BMNAS_FUSE_BN_FINALIZE=0 BMNAS_FUSE_HEAD=0 BMNAS_FUSE_PROLOGUE_PAIR=0 BMNAS_FUSE_BN_APPLY=0 BMNAS_FUSE_BWD_PAIR=0 BMNAS_FUSE_BN_TAIL=0 BMNAS_FUSE_INNER_SUM=0 BMNAS_FUSE_LN_BWD=0 BMNAS_FUSE_NEXT_PAIR=0 BMNAS_FUSE_MIX_EPILOGUE=0 BMNAS_FUSE_MIX_GEMM=0"
+ALL="BMNAS_DEFAULT=1 BMNAS_HIP_GRAPH=0 BMNAS_FOUND_FUSE_TAIL=0 BMNAS_FOUND_THRU=0 BMNAS_LAZY_LN=0 BMNAS_WRITE_ONCE=0 BMNAS_CONV_PIPE=0 BMNAS_FUSE_ATTN_GEMM=0 BMNAS_FUSE_PROLOGUE=0 BMNAS_FUSE_EPILOGUE=0 BMNAS_FUSE_BN_FINALIZE=0 BMNAS_FUSE_HEAD=0 BMNAS_FUSE_PROLOGUE_PAIR=0 BMNAS_FUSE_BN_APPLY=0 BMNAS_FUSE_BWD_PAIR=0 BMNAS_FUSE_BN_TAIL=0 BMNAS_FUSE_INNER_SUM=0 BMNAS_FUSE_LN_BWD=0 BMNAS_FUSE_NEXT_PAIR=0 BMNAS_FUSE_MIX_EPILOGUE=0 BMNAS_FUSE_MIX_GEMM=0"
 for e in ${1:-$ALL}; do
   echo "== $e"
   case $e in
