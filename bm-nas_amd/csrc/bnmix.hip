@@ -1251,7 +1251,7 @@ __device__ __forceinline__ void cell_prologue_body(const ArchPack& P, const Fold
   // side job: zero-fill the caller's forward accumulation buffers (BatchNorm batch sums that the GEMM
   // epilogues add into with atomics, the head's logits) — instead of a memset launch
   for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < scrub4; i += (int64_t)nblocks * 256)
-    st4_wtg<2>(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+    st4_wt(scrub + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
   // hipGraph replays: advance the dropout step counter once, here, before any kernel of this replay
   // reads it (one thread of the last workgroup; every later kernel is ordered after this launch)
   if (step_counter != nullptr && bid == nblocks - 1 && threadIdx.x == 0)
@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void cell_prologue_body(const ArchPack& P, const Fold
     for (int i = bi * 256 + threadIdx.x; i < total; i += F.blocks_per * 256) {
       const int m = i / c4n, c4 = i - m * c4n;
       const float* r = W + (int64_t)m * 2 * F.C + 4 * c4;
-      st4_wtg<2>(We + (int64_t)m * F.C + 4 * c4, f4_add(ld4(r), ld4(r + F.C)));
+      st4_wt(We + (int64_t)m * F.C + 4 * c4, f4_add(ld4(r), ld4(r + F.C)));
     }
     return;
   }
