@@ -1121,6 +1121,8 @@ def headline(a, c, world, shapes, best, eager_ms, rccl, note=None):
                          'then ONE host-issued RCCL all-reduce(avg) of the bucket',
                  'graph': 'fwd+bwd + ONE RCCL all-reduce(avg) of the flat gradient bucket, all inside one hipGraph '
                           'replay (bmnas_allreduce_f32 through the C ABI)',
+                 'graph_k4': 'FOUR consecutive steps per hipGraph replay, each fwd+bwd over a resident batch of its own + ONE '
+                             'RCCL all-reduce(avg) of its flat gradient bucket inside the replay: K steps = K / 4 replays',
                  'overlap': 'fwd+bwd + RCCL all-reduce(avg) of the flat gradient bucket in two parts inside one '
                             'hipGraph replay: the last cell step\'s conv / BatchNorm gradients on a forked stream '
                             'while the first step\'s backward runs, the rest at the end'}[best]
@@ -1448,6 +1450,37 @@ def main():
             log(f'{shape}: ' + ', '.join(f'{t / a.steps * 1e3:.4f}' for t in shapes[shape]) + ' ms/step')
             if statistics.median(shapes[shape]) < statistics.median(shapes[best]):
                 best = shape
+        if ('graph' in shapes and a.steps % 4 == 0 and a.steps >= 4 and os.environ.get('BMNAS_BENCH_K4', '1') != '0'):
+            # the N > 1 counterpart of the one-GPU `k4` shape: FOUR consecutive steps per replay, each over a resident
+            # batch of its own, each ending in its own in-graph all-reduce of its own flat bucket (what a data-parallel
+            # trainer with steps_per_replay = 4 replays).  Still under the watchdog; tried only when the one-step
+            # `graph` shape captured and ran on every rank.
+            ok, g4 = True, None
+            try:
+                ones = [make_step('graph')]
+                for i in range(1, 4):
+                    xs_i, y_i = synth_batch(c, a.batch, device, 100 + i + 10 * rank, a.tier, a.config)
+                    d_i = DPStep(model, c, crit, xs_i, y_i, params, arch, device, comm, loss_scale)
+                    ones.append(d_i.make_step('graph'))
+
+                def four_graph():
+                    out = None
+                    for f in ones:
+                        out = f()
+                    return out
+                g4 = GraphedStep(four_graph, warmup=1)
+            except Exception as e:                   # noqa: BLE001
+                ok = False
+                rccl['graph_k4_error'] = f'{type(e).__name__}: {e}'[:200]
+            if bdist.all_ranks_agree(ok, device):
+                saved_steps, a.steps = a.steps, a.steps // 4
+                try:
+                    shapes['graph_k4'] = measure(g4.replay, a.regions)
+                finally:
+                    a.steps = saved_steps
+                log('graph_k4: ' + ', '.join(f'{t / a.steps * 1e3:.4f}' for t in shapes['graph_k4']) + ' ms/step')
+                if statistics.median(shapes['graph_k4']) < statistics.median(shapes[best]):
+                    best = 'graph_k4'
         if world > 1:
             torch.distributed.barrier()
         guard.cancel()
