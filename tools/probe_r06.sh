@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: A/B runs of variant builds of the library (tools/build_variant.sh NAME flags...) on the headline step
 #   tools/probe_r06.sh NAME[:ENV=V,...] ...   -> gpurun_out/r06_probe_NAME.json + one table line per run
-V=bm-nas_amd/bmnas/variants
+V=$PWD/bm-nas_amd/bmnas/variants
 for spec in "$@"; do
   name=${spec%%:*}; envs=""
   [ "$spec" != "$name" ] && envs=$(echo "${spec#*:}" | tr ',' ' ')
