@@ -1341,8 +1341,8 @@ __global__ __launch_bounds__(256) void cell_prologue_pair_k(ArchPack P, FoldPack
       acc.z = fmaf(wj[j], v[j].z, acc.z);
       acc.w = fmaf(wj[j], v[j].w, acc.w);
     }
-    st4_wt(A.out + 4 * i, acc);
-    st4_wt(A.out2 + 4 * i, f4_scale(acc, s2));
+    st4_w0<0>(A.out + 4 * i, acc);
+    st4_w0<0>(A.out2 + 4 * i, f4_scale(acc, s2));
   }
 }
 

@@ -337,6 +337,18 @@ __device__ __forceinline__ void st4_wtg(float* p, float4 v) {
   else *reinterpret_cast<float4*>(p) = v;
 }
 
+// ... and inside group 0, by kernel (bit K of BMNAS_WT0_MASK; default: all write through): 0 prologue pair h / z, 1 conv
+// forward U, 2 attention forward, 3 node_mix_pre_fwd `pre`, 4 mixsum_pair_fwd_lazy, 5 head_bwd state gradients, 6
+// node_mix_lnp_bwd, 7 data-gradient tiles, 8 attention backward, 9 mixsum_pair_bwd_lazy, 10 mixsum_pair_bwd_x
+#ifndef BMNAS_WT0_MASK
+#define BMNAS_WT0_MASK 0x7FF
+#endif
+template <int K>
+__device__ __forceinline__ void st4_w0(float* p, float4 v) {
+  if constexpr ((BMNAS_WT0_MASK >> K) & 1) st4_wt(p, v);
+  else *reinterpret_cast<float4*>(p) = v;
+}
+
 __device__ __forceinline__ void st16_wt(void* p, uint4 v) {     // the same for 16 raw bytes
 #if defined(BMNAS_NO_WT) || !((BMNAS_WT_MASK >> 5) & 1)
   *reinterpret_cast<uint4*>(p) = v;

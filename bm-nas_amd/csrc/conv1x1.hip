@@ -662,7 +662,7 @@ __device__ __forceinline__ void conv_pipe_fwd_body(const ConvArgs& a, const int 
                                    acc[tn][tj][3] + bj);
       const int so = g * a.spw + ((4 * h) >> a.Lb);
       const bool vo = so < a.b;
-      if (vo) st4_wt(a.dst.p[0] + ((int64_t)so * a.Cj + jj) * a.L + l0, o);
+      if (vo) st4_w0<1>(a.dst.p[0] + ((int64_t)so * a.Cj + jj) * a.L + l0, o);
       if (a.stat == nullptr) {
         bn_tile_stats(a, o, bj, vo, g, jj, h);
       } else if (vo) {                                         // d = u - bias = the bare accumulator
@@ -966,7 +966,7 @@ __device__ __forceinline__ void conv_pipe_bwd_body(const ConvArgs& a, const int 
     if (so >= a.b || d == nullptr) continue;
     float* pp = d + ((int64_t)so * a.Cj + cj) * a.L + l0;
     const float4 o = make_float4(acc[tj][0], acc[tj][1], acc[tj][2], acc[tj][3]);
-    st4_wt(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
+    st4_w0<7>(pp, (a.acc_mask & (1u << q)) ? f4_add(o, ld4(pp)) : o);
   }
 }
 

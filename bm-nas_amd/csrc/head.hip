@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(HeadBwdArgs a, HeadLazy z) {
       float* pp = d + (int64_t)s * a.CL + kin + 4 * h;
       float4 o4 = make_float4(dx[0], dx[1], dx[2], dx[3]);
       if (a.acc_mask & (1u << q)) o4 = f4_add(o4, ld4(pp));
-      st4_wt(pp, o4);
+      st4_w0<5>(pp, o4);
     }
     // feat in (s = 4h + r, k = lo) layout for GEMM 2, recomputed from the state (never stored)
 #pragma unroll

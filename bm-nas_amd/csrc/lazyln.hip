@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void node_mix_pre_fwd_k(
   o.z = g0 * (xv.z + yv.z) + g1 * pv.z + g2 * (va.z * sigmoidf(vg.z) * m2.z) + g3 * (fmaxf(vf.z, 0.f) * m3.z);
   o.w = g0 * (xv.w + yv.w) + g1 * pv.w + g2 * (va.w * sigmoidf(vg.w) * m2.w) + g3 * (fmaxf(vf.w, 0.f) * m3.w);
   const float4 v = f4_add(o, rv);
-  if (act) st4_wt(pre + e, v);
+  if (act) st4_w0<3>(pre + e, v);
   STAMP(0, smp * P + part, 3);
   const int n4 = cl4 - part * kLazyPart < kLazyPart ? cl4 - part * kLazyPart : kLazyPart;
   const float nk = (float)(4 * n4);
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(256) void mixsum_pair_fwd_lazy_k(
   acc.z = fmaf(wj[NIN], n.z, acc.z);
   acc.w = fmaf(wj[NIN], n.w, acc.w);
   if (act) {
-    st4_wt(nout + 4 * i, n);
-    st4_wt(out + 4 * i, acc);
-    st4_wt(out2 + 4 * i, f4_scale(acc, s2));
+    st4_w0<4>(nout + 4 * i, n);
+    st4_w0<4>(out + 4 * i, acc);
+    st4_w0<4>(out2 + 4 * i, f4_scale(acc, s2));
   }
   STAMP(1, smp * P + part, 1);
   if (part == 0 && threadIdx.x == 0) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
     part_[NIN + 2 + 2 * t] = f4_dot(gw, xh);
   }
   if (act) {
-    if (g_full != nullptr) st4_wt(g_full + 4 * i, g4);
+    if (g_full != nullptr) st4_w0<9>(g_full + 4 * i, g4);
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {                           // in order: destinations may alias each other
       float* d = dxs.p[j];
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_lazy_k(
         // (the lazy inputs are pairwise distinct step-node outputs, host-checked: their old values came with the loads)
         rr = f4_add(rr, j >= NIN - NLZ ? oldn[j - (NIN - NLZ) < 0 ? 0 : j - (NIN - NLZ)] : reinterpret_cast<float4*>(d)[i]);
       }
-      st4_wt(d + 4 * i, rr);
+      st4_w0<9>(d + 4 * i, rr);
     }
   }
   STAMP(2, smp * P + part, 2);
@@ -391,8 +391,8 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
       gv.y = rstd * (gyv.y * lw.y - m1 - xh.y * m2);
       gv.z = rstd * (gyv.z * lw.z - m1 - xh.z * m2);
       gv.w = rstd * (gyv.w * lw.w - m1 - xh.w * m2);
-      if (gbuf != nullptr) st4_wt(gbuf + e, gv);
-      if (dresid != nullptr) st4_wt(dresid + e, f4_add(gv, oldr));
+      if (gbuf != nullptr) st4_w0<6>(gbuf + e, gv);
+      if (dresid != nullptr) st4_w0<6>(dresid + e, f4_add(gv, oldr));
       const float4 m2d = drop_mult4(rglu, (uint64_t)e), m3d = drop_mult4(rfc, (uint64_t)e);
       const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
       const float uaq[4] = {ua.x, ua.y, ua.z, ua.w}, ugq[4] = {ug.x, ug.y, ug.z, ug.w},
@@ -418,12 +418,12 @@ __global__ __launch_bounds__(256) void node_mix_lnp_bwd_k(
         sw[2] += df[t] * (ufq[t] - mu[2]) * rs[2];
         sb[0] += da[t]; sb[1] += dg[t]; sb[2] += df[t];
       }
-      st4_wt(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
-      st4_wt(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
-      st4_wt(dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
+      st4_w0<6>(dV + ub, make_float4(da[0], da[1], da[2], da[3]));
+      st4_w0<6>(dV + ub + (int64_t)C * L, make_float4(dg[0], dg[1], dg[2], dg[3]));
+      st4_w0<6>(dV + ub + (int64_t)2 * C * L, make_float4(df[0], df[1], df[2], df[3]));
       const float4 d0 = f4_scale(gv, g0);
-      if (dx != nullptr) st4_wt(dx + e, f4_add((dy == nullptr) ? f4_scale(d0, 2.f) : d0, oldx));
-      if (dy != nullptr) st4_wt(dy + e, f4_add(d0, oldy));
+      if (dx != nullptr) st4_w0<6>(dx + e, f4_add((dy == nullptr) ? f4_scale(d0, 2.f) : d0, oldx));
+      if (dy != nullptr) st4_w0<6>(dy + e, f4_add(d0, oldy));
     }
   }
   STAMP(3, blockIdx.y * gridDim.x + blockIdx.x, 2);

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void mixsum_pair_bwd_x_k(PtrsIn xs, PtrsOut dx
         r.w = fmaf(wx[t][j], gx[t].w, r.w);
       }
       if (acc_mask & (1u << j)) r = f4_add(r, reinterpret_cast<float4*>(d)[i]);
-      st4_wt(d + 4 * i, r);
+      st4_w0<10>(d + 4 * i, r);
     }
   }
   if constexpr (!DOTS) return;

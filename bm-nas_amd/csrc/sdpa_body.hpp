@@ -185,8 +185,8 @@ __device__ __forceinline__ void sdpa_fwd_body(const int g, const float* __restri
       const float4 w = lw[k], bb = lb[k];
       const float4 hh = make_float4((od[k].x - mean) * rstd, (od[k].y - mean) * rstd,
                                     (od[k].z - mean) * rstd, (od[k].w - mean) * rstd);
-      st4_wt(xhat + e, hh);
-      st4_wt(out + e, make_float4(hh.x * w.x + bb.x, hh.y * w.y + bb.y, hh.z * w.z + bb.z, hh.w * w.w + bb.w));
+      st4_w0<2>(xhat + e, hh);
+      st4_w0<2>(out + e, make_float4(hh.x * w.x + bb.x, hh.y * w.y + bb.y, hh.z * w.z + bb.z, hh.w * w.w + bb.w));
     }
   }
 }
@@ -348,10 +348,10 @@ __device__ __forceinline__ void sdpa_bwd_body(
         rx = f4_add(rx, ry);
       } else {
         if (acc_mask & 2u) ry = f4_add(ry, ld4(dy + e));
-        st4_wt(dy + e, ry);
+        st4_w0<8>(dy + e, ry);
       }
       if (acc_mask & 1u) rx = f4_add(rx, ld4(dx + e));
-      st4_wt(dx + e, rx);
+      st4_w0<8>(dx + e, rx);
     }
   }
 }

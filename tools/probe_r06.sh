@@ -1,12 +1,15 @@
 #!/bin/bash
 # round 6: A/B runs of variant builds of the library (tools/build_variant.sh NAME flags...) on the headline step
-#   tools/probe_r06.sh NAME[:ENV=V,...] ...   -> gpurun_out/r06_probe_NAME.json + one table line per run
+#   tools/probe_r06.sh [-q] NAME[:ENV=V,...] ...   -> gpurun_out/r06_probe_NAME.json + one table line per run
+#   -q: step times only (no rocprofv3 child)
 V=$PWD/bm-nas_amd/bmnas/variants
+extra=""
+if [ "$1" = "-q" ]; then extra="--no-roofline"; shift; fi
 for spec in "$@"; do
   name=${spec%%:*}; envs=""
   [ "$spec" != "$name" ] && envs=$(echo "${spec#*:}" | tr ',' ' ')
   lib=${name%%+*}
-  env BMNAS_LIB=$V/libbmnas_$lib.so $envs python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-full-step \
+  env BMNAS_LIB=$V/libbmnas_$lib.so $envs python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-full-step $extra \
       > gpurun_out/r06_probe_$name.json 2> gpurun_out/r06_probe_$name.err
   python - "$name" <<'PY'
 import json, sys
