@@ -151,6 +151,33 @@ def _worker(rank, world, port, tmp):
         for a, b in zip(params, want):
             assert torch.allclose(a.grad, b, rtol=1e-5, atol=1e-6), (n, (a.grad - b).abs().max())
     bdist.set_shard_weight(1.0)
+    # ... and a whole optimizer step with an IDLE replica, the way the trainer loop runs it (`_loop._idle_step`): a global
+    # batch of ONE sample over two ranks leaves rank 1 without samples; it joins the step's collective with zero gradients
+    # and applies the same averaged update — both replicas end where a single process stepping on that sample ends
+    import models.search.train_searchable._loop as loop
+    torch.manual_seed(11)
+    X1, Y1 = torch.randn(1, 6), torch.randn(1, 3)
+    solo = Toy()
+    solo.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        solo.alpha.copy_(model.alpha)
+    sopt = torch.optim.Adam(solo.parameters(), lr=1e-2)
+    opt2 = torch.optim.Adam(model.parameters(), lr=1e-2)          # fresh Adam state on both sides
+    bdist.attach(opt2)
+    start, length = bdist.uneven_bounds(1, rank, world)
+    bdist.set_shard_weight(length * world / 1)
+    if length:
+        opt2.zero_grad()
+        crit(model(X1), Y1).backward()
+        opt2.step()
+    else:
+        loop._idle_step(opt2)
+    bdist.set_shard_weight(1.0)
+    sopt.zero_grad()
+    crit(solo(X1), Y1).backward()
+    sopt.step()
+    for a, b in zip(model.parameters(), solo.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
     # the C-ABI communicator's rendezvous must not strand ranks.  (1) rank 0 cannot create the unique id:
     # it still reaches the broadcast and ships an error sentinel; EVERY rank raises the same RuntimeError, nobody is
     # left inside a collective.  (2) plan(): librccl binds on one rank only -> all ranks agree BEFORE any rendezvous and
