@@ -27,6 +27,47 @@ __global__ __launch_bounds__(256) void hand_k(const float* __restrict__ src, flo
   }
 }
 
+// second table: load flavour LF (0 plain, 1 nt, 2 sc1, 3 sc0 sc1) x store flavour SF (0 plain, 1 sc1, 2 nt, 3 sc0 sc1)
+template <int LF, int SF>
+__global__ __launch_bounds__(256) void hand2_k(const float* __restrict__ src, float* __restrict__ dst, int nwg, int shift) {
+  const int w = ((int)blockIdx.x + shift) % nwg;
+  const float* q = src + ((size_t)w * 256 + threadIdx.x) * 4;
+  f32x4 v;
+  if (LF == 0) asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(q) : "memory");
+  else if (LF == 1) asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(q) : "memory");
+  else if (LF == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(q) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(q) : "memory");
+  v.x += 1.f;
+  float* p = dst + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (SF == 0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else if (SF == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else if (SF == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
+template <int LF, int SF>
+double run2(int nwg, int shift, float* a, float* b) {
+  hipStream_t st;
+  hipStreamCreate(&st);
+  hipGraph_t g;
+  hipGraphExec_t ge;
+  hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  for (int i = 0; i < 20; ++i)
+    hipLaunchKernelGGL((hand2_k<LF, SF>), dim3(nwg), dim3(256), 0, st, (i & 1) ? b : a, (i & 1) ? a : b, nwg, shift);
+  hipStreamEndCapture(st, &g);
+  hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  for (int i = 0; i < 50; ++i) hipGraphLaunch(ge, st);
+  hipStreamSynchronize(st);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < 200; ++i) hipGraphLaunch(ge, st);
+  hipStreamSynchronize(st);
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  hipGraphExecDestroy(ge);
+  hipGraphDestroy(g);
+  hipStreamDestroy(st);
+  return us / (200 * 20);
+}
+
 template <bool WT>
 double run(int nwg, int shift, float* a, float* b) {
   hipStream_t st;
@@ -64,6 +105,15 @@ int main() {
     printf("%-10zu %-8d %6.2f %6.2f %6.2f   %6.2f %6.2f %6.2f\n", bytes, n, run<false>(n, 0, a, b), run<false>(n, 1, a, b),
            run<false>(n, 4, a, b), run<true>(n, 0, a, b), run<true>(n, 1, a, b), run<true>(n, 4, a, b));
     fflush(stdout);
+  }
+  // cross-XCD reader (shift 1), load flavour x store flavour, at the step's tensor sizes
+  printf("\ncross-XCD reader (shift 1): rows = load plain / nt / sc1 / sc0 sc1, columns = store plain / sc1 / nt / sc0 sc1\n");
+  const int wgs2[] = {384, 1152, 2304};      // 1.5 MB (T), 4.7 MB (3 T), 9.4 MB (6 T)
+  for (int n : wgs2) {
+    printf("%zu bytes\n", (size_t)n * 4096);
+#define ROW(LF) printf("  %6.2f %6.2f %6.2f %6.2f\n", run2<LF, 0>(n, 1, a, b), run2<LF, 1>(n, 1, a, b), run2<LF, 2>(n, 1, a, b), run2<LF, 3>(n, 1, a, b)); fflush(stdout);
+    ROW(0) ROW(1) ROW(2) ROW(3)
+#undef ROW
   }
   return 0;
 }
