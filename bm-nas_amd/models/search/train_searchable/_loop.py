@@ -258,6 +258,7 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
             split = _world() > 1 and not _is_sharded(loader)
             if _world() > 1 and _is_sharded(loader):
                 loader.sampler.set_epoch(epoch)          # a new shuffle per epoch, the same on every rank
+            _set_weight(1.0)                             # (a shard weight belongs to ONE scattered batch: none carries over)
             def one_batch(inputs, labels):
                 nonlocal w_graph, w_attempts, loss_sum
                 # nothing of the previous batch's autograd graph may stay referenced while a step is
@@ -408,6 +409,7 @@ def run(model, architect, criterion, optimizer, scheduler, dataloaders, dataset_
                 _set_weight(w_now)
                 one_batch(inputs, labels)
             flush()
+            _set_weight(1.0)
             n = dataset_sizes[phase]
             if _world() > 1:
                 # what the ranks processed together (a DistributedSampler pads; a split covers every sample)
